@@ -1,0 +1,141 @@
+/*
+ * mpcmax.h -- C ABI of libmpcmax.so: the contrast-maximisation (CMax) loss hot path of
+ * tub-rip/MotionPriorCMax, hand-written for AMD MI355X (gfx950).
+ *
+ * The reference has no native code and therefore no FFI to mirror; each entry point below
+ * replaces a stretch of the reference's PyTorch code (cited per function, paths relative to
+ * the reference root).  The Python host side (motionpriorcmax_amd.losses) binds these with
+ * ctypes -- see INTEGRATION.md for the stub a maintainer would add to the reference.
+ *
+ * Conventions
+ *  - all tensor arguments are DEVICE pointers to densely packed fp32 / int32 arrays owned by
+ *    the caller (PyTorch allocates them); the library never frees or retains them;
+ *  - `ws` is a caller-provided scratch buffer of at least mpc_workspace_bytes() bytes; its
+ *    content carries state from a *_fwd call to the matching *_bwd call;
+ *  - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *    synchronising; there is no global mutable state (the last-error string is thread local);
+ *  - return value: 0 ok, >0 a hipError_t, <0 an argument error (MPC_E_*).  No C++ exception
+ *    crosses the ABI.
+ *
+ * Event record layout (one row of events[B][M][6], loader.py:156-161,360-364):
+ *   0:y  1:x  2:t in [0,1]  3:polarity  4:bin index  5:valid (0 for padding rows)
+ * Rows [0,Mp) are the positive block, rows [Mp,M) the negative block (loader.py:392-395); the
+ * polarity split is by ROW INDEX as in focus.py:216-227.
+ */
+#ifndef MPCMAX_H
+#define MPCMAX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_VERSION 100
+
+/* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
+#define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
+#define MPC_F_MASK_BORDER     (1u << 1)  /* mask_image_border      focus.py:208-214 */
+#define MPC_F_POLARITY_SPLIT  (1u << 2)  /* polarity_aware_batching focus.py:216-227 */
+#define MPC_F_NORM_L2         (1u << 3)  /* focus_loss_norm == 'l2' (else 'l1') loss.py:22-25 */
+#define MPC_F_OBJ_VARIANCE    (1u << 4)  /* loss_type == 'variance' loss.py:14-16 (else gradient magnitude) */
+#define MPC_F_DIST_L1         (1u << 5)  /* dist_norm == 'l1' (else squared 'l2') focus.py:132-135 */
+#define MPC_F_SCHEME_IWD      (1u << 6)  /* interpolation_scheme == 'iwd' (else 'mean') focus.py:155-163 */
+#define MPC_F_WANT_NEXT       (1u << 7)  /* also build flow_to_next (smooth_type == 'on_flow_to_next') focus.py:170-178 */
+#define MPC_F_NO_WARP         (1u << 8)  /* splat events at their own (y,x): imager.create_iwe on raw events, logging.py:76-79 */
+#define MPC_F_UNIT_WEIGHT     (1u << 9)  /* weight = 1.0 for every row (create_iwe default weight) */
+#define MPC_F_ATOMIC_PATH     (1u << 10) /* debugging: plain global-atomic kernels instead of the LDS-tiled ones */
+
+/* argument errors */
+#define MPC_E_NULL      (-1)
+#define MPC_E_SHAPE     (-2)
+#define MPC_E_WORKSPACE (-3)
+#define MPC_E_UNSUPPORTED (-4)
+
+typedef struct mpc_shape {
+    int32_t B;      /* samples in the batch                                   */
+    int32_t M;      /* padded events per sample                               */
+    int32_t Mp;     /* num_pos_events: rows [0,Mp) positive, [Mp,M) negative  */
+    int32_t nb;     /* num_bins                                               */
+    int32_t T;      /* num_tref                                               */
+    int32_t H, W;   /* image_shape                                            */
+    int32_t sp;     /* lut_superpixel_size                                    */
+    int32_t hq, wq; /* LUT grid = ceil(H/sp) x ceil(W/sp)                     */
+    int32_t n;      /* trajectories per sample                                */
+    int32_t K;      /* num_knn                                                */
+    uint32_t flags; /* MPC_F_*                                                */
+} mpc_shape;
+
+/* scalars written by mpc_contrast_fwd / mpc_lut_smooth / mpc_finalize into `scal` (device,
+ * MPC_SCAL_COUNT floats) */
+#define MPC_SCAL_LOSS     0   /* focus + smooth                    focus.py:94      */
+#define MPC_SCAL_FOCUS    1   /* 1 / val                           loss.py:12       */
+#define MPC_SCAL_SMOOTH   2   /* smooth_weight * smoothness        focus.py:246     */
+#define MPC_SCAL_VAL      3   /* contrast value                    loss.py:14-27    */
+#define MPC_SCAL_GCOEF    4   /* d focus / d raw-IWE = GCOEF * grad_iwe_unscaled    */
+#define MPC_SCAL_COUNT    8
+
+int mpc_version(void);
+const char *mpc_last_error_string(void);
+
+/* Bytes of scratch needed by any call with this shape. */
+int64_t mpc_workspace_bytes(const mpc_shape *s);
+
+/* ---- A5: KNN flow look-up table (focus.py:115-180) --------------------------------------
+ * traj      [B][T+nb][n][2]  (y,x); rows [0,T) are the reference times, [T,T+nb) the bin mids
+ * flow_lut  [B][nb][hq][wq][T][2]                                   (out)
+ * flow_next [B][nb-1][hq][wq][1][2]  or NULL unless MPC_F_WANT_NEXT (out)
+ * knn_state [3][B][nb][hq*wq] + [B][nb] : K-th distance (f32), K-th index (i32 bits), iwd
+ *           normaliser, then per (sample,bin) the largest K-th distance (out; consumed by _bwd)
+ * idx_out   [B][nb][hq*wq][K] int32, ascending by (distance, index), or NULL (debug/tests)  */
+int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
+                    float *knn_state, int32_t *idx_out, void *ws, void *stream);
+
+/* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants,
+ * focus.py:157-163).  grad_flow_next may be NULL.  grad_traj [B][T+nb][n][2] is overwritten. */
+int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
+                    const float *grad_flow_next, const float *knn_state, float *grad_traj,
+                    void *ws, void *stream);
+
+/* ---- A6-A8: warp + weights + bilinear vote (focus.py:182-230, event_image_converter.py:333-391)
+ * events   [B][M][6], flow_lut [B][nb][hq][wq][T][2], t_ref [T] (device)
+ * iwe_raw  [B*T][P][H][W]  P = 2 with MPC_F_POLARITY_SPLIT else 1     (out, overwritten)   */
+int mpc_event_splat_fwd(const mpc_shape *s, const float *events, const float *flow_lut,
+                        const float *t_ref, float *iwe_raw, void *ws, void *stream);
+
+/* ---- A8 blur + A9 objective (event_image_converter.py:170-175, loss.py:4-27,58-87)
+ * iwe_blur [B*T][P][H][W] (out) ; grad_iwe [B*T][P][H][W] or NULL (out: UNSCALED adjoint image
+ * Blur^T Sobel^T u, or Blur^T (x - mean) for the variance objective; multiply by
+ * scal[MPC_SCAL_GCOEF] to get d focus_loss / d iwe_raw).  Partial sums go to ws; call
+ * mpc_finalize afterwards.                                                                  */
+int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float *iwe_blur, float *grad_iwe,
+                     void *ws, void *stream);
+
+/* ---- A10: smoothness of a flow field (focus.py:232-246, loss.py:29-56)
+ * field [nimg][hq][wq][C] (the LUT layout: nimg = B*nb, C = 2*T; or flow_next: nimg = B*(nb-1),
+ * C = 2).  grad_field (same shape, or NULL) receives d smoothness_loss / d field INCLUDING
+ * smooth_weight.  Partial sums go to ws; call mpc_finalize afterwards.                       */
+int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t nimg, int32_t C,
+                   float smooth_weight, float *grad_field, void *ws, void *stream);
+
+/* Reduce the partial sums of mpc_contrast_fwd and (if smooth_nimg > 0: the nimg, C, weight of
+ * the preceding mpc_lut_smooth call) in fp64 and write scal[MPC_SCAL_*] (device).            */
+int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C, float smooth_weight,
+                 float *scal, void *ws, void *stream);
+
+/* ---- A11: backward of A6-A8 into the LUT.
+ * grad_flow_lut[b][bin][iy][ix][tref][:] (+)= grad_out * scal[GCOEF] * w * bilinear-gradient of
+ * grad_iwe at the warped position.  If accumulate == 0 the buffer is overwritten, else added to
+ * (used to add the event term onto the smoothness term).  grad_out: device scalar or NULL (=1). */
+int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *flow_lut,
+                        const float *t_ref, const float *grad_iwe, const float *scal,
+                        const float *grad_out, float *grad_flow_lut, int32_t accumulate,
+                        void *ws, void *stream);
+
+/* y[i] = a[0] * x[i] (device scalar a; used to scale the smoothness gradient by grad_out). */
+int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCMAX_H */

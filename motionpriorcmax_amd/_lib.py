@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI declared in include/mpcmax.h.
+
+There is NO fallback: if libmpcmax.so is missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libmpcmax.so')
+
+# flags, mirror of include/mpcmax.h
+F_SCALE_BY_DT = 1 << 0
+F_MASK_BORDER = 1 << 1
+F_POLARITY_SPLIT = 1 << 2
+F_NORM_L2 = 1 << 3
+F_OBJ_VARIANCE = 1 << 4
+F_DIST_L1 = 1 << 5
+F_SCHEME_IWD = 1 << 6
+F_WANT_NEXT = 1 << 7
+F_NO_WARP = 1 << 8
+F_UNIT_WEIGHT = 1 << 9
+F_ATOMIC_PATH = 1 << 10
+
+SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 3, 4, 8
+
+EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_knn_lut_fwd',
+           'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
+           'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale']
+
+
+class Shape(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in
+                ('B', 'M', 'Mp', 'nb', 'T', 'H', 'W', 'sp', 'hq', 'wq', 'n', 'K')] + \
+               [('flags', ctypes.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -m motionpriorcmax_amd.build` '
+            '(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for this path.')
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    sp = ctypes.POINTER(Shape)
+    L.mpc_version.restype = ctypes.c_int
+    L.mpc_version.argtypes = []
+    L.mpc_last_error_string.restype = ctypes.c_char_p
+    L.mpc_last_error_string.argtypes = []
+    L.mpc_workspace_bytes.restype = i64
+    L.mpc_workspace_bytes.argtypes = [sp]
+    L.mpc_knn_lut_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_knn_lut_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_event_splat_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp]
+    L.mpc_contrast_fwd.argtypes = [sp, vp, vp, vp, vp, vp]
+    L.mpc_lut_smooth.argtypes = [sp, vp, i32, i32, f32, vp, vp, vp]
+    L.mpc_finalize.argtypes = [sp, i32, i32, f32, vp, vp, vp]
+    L.mpc_event_splat_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.mpc_scale.argtypes = [vp, vp, vp, i64, vp]
+    for name in EXPORTS[3:]:
+        getattr(L, name).restype = ctypes.c_int
+    if L.mpc_version() != 100:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (100)')
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mpc_last_error_string().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (rc={rc}): {msg}')

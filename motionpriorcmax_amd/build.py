@@ -1,0 +1,34 @@
+"""Compile libmpcmax.so (hand-written HIP for gfx950) in-tree with hipcc."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libmpcmax.so')
+SOURCES = ['api.hip', 'contrast.hip', 'events.hip', 'knn.hip']
+FLAGS = ['-shared', '-fPIC', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17',
+         '-Wall', '-Wno-unused-function']
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+           [os.path.join(HERE, '..', 'include', 'mpcmax.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,60 @@
+// libmpcmax: shape validation, workspace layout, version and error reporting.
+#include "common.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void mpc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int mpc_version(void) { return MPC_VERSION; }
+extern "C" const char *mpc_last_error_string(void) { return g_err; }
+
+int mpc_validate_shape(const mpc_shape *s) {
+    MPC_CHECK_ARG(s->B >= 0 && s->M >= 0 && s->Mp >= 0 && s->Mp <= s->M, MPC_E_SHAPE, "bad B/M/Mp");
+    MPC_CHECK_ARG(s->nb >= 1 && s->T >= 1, MPC_E_SHAPE, "need num_bins >= 1 and num_tref >= 1");
+    MPC_CHECK_ARG(s->H >= 3 && s->W >= 3, MPC_E_SHAPE, "image must be at least 3x3 (reflect padding)");
+    MPC_CHECK_ARG(s->sp >= 1, MPC_E_SHAPE, "lut_superpixel_size must be >= 1");
+    MPC_CHECK_ARG(s->hq == (s->H + s->sp - 1) / s->sp && s->wq == (s->W + s->sp - 1) / s->sp, MPC_E_SHAPE,
+                  "hq/wq must equal ceil(H/sp), ceil(W/sp)");
+    MPC_CHECK_ARG(s->n >= 0 && s->K >= 0, MPC_E_SHAPE, "bad n/K");
+    MPC_CHECK_ARG((int64_t)s->B * s->nb * s->hq * s->wq * s->T < (1LL << 30), MPC_E_UNSUPPORTED, "LUT too large");
+    MPC_CHECK_ARG((int64_t)s->B * s->M < (1LL << 40), MPC_E_UNSUPPORTED, "too many events");
+    if (s->flags & (MPC_F_SCALE_BY_DT | MPC_F_POLARITY_SPLIT)) {
+        // focus.py:49-50
+        MPC_CHECK_ARG(s->T == 1, MPC_E_SHAPE, "scale_iwe_by_dt / polarity_aware_batching require num_tref == 1");
+    }
+    return 0;
+}
+
+mpc_ws_layout mpc_layout(const mpc_shape *s) {
+    mpc_ws_layout L;
+    memset(&L, 0, sizeof(L));
+    L.P = (s->flags & MPC_F_POLARITY_SPLIT) ? 2 : 1;
+    L.nimg = s->B * s->T * L.P;
+    L.G = s->hq * s->wq;
+    int64_t off = 0;
+    L.n_cblocks = mpc_cdiv(s->W, MPC_CT_W) * mpc_cdiv(s->H, MPC_CT_H) * (L.nimg > 0 ? L.nimg : 1);
+    L.off_cpart = off; off += mpc_align((int64_t)L.n_cblocks * 2 * sizeof(double));
+    L.n_sblocks_max = mpc_cdiv(s->wq, MPC_ST) * mpc_cdiv(s->hq, MPC_ST) * (s->B > 0 ? s->B : 1) * s->nb * s->T * 2;
+    L.off_spart = off; off += mpc_align((int64_t)L.n_sblocks_max * 2 * sizeof(double));
+    L.off_counts = off; off += mpc_align(64 + (int64_t)(L.nimg > 0 ? L.nimg : 1) * sizeof(float));
+    const int64_t bt = (int64_t)(s->B > 0 ? s->B : 1) * s->nb;
+    L.off_cell_start = off; off += mpc_align(bt * (L.G + 1) * sizeof(int32_t));
+    L.off_spos = off;       off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
+    L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(int32_t));
+    L.total = off;
+    return L;
+}
+
+extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {
+    if (!s) { mpc_set_error("mpc_workspace_bytes: null shape"); return MPC_E_NULL; }
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    return mpc_layout(s).total;
+}

@@ -1,0 +1,91 @@
+// Shared host/device helpers for libmpcmax (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mpcmax.h"
+
+#define MPC_WAVE 64
+
+void mpc_set_error(const char *fmt, ...);
+
+#define MPC_CHECK_ARG(cond, code, msg)                                   \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            mpc_set_error("%s: %s", __func__, msg);                      \
+            return (code);                                               \
+        }                                                                \
+    } while (0)
+
+#define MPC_CHECK_LAUNCH()                                               \
+    do {                                                                 \
+        hipError_t e__ = hipGetLastError();                              \
+        if (e__ != hipSuccess) {                                         \
+            mpc_set_error("%s: %s", __func__, hipGetErrorString(e__));   \
+            return (int)e__;                                             \
+        }                                                                \
+    } while (0)
+
+static inline int64_t mpc_align(int64_t x, int64_t a = 256) { return (x + a - 1) / a * a; }
+static inline int mpc_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- workspace layout -------------------------------------------------------------------
+// One layout function shared by every entry point, so that forward and backward calls agree.
+struct mpc_ws_layout {
+    // contrast / smoothness partial sums (fp64 pairs)
+    int64_t off_cpart;   int32_t n_cblocks;     // [n_cblocks][2] double
+    int64_t off_spart;   int32_t n_sblocks_max; // [n_sblocks_max][2] double
+    int64_t off_counts;                         // int32[8] : n_sblocks used, ...
+    // KNN
+    int64_t off_cell_start;  // int32 [B*nb][G+1]
+    int64_t off_spos;        // float2 [B*nb][n]
+    int64_t off_sidx;        // int32  [B*nb][n]
+    // event partition (LDS-tiled path)
+    int64_t off_fcount;      // int32 [nfb]  fill counters of the forward buckets
+    int64_t off_bcount;      // int32 [nbb]  fill counters of the backward buckets
+    int64_t off_frec;        // float4 [nfb][fcap]
+    int64_t off_brec;        // float4 [nbb][bcap]
+    int32_t P, nimg, G;
+    int32_t strip_rows, n_strips;   // destination strips of the IWE (forward buckets)
+    int32_t cstrip_rows, n_cstrips; // source strips of LUT cell rows (backward buckets)
+    int32_t nfb, nbb, fcap, bcap;
+    int64_t total;
+};
+
+// contrast tiles
+#define MPC_CT_H 32
+#define MPC_CT_W 64
+// smoothness tiles (LUT cells)
+#define MPC_ST 16
+
+mpc_ws_layout mpc_layout(const mpc_shape *s);
+int mpc_validate_shape(const mpc_shape *s);
+
+// ---- device helpers ---------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// Sum of `v` over a workgroup of NT threads (NT multiple of 64); result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double block_sum_d(double v, double *lds /* NT/64 doubles */) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) lds[wv] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += lds[i];
+    }
+    __syncthreads();
+    return r;
+}
+#endif

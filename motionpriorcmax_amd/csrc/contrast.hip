@@ -1,0 +1,470 @@
+// Contrast objective on the Image of Warped Events: 3x3 Gaussian blur (reflect), Sobel (zero pad),
+// gradient-magnitude / variance reductions, and the hand-derived adjoint image.
+//   forward  : reference src/utils/event_image_converter.py:170-175 + src/utils/loss.py:4-27,58-87
+//   backward : SURVEY.md 8a row A11 (closed form of what autograd does in the reference)
+// HBM-bound stencils: every image is read once and written once per kernel, tiles are staged
+// in LDS with their halo, reductions use wavefront shuffles and fp64 block partials.
+#include "common.h"
+
+// torchvision gaussian_blur(kernel_size=3, sigma=1): [a, c, a] = exp(-x^2/2)/sum, fp32
+__device__ __forceinline__ void blur_taps(float &a, float &c) {
+    const float e = 0.60653066f;              // exp(-0.5) in fp32
+    const float s = (e + 1.0f) + e;           // pdf.sum() : e + 1 + e
+    a = e / s;
+    c = 1.0f / s;
+}
+
+__device__ __forceinline__ int reflect1(int i, int n) {
+    // reflect padding of width 1: -1 -> 1, n -> n-2
+    return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: raw -> blurred (+ per-block partial sums)
+// grid (ceil(W/64), ceil(H/32), nimg), 256 threads
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_contrast_fwd(const float *__restrict__ raw,
+                                                      float *__restrict__ blur,
+                                                      double *__restrict__ part, int H, int W,
+                                                      int norm_l2, int variance) {
+    constexpr int TH = MPC_CT_H, TW = MPC_CT_W;
+    __shared__ float s_raw[TH + 4][TW + 4 + 1];
+    __shared__ float s_hb[TH + 4][TW + 2 + 1];
+    __shared__ float s_bl[TH + 2][TW + 2 + 1];
+    __shared__ double s_red[2][4];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t img_off = (size_t)blockIdx.z * H * W;
+    const float *src = raw + img_off;
+    float ka, kc;
+    blur_taps(ka, kc);
+
+    // stage raw tile with a 2-px halo; coordinates -1 and H (W) are the reflect-padding ring
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
+        const int y = ty0 - 2 + ly, x = tx0 - 2 + lx;
+        float v = 0.f;
+        if (y >= -1 && y <= H && x >= -1 && x <= W) v = src[(size_t)reflect1(y, H) * W + reflect1(x, W)];
+        s_raw[ly][lx] = v;
+    }
+    __syncthreads();
+    // horizontal pass: columns tx0-1 .. tx0+TW
+    for (int i = tid; i < (TH + 4) * (TW + 2); i += 256) {
+        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+        s_hb[ly][lx] = ka * s_raw[ly][lx] + kc * s_raw[ly][lx + 1] + ka * s_raw[ly][lx + 2];
+    }
+    __syncthreads();
+    // vertical pass: rows ty0-1 .. ty0+TH ; zero outside the image (Sobel uses zero padding)
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+        const int y = ty0 - 1 + ly, x = tx0 - 1 + lx;
+        float v = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W)
+            v = ka * s_hb[ly][lx] + kc * s_hb[ly + 1][lx] + ka * s_hb[ly + 2][lx];
+        s_bl[ly][lx] = v;
+    }
+    __syncthreads();
+
+    double acc0 = 0.0, acc1 = 0.0;
+    const int cx = tid & 63;
+    for (int ry = tid >> 6; ry < TH; ry += 4) {
+        const int y = ty0 + ry, x = tx0 + cx;
+        if (y < H && x < W) {
+            const int ly = ry + 1, lx = cx + 1;
+            const float b = s_bl[ly][lx];
+            blur[img_off + (size_t)y * W + x] = b;
+            if (variance) {
+                acc0 += (double)b;
+                acc1 += (double)b * (double)b;
+            } else {
+                const float tl = s_bl[ly - 1][lx - 1], tc = s_bl[ly - 1][lx], tr = s_bl[ly - 1][lx + 1];
+                const float ml = s_bl[ly][lx - 1], mr = s_bl[ly][lx + 1];
+                const float bl_ = s_bl[ly + 1][lx - 1], bc = s_bl[ly + 1][lx], br = s_bl[ly + 1][lx + 1];
+                const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
+                const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
+                acc0 += norm_l2 ? (double)(dx * dx + dy * dy) : (double)(fabsf(dx) + fabsf(dy));
+            }
+        }
+    }
+    const double r0 = block_sum_d<256>(acc0, s_red[0]);
+    const double r1 = block_sum_d<256>(acc1, s_red[1]);
+    if (tid == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[2 * bid] = r0;
+        part[2 * bid + 1] = r1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward (gradient magnitude): blurred -> Blur^T Sobel^T u   (unscaled)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float blurT_w(int q, int y, int n, float ka, float kc) {
+    // weight of raw coordinate y in blurred coordinate q (both inside [0,n)), reflect padding
+    const int d = y - q;
+    float w = (d == 0) ? kc : ((d == 1 || d == -1) ? ka : 0.f);
+    if (q == 0 && y == 1) w += ka;
+    if (q == n - 1 && y == n - 2) w += ka;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void k_contrast_bwd_gm(const float *__restrict__ blur,
+                                                         float *__restrict__ gimg, int H, int W,
+                                                         int norm_l2) {
+    constexpr int TH = MPC_CT_H, TW = MPC_CT_W;
+    __shared__ float s_bl[TH + 6][TW + 6 + 1];
+    __shared__ float s_ux[TH + 4][TW + 4 + 1];
+    __shared__ float s_uy[TH + 4][TW + 4 + 1];
+    __shared__ float s_gb[TH + 2][TW + 2 + 1];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t img_off = (size_t)blockIdx.z * H * W;
+    const float *src = blur + img_off;
+    float ka, kc;
+    blur_taps(ka, kc);
+
+    for (int i = tid; i < (TH + 6) * (TW + 6); i += 256) {
+        const int ly = i / (TW + 6), lx = i - ly * (TW + 6);
+        const int y = ty0 - 3 + ly, x = tx0 - 3 + lx;
+        s_bl[ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    // u = d|grad|/d(dx,dy) on rows ty0-2.., zero outside the image
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
+        const int y = ty0 - 2 + ly, x = tx0 - 2 + lx;
+        float ux = 0.f, uy = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const int by = ly + 1, bx = lx + 1;
+            const float tl = s_bl[by - 1][bx - 1], tc = s_bl[by - 1][bx], tr = s_bl[by - 1][bx + 1];
+            const float ml = s_bl[by][bx - 1], mr = s_bl[by][bx + 1];
+            const float bl_ = s_bl[by + 1][bx - 1], bc = s_bl[by + 1][bx], br = s_bl[by + 1][bx + 1];
+            const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
+            const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
+            if (norm_l2) {
+                ux = 2.f * dx;
+                uy = 2.f * dy;
+            } else {
+                ux = (dx > 0.f) ? 1.f : ((dx < 0.f) ? -1.f : 0.f);
+                uy = (dy > 0.f) ? 1.f : ((dy < 0.f) ? -1.f : 0.f);
+            }
+        }
+        s_ux[ly][lx] = ux;
+        s_uy[ly][lx] = uy;
+    }
+    __syncthreads();
+    // gB[p] = sum_d Kx(d) ux[p-d] + Ky(d) uy[p-d]   (adjoint of zero-padded correlation)
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+        const int y = ty0 - 1 + ly, x = tx0 - 1 + lx;
+        float g = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const int uy_ = ly + 1, ux_ = lx + 1;
+            // Kx(dy,dx) = sm(dy)*sx(dx), sx=(-1,0,1), sm=(1,2,1); contribution Kx(d)*ux[p-d]
+            // p-d with dx=+1 is column ux_-1 (weight +1), dx=-1 is column ux_+1 (weight -1)
+            const float gx = (s_ux[uy_ + 1][ux_ - 1] - s_ux[uy_ + 1][ux_ + 1]) +
+                             2.f * (s_ux[uy_][ux_ - 1] - s_ux[uy_][ux_ + 1]) +
+                             (s_ux[uy_ - 1][ux_ - 1] - s_ux[uy_ - 1][ux_ + 1]);
+            const float gy = (s_uy[uy_ - 1][ux_ + 1] - s_uy[uy_ + 1][ux_ + 1]) +
+                             2.f * (s_uy[uy_ - 1][ux_] - s_uy[uy_ + 1][ux_]) +
+                             (s_uy[uy_ - 1][ux_ - 1] - s_uy[uy_ + 1][ux_ - 1]);
+            g = gx + gy;
+        }
+        s_gb[ly][lx] = g;
+    }
+    __syncthreads();
+    const int cx = tid & 63;
+    for (int ry = tid >> 6; ry < TH; ry += 4) {
+        const int y = ty0 + ry, x = tx0 + cx;
+        if (y < H && x < W) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int qy = y + dy;
+                if (qy < 0 || qy >= H) continue;
+                const float wy = blurT_w(qy, y, H, ka, kc);
+                float row = 0.f;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int qx = x + dx;
+                    if (qx < 0 || qx >= W) continue;
+                    row += blurT_w(qx, x, W, ka, kc) * s_gb[ry + 1 + dy][cx + 1 + dx];
+                }
+                acc += wy * row;
+            }
+            gimg[img_off + (size_t)y * W + x] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward (variance objective): blurred -> Blur^T (x - mean_img)   (unscaled)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_image_means(const double *__restrict__ part,
+                                                     float *__restrict__ means, int tiles_per_img,
+                                                     int HW) {
+    __shared__ double s_red[4];
+    const int img = blockIdx.x;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < tiles_per_img; i += 256) a += part[2 * ((size_t)img * tiles_per_img + i)];
+    const double r = block_sum_d<256>(a, s_red);
+    if (threadIdx.x == 0) means[img] = (float)(r / (double)HW);
+}
+
+__global__ __launch_bounds__(256) void k_contrast_bwd_var(const float *__restrict__ blur,
+                                                          const float *__restrict__ means,
+                                                          float *__restrict__ gimg, int H, int W) {
+    constexpr int TH = MPC_CT_H, TW = MPC_CT_W;
+    __shared__ float s_gb[TH + 2][TW + 2 + 1];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t img_off = (size_t)blockIdx.z * H * W;
+    const float mean = means[blockIdx.z];
+    float ka, kc;
+    blur_taps(ka, kc);
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
+        const int y = ty0 - 1 + ly, x = tx0 - 1 + lx;
+        s_gb[ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? blur[img_off + (size_t)y * W + x] - mean : 0.f;
+    }
+    __syncthreads();
+    const int cx = tid & 63;
+    for (int ry = tid >> 6; ry < TH; ry += 4) {
+        const int y = ty0 + ry, x = tx0 + cx;
+        if (y < H && x < W) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int qy = y + dy;
+                if (qy < 0 || qy >= H) continue;
+                const float wy = blurT_w(qy, y, H, ka, kc);
+                float row = 0.f;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int qx = x + dx;
+                    if (qx < 0 || qx >= W) continue;
+                    row += blurT_w(qx, x, W, ka, kc) * s_gb[ry + 1 + dy][cx + 1 + dx];
+                }
+                acc += wy * row;
+            }
+            gimg[img_off + (size_t)y * W + x] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// smoothness of a flow field stored [nimg][hq][wq][C]: forward partial sums + gradient
+// grid (ceil(wq/16), ceil(hq/16), nimg*C), 256 threads  (one channel per block)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ field,
+                                                    float *__restrict__ gfield,
+                                                    double *__restrict__ part, int hq, int wq, int C,
+                                                    float gscale /* smooth_weight/(2*count) */) {
+    constexpr int TS = MPC_ST;
+    __shared__ float s_f[TS + 4][TS + 4 + 1];
+    __shared__ float s_vx[TS + 2][TS + 2 + 1];
+    __shared__ float s_vy[TS + 2][TS + 2 + 1];
+    __shared__ double s_red[2][4];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.z / C, ch = blockIdx.z - img * C;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const size_t base = (size_t)img * hq * wq * C + ch;
+    const float eps2 = 1e-3f * 1e-3f;   // charbonnier epsilon ** 2 (loss.py:46,55)
+
+    for (int i = tid; i < (TS + 4) * (TS + 4); i += 256) {
+        const int ly = i / (TS + 4), lx = i - ly * (TS + 4);
+        const int y = y0 - 2 + ly, x = x0 - 2 + lx;
+        s_f[ly][lx] = (y >= 0 && y < hq && x >= 0 && x < wq) ? field[base + ((size_t)y * wq + x) * C] : 0.f;
+    }
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = tid; i < (TS + 2) * (TS + 2); i += 256) {
+        const int ly = i / (TS + 2), lx = i - ly * (TS + 2);
+        const int y = y0 - 1 + ly, x = x0 - 1 + lx;
+        float vx = 0.f, vy = 0.f;
+        if (y >= 0 && y < hq && x >= 0 && x < wq) {
+            const int by = ly + 1, bx = lx + 1;
+            const float tl = s_f[by - 1][bx - 1], tc = s_f[by - 1][bx], tr = s_f[by - 1][bx + 1];
+            const float ml = s_f[by][bx - 1], mr = s_f[by][bx + 1];
+            const float bl_ = s_f[by + 1][bx - 1], bc = s_f[by + 1][bx], br = s_f[by + 1][bx + 1];
+            const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
+            const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
+            const float sx = sqrtf(dx * dx + eps2), sy = sqrtf(dy * dy + eps2);
+            vx = dx / sx;
+            vy = dy / sy;
+            if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) {   // own cell, not halo
+                a0 += (double)sx;
+                a1 += (double)sy;
+            }
+        }
+        s_vx[ly][lx] = vx;
+        s_vy[ly][lx] = vy;
+    }
+    __syncthreads();
+    if (gfield != nullptr) {
+        const int lx = tid & 15, ly = tid >> 4;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y < hq && x < wq) {
+            const int uy_ = ly + 1, ux_ = lx + 1;
+            const float gx = (s_vx[uy_ + 1][ux_ - 1] - s_vx[uy_ + 1][ux_ + 1]) +
+                             2.f * (s_vx[uy_][ux_ - 1] - s_vx[uy_][ux_ + 1]) +
+                             (s_vx[uy_ - 1][ux_ - 1] - s_vx[uy_ - 1][ux_ + 1]);
+            const float gy = (s_vy[uy_ - 1][ux_ + 1] - s_vy[uy_ + 1][ux_ + 1]) +
+                             2.f * (s_vy[uy_ - 1][ux_] - s_vy[uy_ + 1][ux_]) +
+                             (s_vy[uy_ - 1][ux_ - 1] - s_vy[uy_ + 1][ux_ - 1]);
+            gfield[base + ((size_t)y * wq + x) * C] = gscale * (gx + gy);
+        }
+    }
+    const double r0 = block_sum_d<256>(a0, s_red[0]);
+    const double r1 = block_sum_d<256>(a1, s_red[1]);
+    if (tid == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[2 * bid] = r0;
+        part[2 * bid + 1] = r1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: fp64 reduction of the partials -> device scalars
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const double *__restrict__ cpart, int n_cblocks,
+                                                  int tiles_per_img, int nimg, int HW,
+                                                  const double *__restrict__ spart, int n_sblocks,
+                                                  double smooth_count, float smooth_weight,
+                                                  int variance, float *__restrict__ scal) {
+    __shared__ double s_red[2][4];
+    __shared__ double s_var;
+    const int tid = threadIdx.x;
+    double val = 0.0, gcoef = 0.0;
+    if (!variance) {
+        double a = 0.0;
+        for (int i = tid; i < n_cblocks; i += 256) a += cpart[2 * (size_t)i];
+        const double tot = block_sum_d<256>(a, s_red[0]);
+        const double N = (double)nimg * (double)HW;
+        val = tot / N;
+        gcoef = -1.0 / (val * val) / N;
+    } else {
+        // mean over images of the unbiased variance over H*W (loss.py:14-16)
+        if (tid == 0) s_var = 0.0;
+        __syncthreads();
+        for (int img = 0; img < nimg; ++img) {
+            double a = 0.0, b = 0.0;
+            for (int i = tid; i < tiles_per_img; i += 256) {
+                a += cpart[2 * ((size_t)img * tiles_per_img + i)];
+                b += cpart[2 * ((size_t)img * tiles_per_img + i) + 1];
+            }
+            const double s1 = block_sum_d<256>(a, s_red[0]);
+            const double s2 = block_sum_d<256>(b, s_red[1]);
+            if (tid == 0) s_var += (s2 - s1 * s1 / (double)HW) / (double)(HW - 1);
+        }
+        __syncthreads();
+        val = s_var / (double)nimg;
+        gcoef = -1.0 / (val * val) * 2.0 / ((double)(HW - 1) * (double)nimg);
+    }
+    double smooth = 0.0;
+    if (n_sblocks > 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = tid; i < n_sblocks; i += 256) {
+            a += spart[2 * (size_t)i];
+            b += spart[2 * (size_t)i + 1];
+        }
+        const double sx = block_sum_d<256>(a, s_red[0]);
+        const double sy = block_sum_d<256>(b, s_red[1]);
+        smooth = (double)smooth_weight * ((sx / smooth_count + sy / smooth_count) / 2.0);
+    }
+    if (tid == 0) {
+        const double focus = 1.0 / val;
+        scal[MPC_SCAL_LOSS] = (float)(focus + smooth);
+        scal[MPC_SCAL_FOCUS] = (float)focus;
+        scal[MPC_SCAL_SMOOTH] = (float)smooth;
+        scal[MPC_SCAL_VAL] = (float)val;
+        scal[MPC_SCAL_GCOEF] = (float)gcoef;
+        scal[5] = scal[6] = scal[7] = 0.f;
+    }
+}
+
+__global__ void k_scale(const float *__restrict__ x, const float *__restrict__ a,
+                        float *__restrict__ y, int64_t n) {
+    const float s = a[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = s * x[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------
+extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float *iwe_blur,
+                                float *grad_iwe, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && iwe_raw && iwe_blur && ws, MPC_E_NULL, "null argument");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const mpc_ws_layout L = mpc_layout(s);
+    hipStream_t st = (hipStream_t)stream;
+    double *cpart = (double *)((char *)ws + L.off_cpart);
+    const dim3 grid(mpc_cdiv(s->W, MPC_CT_W), mpc_cdiv(s->H, MPC_CT_H), L.nimg);
+    const int variance = (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0;
+    const int l2 = (s->flags & MPC_F_NORM_L2) ? 1 : 0;
+    hipLaunchKernelGGL(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
+    MPC_CHECK_LAUNCH();
+    if (grad_iwe) {
+        if (!variance) {
+            hipLaunchKernelGGL(k_contrast_bwd_gm, grid, dim3(256), 0, st, iwe_blur, grad_iwe, s->H, s->W, l2);
+        } else {
+            float *means = (float *)((char *)ws + L.off_counts) + 8;   // nimg floats after the counters
+            hipLaunchKernelGGL(k_image_means, dim3(L.nimg), dim3(256), 0, st, cpart, means,
+                               (int)(grid.x * grid.y), s->H * s->W);
+            hipLaunchKernelGGL(k_contrast_bwd_var, grid, dim3(256), 0, st, iwe_blur, means, grad_iwe, s->H, s->W);
+        }
+        MPC_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t nimg, int32_t C,
+                              float smooth_weight, float *grad_field, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && field && ws, MPC_E_NULL, "null argument");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const mpc_ws_layout L = mpc_layout(s);
+    const dim3 grid(mpc_cdiv(s->wq, MPC_ST), mpc_cdiv(s->hq, MPC_ST), nimg * C);
+    const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
+    MPC_CHECK_ARG(nimg > 0 && C > 0 && nblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
+    hipStream_t st = (hipStream_t)stream;
+    double *spart = (double *)((char *)ws + L.off_spart);
+    const double count = (double)nimg * C * s->hq * s->wq;
+    const float gscale = (float)((double)smooth_weight / (2.0 * count));
+    hipLaunchKernelGGL(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C,
+                            float smooth_weight, float *scal, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && scal && ws, MPC_E_NULL, "null argument");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const mpc_ws_layout L = mpc_layout(s);
+    const int tiles = mpc_cdiv(s->W, MPC_CT_W) * mpc_cdiv(s->H, MPC_CT_H);
+    int64_t nsblk = 0;
+    double count = 1.0;
+    if (smooth_nimg > 0) {
+        nsblk = (int64_t)mpc_cdiv(s->wq, MPC_ST) * mpc_cdiv(s->hq, MPC_ST) * smooth_nimg * smooth_C;
+        MPC_CHECK_ARG(nsblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
+        count = (double)smooth_nimg * smooth_C * s->hq * s->wq;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       (const double *)((char *)ws + L.off_cpart), L.n_cblocks, tiles, L.nimg,
+                       s->H * s->W, (const double *)((char *)ws + L.off_spart), (int)nsblk, count,
+                       smooth_weight, (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0, scal);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *stream) {
+    MPC_CHECK_ARG(x && a && y, MPC_E_NULL, "null argument");
+    if (count <= 0) return 0;
+    const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, y, count);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,122 @@
+"""FocusLoss behind the reference's loss plugin API, computed by the HIP kernels of libmpcmax.
+
+Same constructor keys, attributes and `calc` contract as reference src/losses/focus.py:9-113, so
+`TrajectoryNet.step` (src/modules/trajectory_net.py:142-161) and the image-logging callback
+(src/utils/logging.py:53-120) can use it unchanged."""
+import torch
+
+from . import base
+from .. import ops
+from ..utils.event_image_converter import EventImageConverter
+
+
+class FocusLoss(base.TrajectoryLossBase):
+    """
+    Args (reference focus.py:13-27):
+        image_shape (tuple): (height, width).
+        num_tref (int): number of reference times; 1 = one random reference time.
+        num_bins (int): number of time bins of the flow look-up table.
+        num_knn (int): nearest trajectories averaged per look-up-table cell.
+        smooth_weight (float): weight of the smoothness term.
+        lut_superpixel_size (int): pixel size of one look-up-table cell.
+        focus_loss_norm (str): 'l1' or 'l2' gradient-magnitude norm.
+        dist_norm (str): 'l1' or 'l2' neighbour distance.
+        scale_iwe_by_dt, mask_image_border, polarity_aware_batching (bool)
+        interpolation_scheme (str): 'mean' or 'iwd'.
+        smooth_type (str): 'on_flow_to_tref' or 'on_flow_to_next'.
+        loss_type (str, build-side extension): 'gradient_magnitude' (what the reference hard-codes,
+            focus.py:90-91) or 'variance' (reference src/utils/loss.py:14-16).
+    """
+
+    def __init__(self, image_shape, num_tref, num_bins, num_knn, smooth_weight,
+                 lut_superpixel_size, focus_loss_norm, dist_norm,
+                 scale_iwe_by_dt, mask_image_border, polarity_aware_batching,
+                 interpolation_scheme, smooth_type, loss_type='gradient_magnitude', profiler=None,
+                 **kwargs):
+        super().__init__()
+        self.image_shape = image_shape
+        self.num_tref = num_tref
+        self.num_bins = num_bins
+        self.num_knn = num_knn
+        self.smooth_weight = smooth_weight
+        self.lut_superpixel_size = lut_superpixel_size
+        self.focus_loss_norm = focus_loss_norm
+        self.dist_norm = dist_norm
+        self.scale_iwe_by_dt = scale_iwe_by_dt
+        self.mask_image_border = mask_image_border
+        self.polarity_aware_batching = polarity_aware_batching
+        self.interpolation_scheme = interpolation_scheme
+        self.smooth_type = smooth_type
+        self.loss_type = loss_type
+        self.profiler = profiler
+        self.is_needing_offsets = True
+        self.imager = EventImageConverter(self.image_shape)
+
+        assert not scale_iwe_by_dt or num_tref == 1
+        assert not polarity_aware_batching or num_tref == 1
+        assert not smooth_type == 'on_flow_to_next' or num_tref == 1
+        if focus_loss_norm not in ('l1', 'l2') or dist_norm not in ('l1', 'l2'):
+            raise ValueError
+        if loss_type not in ('gradient_magnitude', 'variance'):
+            raise ValueError
+        if num_knn > 1 and interpolation_scheme not in ('mean', 'iwd'):
+            raise ValueError
+        if smooth_weight != 0 and smooth_type not in ('on_flow_to_tref', 'on_flow_to_next'):
+            raise ValueError
+
+        self._cfg = ops.PathConfig(
+            image_shape=(int(image_shape[0]), int(image_shape[1])), num_tref=int(num_tref),
+            num_bins=int(num_bins), num_knn=int(num_knn), smooth_weight=float(smooth_weight),
+            sp=int(lut_superpixel_size), norm_l2=(focus_loss_norm == 'l2'), dist_l1=(dist_norm == 'l1'),
+            scale_by_dt=bool(scale_iwe_by_dt), mask_border=bool(mask_image_border),
+            polarity_split=bool(polarity_aware_batching),
+            scheme_iwd=(interpolation_scheme == 'iwd'), smooth_on_next=(smooth_type == 'on_flow_to_next'),
+            variance=(loss_type == 'variance'), atomic_path=bool(kwargs.get('debug_atomic_path', False)))
+
+    def get_reconstruction_times(self, device):
+        """Reference focus.py:53-64: [t_ref..., bin mid-times]."""
+        if self.num_tref > 1:
+            t_ref = torch.linspace(0, 1, self.num_tref, device=device)
+        elif self.num_tref == 1:
+            t_ref = torch.rand(1, device=device)  # random reference time
+        else:
+            raise ValueError("Invalid value for num_tref. Must be >= 1.")
+
+        t_bins = torch.linspace(0, 1, self.num_bins + 1, device=device)
+        t_mid = (t_bins[:-1] + t_bins[1:]) / 2
+        return torch.concat((t_ref, t_mid), dim=0)
+
+    def calc(self, trajectories, times, batch):
+        """Reference focus.py:66-113.
+
+        trajectories [B, num_tref + num_bins, n, 2] (y, x), times [num_tref + num_bins],
+        batch['events'] [B, M, 6], batch['num_pos_events'] (int, with polarity_aware_batching).
+        Returns (loss with grad, {'focus_loss', 'smoothness_loss'} detached,
+                 {'iwes': [B, T, 2, H, W] or [B, T, H, W]} detached)."""
+        events = batch['events']
+        num_pos_events = batch['num_pos_events'] if 'num_pos_events' in batch else -1
+        assert not self.polarity_aware_batching or num_pos_events > -1
+
+        t_ref = times[:self.num_tref]
+        if self.profiler is not None:
+            with torch.profiler.record_function('mpcmax::FocusLoss.calc'):
+                out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events))
+        else:
+            out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events))
+        loss, focus_loss, smooth_loss, iwes = out
+
+        h, w = self._cfg.image_shape
+        b = events.shape[0]
+        if self.polarity_aware_batching:
+            iwes = iwes.reshape(b, self.num_tref, 2, h, w)
+        else:
+            iwes = iwes.reshape(b, self.num_tref, h, w)
+
+        log_metadata = {
+            'focus_loss': focus_loss.detach(),
+            'smoothness_loss': smooth_loss.detach(),
+        }
+        misc_metadata = {
+            'iwes': iwes.detach()
+        }
+        return loss, log_metadata, misc_metadata

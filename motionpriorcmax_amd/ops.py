@@ -1,0 +1,351 @@
+"""torch-facing wrappers of the HIP kernels behind include/mpcmax.h.
+
+PyTorch is used only for device memory, the current HIP stream and autograd plumbing; every
+numerical step of the path runs in libmpcmax.so.  Tensors must live on a GPU: there is no CPU
+or eager fallback (a CPU tensor raises)."""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib as C
+
+
+@dataclass(frozen=True)
+class PathConfig:
+    """Static configuration of one FocusLoss instance (reference focus.py:28-45)."""
+    image_shape: tuple
+    num_tref: int
+    num_bins: int
+    num_knn: int
+    smooth_weight: float
+    sp: int
+    norm_l2: bool
+    dist_l1: bool
+    scale_by_dt: bool
+    mask_border: bool
+    polarity_split: bool
+    scheme_iwd: bool
+    smooth_on_next: bool
+    variance: bool = False
+    atomic_path: bool = False
+
+    def flags(self):
+        f = 0
+        f |= C.F_SCALE_BY_DT if self.scale_by_dt else 0
+        f |= C.F_MASK_BORDER if self.mask_border else 0
+        f |= C.F_POLARITY_SPLIT if self.polarity_split else 0
+        f |= C.F_NORM_L2 if self.norm_l2 else 0
+        f |= C.F_OBJ_VARIANCE if self.variance else 0
+        f |= C.F_DIST_L1 if self.dist_l1 else 0
+        f |= C.F_SCHEME_IWD if self.scheme_iwd else 0
+        f |= C.F_WANT_NEXT if (self.smooth_on_next and self.smooth_weight > 0) else 0
+        f |= C.F_ATOMIC_PATH if self.atomic_path else 0
+        return f
+
+    @property
+    def lut_grid(self):
+        h, w = self.image_shape
+        return (h + self.sp - 1) // self.sp, (w + self.sp - 1) // self.sp
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a GPU tensor: the CMax path runs in libmpcmax.so (HIP, '
+                           f'gfx950) and has no CPU fallback (got device {t.device})')
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_shape(cfg: PathConfig, B, M, Mp, n, extra_flags=0, K=None):
+    hq, wq = cfg.lut_grid
+    return C.Shape(B=B, M=M, Mp=Mp, nb=cfg.num_bins, T=cfg.num_tref, H=cfg.image_shape[0],
+                   W=cfg.image_shape[1], sp=cfg.sp, hq=hq, wq=wq, n=n,
+                   K=cfg.num_knn if K is None else K, flags=cfg.flags() | extra_flags)
+
+
+def alloc_workspace(shape: C.Shape, device) -> torch.Tensor:
+    nbytes = C.lib().mpc_workspace_bytes(ctypes.byref(shape))
+    if nbytes < 0:
+        C.check(int(nbytes), 'mpc_workspace_bytes')
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+# stage wrappers (no autograd)
+# ------------------------------------------------------------------------------------------
+def knn_lut_fwd(cfg, shape, traj, ws, want_idx=False):
+    dev = traj.device
+    B, nb, T, K = shape.B, shape.nb, shape.T, shape.K
+    hq, wq = shape.hq, shape.wq
+    Q = hq * wq
+    flow_lut = torch.empty((B, nb, hq, wq, T, 2), dtype=torch.float32, device=dev)
+    flow_next = None
+    if shape.flags & C.F_WANT_NEXT:
+        flow_next = torch.empty((B, max(nb - 1, 0), hq, wq, 1, 2), dtype=torch.float32, device=dev)
+    state = torch.empty(3 * B * nb * Q + B * nb, dtype=torch.float32, device=dev)
+    idx = torch.empty((B, nb, Q, K), dtype=torch.int32, device=dev) if want_idx else None
+    C.check(C.lib().mpc_knn_lut_fwd(ctypes.byref(shape), _ptr(traj), _ptr(flow_lut), _ptr(flow_next),
+                                    _ptr(state), _ptr(idx), _ptr(ws), _stream(dev)), 'mpc_knn_lut_fwd')
+    return flow_lut, flow_next, state, idx
+
+
+def knn_lut_bwd(shape, traj, g_lut, g_next, state, ws):
+    g_traj = torch.empty_like(traj)
+    C.check(C.lib().mpc_knn_lut_bwd(ctypes.byref(shape), _ptr(traj), _ptr(g_lut), _ptr(g_next),
+                                    _ptr(state), _ptr(g_traj), _ptr(ws), _stream(traj.device)),
+            'mpc_knn_lut_bwd')
+    return g_traj
+
+
+def event_splat_fwd(shape, events, flow_lut, t_ref, ws):
+    dev = events.device
+    P = 2 if shape.flags & C.F_POLARITY_SPLIT else 1
+    raw = torch.empty((shape.B * shape.T, P, shape.H, shape.W), dtype=torch.float32, device=dev)
+    C.check(C.lib().mpc_event_splat_fwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
+                                        _ptr(raw), _ptr(ws), _stream(dev)), 'mpc_event_splat_fwd')
+    return raw
+
+
+def contrast_fwd(shape, raw, ws, want_grad):
+    blur = torch.empty_like(raw)
+    gimg = torch.empty_like(raw) if want_grad else None
+    C.check(C.lib().mpc_contrast_fwd(ctypes.byref(shape), _ptr(raw), _ptr(blur), _ptr(gimg), _ptr(ws),
+                                     _stream(raw.device)), 'mpc_contrast_fwd')
+    return blur, gimg
+
+
+def lut_smooth(shape, field, nimg, Cch, weight, ws, want_grad):
+    g = torch.empty_like(field) if want_grad else None
+    C.check(C.lib().mpc_lut_smooth(ctypes.byref(shape), _ptr(field), nimg, Cch, float(weight), _ptr(g),
+                                   _ptr(ws), _stream(field.device)), 'mpc_lut_smooth')
+    return g
+
+
+def finalize(shape, smooth_nimg, smooth_C, weight, ws, device):
+    scal = torch.empty(C.SCAL_COUNT, dtype=torch.float32, device=device)
+    C.check(C.lib().mpc_finalize(ctypes.byref(shape), smooth_nimg, smooth_C, float(weight), _ptr(scal),
+                                 _ptr(ws), _stream(device)), 'mpc_finalize')
+    return scal
+
+
+def event_splat_bwd(shape, events, flow_lut, t_ref, gimg, scal, grad_out, g_lut, accumulate, ws):
+    C.check(C.lib().mpc_event_splat_bwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
+                                        _ptr(gimg), _ptr(scal), _ptr(grad_out), _ptr(g_lut),
+                                        1 if accumulate else 0, _ptr(ws), _stream(events.device)),
+            'mpc_event_splat_bwd')
+    return g_lut
+
+
+def scale(x, a):
+    y = torch.empty_like(x)
+    C.check(C.lib().mpc_scale(_ptr(x), _ptr(a), _ptr(y), x.numel(), _stream(x.device)), 'mpc_scale')
+    return y
+
+
+def _check_events(events, cfg, num_pos):
+    _require_gpu(events, "batch['events']")
+    if events.dim() != 3 or events.shape[-1] != 6:
+        raise ValueError(f"events must be [B, M, 6], got {tuple(events.shape)}")
+    B, M, _ = events.shape
+    if cfg.polarity_split:
+        if not (0 <= num_pos <= M):
+            raise ValueError(f'num_pos_events={num_pos} outside [0, {M}]')
+        Mp = int(num_pos)
+    else:
+        Mp = M
+    return B, M, Mp
+
+
+# ------------------------------------------------------------------------------------------
+# autograd: the whole loss  trajectories -> (loss, focus, smooth, iwes)
+# ------------------------------------------------------------------------------------------
+class FocusCalcFn(torch.autograd.Function):
+    """FocusLoss.calc (reference focus.py:66-113) as one differentiable op: KNN LUT -> smoothness
+    -> warp + vote -> blur + objective in forward, hand-derived backward to `trajectories`."""
+
+    @staticmethod
+    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int):
+        _require_gpu(trajectories, 'trajectories')
+        B, M, Mp = _check_events(events, cfg, num_pos)
+        T, nb = cfg.num_tref, cfg.num_bins
+        if trajectories.dim() != 4 or trajectories.shape[0] != B or trajectories.shape[1] != T + nb \
+                or trajectories.shape[3] != 2:
+            raise ValueError(f'trajectories must be [B={B}, {T + nb}, n, 2], got {tuple(trajectories.shape)}')
+        dev = trajectories.device
+        traj = _f32c(trajectories.detach())
+        ev = _f32c(events.detach())
+        tr = _f32c(t_ref.detach().to(dev))
+        n = traj.shape[2]
+        shape = make_shape(cfg, B, M, Mp, n)
+        ws = alloc_workspace(shape, dev)
+        need_grad = trajectories.requires_grad
+
+        flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
+        g_field = None
+        s_nimg = s_C = 0
+        if cfg.smooth_weight > 0:
+            if cfg.smooth_on_next:
+                field, s_nimg, s_C = flow_next, B * (nb - 1), 2
+            else:
+                field, s_nimg, s_C = flow_lut, B * nb, 2 * T
+            if s_nimg > 0:
+                g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
+        raw = event_splat_fwd(shape, ev, flow_lut, tr, ws)
+        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+        scal = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
+
+        ctx.cfg, ctx.shape = cfg, shape
+        ctx.ws = ws
+        ctx.save_for_backward(traj, ev, tr, flow_lut, state, gimg, scal, g_field)
+        loss = scal[C.SCAL_LOSS].clone()
+        focus = scal[C.SCAL_FOCUS].clone()
+        smooth = scal[C.SCAL_SMOOTH].clone()
+        ctx.mark_non_differentiable(focus, smooth, blur)
+        return loss, focus, smooth, blur
+
+    @staticmethod
+    def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
+        cfg, shape, ws = ctx.cfg, ctx.shape, ctx.ws
+        traj, ev, tr, flow_lut, state, gimg, scal, g_field = ctx.saved_tensors
+        g = _f32c(g_loss.reshape(1))
+        g_next = None
+        if g_field is not None and not cfg.smooth_on_next:
+            g_lut = scale(g_field, g)
+            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, True, ws)
+        else:
+            g_lut = torch.empty_like(flow_lut)
+            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, False, ws)
+            if g_field is not None:
+                g_next = scale(g_field, g)
+        g_traj = knn_lut_bwd(shape, traj, g_lut, g_next, state, ws)
+        return g_traj, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# autograd: stage-level ops (used by tests, the bench's event-path figure and other callers)
+# ------------------------------------------------------------------------------------------
+class EventFocusFn(torch.autograd.Function):
+    """A6-A9 with the LUT given: flow_lut -> (focus_loss, iwes_blurred, iwes_raw)."""
+
+    @staticmethod
+    def forward(ctx, flow_lut, events, t_ref, cfg: PathConfig, num_pos: int):
+        _require_gpu(flow_lut, 'flow_lut')
+        B, M, Mp = _check_events(events, cfg, num_pos)
+        dev = flow_lut.device
+        lut = _f32c(flow_lut.detach())
+        ev = _f32c(events.detach())
+        tr = _f32c(t_ref.detach().to(dev))
+        shape = make_shape(cfg, B, M, Mp, 0, K=0)
+        ws = alloc_workspace(shape, dev)
+        need_grad = flow_lut.requires_grad
+        raw = event_splat_fwd(shape, ev, lut, tr, ws)
+        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+        scal = finalize(shape, 0, 0, 0.0, ws, dev)
+        ctx.shape, ctx.ws = shape, ws
+        ctx.save_for_backward(ev, tr, lut, gimg, scal)
+        focus = scal[C.SCAL_FOCUS].clone()
+        ctx.mark_non_differentiable(blur, raw)
+        return focus, blur, raw
+
+    @staticmethod
+    def backward(ctx, g_focus, g_blur, g_raw):
+        ev, tr, lut, gimg, scal = ctx.saved_tensors
+        g = _f32c(g_focus.reshape(1))
+        g_lut = torch.empty_like(lut)
+        event_splat_bwd(ctx.shape, ev, lut, tr, gimg, scal, g, g_lut, False, ctx.ws)
+        return g_lut, None, None, None, None
+
+
+class KnnLutFn(torch.autograd.Function):
+    """A5: trajectories -> (flow_lut, flow_next or empty)."""
+
+    @staticmethod
+    def forward(ctx, trajectories, cfg: PathConfig):
+        _require_gpu(trajectories, 'trajectories')
+        traj = _f32c(trajectories.detach())
+        B, _, n, _ = traj.shape
+        shape = make_shape(cfg, B, 0, 0, n)
+        ws = alloc_workspace(shape, traj.device)
+        flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
+        ctx.shape, ctx.ws = shape, ws
+        ctx.has_next = flow_next is not None
+        ctx.save_for_backward(traj, state)
+        if flow_next is None:
+            flow_next = traj.new_zeros(0)
+        return flow_lut, flow_next
+
+    @staticmethod
+    def backward(ctx, g_lut, g_next):
+        traj, state = ctx.saved_tensors
+        g_lut = _f32c(g_lut)
+        g_next = _f32c(g_next) if ctx.has_next else None
+        return knn_lut_bwd(ctx.shape, traj, g_lut, g_next, state, ctx.ws), None
+
+
+class LutSmoothFn(torch.autograd.Function):
+    """A10: field [nimg, hq, wq, C] -> smooth_weight * smoothness."""
+
+    @staticmethod
+    def forward(ctx, field, cfg: PathConfig, weight: float):
+        _require_gpu(field, 'field')
+        f = _f32c(field.detach())
+        nimg, hq, wq, Cch = f.shape
+        if (hq, wq) != cfg.lut_grid:
+            raise ValueError(f'field grid {(hq, wq)} does not match the LUT grid {cfg.lut_grid}')
+        B = max(1, -(-nimg * Cch // (cfg.num_bins * cfg.num_tref * 2)))
+        shape = make_shape(cfg, B, 0, 0, 0, K=0)
+        ws = alloc_workspace(shape, f.device)
+        g = lut_smooth(shape, f, nimg, Cch, weight, ws, field.requires_grad)
+        # only the smoothness scalar of finalize is meaningful here (no contrast pass was run)
+        scal = finalize(shape, nimg, Cch, weight, ws, f.device)
+        ctx.save_for_backward(g)
+        return scal[C.SCAL_SMOOTH].clone()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (g,) = ctx.saved_tensors
+        return scale(g, _f32c(g_out.reshape(1))), None, None
+
+
+def knn_indices(cfg: PathConfig, trajectories):
+    """Debug/test helper: the K neighbour indices [B, nb, Q, K] (ascending distance, index)."""
+    _require_gpu(trajectories, 'trajectories')
+    traj = _f32c(trajectories.detach())
+    B, _, n, _ = traj.shape
+    shape = make_shape(cfg, B, 0, 0, n)
+    ws = alloc_workspace(shape, traj.device)
+    _, _, _, idx = knn_lut_fwd(cfg, shape, traj, ws, want_idx=True)
+    return idx
+
+
+def splat_events(image_shape, pos_weight_rows, unit_weight, blur):
+    """imager path (reference event_image_converter.py:45-74,134-176 'bilinear_vote'):
+    rows [nimg, m, 6] with (y, x, -, -, -, weight) -> [nimg, H, W], optionally blurred."""
+    _require_gpu(pos_weight_rows, 'events')
+    rows = _f32c(pos_weight_rows)
+    nimg, m, _ = rows.shape
+    cfg = PathConfig(image_shape=tuple(image_shape), num_tref=1, num_bins=1, num_knn=0, smooth_weight=0.0,
+                     sp=max(image_shape), norm_l2=False, dist_l1=False, scale_by_dt=False, mask_border=False,
+                     polarity_split=False, scheme_iwd=False, smooth_on_next=False)
+    extra = C.F_NO_WARP | (C.F_UNIT_WEIGHT if unit_weight else 0)
+    shape = make_shape(cfg, nimg, m, m, 0, extra_flags=extra, K=0)
+    ws = alloc_workspace(shape, rows.device)
+    raw = event_splat_fwd(shape, rows, None, None, ws)
+    if blur:
+        raw, _ = contrast_fwd(shape, raw, ws, False)
+    return raw[:, 0]

@@ -1,0 +1,118 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/mpcmax.h declares, shape
+validation, and the host-side mirror of the reference's loss plugin API."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'mpcmax.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(mpc_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from motionpriorcmax_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _header_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), f'{n} declared in include/mpcmax.h but not exported'
+    assert sorted(_lib.EXPORTS) == names
+
+
+def _shape(**kw):
+    from motionpriorcmax_amd import _lib
+    d = dict(B=2, M=1000, Mp=500, nb=5, T=1, H=48, W=64, sp=4, hq=12, wq=16, n=192, K=4, flags=0)
+    d.update(kw)
+    return _lib.Shape(**d)
+
+
+def test_workspace_bytes_and_validation_are_host_only():
+    from motionpriorcmax_amd import _lib
+    L = _lib.lib()
+    s = _shape()
+    n1 = L.mpc_workspace_bytes(ctypes.byref(s))
+    assert n1 > 0
+    n2 = L.mpc_workspace_bytes(ctypes.byref(_shape(B=4)))
+    assert n2 > n1
+    bad = _shape(hq=13)
+    assert L.mpc_workspace_bytes(ctypes.byref(bad)) == -2
+    assert b'hq/wq' in L.mpc_last_error_string()
+    assert L.mpc_workspace_bytes(ctypes.byref(_shape(T=2, flags=_lib.F_SCALE_BY_DT))) == -2
+    assert L.mpc_workspace_bytes(ctypes.byref(_shape(H=2))) == -2
+
+
+def test_null_arguments_are_rejected_without_touching_the_gpu():
+    from motionpriorcmax_amd import _lib
+    L = _lib.lib()
+    s = _shape()
+    assert L.mpc_event_splat_fwd(ctypes.byref(s), None, None, None, None, None, None) == -1
+    assert L.mpc_knn_lut_fwd(ctypes.byref(s), None, None, None, None, None, None, None) == -1
+    assert L.mpc_contrast_fwd(ctypes.byref(s), None, None, None, None, None) == -1
+
+
+CFG = dict(image_shape=(48, 64), num_tref=1, num_bins=5, num_knn=4, smooth_weight=0.003,
+           lut_superpixel_size=4, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True,
+           mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+           smooth_type='on_flow_to_tref')
+
+
+def test_factory_and_attributes():
+    from motionpriorcmax_amd import LossFactory, TrajectoryLossBase
+    L = LossFactory.get_loss_calculator('FOCUS', dict(CFG, some_unknown_key=1), profiler=None)
+    assert isinstance(L, TrajectoryLossBase)
+    assert L.is_needing_offsets is True
+    assert hasattr(L.imager, 'create_iwe')
+    with pytest.raises(ValueError, match='Unsupported loss type'):
+        LossFactory.get_loss_calculator('NOPE', CFG)
+    with pytest.raises(AssertionError):
+        LossFactory.get_loss_calculator('FOCUS', dict(CFG, num_tref=2))
+    t = L.get_reconstruction_times('cpu')
+    assert t.shape == (6,) and 0 <= t[0] < 1
+    np.testing.assert_allclose(t[1:].numpy(), [0.1, 0.3, 0.5, 0.7, 0.9], atol=1e-6)
+    L3 = LossFactory.get_loss_calculator('FOCUS', dict(CFG, num_tref=3, scale_iwe_by_dt=False,
+                                                       polarity_aware_batching=False))
+    np.testing.assert_allclose(L3.get_reconstruction_times('cpu')[:3].numpy(), [0, 0.5, 1])
+
+
+def test_cpu_tensors_fail_loudly():
+    from motionpriorcmax_amd import LossFactory
+    g = load_golden('g3_squeeze_k1')
+    L = LossFactory.get_loss_calculator('FOCUS', g['cfg'])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        L.calc(torch.from_numpy(g['trajectories']), torch.from_numpy(g['times']),
+               {'events': torch.from_numpy(g['events'])})
+    with pytest.raises(AssertionError):
+        Lp = LossFactory.get_loss_calculator('FOCUS', CFG)
+        Lp.calc(torch.zeros(1, 6, 192, 2), torch.zeros(6), {'events': torch.zeros(1, 10, 6)})
+
+
+@pytest.mark.parametrize('name', ['g1_allflags', 'g5a_dct3_l2', 'g5b_poly3'])
+def test_host_trajectory_helpers_match_reference(name):
+    """The caller-side trajectory construction (TrajectoryNet.calculate_trajectories_at_t,
+    trajectory_net.py:101-119) built from this package's utils."""
+    from motionpriorcmax_amd import utils
+    g = load_golden(name)
+    cg = torch.from_numpy(g['coeff_grid'])
+    times = torch.from_numpy(g['times'])
+    k, bt = int(g['num_basis']), str(g['basis_type'])
+    mask = utils.get_optical_flow_tile_mask(g['cfg']['image_shape'], int(g['patch']))
+    coeffs, pos, _ = utils.coeffs_grid_to_list(cg, mask, num_coeffs=k)
+    traj = utils.compute_basis(coeffs, times, k, bt) - utils.compute_basis(coeffs, torch.zeros(1), k, bt)
+    traj = (traj + pos[None, :, None, :]).permute(0, 2, 1, 3)
+    np.testing.assert_allclose(traj.numpy(), g['trajectories'], atol=1e-5)
+
+
+def test_bernstein_basis_matches_reference():
+    from motionpriorcmax_amd import utils
+    g = load_golden('g6_bezier10')
+    bm = utils.bernstein_basis(g['timestamps'], 10)
+    p = torch.from_numpy(g['params']).view(2, 2, 10, 6, 8)
+    np.testing.assert_allclose(torch.einsum('bdphw,tp->tbdhw', p, bm).numpy(), g['flows'], atol=1e-5)
