@@ -246,29 +246,30 @@ def test_full_size_mass_conservation_and_shift():
     np.testing.assert_allclose(r3[..., 8:, 12:].cpu().numpy(), r2[..., :-8, :-12].cpu().numpy(), atol=1e-4)
 
 
-def test_full_size_gradient_is_directional_derivative():
-    """<dL/dLUT, d> matches a central finite difference of the loss along a random smooth
-    direction d (size-independent check of the hand-derived backward at 480x640 / 200k events)."""
+@pytest.mark.parametrize('norm', ['l1', 'l2'])
+def test_full_size_event_path_vs_oracle(norm):
+    """480x640, 200k events: the CPU oracle's event path (LUT given) finishes in seconds, so the
+    HIP forward and the hand-derived backward are compared with it directly at BASELINE size."""
     from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
     dev = _dev()
     ev, num_pos, lut = _full_size_inputs(B=1)
-    L = _loss_obj(dict(image_shape=(480, 640), num_tref=1, num_bins=15, num_knn=32, smooth_weight=0.0,
-                       lut_superpixel_size=4, focus_loss_norm='l2', dist_norm='l2', scale_iwe_by_dt=True,
-                       mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
-                       smooth_type='on_flow_to_tref'))
-    t_ref = torch.tensor([0.41], device=dev)
-    evd = ev.to(dev)
+    cfg = dict(image_shape=(480, 640), num_tref=1, num_bins=15, num_knn=32, smooth_weight=0.0,
+               lut_superpixel_size=4, focus_loss_norm=norm, dist_norm='l2', scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    lo = lut.clone().requires_grad_(True)
+    fo, iwo, rawo = O.FocusLossOracle(**cfg).event_path(ev, lo, torch.tensor([0.41]), num_pos)
+    fo.backward()
+    L = _loss_obj(cfg)
     lt = lut.to(dev).requires_grad_(True)
-    f, _, _ = ops.EventFocusFn.apply(lt, evd, t_ref, L._cfg, num_pos)
+    f, blur, raw = ops.EventFocusFn.apply(lt, ev.to(dev), torch.tensor([0.41], device=dev), L._cfg, num_pos)
     f.backward()
-    g = torch.Generator().manual_seed(9)
-    d = torch.randn(lut.shape, generator=g).to(dev)
-    eps = 1e-3
-    fp, _, _ = ops.EventFocusFn.apply(lt.detach() + eps * d, evd, t_ref, L._cfg, num_pos)
-    fm, _, _ = ops.EventFocusFn.apply(lt.detach() - eps * d, evd, t_ref, L._cfg, num_pos)
-    fd = (fp.double().item() - fm.double().item()) / (2 * eps)
-    an = (lt.grad.double() * d.double()).sum().item()
-    assert abs(fd - an) <= 0.05 * abs(an) + 1e-9
+    assert abs(f.item() - fo.item()) <= 2e-6 * abs(fo.item())
+    np.testing.assert_allclose(raw.cpu().numpy(), rawo.detach().numpy(), atol=1e-5 * rawo.max().item())
+    np.testing.assert_allclose(blur.cpu().numpy(), iwo.detach().numpy(), atol=1e-5 * iwo.max().item())
+    # a few sign() flips of near-zero Sobel responses are legitimate for 'l1' (SURVEY section 4)
+    assert _rel_l2(lt.grad.cpu().numpy(), lo.grad.numpy()) < (2e-3 if norm == 'l1' else 1e-4)
 
 
 def test_full_size_knn_against_bruteforce_sample():
