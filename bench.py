@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Benchmark of the CMax loss hot path (BASELINE.json metric: Mevents/s through the CMax loss
+forward + backward, DSEC 480x640).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C4]
+
+A step = FocusLoss.calc(trajectories, times, batch) + backward to `trajectories` on one synthetic
+batch that is already resident in HBM.  With N > 1 (one process per GPU, launched by
+torch.distributed.run) every rank processes its own shard of the batch (weak scaling, no
+data-path collective) and the averaged network gradient (124 MB fp32, the reference UNet) is
+all-reduced over RCCL on a side stream, overlapped with the next step's loss.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+`roofline` (dominant kernel, algorithmic bytes / HIP-event time / 8 TB/s) and `cpu_baseline`
+(the CPU oracle timed on the host cores on a bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+WORKLOADS = {
+    # name: (B per GPU, events per sample, num_bins, num_basis, smooth_type, smooth_weight, description)
+    'C2': dict(B=1, M=50_000, nb=15, k=1, smooth_type='on_flow_to_tref', smooth_weight=0.003,
+               desc='DSEC 480x640, 50k events/window, poly-k1, batch=1 (BASELINE configs[1])'),
+    'C3': dict(B=14, M=200_000, nb=15, k=3, smooth_type='on_flow_to_tref', smooth_weight=0.003,
+               desc='DSEC 480x640, 200k events/window, poly-k3, batch=14 per GPU (BASELINE configs[2]; '
+                    'the per-GPU shard of configs[4] = batch 112 on 8 GPUs)'),
+    'C4': dict(B=1, M=500_000, nb=41, k=10, smooth_type='on_flow_to_next', smooth_weight=0.06,
+               desc='EVIMO2 480x640, 500k events/window, Bezier degree 10, 41 bins, batch=1 (BASELINE configs[3])'),
+}
+H, W, SP, PATCH, KNN = 480, 640, 4, 4, 32
+
+
+def loss_config(wl):
+    return dict(image_shape=(H, W), num_tref=1, num_bins=wl['nb'], num_knn=KNN,
+                smooth_weight=wl['smooth_weight'], lut_superpixel_size=SP, focus_loss_norm='l1',
+                dist_norm='l2', scale_iwe_by_dt=True, mask_image_border=True,
+                polarity_aware_batching=True, interpolation_scheme='mean', smooth_type=wl['smooth_type'])
+
+
+def synth_inputs(wl, seed, B=None):
+    """Seeded synthetic batch: events [B,M,6] + trajectories [B,1+nb,n,2] on CPU."""
+    from motionpriorcmax_amd import utils
+    from motionpriorcmax_amd.utils.synth import synth_events, bin_mid_times
+    B = wl['B'] if B is None else B
+    nb, k = wl['nb'], wl['k']
+    ev, num_pos = synth_events(B, wl['M'], (H, W), nb, seed=seed, pad_frac=0.02, time_sorted=True)
+    g = torch.Generator().manual_seed(seed + 7)
+    times = torch.cat((torch.tensor([0.41]), bin_mid_times(nb)))
+    mask = utils.get_optical_flow_tile_mask((H, W), PATCH)
+    if wl is WORKLOADS['C4']:
+        # Bezier control points N(0, 2^2) per tile, (x, y) channel order (bezier.py / polynomial.py:60-61)
+        params = torch.randn(B, 2, k, H // PATCH, W // PATCH, generator=g) * 2.0
+        bm = utils.bernstein_basis(times.numpy(), k)                       # [n_t, k]
+        flow = torch.einsum('bdphw,tp->btdhw', params, bm)                 # [B, n_t, 2(x,y), h, w]
+        pos = torch.nonzero(mask).float()
+        disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), -1).reshape(B, len(times), -1, 2)
+        traj = disp + pos[None, None]
+    else:
+        sigma = 3.0 if k == 1 else 1.0
+        coeff = torch.randn(B, 1, 2 * k, H, W, generator=g) * sigma
+        coeffs, pos, _ = utils.coeffs_grid_to_list(coeff, mask, num_coeffs=k)
+        traj = utils.compute_basis(coeffs, times, k, 'polynomial') - \
+            utils.compute_basis(coeffs, torch.zeros(1), k, 'polynomial')
+        traj = (traj + pos[None, :, None, :]).permute(0, 2, 1, 3).contiguous()
+    return ev, num_pos, traj.contiguous(), times
+
+
+def algorithmic_bytes(B, M, nb, T=1, P=2):
+    """events read once per pass, IWE written + read once, LUT read + dLUT written."""
+    hq, wq = H // SP, W // SP
+    return 48 * B * M + 8 * B * T * P * H * W + 16 * B * nb * hq * wq * T
+
+
+def stage_bytes(B, M, nb, n, T=1, P=2):
+    """Algorithmic HBM bytes per C-ABI stage ('Kernels and their rooflines')."""
+    Q = (H // SP) * (W // SP)
+    lut = 8 * B * nb * Q * T
+    img = 4 * B * T * P * H * W
+    traj = 8 * B * (T + nb) * n
+    return {
+        'mpc_knn_lut_fwd': traj + lut,
+        'mpc_knn_lut_bwd': lut + traj,
+        'mpc_lut_smooth': lut,
+        'mpc_event_splat_fwd': 24 * B * M + lut + img,
+        'mpc_contrast_fwd': 2 * img,
+        'mpc_event_splat_bwd': 24 * B * M + lut,
+        'mpc_finalize': 0, 'mpc_scale': 0,
+    }
+
+
+def cpu_baseline(wl, budget_s=20.0):
+    """The CPU oracle (a restatement of the reference's PyTorch CPU path, `kind: port`) timed on
+    the host cores on a bounded sample of the same workload: the event path (warp -> IWE ->
+    objective -> autograd backward to the LUT) on ONE sample of the batch, plus the brute-force
+    KNN LUT on a slice of the query cells of one (sample, bin), extrapolated linearly to the
+    whole batch (the KNN cost does not depend on the event count)."""
+    from oracle import focus_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    ev, num_pos, traj, times = synth_inputs(wl, seed=0, B=1)
+    cfg = loss_config(wl)
+    Lo = O.FocusLossOracle(**cfg)
+    nb = wl['nb']
+    hq, wq = H // SP, W // SP
+    g = torch.Generator().manual_seed(5)
+    lut = torch.randn(1, nb, hq, wq, 1, 2, generator=g)
+
+    def event_step():
+        lt = lut.clone().requires_grad_(True)
+        f, _, _ = Lo.event_path(ev, lt, times[:1], num_pos)
+        (f + Lo.smooth_loss(lt, None) if cfg['smooth_type'] == 'on_flow_to_tref' else f).backward()
+    event_step()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < budget_s * 0.4 and reps < 20):
+        event_step()
+        reps += 1
+    t_event = (time.perf_counter() - t0) / reps
+    # KNN: a slice of the queries of one (sample, bin)
+    grid, _, _ = O.lut_grid_points((H, W), SP)
+    q_slice = 1024
+    pts = traj[0, 1]
+    O.knn_indices(pts, grid[:256], KNN, 'l2')
+    t0 = time.perf_counter()
+    O.knn_indices(pts, grid[:q_slice], KNN, 'l2', q_chunk=512)
+    t_knn_slice = time.perf_counter() - t0
+    t_knn_sample = t_knn_slice * (hq * wq / q_slice) * nb
+    valid = float(ev[..., 5].sum())
+    t_sample = t_event + t_knn_sample
+    return {
+        'value': valid / t_sample / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'kind': 'port',
+        'sample': (f'1 sample of the batch ({int(valid)} valid events): event path fwd+bwd timed '
+                   f'{reps}x = {t_event * 1e3:.1f} ms; brute-force KNN timed on {q_slice} of {hq * wq} '
+                   f'query cells of one bin = {t_knn_slice:.2f} s, extrapolated x{hq * wq // q_slice}x{nb} bins '
+                   f'= {t_knn_sample:.1f} s/sample'),
+        'event_path_only_value': valid / t_event / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='C3', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-grad-allreduce', action='store_true',
+                    help='N>1: skip the overlapped 124 MB network-gradient all-reduce')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--also', default='C2,C4', help='extra workloads reported in the "also" field (N=1 only)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the CMax path has no CPU fallback')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from motionpriorcmax_amd import LossFactory, ops, dp
+
+    def run_workload(name, steps, warmup, with_comm):
+        wl = WORKLOADS[name]
+        ev, num_pos, traj, times = synth_inputs(wl, seed=1000 * rank + 1)
+        L = LossFactory.get_loss_calculator('FOCUS', loss_config(wl))
+        evd, times_d = ev.to(dev), times.to(dev)
+        trajd = traj.to(dev).requires_grad_(True)
+        batch = {'events': evd, 'num_pos_events': num_pos}
+        valid_local = float(ev[..., 5].sum())
+        reducer = dp.GradAllReducer(device=dev) if (with_comm and world > 1) else None
+
+        def step():
+            loss, _, _ = L.calc(trajd, times_d, batch)
+            loss.backward()
+            trajd.grad = None
+            if reducer is not None:
+                reducer.wait()       # previous step's all-reduce must be done before "the optimizer"
+                reducer.start()      # this step's network gradient; overlaps the next step's loss
+            return loss
+
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        if reducer is not None:
+            reducer.wait()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
+        total_valid = dp.sum_over_ranks(valid_local, dev)
+
+        # instrumented pass: HIP events around every C-ABI call, on the stream they launch on
+        ops.STAGE_TIMER = ops.StageTimer()
+        for _ in range(steps):
+            loss, _, _ = L.calc(trajd, times_d, batch)
+            loss.backward()
+            trajd.grad = None
+        stages = ops.STAGE_TIMER.summary()
+        ops.STAGE_TIMER = None
+        return dict(wl=wl, dt=dt, steps=steps, total_valid=total_valid, stages=stages,
+                    loss=float(last.item()), n=traj.shape[2])
+
+    r = run_workload(args.workload, args.steps, args.warmup, not args.no_grad_allreduce)
+    wl = r['wl']
+    ms_per_step = 1e3 * r['dt'] / r['steps']
+    value = r['total_valid'] * r['steps'] / r['dt'] / 1e6
+
+    def roofline_of(res):
+        wl_ = res['wl']
+        sb = stage_bytes(wl_['B'], wl_['M'], wl_['nb'], res['n'])
+        per_step = {}
+        for name, st in res['stages'].items():
+            calls = st['launches'] / res['steps']
+            per_step[name] = {'us_per_step': st['avg_us'] * calls, 'calls_per_step': calls,
+                              'algorithmic_MB': sb.get(name, 0) / 1e6}
+        dom = max(per_step, key=lambda k: per_step[k]['us_per_step'])
+        d = per_step[dom]
+        ach = d['algorithmic_MB'] * 1e6 / (d['us_per_step'] * 1e-6) / 1e9 if d['us_per_step'] > 0 else 0.0
+        gpu_us = sum(v['us_per_step'] for v in per_step.values())
+        path_b = algorithmic_bytes(wl_['B'], wl_['M'], wl_['nb'])
+        return {
+            'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+            'kernel_us': round(d['us_per_step'], 1),
+            'path': {'algorithmic_MB': round(path_b / 1e6, 2), 'gpu_us_per_step': round(gpu_us, 1),
+                     'achieved': round(path_b / (gpu_us * 1e-6) / 1e9, 1) if gpu_us > 0 else 0.0,
+                     'frac': round(path_b / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if gpu_us > 0 else 0.0},
+            'stages_us_per_step': {k: round(v['us_per_step'], 1) for k, v in sorted(per_step.items())},
+        }
+
+    out = {
+        'metric': 'Mevents/s through CMax loss fwd+bwd, DSEC 480x640',
+        'value': round(value, 3), 'unit': 'Mevents/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f"{args.workload}: {wl['desc']}", 'batch_per_gpu': wl['B'],
+                   'global_batch': wl['B'] * world, 'events_per_sample': wl['M'], 'num_bins': wl['nb'],
+                   'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
+                   'grad_allreduce_MB': 0 if (world == 1 or args.no_grad_allreduce)
+                   else round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2)},
+        'loss': r['loss'],
+        'roofline': roofline_of(r),
+    }
+    if rank == 0 and world == 1:
+        also = {}
+        for name in [a for a in args.also.split(',') if a and a != args.workload]:
+            ra = run_workload(name, max(5, args.steps // 2), 3, False)
+            rf = roofline_of(ra)
+            also[name] = {'value': round(ra['total_valid'] * ra['steps'] / ra['dt'] / 1e6, 3),
+                          'ms_per_step': round(1e3 * ra['dt'] / ra['steps'], 4),
+                          'path_frac': rf['path']['frac'], 'stages_us_per_step': rf['stages_us_per_step']}
+        out['also'] = also
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -51,6 +51,42 @@ class PathConfig:
         return (h + self.sp - 1) // self.sp, (w + self.sp - 1) // self.sp
 
 
+class StageTimer:
+    """Optional per-stage HIP-event timing (bench.py): events are recorded on the stream the
+    kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {'launches': len(ms), 'avg_us': 1e3 * sum(ms) / max(len(ms), 1)}
+        return out
+
+
+STAGE_TIMER = None   # set to a StageTimer to time every C-ABI call
+
+
+class _stage:
+    def __init__(self, name, device):
+        self.name, self.device = name, device
+
+    def __enter__(self):
+        if STAGE_TIMER is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if STAGE_TIMER is not None:
+            self.b.record(torch.cuda.current_stream(self.device))
+            STAGE_TIMER.records.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _require_gpu(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise RuntimeError(f'{name} must be a GPU tensor: the CMax path runs in libmpcmax.so (HIP, '
@@ -99,16 +135,18 @@ def knn_lut_fwd(cfg, shape, traj, ws, want_idx=False):
         flow_next = torch.empty((B, max(nb - 1, 0), hq, wq, 1, 2), dtype=torch.float32, device=dev)
     state = torch.empty(3 * B * nb * Q + B * nb, dtype=torch.float32, device=dev)
     idx = torch.empty((B, nb, Q, K), dtype=torch.int32, device=dev) if want_idx else None
-    C.check(C.lib().mpc_knn_lut_fwd(ctypes.byref(shape), _ptr(traj), _ptr(flow_lut), _ptr(flow_next),
-                                    _ptr(state), _ptr(idx), _ptr(ws), _stream(dev)), 'mpc_knn_lut_fwd')
+    with _stage('mpc_knn_lut_fwd', dev):
+        C.check(C.lib().mpc_knn_lut_fwd(ctypes.byref(shape), _ptr(traj), _ptr(flow_lut), _ptr(flow_next),
+                                        _ptr(state), _ptr(idx), _ptr(ws), _stream(dev)), 'mpc_knn_lut_fwd')
     return flow_lut, flow_next, state, idx
 
 
 def knn_lut_bwd(shape, traj, g_lut, g_next, state, ws):
     g_traj = torch.empty_like(traj)
-    C.check(C.lib().mpc_knn_lut_bwd(ctypes.byref(shape), _ptr(traj), _ptr(g_lut), _ptr(g_next),
-                                    _ptr(state), _ptr(g_traj), _ptr(ws), _stream(traj.device)),
-            'mpc_knn_lut_bwd')
+    with _stage('mpc_knn_lut_bwd', traj.device):
+        C.check(C.lib().mpc_knn_lut_bwd(ctypes.byref(shape), _ptr(traj), _ptr(g_lut), _ptr(g_next),
+                                        _ptr(state), _ptr(g_traj), _ptr(ws), _stream(traj.device)),
+                'mpc_knn_lut_bwd')
     return g_traj
 
 
@@ -116,44 +154,50 @@ def event_splat_fwd(shape, events, flow_lut, t_ref, ws):
     dev = events.device
     P = 2 if shape.flags & C.F_POLARITY_SPLIT else 1
     raw = torch.empty((shape.B * shape.T, P, shape.H, shape.W), dtype=torch.float32, device=dev)
-    C.check(C.lib().mpc_event_splat_fwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
-                                        _ptr(raw), _ptr(ws), _stream(dev)), 'mpc_event_splat_fwd')
+    with _stage('mpc_event_splat_fwd', dev):
+        C.check(C.lib().mpc_event_splat_fwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
+                                            _ptr(raw), _ptr(ws), _stream(dev)), 'mpc_event_splat_fwd')
     return raw
 
 
 def contrast_fwd(shape, raw, ws, want_grad):
     blur = torch.empty_like(raw)
     gimg = torch.empty_like(raw) if want_grad else None
-    C.check(C.lib().mpc_contrast_fwd(ctypes.byref(shape), _ptr(raw), _ptr(blur), _ptr(gimg), _ptr(ws),
-                                     _stream(raw.device)), 'mpc_contrast_fwd')
+    with _stage('mpc_contrast_fwd', raw.device):
+        C.check(C.lib().mpc_contrast_fwd(ctypes.byref(shape), _ptr(raw), _ptr(blur), _ptr(gimg), _ptr(ws),
+                                         _stream(raw.device)), 'mpc_contrast_fwd')
     return blur, gimg
 
 
 def lut_smooth(shape, field, nimg, Cch, weight, ws, want_grad):
     g = torch.empty_like(field) if want_grad else None
-    C.check(C.lib().mpc_lut_smooth(ctypes.byref(shape), _ptr(field), nimg, Cch, float(weight), _ptr(g),
-                                   _ptr(ws), _stream(field.device)), 'mpc_lut_smooth')
+    with _stage('mpc_lut_smooth', field.device):
+        C.check(C.lib().mpc_lut_smooth(ctypes.byref(shape), _ptr(field), nimg, Cch, float(weight), _ptr(g),
+                                       _ptr(ws), _stream(field.device)), 'mpc_lut_smooth')
     return g
 
 
 def finalize(shape, smooth_nimg, smooth_C, weight, ws, device):
     scal = torch.empty(C.SCAL_COUNT, dtype=torch.float32, device=device)
-    C.check(C.lib().mpc_finalize(ctypes.byref(shape), smooth_nimg, smooth_C, float(weight), _ptr(scal),
-                                 _ptr(ws), _stream(device)), 'mpc_finalize')
+    with _stage('mpc_finalize', device):
+        C.check(C.lib().mpc_finalize(ctypes.byref(shape), smooth_nimg, smooth_C, float(weight), _ptr(scal),
+                                     _ptr(ws), _stream(device)), 'mpc_finalize')
     return scal
 
 
 def event_splat_bwd(shape, events, flow_lut, t_ref, gimg, scal, grad_out, g_lut, accumulate, ws):
-    C.check(C.lib().mpc_event_splat_bwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
-                                        _ptr(gimg), _ptr(scal), _ptr(grad_out), _ptr(g_lut),
-                                        1 if accumulate else 0, _ptr(ws), _stream(events.device)),
-            'mpc_event_splat_bwd')
+    with _stage('mpc_event_splat_bwd', events.device):
+        C.check(C.lib().mpc_event_splat_bwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
+                                            _ptr(gimg), _ptr(scal), _ptr(grad_out), _ptr(g_lut),
+                                            1 if accumulate else 0, _ptr(ws), _stream(events.device)),
+                'mpc_event_splat_bwd')
     return g_lut
 
 
 def scale(x, a):
     y = torch.empty_like(x)
-    C.check(C.lib().mpc_scale(_ptr(x), _ptr(a), _ptr(y), x.numel(), _stream(x.device)), 'mpc_scale')
+    with _stage('mpc_scale', x.device):
+        C.check(C.lib().mpc_scale(_ptr(x), _ptr(a), _ptr(y), x.numel(), _stream(x.device)), 'mpc_scale')
     return y
 
 
