@@ -263,7 +263,8 @@ def main():
     if rank == 0 and world == 1:
         also = {}
         for name in [a for a in args.also.split(',') if a and a != args.workload]:
-            ra = run_workload(name, max(5, args.steps // 2), 3, False)
+            torch.cuda.empty_cache()     # the allocator otherwise frees/reallocates inside the timed steps
+            ra = run_workload(name, max(5, args.steps // 2), 5, False)
             rf = roofline_of(ra)
             also[name] = {'value': round(ra['total_valid'] * ra['steps'] / ra['dt'] / 1e6, 3),
                           'ms_per_step': round(1e3 * ra['dt'] / ra['steps'], 4),

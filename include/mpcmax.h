@@ -85,8 +85,9 @@ int64_t mpc_workspace_bytes(const mpc_shape *s);
  * traj      [B][T+nb][n][2]  (y,x); rows [0,T) are the reference times, [T,T+nb) the bin mids
  * flow_lut  [B][nb][hq][wq][T][2]                                   (out)
  * flow_next [B][nb-1][hq][wq][1][2]  or NULL unless MPC_F_WANT_NEXT (out)
- * knn_state [3][B][nb][hq*wq] + [B][nb] : K-th distance (f32), K-th index (i32 bits), iwd
- *           normaliser, then per (sample,bin) the largest K-th distance (out; consumed by _bwd)
+ * knn_state [3][B][nb][hq*wq] + [B][nb][ceil(hq/16)*ceil(wq/16)] : K-th distance (f32), K-th
+ *           index (i32 bits), iwd normaliser, then the largest K-th distance of every 16x16
+ *           cell tile (out; consumed by _bwd)
  * idx_out   [B][nb][hq*wq][K] int32, ascending by (distance, index), or NULL (debug/tests)  */
 int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                     float *knn_state, int32_t *idx_out, void *ws, void *stream);

@@ -48,6 +48,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_cell_start = off; off += mpc_align(bt * (L.G + 1) * sizeof(int32_t));
     L.off_spos = off;       off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
     L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(int32_t));
+    L.off_knn_tmp_g = off;  off += mpc_align(bt * (int64_t)s->n * s->T * 2 * sizeof(float));
+    L.off_knn_tmp_a = off;  off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
     L.total = off;
     return L;
 }

@@ -40,6 +40,8 @@ struct mpc_ws_layout {
     int64_t off_cell_start;  // int32 [B*nb][G+1]
     int64_t off_spos;        // float2 [B*nb][n]
     int64_t off_sidx;        // int32  [B*nb][n]
+    int64_t off_knn_tmp_g;   // float2 [B*nb][n][T]  backward partials
+    int64_t off_knn_tmp_a;   // float2 [B*nb][n]
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb]  fill counters of the forward buckets
     int64_t off_bcount;      // int32 [nbb]  fill counters of the backward buckets

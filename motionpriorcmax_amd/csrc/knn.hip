@@ -11,6 +11,7 @@
 // No index tensor is materialised: the backward re-derives membership from the saved K-th key.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define KNN_BINS 32
 #define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
@@ -50,14 +51,12 @@ __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float p
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start,
-                                                     float2 *__restrict__ spos, int *__restrict__ sidx,
-                                                     unsigned *__restrict__ rmax) {
+                                                     float2 *__restrict__ spos, int *__restrict__ sidx) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
     const int tid = threadIdx.x;
     const int bt = blockIdx.x, b = bt / p.nb, t = bt - b * p.nb;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
-    if (tid == 0) rmax[bt] = 0u;
     for (int g = tid; g < p.G; g += 1024) s_cnt[g] = 0;
     __syncthreads();
     for (int i = tid; i < p.n; i += 1024) {
@@ -101,9 +100,287 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 }
 
 // ------------------------------------------------------------------------------------------
-// query: one thread per LUT cell; 16x16 cells per workgroup
-// grid (ceil(wq/16), ceil(hq/16), B*nb), 256 threads
+// query: one thread per LUT cell; 16x16 cells per workgroup.  The candidate points of the tile
+// and a halo of RH cell rings are staged in LDS (positions, indices, flows), so the selection
+// passes never leave the CU; a thread that needs a larger radius (or a workgroup whose region
+// overflows the LDS budget) finishes on the global arrays with the same code.
+// grid (ceil(wq/16), ceil(hq/16), B*nb), 256 threads, dynamic LDS
 // ------------------------------------------------------------------------------------------
+struct QueryCtx {
+    // global
+    const int *cs;          // cell_start of this (sample, bin)
+    const float2 *spos;
+    const int *sidx;
+    const float2 *traj_b;   // trajectories of this sample: [T+nb][n]
+    // LDS
+    const int *lcs;         // [RW][RW+1]
+    const float2 *lpos;
+    const int *lidx;
+    const float2 *lf0;      // flow to t_ref (T == 1 only)
+    const float2 *lf1;      // flow to the next bin (want_next only)
+    int ry0, rx0, RW, RH;
+};
+
+template <bool LDS>
+struct Acc {
+    const KnnParams &p;
+    const QueryCtx &c;
+    int t;
+    __device__ __forceinline__ void range(int yy, int x0, int x1, int &js, int &je) const {
+        if (LDS) {
+            const int *row = c.lcs + (yy - c.ry0) * (c.RW + 1);
+            js = row[x0 - c.rx0];
+            je = row[x1 + 1 - c.rx0];
+        } else {
+            js = c.cs[yy * p.wq + x0];
+            je = c.cs[yy * p.wq + x1 + 1];
+        }
+    }
+    __device__ __forceinline__ float2 pos(int j) const { return LDS ? c.lpos[j] : c.spos[j]; }
+    __device__ __forceinline__ int idx(int j) const { return LDS ? c.lidx[j] : c.sidx[j]; }
+    __device__ __forceinline__ float2 flow_ref(int j, int tr, float2 pj) const {
+        if (LDS && p.T == 1) return c.lf0[j];
+        const float2 a = c.traj_b[(size_t)tr * p.n + idx(j)];
+        return make_float2(a.x - pj.x, a.y - pj.y);          // traj(t_ref) - traj(t_mid)
+    }
+    __device__ __forceinline__ float2 flow_next(int j, float2 pj) const {
+        if (LDS) return c.lf1[j];
+        const float2 a = c.traj_b[(size_t)(p.T + t + 1) * p.n + idx(j)];
+        return make_float2(a.x - pj.x, a.y - pj.y);          // traj(t_mid[i+1]) - traj(t_mid[i])
+    }
+};
+
+// Returns false if the search needs more rings than the LDS halo holds (LDS variant only).
+template <bool LDS>
+__device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int t, int cy, int cx,
+                              int r_init, unsigned (*s_hist)[256], float *__restrict__ flow_lut,
+                              float *__restrict__ flow_next, float *__restrict__ knn_state,
+                              int *__restrict__ idx_out, float &dK_out) {
+    const Acc<LDS> A{p, c, t};
+    const int tid = threadIdx.x;
+    const int bt = b * p.nb + t;
+    const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+    // ---- 1. grow the search square until K candidates are provably the nearest ---------------
+    int r = r_init, y0, y1, x0, x1, cnt;
+    {   // next to the image border the square is clipped: start with one of the same cell count
+        const int want = (2 * r_init + 1) * (2 * r_init + 1);
+        for (;;) {
+            const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
+            const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
+            if (hh * ww >= want || (hh == p.hq && ww == p.wq) || (LDS && r >= c.RH)) break;
+            ++r;
+        }
+    }
+    float upper, scale;
+    bool whole;
+    for (;;) {
+        if (LDS && r > c.RH) return false;
+        y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
+        x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
+        whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
+        if (whole) {
+            if (LDS) return false;
+            // every point is a candidate: range of the histogram = largest distance
+            float dmax = 0.f;
+            for (int j = 0; j < p.n; ++j) {
+                const float2 q = c.spos[j];
+                dmax = fmaxf(dmax, pair_dist(qy, qx, q.x, q.y, p.l1));
+            }
+            upper = INFINITY;
+            scale = dmax > 0.f ? (float)KNN_BINS / dmax : 0.f;
+        } else {
+            // anything outside the square is at least lb away along one axis
+            const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
+            upper = p.l1 ? lb : lb * lb;
+            scale = (float)KNN_BINS / upper;
+        }
+#pragma unroll
+        for (int h = 0; h < KNN_BINS / 2; ++h) s_hist[h][tid] = 0u;
+        cnt = 0;
+        for (int yy = y0; yy <= y1; ++yy) {
+            int js, je;
+            A.range(yy, x0, x1, js, je);
+            for (int j = js; j < je; ++j) {
+                const float2 q = A.pos(j);
+                const float d = pair_dist(qy, qx, q.x, q.y, p.l1);
+                if (d < upper) {
+                    const int bin = min((int)(d * scale), KNN_BINS - 1);
+                    atomicAdd(&s_hist[bin >> 1][tid], (bin & 1) ? 0x10000u : 1u);   // private column, fire-and-forget
+                    ++cnt;
+                }
+            }
+        }
+        if (cnt >= p.K || whole) break;
+        r += 1 + (r >> 2);
+    }
+    // ---- 2. bin holding the K-th smallest ----------------------------------------------------
+    int bstar = KNN_BINS - 1, before = 0;
+    {
+        int cum = 0;
+        bool found = false;
+#pragma unroll
+        for (int h = 0; h < KNN_BINS / 2; ++h) {
+            const unsigned wv = s_hist[h][tid];
+            const int c0 = (int)(wv & 0xffffu), c1 = (int)(wv >> 16);
+            if (!found && cum + c0 >= p.K) { bstar = 2 * h; before = cum; found = true; }
+            cum += c0;
+            if (!found && cum + c1 >= p.K) { bstar = 2 * h + 1; before = cum; found = true; }
+            cum += c1;
+        }
+    }
+    // ---- 3. second scan: sum the flows of the bins below bstar (num_tref == 1), and list the
+    //         keys inside bstar in the thread's (now dead) histogram column -----------------------
+    const int need = p.K - before;
+    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
+    const size_t BQ = (size_t)p.B * p.nb * p.G;
+    const bool fuse = (p.T == 1);
+    const bool do_next0 = p.want_next && (t < p.nb - 1);
+    float sy = 0.f, sx = 0.f, sw = 0.f, ny = 0.f, nx = 0.f;
+    int m = 0;
+    for (int yy = y0; yy <= y1; ++yy) {
+        int js, je;
+        A.range(yy, x0, x1, js, je);
+        for (int j = js; j < je; ++j) {
+            const float2 pj = A.pos(j);
+            const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+            if (!(d < upper)) continue;
+            const int bin = min((int)(d * scale), KNN_BINS - 1);
+            if (bin < bstar) {
+                if (fuse) {
+                    const float2 f = A.flow_ref(j, 0, pj);
+                    if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
+                    else { sy += f.x; sx += f.y; }
+                    if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
+                }
+            } else if (bin == bstar) {
+                if (m < KNN_BINS / 4) { s_hist[2 * m][tid] = __float_as_uint(d); s_hist[2 * m + 1][tid] = (unsigned)j; }
+                ++m;
+            }
+        }
+    }
+    float dK = 0.f; int iK = -1;
+    bool listed = (m <= KNN_BINS / 4);
+    if (listed) {
+        // rank the <= 8 listed keys by (distance, index); the first `need` of them are neighbours
+        for (int a = 0; a < m; ++a) {
+            const float da = __uint_as_float(s_hist[2 * a][tid]);
+            const int ja = (int)s_hist[2 * a + 1][tid];
+            const int ia = A.idx(ja);
+            int rank = 0;
+            for (int e = 0; e < m; ++e) {
+                const float de = __uint_as_float(s_hist[2 * e][tid]);
+                const int ie = A.idx((int)s_hist[2 * e + 1][tid]);
+                rank += (de < da || (de == da && ie < ia)) ? 1 : 0;
+            }
+            if (rank < need) {
+                if (fuse) {
+                    const float2 pj = A.pos(ja);
+                    const float2 f = A.flow_ref(ja, 0, pj);
+                    if (p.iwd) { const float w = 1.f / (da + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
+                    else { sy += f.x; sx += f.y; }
+                    if (do_next0) { const float2 g = A.flow_next(ja, pj); ny += g.x; nx += g.y; }
+                }
+                if (rank == need - 1) { dK = da; iK = ia; }
+            }
+        }
+    } else {
+        // more keys in the bin than the list holds (heavy ties): select by repeated minimum
+        float ld = -1.f; int li = -1;
+        for (int it = 0; it < need; ++it) {
+            float bd = INFINITY; int bi = 0x7fffffff;
+            for (int yy = y0; yy <= y1; ++yy) {
+                int js, je;
+                A.range(yy, x0, x1, js, je);
+                for (int j = js; j < je; ++j) {
+                    const float2 pj = A.pos(j);
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                    if (!(d < upper)) continue;
+                    if (min((int)(d * scale), KNN_BINS - 1) != bstar) continue;
+                    if (d < ld || d > bd) continue;
+                    const int id = A.idx(j);
+                    const bool gt_last = (d > ld) || (id > li);
+                    const bool lt_best = (d < bd) || (id < bi);
+                    if (gt_last && lt_best) { bd = d; bi = id; }
+                }
+            }
+            ld = bd; li = bi;
+        }
+        dK = ld; iK = li;
+    }
+    // ---- 4. outputs; a full membership scan per reference time where the sums were not fused ----
+    float norm = 0.f;
+    if (fuse && listed) {
+        float2 ov;
+        if (p.iwd) { ov.x = sy / sw; ov.y = sx / sw; norm = sw; }
+        else { ov.x = sy / (float)p.K; ov.y = sx / (float)p.K; }
+        reinterpret_cast<float2 *>(flow_lut)[q] = ov;
+        if (do_next0) {
+            float2 on; on.x = ny / (float)p.K; on.y = nx / (float)p.K;
+            reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
+        }
+    } else {
+        for (int tr = 0; tr < p.T; ++tr) {
+            sy = sx = sw = ny = nx = 0.f;
+            const bool do_next = (tr == 0) && do_next0;
+            for (int yy = y0; yy <= y1; ++yy) {
+                int js, je;
+                A.range(yy, x0, x1, js, je);
+                for (int j = js; j < je; ++j) {
+                    const float2 pj = A.pos(j);
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                    if (d > dK) continue;
+                    if (d == dK && A.idx(j) > iK) continue;
+                    const float2 f = A.flow_ref(j, tr, pj);
+                    if (p.iwd) {
+                        const float w = 1.f / (d + 1e-9f);
+                        sy += w * f.x; sx += w * f.y; sw += w;
+                    } else {
+                        sy += f.x; sx += f.y;
+                    }
+                    if (do_next) {
+                        const float2 g = A.flow_next(j, pj);
+                        ny += g.x; nx += g.y;
+                    }
+                }
+            }
+            float2 ov;
+            if (p.iwd) { ov.x = sy / sw; ov.y = sx / sw; norm = sw; }
+            else { ov.x = sy / (float)p.K; ov.y = sx / (float)p.K; }
+            reinterpret_cast<float2 *>(flow_lut)[q * p.T + tr] = ov;
+            if (do_next) {
+                float2 on; on.x = ny / (float)p.K; on.y = nx / (float)p.K;
+                reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
+            }
+        }
+    }
+    knn_state[q] = dK;
+    reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
+    knn_state[2 * BQ + q] = norm;
+    // ---- 5. optional: the K indices in ascending (distance, index) order ---------------------
+    if (idx_out != nullptr) {
+        float pd = -1.f; int pi = -1;
+        for (int k = 0; k < p.K; ++k) {
+            float bd = INFINITY; int bi = 0x7fffffff;
+            for (int yy = y0; yy <= y1; ++yy) {
+                int js, je;
+                A.range(yy, x0, x1, js, je);
+                for (int j = js; j < je; ++j) {
+                    const float2 pj = A.pos(j);
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                    const int id = A.idx(j);
+                    const bool gt_last = (d > pd) || (d == pd && id > pi);
+                    const bool lt_best = (d < bd) || (d == bd && id < bi);
+                    if (gt_last && lt_best) { bd = d; bi = id; }
+                }
+            }
+            pd = bd; pi = bi;
+            idx_out[q * p.K + k] = bi;
+        }
+    }
+    dK_out = dK;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const float *__restrict__ traj,
                                                    const int *__restrict__ cell_start,
                                                    const float2 *__restrict__ spos,
@@ -112,258 +389,575 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
                                                    float *__restrict__ flow_next,
                                                    float *__restrict__ knn_state,
                                                    int *__restrict__ idx_out,
-                                                   unsigned *__restrict__ rmax, int r_init) {
-    __shared__ unsigned s_hist[KNN_BINS / 2][256];   // 32 bins x u16 per thread
-    __shared__ unsigned s_max[4];
+                                                   float *__restrict__ tile_dkmax, int r_init, int RH,
+                                                   int cap) {
+    extern __shared__ unsigned char s_dyn[];
+    __shared__ float s_maxf[4];
+    __shared__ int s_rowbase[64 + 1];   // RW <= 48
+    __shared__ int s_rowg[64];
+    __shared__ int s_use_lds;
     const int tid = threadIdx.x;
     const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
+    const int RW = 16 + 2 * RH;
+    // dynamic LDS carve-up (all sizes multiples of 16 bytes)
+    unsigned (*s_hist)[256] = reinterpret_cast<unsigned (*)[256]>(s_dyn);
+    size_t o = (size_t)(KNN_BINS / 2) * 256 * 4;
+    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
+    float2 *lf0 = reinterpret_cast<float2 *>(s_dyn + o); o += (p.T == 1) ? (size_t)cap * 8 : 0;
+    float2 *lf1 = reinterpret_cast<float2 *>(s_dyn + o); o += p.want_next ? (size_t)cap * 8 : 0;
+    int *lidx = reinterpret_cast<int *>(s_dyn + o); o += (size_t)cap * 4;
+    int *lcs = reinterpret_cast<int *>(s_dyn + o);
+
+    QueryCtx c;
+    c.cs = cell_start + (size_t)bt * (p.G + 1);
+    c.spos = spos + (size_t)bt * p.n;
+    c.sidx = sidx + (size_t)bt * p.n;
+    c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
+    c.lcs = lcs; c.lpos = lpos; c.lidx = lidx; c.lf0 = lf0; c.lf1 = lf1;
+    c.RW = RW; c.RH = RH;
+    c.ry0 = blockIdx.y * 16 - RH;
+    c.rx0 = blockIdx.x * 16 - RH;
+
+    // ---- stage the region (tile + RH rings) ---------------------------------------------------
+    const int xlo = max(c.rx0, 0), xhi = min(c.rx0 + RW - 1, p.wq - 1);
+    if (tid < RW) {
+        const int yy = c.ry0 + tid;
+        int gs = 0, ge = 0;
+        if (yy >= 0 && yy < p.hq) { gs = c.cs[yy * p.wq + xlo]; ge = c.cs[yy * p.wq + xhi + 1]; }
+        s_rowg[tid] = gs;
+        s_rowbase[tid + 1] = ge - gs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        s_rowbase[0] = 0;
+        for (int rr = 0; rr < RW; ++rr) { const int cnt = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + cnt; run += cnt; }
+        s_use_lds = (run <= cap) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool use_lds = s_use_lds != 0;
+    if (use_lds) {
+        const int total = s_rowbase[RW];
+        for (int i = tid; i < RW * (RW + 1); i += 256) {
+            const int rr = i / (RW + 1), cc = i - rr * (RW + 1);
+            const int yy = c.ry0 + rr;
+            int v = s_rowbase[rr];
+            if (yy >= 0 && yy < p.hq) {
+                const int xx = min(max(c.rx0 + cc, xlo), xhi + 1);
+                v += c.cs[yy * p.wq + xx] - s_rowg[rr];
+            }
+            lcs[i] = v;
+        }
+        const float2 *tref0 = c.traj_b;                                   // T == 1: the reference time
+        const float2 *tnext = c.traj_b + (size_t)(p.T + t + 1) * p.n;     // next bin (if any)
+        const bool has_next = p.want_next && (t < p.nb - 1);
+        for (int i = tid; i < total; i += 256) {
+            int lo = 0, hi = RW;             // row rr with s_rowbase[rr] <= i < s_rowbase[rr+1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= i) lo = mid; else hi = mid; }
+            const int g = s_rowg[lo] + (i - s_rowbase[lo]);
+            const float2 pj = c.spos[g];
+            const int id = c.sidx[g];
+            lpos[i] = pj;
+            lidx[i] = id;
+            if (p.T == 1) { const float2 a = tref0[id]; lf0[i] = make_float2(a.x - pj.x, a.y - pj.y); }
+            if (has_next) { const float2 a = tnext[id]; lf1[i] = make_float2(a.x - pj.x, a.y - pj.y); }
+        }
+    }
+    __syncthreads();
+
     const int cy = blockIdx.y * 16 + (tid >> 4), cx = blockIdx.x * 16 + (tid & 15);
-    const bool active = cy < p.hq && cx < p.wq;
+    float dK = 0.f;
+    if (cy < p.hq && cx < p.wq) {
+        bool done = false;
+        if (use_lds) done = knn_one_query<true>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+        if (!done) knn_one_query<false>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+    }
+    // largest K-th distance of this tile: bounds the backward's search windows
+    float m = dK;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_down(m, o2, 64));
+    if ((tid & 63) == 0) s_maxf[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0)
+        tile_dkmax[((size_t)bt * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
+            fmaxf(fmaxf(s_maxf[0], s_maxf[1]), fmaxf(s_maxf[2], s_maxf[3]));
+}
+
+// ------------------------------------------------------------------------------------------
+// query, point-centric form ('mean' scheme, num_tref == 1): the regular side of the problem is
+// the QUERY lattice, so the loops run over the staged points and, for each point, over the
+// query cells of the tile within reach of the point's home cell -- near-uniform trip counts
+// instead of the per-query divergence of the search above.  Per query the workgroup keeps in LDS:
+// its search radius (larger next to the image border, where the neighbourhood is clipped), a
+// 32-bin distance histogram, the flow sums of all points in bins below the bin of the K-th
+// smallest, and a short list of the keys inside that bin, from which the owning thread picks the
+// remaining neighbours exactly.  All LDS accumulation is INTEGER: ds_add_u32 for the histogram
+// and Q33.30 fixed point with ds_add_u64 for the flow sums (measured on gfx950: ds_add_f32 takes
+// ~193 cycles per wave-instruction against 6-12 for the integer forms, profiles/
+// r01_ubench_lds_atomics.txt); integer sums also make the LUT bitwise reproducible.
+// Queries the fixed budget cannot serve (too few candidates, list overflow) finish in the
+// per-thread search above.
+// grid (ceil(wq/16), ceil(hq/16), B*nb), KNN_TILE_THREADS threads, dynamic LDS
+// ------------------------------------------------------------------------------------------
+#define KNN_LCAP 8
+#define KNN_TILE_THREADS 512
+#define KNN_FIX_SHIFT 30
+
+__device__ __forceinline__ long long to_fixed(float v) {
+    // exact split: integer part + fraction, |v| < 2^31
+    const float hi = truncf(v);
+    const float lo = v - hi;
+    return ((long long)(int)hi << KNN_FIX_SHIFT) + (long long)(int)(lo * (float)(1 << KNN_FIX_SHIFT));
+}
+__device__ __forceinline__ float from_fixed(long long a) {
+    return (float)((double)a * (1.0 / (double)(1 << KNN_FIX_SHIFT)));
+}
+
+__global__ __launch_bounds__(KNN_TILE_THREADS) void k_knn_query_tile(
+    const KnnParams p, const float *__restrict__ traj, const int *__restrict__ cell_start,
+    const float2 *__restrict__ spos, const int *__restrict__ sidx, float *__restrict__ flow_lut,
+    float *__restrict__ flow_next, float *__restrict__ knn_state, int *__restrict__ idx_out,
+    float *__restrict__ tile_dkmax, int r_base, int RH_MAX, int cap, int *__restrict__ dbg) {
+    constexpr int NT = KNN_TILE_THREADS;
+    extern __shared__ unsigned char s_dyn[];
+    __shared__ float s_maxf[NT / 64];
+    __shared__ int s_maxi[NT / 64];
+    __shared__ int s_rowbase[80 + 1];
+    __shared__ int s_rowg[80];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
+    const int ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
+    const int ty1 = min(ty0 + 15, p.hq - 1), tx1 = min(tx0 + 15, p.wq - 1);
+    // LDS carve-up
+    unsigned (*s_hist)[256] = reinterpret_cast<unsigned (*)[256]>(s_dyn);
+    // the key list reuses the histogram storage (the histogram is dead once bstar is known)
+    float (*l_ld)[256] = reinterpret_cast<float (*)[256]>(s_dyn);
+    int (*l_li)[256] = reinterpret_cast<int (*)[256]>(s_dyn + KNN_LCAP * 256 * 4);
+    size_t o = (size_t)(KNN_BINS / 2) * 256 * 4;
+    unsigned long long (*l_acc)[256] = reinterpret_cast<unsigned long long (*)[256]>(s_dyn + o); o += 4 * 256 * 8;
+    float4 *l_par = reinterpret_cast<float4 *>(s_dyn + o); o += 256 * 16;   // {upper, scale, r_q, bstar}
+    int *l_cnt = reinterpret_cast<int *>(s_dyn + o); o += 256 * 4;
+    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
+    float2 *lf0 = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
+    float2 *lf1 = reinterpret_cast<float2 *>(s_dyn + o); o += p.want_next ? (size_t)cap * 8 : 0;
+    int *lidx = reinterpret_cast<int *>(s_dyn + o);
+
     const int *cs = cell_start + (size_t)bt * (p.G + 1);
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const int *si_ = sidx + (size_t)bt * p.n;
+    const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
+    const bool has_next = p.want_next && (t < p.nb - 1);
+    const bool qthread = tid < 256;                           // threads that own a query
+    const int cy = ty0 + ((tid & 255) >> 4), cx = tx0 + (tid & 15);
+    const bool active = qthread && cy < p.hq && cx < p.wq;
+
+    // ---- per-query search radius: r_base inside the image, larger where the square is clipped ----
+    int rq = 0;
+    float q_upper = 0.f, q_scale = 0.f;
+    if (active) {
+        const int want = (2 * r_base + 1) * (2 * r_base + 1);
+        rq = r_base;
+        for (;;) {
+            const int hh = min(cy + rq, p.hq - 1) - max(cy - rq, 0) + 1;
+            const int ww = min(cx + rq, p.wq - 1) - max(cx - rq, 0) + 1;
+            if (hh * ww >= want || rq >= RH_MAX || (hh == p.hq && ww == p.wq)) break;
+            ++rq;
+        }
+        const float lb = ((float)rq + 0.5f) * (float)p.sp - KNN_SLACK;
+        q_upper = p.l1 ? lb : lb * lb;
+        q_scale = (float)KNN_BINS / q_upper;
+    }
+    if (qthread) l_par[tid] = make_float4(q_upper, q_scale, active ? (float)rq : -1.f, -1.f);
+    int rmax = rq;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) rmax = max(rmax, __shfl_down(rmax, o2, 64));
+    if ((tid & 63) == 0) s_maxi[tid >> 6] = rmax;
+    __syncthreads();
+    rmax = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) rmax = max(rmax, s_maxi[w]);
+
+    // ---- stage the points of (tile +- rmax rings) ---------------------------------------------
+    const int RW = 16 + 2 * rmax;
+    const int ry0 = ty0 - rmax, rx0 = tx0 - rmax;
+    const int xlo = max(rx0, 0), xhi = min(rx0 + RW - 1, p.wq - 1);
+    if (tid < RW) {
+        const int yy = ry0 + tid;
+        int gs = 0, ge = 0;
+        if (yy >= 0 && yy < p.hq) { gs = cs[yy * p.wq + xlo]; ge = cs[yy * p.wq + xhi + 1]; }
+        s_rowg[tid] = gs;
+        s_rowbase[tid + 1] = ge - gs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        s_rowbase[0] = 0;
+        for (int rr = 0; rr < RW; ++rr) { const int c = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + c; run += c; }
+        s_flag = (run <= cap) ? 1 : 0;
+    }
+    __syncthreads();
+    const int total = s_rowbase[RW];
+    const bool staged = s_flag != 0;
+    bool fallback = active && !staged;
     float dK = 0.f;
 
-    if (active) {
-        const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-        // ---- 1. grow the search square until K candidates are provably the nearest -------
-        int r = r_init, y0, y1, x0, x1, cnt;
-        float upper, scale;
-        bool whole;
-        for (;;) {
-            y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
-            x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
-            whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
-            if (whole) {
-                // every point is a candidate: range of the histogram = largest distance
-                float dmax = 0.f;
-                for (int j = 0; j < p.n; ++j) {
-                    const float2 c = sp_[j];
-                    dmax = fmaxf(dmax, pair_dist(qy, qx, c.x, c.y, p.l1));
-                }
-                upper = INFINITY;
-                scale = dmax > 0.f ? (float)KNN_BINS / dmax : 0.f;
-            } else {
-                // anything outside the square is at least lb away along one axis
-                const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
-                upper = p.l1 ? lb : lb * lb;
-                scale = (float)KNN_BINS / upper;
-            }
+    if (staged) {
+        for (int i = tid; i < total; i += NT) {
+            int lo = 0, hi = RW;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= i) lo = mid; else hi = mid; }
+            const int g = s_rowg[lo] + (i - s_rowbase[lo]);
+            const float2 pj = sp_[g];
+            const int id = si_[g];
+            lpos[i] = pj;
+            lidx[i] = id;
+            const float2 a = traj_b[id];                                   // t_ref row (T == 1)
+            lf0[i] = make_float2(a.x - pj.x, a.y - pj.y);
+            if (has_next) { const float2 a2 = traj_b[(size_t)(p.T + t + 1) * p.n + id]; lf1[i] = make_float2(a2.x - pj.x, a2.y - pj.y); }
+        }
+        if (qthread) {
 #pragma unroll
             for (int h = 0; h < KNN_BINS / 2; ++h) s_hist[h][tid] = 0u;
-            cnt = 0;
-            for (int yy = y0; yy <= y1; ++yy) {
-                const int js = cs[yy * p.wq + x0], je = cs[yy * p.wq + x1 + 1];
-                for (int j = js; j < je; ++j) {
-                    const float2 c = sp_[j];
-                    const float d = pair_dist(qy, qx, c.x, c.y, p.l1);
-                    if (d < upper) {
-                        const int bin = min((int)(d * scale), KNN_BINS - 1);
-                        s_hist[bin >> 1][tid] += (bin & 1) ? 0x10000u : 1u;
-                        ++cnt;
-                    }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) l_acc[a][tid] = 0ull;
+            l_cnt[tid] = 0;
+        }
+        __syncthreads();
+        // ---- pass 1: distance histograms ---------------------------------------------------
+        for (int i = tid; i < total; i += NT) {
+            const float2 pj = lpos[i];
+            const int hy = cell_of(pj.x, p.sp, p.hq), hx = cell_of(pj.y, p.sp, p.wq);
+            const int ya = max(hy - rmax, ty0), yb = min(hy + rmax, ty1);
+            const int xa = max(hx - rmax, tx0), xb = min(hx + rmax, tx1);
+            for (int yy = ya; yy <= yb; ++yy) {
+                const float dy = ((float)(yy * p.sp) + p.off) - pj.x;
+                const float dy2 = p.l1 ? fabsf(dy) : dy * dy;
+                const int ady = abs(yy - hy);
+                for (int xx = xa; xx <= xb; ++xx) {
+                    const int ql = (yy - ty0) * 16 + (xx - tx0);
+                    const float4 par = l_par[ql];
+                    const float dx = ((float)(xx * p.sp) + p.off) - pj.y;
+                    const float d = dy2 + (p.l1 ? fabsf(dx) : dx * dx);
+                    const int bin = min((int)(d * par.y), KNN_BINS - 1);
+                    if ((float)max(ady, abs(xx - hx)) <= par.z && d < par.x)
+                        atomicAdd(&s_hist[bin >> 1][ql], (bin & 1) ? 0x10000u : 1u);
                 }
             }
-            if (cnt >= p.K || whole) break;
-            r += 1 + (r >> 2);
         }
-        // ---- 2. bin holding the K-th smallest ------------------------------------------------
-        int bstar = KNN_BINS - 1, before = 0;
-        {
+        __syncthreads();
+        // ---- bin of the K-th smallest, per query --------------------------------------------
+        int bstar = -1, need = 0;
+        if (active) {
             int cum = 0;
             bool found = false;
 #pragma unroll
             for (int h = 0; h < KNN_BINS / 2; ++h) {
                 const unsigned wv = s_hist[h][tid];
                 const int c0 = (int)(wv & 0xffffu), c1 = (int)(wv >> 16);
-                if (!found && cum + c0 >= p.K) { bstar = 2 * h; before = cum; found = true; }
+                if (!found && cum + c0 >= p.K) { bstar = 2 * h; need = p.K - cum; found = true; }
                 cum += c0;
-                if (!found && cum + c1 >= p.K) { bstar = 2 * h + 1; before = cum; found = true; }
+                if (!found && cum + c1 >= p.K) { bstar = 2 * h + 1; need = p.K - cum; found = true; }
                 cum += c1;
             }
+            if (!found) { fallback = true; atomicAdd(&dbg[3], 1); }   // fewer than K candidates below the ring bound
+            l_par[tid].w = (float)bstar;
         }
-        // ---- 3. the (K - before) smallest keys inside that bin, by repeated minimum ----------
-        const int need = p.K - before;
-        float ld = -1.f; int li = -1;               // last selected key
-        for (int it = 0; it < need; ++it) {
-            float bd = INFINITY; int bi = 0x7fffffff;
-            for (int yy = y0; yy <= y1; ++yy) {
-                const int js = cs[yy * p.wq + x0], je = cs[yy * p.wq + x1 + 1];
-                for (int j = js; j < je; ++j) {
-                    const float2 c = sp_[j];
-                    const float d = pair_dist(qy, qx, c.x, c.y, p.l1);
-                    if (!(d < upper)) continue;
-                    if (min((int)(d * scale), KNN_BINS - 1) != bstar) continue;
-                    const int id = si_[j];
-                    const bool gt_last = (d > ld) || (d == ld && id > li);
-                    const bool lt_best = (d < bd) || (d == bd && id < bi);
-                    if (gt_last && lt_best) { bd = d; bi = id; }
-                }
-            }
-            ld = bd; li = bi;
-        }
-        dK = ld;
-        const int iK = li;
-        // ---- 4. weighted sum of the neighbours' flows ----------------------------------------
-        const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
-        const size_t BQ = (size_t)p.B * p.nb * p.G;
-        const float2 *tmid = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
-        float norm = 0.f;
-        for (int tr = 0; tr < p.T; ++tr) {
-            const float2 *tref = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + tr) * p.n;
-            float sy = 0.f, sx = 0.f, sw = 0.f;
-            for (int yy = y0; yy <= y1; ++yy) {
-                const int js = cs[yy * p.wq + x0], je = cs[yy * p.wq + x1 + 1];
-                for (int j = js; j < je; ++j) {
-                    const float2 c = sp_[j];
-                    const float d = pair_dist(qy, qx, c.x, c.y, p.l1);
-                    const int id = si_[j];
-                    if ((d < dK) || (d == dK && id <= iK)) {
-                        const float2 a = tref[id];
-                        const float fy = a.x - c.x, fx = a.y - c.y;     // traj(t_ref) - traj(t_mid)
-                        if (p.iwd) {
-                            const float w = 1.f / (d + 1e-9f);
-                            sy += w * fy; sx += w * fx; sw += w;
-                        } else {
-                            sy += fy; sx += fx;
+        __syncthreads();                          // histograms are dead from here on (list aliases them)
+        // ---- pass 2: sum the flows below that bin, list the keys inside it ------------------
+        for (int i = tid; i < total; i += NT) {
+            const float2 pj = lpos[i];
+            const float2 f = lf0[i];
+            const long long fy_fix = to_fixed(f.x), fx_fix = to_fixed(f.y);
+            long long ny_fix = 0, nx_fix = 0;
+            if (has_next) { const float2 fn = lf1[i]; ny_fix = to_fixed(fn.x); nx_fix = to_fixed(fn.y); }
+            const int hy = cell_of(pj.x, p.sp, p.hq), hx = cell_of(pj.y, p.sp, p.wq);
+            const int ya = max(hy - rmax, ty0), yb = min(hy + rmax, ty1);
+            const int xa = max(hx - rmax, tx0), xb = min(hx + rmax, tx1);
+            for (int yy = ya; yy <= yb; ++yy) {
+                const float dy = ((float)(yy * p.sp) + p.off) - pj.x;
+                const float dy2 = p.l1 ? fabsf(dy) : dy * dy;
+                const int ady = abs(yy - hy);
+                for (int xx = xa; xx <= xb; ++xx) {
+                    const int ql = (yy - ty0) * 16 + (xx - tx0);
+                    const float4 par = l_par[ql];
+                    const float dx = ((float)(xx * p.sp) + p.off) - pj.y;
+                    const float d = dy2 + (p.l1 ? fabsf(dx) : dx * dx);
+                    if (!((float)max(ady, abs(xx - hx)) <= par.z && d < par.x)) continue;
+                    const float fb = (float)min((int)(d * par.y), KNN_BINS - 1);
+                    if (fb < par.w) {
+                        atomicAdd(&l_acc[0][ql], (unsigned long long)fy_fix);
+                        atomicAdd(&l_acc[1][ql], (unsigned long long)fx_fix);
+                        if (has_next) {
+                            atomicAdd(&l_acc[2][ql], (unsigned long long)ny_fix);
+                            atomicAdd(&l_acc[3][ql], (unsigned long long)nx_fix);
                         }
+                    } else if (fb == par.w) {
+                        const int slot = atomicAdd(&l_cnt[ql], 1);
+                        if (slot < KNN_LCAP) { l_ld[slot][ql] = d; l_li[slot][ql] = i; }
                     }
                 }
             }
-            float2 o;
-            if (p.iwd) { o.x = sy / sw; o.y = sx / sw; norm = sw; }
-            else { o.x = sy / (float)p.K; o.y = sx / (float)p.K; }
-            reinterpret_cast<float2 *>(flow_lut)[q * p.T + tr] = o;
         }
-        if (p.want_next && t < p.nb - 1) {
-            const float2 *tnx = tmid + p.n;
-            float sy = 0.f, sx = 0.f;
-            for (int yy = y0; yy <= y1; ++yy) {
-                const int js = cs[yy * p.wq + x0], je = cs[yy * p.wq + x1 + 1];
-                for (int j = js; j < je; ++j) {
-                    const float2 c = sp_[j];
-                    const float d = pair_dist(qy, qx, c.x, c.y, p.l1);
-                    const int id = si_[j];
-                    if ((d < dK) || (d == dK && id <= iK)) {
-                        const float2 a = tnx[id];
-                        sy += a.x - c.x; sx += a.y - c.y;
+        __syncthreads();
+        // ---- finish per query: the `need` smallest (distance, index) keys of the list ----------
+        if (active && !fallback) {
+            const int m = l_cnt[tid];
+            if (m > KNN_LCAP) {
+                fallback = true;
+                atomicAdd(&dbg[2], 1);
+            } else {
+                long long sy = (long long)l_acc[0][tid], sx = (long long)l_acc[1][tid];
+                long long ny = (long long)l_acc[2][tid], nx = (long long)l_acc[3][tid];
+                float kd = 0.f; int ki = -1;
+                for (int a = 0; a < m; ++a) {
+                    const float da = l_ld[a][tid]; const int la = l_li[a][tid]; const int ia = lidx[la];
+                    int rank = 0;
+                    for (int c = 0; c < m; ++c) {
+                        const float dc = l_ld[c][tid]; const int ic = lidx[l_li[c][tid]];
+                        rank += (dc < da || (dc == da && ic < ia)) ? 1 : 0;
+                    }
+                    if (rank < need) {
+                        const float2 f = lf0[la];
+                        sy += to_fixed(f.x); sx += to_fixed(f.y);
+                        if (has_next) { const float2 fn = lf1[la]; ny += to_fixed(fn.x); nx += to_fixed(fn.y); }
+                        if (rank == need - 1) { kd = da; ki = ia; }
                     }
                 }
-            }
-            float2 o; o.x = sy / (float)p.K; o.y = sx / (float)p.K;
-            reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = o;
-        }
-        knn_state[q] = dK;
-        reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
-        knn_state[2 * BQ + q] = norm;
-        // ---- 5. optional: the K indices in ascending (distance, index) order -----------------
-        if (idx_out != nullptr) {
-            float pd = -1.f; int pi = -1;
-            for (int k = 0; k < p.K; ++k) {
-                float bd = INFINITY; int bi = 0x7fffffff;
-                for (int yy = y0; yy <= y1; ++yy) {
-                    const int js = cs[yy * p.wq + x0], je = cs[yy * p.wq + x1 + 1];
-                    for (int j = js; j < je; ++j) {
-                        const float2 c = sp_[j];
-                        const float d = pair_dist(qy, qx, c.x, c.y, p.l1);
-                        const int id = si_[j];
-                        const bool gt_last = (d > pd) || (d == pd && id > pi);
-                        const bool lt_best = (d < bd) || (d == bd && id < bi);
-                        if (gt_last && lt_best) { bd = d; bi = id; }
-                    }
+                const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
+                const size_t BQ = (size_t)p.B * p.nb * p.G;
+                float2 ov;
+                ov.x = from_fixed(sy) / (float)p.K;
+                ov.y = from_fixed(sx) / (float)p.K;
+                reinterpret_cast<float2 *>(flow_lut)[q] = ov;
+                if (has_next) {
+                    float2 on; on.x = from_fixed(ny) / (float)p.K; on.y = from_fixed(nx) / (float)p.K;
+                    reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
                 }
-                pd = bd; pi = bi;
-                idx_out[q * p.K + k] = bi;
+                knn_state[q] = kd;
+                reinterpret_cast<int *>(knn_state)[BQ + q] = ki;
+                knn_state[2 * BQ + q] = 0.f;
+                dK = kd;
             }
         }
     }
-    // largest K-th distance of this (sample, bin): bounds the backward's search window
-    unsigned m = __float_as_uint(dK);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down((int)m, o, 64));
-    if ((tid & 63) == 0) s_max[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0) atomicMax(&rmax[bt], max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+    // ---- queries the tile pass could not serve, and the optional sorted index output ------------
+    if (!staged && tid == 0) atomicAdd(&dbg[1], 1);
+    if (active && (fallback || idx_out != nullptr)) {
+        if (fallback) atomicAdd(&dbg[0], 1);
+        QueryCtx c;
+        c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
+        c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
+        c.ry0 = c.rx0 = c.RW = c.RH = 0;
+        knn_one_query<false>(p, c, b, t, cy, cx, r_base, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+    }
+    // largest K-th distance of this tile: bounds the backward's search windows
+    float m = dK;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_down(m, o2, 64));
+    if ((tid & 63) == 0) s_maxf[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float mm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) mm = fmaxf(mm, s_maxf[w]);
+        tile_dkmax[((size_t)bt * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: one thread per (sample, trajectory point); loops over the bins and gathers the
-// gradient of every query cell that has this point among its K nearest.
+// backward, step 1: one thread per bucketed trajectory point of a 16x16 cell tile.  The K-th
+// keys and LUT gradients of the tile and a halo of RQ cells are staged in LDS; each point scans
+// the query cells within the largest K-th distance of its (sample, bin) and gathers the gradient
+// of every cell that has the point among its K nearest.  Writes per-(bin, point) partials.
+// grid (ceil(wq/16), ceil(hq/16), B*nb), 256 threads, dynamic LDS
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_knn_bwd(const KnnParams p, const float *__restrict__ traj,
-                                                 const float *__restrict__ glut,
-                                                 const float *__restrict__ gnext,
-                                                 const float *__restrict__ knn_state,
-                                                 const unsigned *__restrict__ rmax,
-                                                 float *__restrict__ gtraj) {
-    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gi >= (size_t)p.B * p.n) return;
-    const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
+#define KNN_RQ_MAX 7
+__global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const int *__restrict__ cell_start,
+                                                        const float2 *__restrict__ spos,
+                                                        const int *__restrict__ sidx,
+                                                        const float *__restrict__ glut,
+                                                        const float *__restrict__ gnext,
+                                                        const float *__restrict__ knn_state,
+                                                        const float *__restrict__ tile_dkmax,
+                                                        float2 *__restrict__ tmp_g,   // [B*nb][n][T]
+                                                        float2 *__restrict__ tmp_a) { // [B*nb][n]
+    extern __shared__ unsigned char s_dyn[];
+    __shared__ int s_rowbase[17];
+    __shared__ int s_rowg[16];
+    const int tid = threadIdx.x;
+    const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const float2 *tr2 = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
-    float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (p.T + p.nb) * p.n;
-    for (int tr = 0; tr < p.T; ++tr) g2[(size_t)tr * p.n + i] = make_float2(0.f, 0.f);
-    float2 carry = make_float2(0.f, 0.f);   // flow_to_next term arriving from bin t-1
+    // Reach of this tile's points: the largest K-th distance among the tiles whose queries can
+    // reach into this tile at all (Chebyshev gap between our cell areas and their query centres).
+    __shared__ float s_R[4];
+    {
+        const int ntx = gridDim.x, nty = gridDim.y;
+        const float ay0 = (float)(blockIdx.y * 16 * p.sp) - 0.5f, ay1 = (float)(min(blockIdx.y * 16 + 16, (unsigned)p.hq) * p.sp) - 0.5f;
+        const float ax0 = (float)(blockIdx.x * 16 * p.sp) - 0.5f, ax1 = (float)(min(blockIdx.x * 16 + 16, (unsigned)p.wq) * p.sp) - 0.5f;
+        float rloc = 0.f;
+        for (int tb = tid; tb < ntx * nty; tb += 256) {
+            const int by = tb / ntx, bx = tb - by * ntx;
+            const float dk = tile_dkmax[(size_t)bt * ntx * nty + tb];
+            const float lin = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
+            const float qy0 = (float)(by * 16 * p.sp) + p.off, qy1 = (float)((min(by * 16 + 16, p.hq) - 1) * p.sp) + p.off;
+            const float qx0 = (float)(bx * 16 * p.sp) + p.off, qx1 = (float)((min(bx * 16 + 16, p.wq) - 1) * p.sp) + p.off;
+            const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
+            const float gx = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
+            if (lin >= fmaxf(gy, gx)) rloc = fmaxf(rloc, lin);
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) rloc = fmaxf(rloc, __shfl_down(rloc, o2, 64));
+        if ((tid & 63) == 0) s_R[tid >> 6] = rloc;
+        __syncthreads();
+    }
+    const float R = fmaxf(fmaxf(s_R[0], s_R[1]), fmaxf(s_R[2], s_R[3]));
+    const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;
+    const bool use_lds = RQ_need <= KNN_RQ_MAX;
+    const int RQ = use_lds ? RQ_need : 0;
+    const int RW = 16 + 2 * RQ;
+    const int ry0 = blockIdx.y * 16 - RQ, rx0 = blockIdx.x * 16 - RQ;
+    float *ldK = reinterpret_cast<float *>(s_dyn);
+    int *liK = reinterpret_cast<int *>(s_dyn + (size_t)RW * RW * 4);
+    float *lnorm = reinterpret_cast<float *>(s_dyn + (size_t)RW * RW * 8);
+    float2 *lg = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 12);
+    float2 *lgn = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 20);
+    const bool has_next = (gnext != nullptr) && (t < p.nb - 1);
+    const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
+    const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G * p.T;
+    if (use_lds) {
+        for (int i = tid; i < RW * RW; i += 256) {
+            const int rr = i / RW, cc = i - rr * RW;
+            const int yy = ry0 + rr, xx = rx0 + cc;
+            float dk = -1.f, nm = 1.f; int ik = -1;
+            float2 g = make_float2(0.f, 0.f), gn = make_float2(0.f, 0.f);
+            if (yy >= 0 && yy < p.hq && xx >= 0 && xx < p.wq) {
+                const size_t q = (size_t)bt * p.G + (size_t)yy * p.wq + xx;
+                dk = knn_state[q];
+                ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                if (p.iwd) nm = knn_state[2 * BQ + q];
+                if (p.T == 1) g = gl2[(size_t)yy * p.wq + xx];
+                if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
+            }
+            ldK[i] = dk; liK[i] = ik; lnorm[i] = nm; lg[i] = g; lgn[i] = gn;
+        }
+    }
+    // points of the tile: per tile row a contiguous range of the bucketed arrays
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    if (tid < 16) {
+        const int yy = blockIdx.y * 16 + tid;
+        int gs = 0, ge = 0;
+        if (yy < p.hq) {
+            const int xa = blockIdx.x * 16, xb = min(xa + 16, p.wq);
+            gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
+        }
+        s_rowg[tid] = gs;
+        s_rowbase[tid + 1] = ge - gs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        s_rowbase[0] = 0;
+        for (int rr = 0; rr < 16; ++rr) { const int c = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + c; run += c; }
+    }
+    __syncthreads();
+    const int total = s_rowbase[16];
     const float invK = 1.f / (float)p.K;
-    for (int t = 0; t < p.nb; ++t) {
-        const int bt = b * p.nb + t;
-        const float2 pt = tr2[(size_t)(p.T + t) * p.n + i];
-        const float rm = __uint_as_float(rmax[bt]);
-        const float R = (p.l1 ? rm : sqrtf(rm)) * 1.0001f + 0.01f;
+    const float2 *sp_ = spos + (size_t)bt * p.n;
+    const int *si_ = sidx + (size_t)bt * p.n;
+    for (int pi = tid; pi < total; pi += 256) {
+        int lo = 0, hi = 16;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
+        const int g = s_rowg[lo] + (pi - s_rowbase[lo]);
+        const float2 pt = sp_[g];
+        const int i = si_[g];
         int y0 = (int)ceilf((pt.x - R - p.off) / (float)p.sp) - 1;
         int y1 = (int)floorf((pt.x + R - p.off) / (float)p.sp) + 1;
         int x0 = (int)ceilf((pt.y - R - p.off) / (float)p.sp) - 1;
         int x1 = (int)floorf((pt.y + R - p.off) / (float)p.sp) + 1;
         y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, p.hq - 1); x1 = min(x1, p.wq - 1);
-        float2 gmid = make_float2(0.f, 0.f);      // d loss / d traj(t_mid)[b,t,i]
+        if (use_lds) {   // the staged region always covers the window (see the note on clamped cells)
+            y0 = max(y0, ry0); x0 = max(x0, rx0); y1 = min(y1, ry0 + RW - 1); x1 = min(x1, rx0 + RW - 1);
+        }
+        float2 an = make_float2(0.f, 0.f);
         for (int tr = 0; tr < p.T; ++tr) {
             float ay = 0.f, ax = 0.f;
             for (int cy = y0; cy <= y1; ++cy) {
                 const float qy = (float)(cy * p.sp) + p.off;
                 for (int cx = x0; cx <= x1; ++cx) {
                     const float qx = (float)(cx * p.sp) + p.off;
-                    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
                     const float d = pair_dist(qy, qx, pt.x, pt.y, p.l1);
-                    const float dK = knn_state[q];
-                    if (d < dK || (d == dK && i <= reinterpret_cast<const int *>(knn_state)[BQ + q])) {
-                        const float w = p.iwd ? (1.f / (d + 1e-9f)) / knn_state[2 * BQ + q] : invK;
-                        const float2 g = reinterpret_cast<const float2 *>(glut)[q * p.T + tr];
-                        ay += w * g.x; ax += w * g.y;
+                    float dk, nm; int ik; float2 gq, gnq;
+                    if (use_lds) {
+                        const int li = (cy - ry0) * RW + (cx - rx0);
+                        dk = ldK[li];
+                        if (d > dk) continue;
+                        ik = liK[li];
+                        if (d == dk && i > ik) continue;
+                        nm = lnorm[li];
+                        gq = (p.T == 1) ? lg[li] : gl2[((size_t)cy * p.wq + cx) * p.T + tr];
+                        gnq = lgn[li];
+                    } else {
+                        const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
+                        dk = knn_state[q];
+                        if (d > dk) continue;
+                        ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                        if (d == dk && i > ik) continue;
+                        nm = p.iwd ? knn_state[2 * BQ + q] : 1.f;
+                        gq = gl2[((size_t)cy * p.wq + cx) * p.T + tr];
+                        gnq = has_next ? gn2[(size_t)cy * p.wq + cx] : make_float2(0.f, 0.f);
                     }
+                    const float w = p.iwd ? (1.f / (d + 1e-9f)) / nm : invK;
+                    ay += w * gq.x; ax += w * gq.y;
+                    if (tr == 0 && has_next) { an.x += invK * gnq.x; an.y += invK * gnq.y; }
                 }
             }
-            float2 cur = g2[(size_t)tr * p.n + i];
-            cur.x += ay; cur.y += ax;
-            g2[(size_t)tr * p.n + i] = cur;
-            gmid.x -= ay; gmid.y -= ax;
+            tmp_g[((size_t)bt * p.n + i) * p.T + tr] = make_float2(ay, ax);
         }
-        gmid.x += carry.x; gmid.y += carry.y;
-        carry = make_float2(0.f, 0.f);
-        if (gnext != nullptr && t < p.nb - 1) {
-            float ay = 0.f, ax = 0.f;
-            for (int cy = y0; cy <= y1; ++cy) {
-                const float qy = (float)(cy * p.sp) + p.off;
-                for (int cx = x0; cx <= x1; ++cx) {
-                    const float qx = (float)(cx * p.sp) + p.off;
-                    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
-                    const float d = pair_dist(qy, qx, pt.x, pt.y, p.l1);
-                    const float dK = knn_state[q];
-                    if (d < dK || (d == dK && i <= reinterpret_cast<const int *>(knn_state)[BQ + q])) {
-                        const float2 g = reinterpret_cast<const float2 *>(gnext)[(size_t)(b * (p.nb - 1) + t) * p.G + (size_t)cy * p.wq + cx];
-                        ay += invK * g.x; ax += invK * g.y;
-                    }
-                }
-            }
-            gmid.x -= ay; gmid.y -= ax;
-            carry = make_float2(ay, ax);
+        tmp_a[(size_t)bt * p.n + i] = an;
+    }
+}
+
+// backward, step 2: one thread per (sample, trajectory point): combine the per-bin partials.
+//   d traj(t_ref)[tr] = sum_t g[t][tr];   d traj(t_mid)[t] = -sum_tr g[t][tr] - a[t] + a[t-1]
+__global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, const float2 *__restrict__ tmp_g,
+                                                         const float2 *__restrict__ tmp_a,
+                                                         float *__restrict__ gtraj) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= (size_t)p.B * p.n) return;
+    const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
+    float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (p.T + p.nb) * p.n;
+    for (int tr = 0; tr < p.T; ++tr) {
+        float sy = 0.f, sx = 0.f;
+        for (int t = 0; t < p.nb; ++t) {
+            const float2 g = tmp_g[((size_t)(b * p.nb + t) * p.n + i) * p.T + tr];
+            sy += g.x; sx += g.y;
         }
-        g2[(size_t)(p.T + t) * p.n + i] = gmid;
+        g2[(size_t)tr * p.n + i] = make_float2(sy, sx);
+    }
+    float2 carry = make_float2(0.f, 0.f);
+    for (int t = 0; t < p.nb; ++t) {
+        float my = 0.f, mx = 0.f;
+        for (int tr = 0; tr < p.T; ++tr) {
+            const float2 g = tmp_g[((size_t)(b * p.nb + t) * p.n + i) * p.T + tr];
+            my -= g.x; mx -= g.y;
+        }
+        const float2 a = tmp_a[(size_t)(b * p.nb + t) * p.n + i];
+        my += carry.x - a.x; mx += carry.y - a.y;
+        carry = a;
+        g2[(size_t)(p.T + t) * p.n + i] = make_float2(my, mx);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
+static int set_max_lds(const void *fn, const char *who) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) { mpc_set_error("%s: %s", who, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                                float *knn_state, int32_t *idx_out, void *ws, void *stream) {
     MPC_CHECK_ARG(s && traj && flow_lut && knn_state && ws, MPC_E_NULL, "null argument");
@@ -374,26 +968,65 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     MPC_CHECK_ARG(s->n < 65536, MPC_E_UNSUPPORTED, "more than 65535 trajectories per sample");
     const KnnParams p = knn_params(s);
     MPC_CHECK_ARG((size_t)p.G * 4 <= 150 * 1024, MPC_E_UNSUPPORTED, "LUT grid too large for the LDS counting sort");
+    if (s->B == 0) return 0;
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
     int *cell_start = (int *)((char *)ws + L.off_cell_start);
     float2 *spos = (float2 *)((char *)ws + L.off_spos);
     int *sidx = (int *)((char *)ws + L.off_sidx);
-    unsigned *rmax = reinterpret_cast<unsigned *>(knn_state) + 3 * (size_t)s->B * s->nb * p.G;
+    float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_knn_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        if ((rc = set_max_lds((const void *)k_knn_bucket, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_query, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_query_tile, __func__))) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_knn_bucket, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx, rmax);
+    (void)hipMemsetAsync((char *)ws + L.off_counts, 0, 32, st);      // statistics of the query kernel (tests, tuning)
+    hipLaunchKernelGGL(k_knn_bucket, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
     MPC_CHECK_LAUNCH();
-    // smallest square that can hold K points at one point per cell and pass the ring bound
-    int r_init = (int)ceil(sqrt((double)s->K / 3.14159265) * ((double)s->n > 0 ? sqrt((double)p.G / (double)s->n) : 1.0) - 0.5);
+    // smallest square that can hold K points at the mean point density and pass the ring bound
+    const double dens = (double)s->n / (double)p.G;
+    int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
     if (r_init < 1) r_init = 1;
     const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
-    hipLaunchKernelGGL(k_knn_query, grid, dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut,
-                       flow_next, knn_state, idx_out, rmax, r_init);
+    // tuning switch (A/B measurements): MPC_KNN_MODE = thread (default) | tile | global.
+    // Measured at B=14, 480x640, K=32 (round 1): thread 934 us, global 947 us, tile 2053 us.
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("MPC_KNN_MODE");
+        mode = (e && e[0] == 't' && e[1] == 'i') ? 0 : ((e && e[0] == 'g') ? 2 : 1);
+    }
+    if (s->T == 1 && !p.iwd && mode == 0) {
+        // one ring of slack over the tight radius: a jittered lattice then almost never fails the
+        // "K candidates below the ring bound" test; border queries enlarge their own radius
+        const int r_base = r_init + 1;
+        int RH = 2 * r_base;                      // a corner query sees a quarter of its square
+        if (RH > 32) RH = 32;
+        const size_t per_pt = 8 + 8 + 4 + (p.want_next ? 8 : 0);
+        const size_t fixed = (size_t)(KNN_BINS / 2) * 256 * 4 + 4 * 256 * 8 + 256 * 16 + 256 * 4 + 64;
+        const size_t budget = 52 * 1024;
+        int cap = (int)((budget - fixed) / per_pt / 64 * 64);
+        if (cap < 64) cap = 64;
+        const size_t lds = fixed + per_pt * cap;
+        hipLaunchKernelGGL(k_knn_query_tile, grid, dim3(KNN_TILE_THREADS), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+                           flow_next, knn_state, idx_out, tile_dkmax, r_base, RH, cap, (int *)((char *)ws + L.off_counts));
+    } else {
+        int RH = r_init + 1;
+        if (RH > 16) RH = 16;
+        const int RW = 16 + 2 * RH;
+        int cap = (int)(2.0 * dens * RW * RW) + 256;
+        cap = (cap + 63) / 64 * 64;
+        const size_t per_pt = 8 + 4 + (s->T == 1 ? 8 : 0) + (p.want_next ? 8 : 0);
+        const size_t fixed = (size_t)(KNN_BINS / 2) * 256 * 4 + (size_t)RW * (RW + 1) * 4 + 64;
+        const size_t budget = 64 * 1024;
+        if (fixed + per_pt * cap > budget) cap = (int)((budget - fixed) / per_pt / 64 * 64);
+        if (cap < 64) cap = 64;
+        if (mode == 2) cap = 0;                    // nothing staged: every query searches the global arrays
+        const size_t lds = fixed + per_pt * cap;
+        hipLaunchKernelGGL(k_knn_query, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap);
+    }
     MPC_CHECK_LAUNCH();
     return 0;
 }
@@ -404,11 +1037,29 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     MPC_CHECK_ARG(s && traj && grad_flow_lut && knn_state && grad_traj && ws, MPC_E_NULL, "null argument");
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
+    if (s->B == 0) return 0;
     const KnnParams p = knn_params(s);
-    const unsigned *rmax = reinterpret_cast<const unsigned *>(knn_state) + 3 * (size_t)s->B * s->nb * p.G;
+    const mpc_ws_layout L = mpc_layout(s);
+    hipStream_t st = (hipStream_t)stream;
+    const int *cell_start = (const int *)((char *)ws + L.off_cell_start);
+    const float2 *spos = (const float2 *)((char *)ws + L.off_spos);
+    const int *sidx = (const int *)((char *)ws + L.off_sidx);
+    float2 *tmp_g = (float2 *)((char *)ws + L.off_knn_tmp_g);
+    float2 *tmp_a = (float2 *)((char *)ws + L.off_knn_tmp_a);
+    const float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if ((rc = set_max_lds((const void *)k_knn_bwd_points, __func__))) return rc;
+        attr_set = true;
+    }
+    const int RWmax = 16 + 2 * KNN_RQ_MAX;
+    const size_t lds = (size_t)RWmax * RWmax * 28;
+    const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
+    hipLaunchKernelGGL(k_knn_bwd_points, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
+                       grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a);
+    MPC_CHECK_LAUNCH();
     const int64_t total = (int64_t)s->B * s->n;
-    hipLaunchKernelGGL(k_knn_bwd, dim3(mpc_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, p, traj,
-                       grad_flow_lut, grad_flow_next, knn_state, rmax, grad_traj);
+    hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g, tmp_a, grad_traj);
     MPC_CHECK_LAUNCH();
     return 0;
 }
