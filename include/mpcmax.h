@@ -45,6 +45,7 @@ extern "C" {
 #define MPC_F_NO_WARP         (1u << 8)  /* splat events at their own (y,x): imager.create_iwe on raw events, logging.py:76-79 */
 #define MPC_F_UNIT_WEIGHT     (1u << 9)  /* weight = 1.0 for every row (create_iwe default weight) */
 #define MPC_F_ATOMIC_PATH     (1u << 10) /* debugging: plain global-atomic kernels instead of the LDS-tiled ones */
+#define MPC_F_NO_BWD_RECORDS  (1u << 11) /* forward only: mpc_event_splat_fwd need not keep records for _bwd */
 
 /* argument errors */
 #define MPC_E_NULL      (-1)

@@ -19,6 +19,7 @@ F_WANT_NEXT = 1 << 7
 F_NO_WARP = 1 << 8
 F_UNIT_WEIGHT = 1 << 9
 F_ATOMIC_PATH = 1 << 10
+F_NO_BWD_RECORDS = 1 << 11
 
 SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 3, 4, 8
 

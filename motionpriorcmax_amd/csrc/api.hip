@@ -50,6 +50,36 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(int32_t));
     L.off_knn_tmp_g = off;  off += mpc_align(bt * (int64_t)s->n * s->T * 2 * sizeof(float));
     L.off_knn_tmp_a = off;  off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
+    // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
+    const int64_t lds_budget = 150 * 1024;
+    L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));
+    if (L.strip_rows > s->H) L.strip_rows = s->H;
+    L.cstrip_rows = (int)(lds_budget / ((int64_t)s->wq * 16));
+    if (L.cstrip_rows > s->hq) L.cstrip_rows = s->hq;
+    if (L.strip_rows > 0 && L.cstrip_rows > 0 && s->T == 1 && s->B > 0 && !(s->flags & MPC_F_ATOMIC_PATH)) {
+        L.n_strips = mpc_cdiv(s->H, L.strip_rows);
+        L.strip_rows = mpc_cdiv(s->H, L.n_strips);          // equalise the strips
+        L.n_cstrips = mpc_cdiv(s->hq, L.cstrip_rows);
+        L.cstrip_rows = mpc_cdiv(s->hq, L.n_cstrips);
+        L.nfb = s->B * L.P * L.n_strips;
+        L.nbb = s->B * s->nb * L.n_cstrips;
+        const int64_t mpol = (L.P == 2) ? (s->Mp > s->M - s->Mp ? s->Mp : s->M - s->Mp) : s->M;
+        int64_t fc = 4 * ((mpol + L.n_strips - 1) / L.n_strips);
+        if (fc < 8192) fc = 8192;
+        if (fc > mpol) fc = mpol;
+        int64_t bc = 4 * (((int64_t)s->M + (int64_t)s->nb * L.n_cstrips - 1) / ((int64_t)s->nb * L.n_cstrips));
+        if (bc < 8192) bc = 8192;
+        if (bc > s->M) bc = s->M;
+        L.fcap = (int)(fc > 0 ? fc : 1);
+        L.bcap = (int)(bc > 0 ? bc : 1);
+        L.off_fcount = off; off += mpc_align((int64_t)(L.nfb + L.nbb + 8) * sizeof(int32_t));
+        L.off_frec = off;   off += mpc_align((int64_t)L.nfb * L.fcap * 16);
+        L.off_brec = off;   off += mpc_align((int64_t)L.nbb * L.bcap * 16);
+        L.off_fovf = off;   off += mpc_align((int64_t)2 * s->B * s->M * 16 + 16);
+        L.off_bovf = off;   off += mpc_align((int64_t)s->B * s->M * 16 + 16);
+    } else {
+        L.strip_rows = L.cstrip_rows = 0;
+    }
     L.total = off;
     return L;
 }

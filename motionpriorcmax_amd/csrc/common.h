@@ -43,10 +43,11 @@ struct mpc_ws_layout {
     int64_t off_knn_tmp_g;   // float2 [B*nb][n][T]  backward partials
     int64_t off_knn_tmp_a;   // float2 [B*nb][n]
     // event partition (LDS-tiled path)
-    int64_t off_fcount;      // int32 [nfb]  fill counters of the forward buckets
-    int64_t off_bcount;      // int32 [nbb]  fill counters of the backward buckets
+    int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, spill counters, marker
     int64_t off_frec;        // float4 [nfb][fcap]
     int64_t off_brec;        // float4 [nbb][bcap]
+    int64_t off_fovf;        // float4 [2*B*M]  forward spill list
+    int64_t off_bovf;        // float4 [B*M]    backward spill list
     int32_t P, nimg, G;
     int32_t strip_rows, n_strips;   // destination strips of the IWE (forward buckets)
     int32_t cstrip_rows, n_cstrips; // source strips of LUT cell rows (backward buckets)

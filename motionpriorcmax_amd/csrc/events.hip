@@ -151,6 +151,282 @@ __global__ __launch_bounds__(256) void k_splat_bwd_atomic(const mpc_shape s,
     }
 }
 
+// ==========================================================================================
+// v1: LDS-tiled path (num_tref == 1)
+//
+//   forward   k_ev_bin     one pass over the events: warp, weight, and append a 16-byte record to
+//                          (a) the bucket of the destination strip(s) of the image it votes into
+//                          and (b) the bucket of its (time bin, source LUT strip) for the backward
+//             k_iwe_accum  one workgroup per (image, strip): the strip lives in LDS as 64-bit
+//                          fixed point (Q33.30), records are voted with ds_add_u64 -- the global
+//                          scatter becomes an on-chip accumulate -- and the strip is written once
+//                          with plain coalesced stores (no zero-fill, no global atomics)
+//   backward  k_lut_accum  one workgroup per (sample, bin, LUT strip): gathers the 4 taps of the
+//                          adjoint image per record and accumulates d/dLUT in LDS (Q33.30)
+//   overflow  records beyond a bucket's capacity go to a spill list and are applied afterwards
+//             with global atomics (exact for any event distribution; empty in the common case)
+//
+// Why fixed point: on gfx950 ds_add_f32 serialises the wave (~193 cycles per instruction) while
+// ds_add_u64 takes ~8-12 (profiles/r01_ubench_lds_atomics.txt).  Q33.30 resolves 9.3e-10, finer
+// than fp32 accumulation of the same taps, and integer sums are order independent, so the
+// image is bitwise reproducible from run to run.
+// ==========================================================================================
+#define EV_PER_THREAD 4
+#define EV_FIX_SHIFT 30
+#define EV_MARKER 0x6d706331   // 'mpc1': backward records of this workspace are valid
+
+struct BinLayout {
+    int SR, NS, CSR, NCS, NF, NBk, fcap, bcap, P;
+    int *gcount;            // [NF + NBk + 8]
+    float4 *frec, *brec;    // bucket storage
+    float4 *fovf, *bovf;    // spill lists
+};
+
+__device__ __forceinline__ long long ev_to_fixed_small(float v) {   // |v| < 2
+    return (long long)(int)(v * (float)(1 << EV_FIX_SHIFT));
+}
+__device__ __forceinline__ long long ev_to_fixed(float v) {         // |v| < 2^31
+    const float hi = truncf(v);
+    return ((long long)(int)hi << EV_FIX_SHIFT) + (long long)(int)((v - hi) * (float)(1 << EV_FIX_SHIFT));
+}
+__device__ __forceinline__ float ev_from_fixed(long long a) {
+    return (float)((double)a * (1.0 / (double)(1 << EV_FIX_SHIFT)));
+}
+
+// grid (ceil(M / (256*EV_PER_THREAD)), B), 256 threads, dynamic LDS = (P*NS + nb*NCS) * 2 ints
+__global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayout L,
+                                                const float *__restrict__ events,
+                                                const float *__restrict__ lut,
+                                                const float *__restrict__ t_ref, int want_bwd) {
+    extern __shared__ int s_cnt[];          // [nloc] local counts, then [nloc] global bases
+    const EvParams p = make_params(s);
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int nf_loc = p.P * L.NS, nb_loc = want_bwd ? p.nb * L.NCS : 0, nloc = nf_loc + nb_loc;
+    int *s_base = s_cnt + nloc;
+    for (int i = tid; i < nloc; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    const float tref = (p.flags & MPC_F_SCALE_BY_DT) ? t_ref[0] : 0.f;
+
+    float ry[EV_PER_THREAD], rx[EV_PER_THREAD], rw[EV_PER_THREAD];
+    int f0[EV_PER_THREAD], f1[EV_PER_THREAD], bk[EV_PER_THREAD];     // local bucket ids (-1: none)
+    int r0[EV_PER_THREAD], r1[EV_PER_THREAD], rb[EV_PER_THREAD];     // ranks inside the block
+    unsigned aux[EV_PER_THREAD];
+    int lutidx[EV_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < EV_PER_THREAD; ++k) {
+        const int i = (blockIdx.x * EV_PER_THREAD + k) * 256 + tid;
+        f0[k] = f1[k] = bk[k] = -1;
+        r0[k] = r1[k] = rb[k] = 0;
+        ry[k] = rx[k] = rw[k] = 0.f; aux[k] = 0u; lutidx[k] = 0;
+        if (i >= p.M) continue;
+        float e[6];
+        load_event(events, (size_t)b * p.M + i, e);
+        Warped o;
+        if (!warp_event(p, e, b, 0, lut, tref, o)) continue;
+        const bool xin = (o.x0 + 1 >= 0) && (o.x0 < p.W);
+        const bool yin0 = o.y0 >= 0 && o.y0 < p.H, yin1 = o.y0 + 1 >= 0 && o.y0 + 1 < p.H;
+        if (!xin || !(yin0 || yin1)) continue;            // no tap inside the image
+        const int pol = (p.P == 2 && i >= p.Mp) ? 1 : 0;
+        ry[k] = o.y; rx[k] = o.x; rw[k] = o.w;
+        const int s0 = yin0 ? o.y0 / L.SR : -1, s1 = yin1 ? (o.y0 + 1) / L.SR : -1;
+        if (s0 >= 0) { f0[k] = pol * L.NS + s0; r0[k] = atomicAdd(&s_cnt[f0[k]], 1); }
+        if (s1 >= 0 && s1 != s0) { f1[k] = pol * L.NS + s1; r1[k] = atomicAdd(&s_cnt[f1[k]], 1); }
+        if (want_bwd && o.lut >= 0) {
+            // o.lut = ((b*nb + it)*hq + iy)*wq + ix   (T == 1)
+            const int cell = o.lut - (b * p.nb) * p.hq * p.wq;
+            const int it = cell / (p.hq * p.wq), rem = cell - it * p.hq * p.wq;
+            const int iy = rem / p.wq;
+            const int cst = iy / L.CSR;
+            bk[k] = nf_loc + it * L.NCS + cst;
+            rb[k] = atomicAdd(&s_cnt[bk[k]], 1);
+            aux[k] = ((unsigned)pol << 31) | (unsigned)(rem - cst * L.CSR * p.wq);
+            lutidx[k] = o.lut;
+        }
+    }
+    __syncthreads();
+    // reserve the block's slots in the global buckets
+    for (int i = tid; i < nloc; i += 256) {
+        const int c = s_cnt[i];
+        int g;
+        if (i < nf_loc) g = (b * p.P + i / L.NS) * L.NS + (i % L.NS);
+        else g = L.NF + b * p.nb * L.NCS + (i - nf_loc);
+        s_base[i] = c > 0 ? atomicAdd(&L.gcount[g], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EV_PER_THREAD; ++k) {
+        const int pol = (int)(aux[k] >> 31);
+        if (f0[k] >= 0 || f1[k] >= 0) {
+            const int polf = (f0[k] >= 0 ? f0[k] : f1[k]) / L.NS;
+            const float4 rec = make_float4(ry[k], rx[k], rw[k], __int_as_float(b * p.P + polf));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int lb = h ? f1[k] : f0[k];
+                if (lb < 0) continue;
+                const int slot = s_base[lb] + (h ? r1[k] : r0[k]);
+                const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
+                if (slot < L.fcap) L.frec[(size_t)g * L.fcap + slot] = rec;
+                else {
+                    // spill: the strip id rides in the sign-free high bits of the image id
+                    const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 0], 1);
+                    L.fovf[ov] = make_float4(ry[k], rx[k], rw[k], __int_as_float(((lb % L.NS) << 20) | (b * p.P + polf)));
+                }
+            }
+        }
+        if (bk[k] >= 0) {
+            const int slot = s_base[bk[k]] + rb[k];
+            const int g = L.NF + b * p.nb * L.NCS + (bk[k] - nf_loc);
+            if (slot < L.bcap) L.brec[(size_t)(g - L.NF) * L.bcap + slot] = make_float4(ry[k], rx[k], rw[k], __uint_as_float(aux[k]));
+            else {
+                const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 1], 1);
+                L.bovf[ov] = make_float4(ry[k], rx[k], rw[k], __uint_as_float(((unsigned)pol << 31) | (unsigned)lutidx[k]));
+            }
+        }
+    }
+    if (want_bwd && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) L.gcount[L.NF + L.NBk + 2] = EV_MARKER;
+}
+
+// taps of one record restricted to rows [row0, row1): calls f(yy, xx, value)
+template <typename F>
+__device__ __forceinline__ void record_taps(float y, float x, float w, int H, int W, int row0, int row1, F f) {
+    const float y0f = floorf(y + 1e-6f), x0f = floorf(x + 1e-6f);
+    const float fy = y - y0f, fx = x - x0f;
+    const int y0 = (int)fminf(fmaxf(y0f, -4.f), (float)H + 4.f), x0 = (int)fminf(fmaxf(x0f, -4.f), (float)W + 4.f);
+    const bool r0 = y0 >= row0 && y0 < row1, r1 = y0 + 1 >= row0 && y0 + 1 < row1;
+    const bool c0 = x0 >= 0 && x0 < W, c1 = x0 + 1 >= 0 && x0 + 1 < W;
+    if (r0 && c0) f(y0, x0, (1.f - fy) * (1.f - fx) * w);
+    if (r1 && c0) f(y0 + 1, x0, fy * (1.f - fx) * w);
+    if (r0 && c1) f(y0, x0 + 1, (1.f - fy) * fx * w);
+    if (r1 && c1) f(y0 + 1, x0 + 1, fy * fx * w);
+}
+
+// grid NF, 1024 threads, dynamic LDS = SR * W * 8 bytes
+__global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__restrict__ iwe, int H, int W) {
+    extern __shared__ unsigned long long s_acc[];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x, img = g / L.NS, strip = g - img * L.NS;
+    const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
+    const int npix = (row1 - row0) * W;
+    for (int i = tid; i < npix; i += 1024) s_acc[i] = 0ull;
+    __syncthreads();
+    const int n = min(L.gcount[g], L.fcap);
+    const float4 *rec = L.frec + (size_t)g * L.fcap;
+    for (int r = tid; r < n; r += 1024) {
+        const float4 e = rec[r];
+        record_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) {
+            atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed_small(v));
+        });
+    }
+    __syncthreads();
+    float *dst = iwe + ((size_t)img * H + row0) * W;
+    for (int i = tid; i < npix; i += 1024) dst[i] = ev_from_fixed((long long)s_acc[i]);
+}
+
+// spill records of the forward pass (rare): global float atomics after the strips were written
+__global__ __launch_bounds__(256) void k_iwe_overflow(const BinLayout L, float *__restrict__ iwe, int H, int W) {
+    const int n = L.gcount[L.NF + L.NBk + 0];
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        const float4 e = L.fovf[r];
+        const int code = __float_as_int(e.w), img = code & 0xfffff, strip = code >> 20;
+        const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
+        float *dst = iwe + (size_t)img * H * W;
+        record_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) { atomicAdd(dst + (size_t)yy * W + xx, v); });
+    }
+}
+
+// gradient of one record w.r.t. its warped position from the adjoint image (unscaled)
+__device__ __forceinline__ void record_grad(float y, float x, float w, const float *__restrict__ g, int H, int W,
+                                            float &gy, float &gx) {
+    const float y0f = floorf(y + 1e-6f), x0f = floorf(x + 1e-6f);
+    const float fy = y - y0f, fx = x - x0f;
+    const int y0 = (int)fminf(fmaxf(y0f, -4.f), (float)H + 4.f), x0 = (int)fminf(fmaxf(x0f, -4.f), (float)W + 4.f);
+    const bool r0 = y0 >= 0 && y0 < H, r1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const bool c0 = x0 >= 0 && x0 < W, c1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const float g00 = (r0 && c0) ? g[(size_t)y0 * W + x0] : 0.f;
+    const float g10 = (r1 && c0) ? g[(size_t)(y0 + 1) * W + x0] : 0.f;
+    const float g01 = (r0 && c1) ? g[(size_t)y0 * W + x0 + 1] : 0.f;
+    const float g11 = (r1 && c1) ? g[(size_t)(y0 + 1) * W + x0 + 1] : 0.f;
+    gy = w * ((1.f - fx) * (g10 - g00) + fx * (g11 - g01));
+    gx = w * ((1.f - fy) * (g01 - g00) + fy * (g11 - g10));
+}
+
+// grid NBk, 1024 threads, dynamic LDS = CSR * wq * 2 * 8 bytes
+__global__ __launch_bounds__(1024) void k_lut_accum(const mpc_shape s, const BinLayout L,
+                                                    const float *__restrict__ gimg,
+                                                    const float *__restrict__ scal,
+                                                    const float *__restrict__ grad_out,
+                                                    float *__restrict__ glut, int accumulate) {
+    extern __shared__ unsigned long long s_acc[];
+    const EvParams p = make_params(s);
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x;                         // (b*nb + it)*NCS + cstrip
+    const int bt = g / L.NCS, cst = g - bt * L.NCS, b = bt / p.nb;
+    const int crow0 = cst * L.CSR, crow1 = min(crow0 + L.CSR, p.hq);
+    const int ncell = (crow1 - crow0) * p.wq;
+    for (int i = tid; i < 2 * ncell; i += 1024) s_acc[i] = 0ull;
+    __syncthreads();
+    const bool valid = L.gcount[L.NF + L.NBk + 2] == EV_MARKER;
+    const int n = valid ? min(L.gcount[L.NF + g], L.bcap) : 0;
+    const float4 *rec = L.brec + (size_t)g * L.bcap;
+    for (int r = tid; r < n; r += 1024) {
+        const float4 e = rec[r];
+        const unsigned a = __float_as_uint(e.w);
+        const int pol = (int)(a >> 31), cell = (int)(a & 0x7fffffffu);
+        float gy, gx;
+        record_grad(e.x, e.y, e.z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy, gx);
+        atomicAdd(&s_acc[2 * cell], (unsigned long long)ev_to_fixed(gy));
+        atomicAdd(&s_acc[2 * cell + 1], (unsigned long long)ev_to_fixed(gx));
+    }
+    __syncthreads();
+    const float coef = valid ? scal[MPC_SCAL_GCOEF] * (grad_out ? grad_out[0] : 1.f) : __int_as_float(0x7fc00000);
+    float2 *dst = reinterpret_cast<float2 *>(glut) + ((size_t)bt * p.hq + crow0) * p.wq;
+    for (int i = tid; i < ncell; i += 1024) {
+        float2 v = make_float2(coef * ev_from_fixed((long long)s_acc[2 * i]), coef * ev_from_fixed((long long)s_acc[2 * i + 1]));
+        if (accumulate) { const float2 o = dst[i]; v.x += o.x; v.y += o.y; }
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lut_overflow(const mpc_shape s, const BinLayout L,
+                                                      const float *__restrict__ gimg,
+                                                      const float *__restrict__ scal,
+                                                      const float *__restrict__ grad_out,
+                                                      float *__restrict__ glut) {
+    const EvParams p = make_params(s);
+    const int n = L.gcount[L.NF + L.NBk + 1];
+    const float coef = scal[MPC_SCAL_GCOEF] * (grad_out ? grad_out[0] : 1.f);
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        const float4 e = L.bovf[r];
+        const unsigned a = __float_as_uint(e.w);
+        const int pol = (int)(a >> 31), lutidx = (int)(a & 0x7fffffffu);
+        const int b = lutidx / (p.nb * p.hq * p.wq);
+        float gy, gx;
+        record_grad(e.x, e.y, e.z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy, gx);
+        atomicAdd(glut + 2 * (size_t)lutidx, coef * gy);
+        atomicAdd(glut + 2 * (size_t)lutidx + 1, coef * gx);
+    }
+}
+
+static BinLayout bin_layout(const mpc_shape *s, const mpc_ws_layout &L, void *ws) {
+    BinLayout B;
+    B.SR = L.strip_rows; B.NS = L.n_strips; B.CSR = L.cstrip_rows; B.NCS = L.n_cstrips;
+    B.NF = L.nfb; B.NBk = L.nbb; B.fcap = L.fcap; B.bcap = L.bcap; B.P = L.P;
+    B.gcount = (int *)((char *)ws + L.off_fcount);
+    B.frec = (float4 *)((char *)ws + L.off_frec);
+    B.brec = (float4 *)((char *)ws + L.off_brec);
+    B.fovf = (float4 *)((char *)ws + L.off_fovf);
+    B.bovf = (float4 *)((char *)ws + L.off_bovf);
+    return B;
+}
+
+static bool use_tiled(const mpc_shape *s, const mpc_ws_layout &L) { return !(s->flags & MPC_F_ATOMIC_PATH) && s->T == 1 && L.strip_rows > 0 && L.cstrip_rows > 0; }
+
+static int set_max_lds_ev(const void *fn, const char *who) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e != hipSuccess) { mpc_set_error("%s: %s", who, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
@@ -163,6 +439,31 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
     if (rc) return rc;
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
+    if (use_tiled(s, L)) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if ((rc = set_max_lds_ev((const void *)k_iwe_accum, __func__))) return rc;
+            if ((rc = set_max_lds_ev((const void *)k_lut_accum, __func__))) return rc;
+            attr_set = true;
+        }
+        const BinLayout BL = bin_layout(s, L, ws);
+        const int want_bwd = (s->flags & (MPC_F_NO_WARP | MPC_F_NO_BWD_RECORDS)) ? 0 : 1;
+        hipError_t e0 = hipMemsetAsync(BL.gcount, 0, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st);
+        if (e0 != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e0)); return (int)e0; }
+        if (s->B > 0 && s->M > 0) {
+            const dim3 grid(mpc_cdiv(s->M, 256 * EV_PER_THREAD), s->B);
+            const size_t lds = (size_t)(L.P * L.n_strips + s->nb * L.n_cstrips) * 2 * sizeof(int);
+            hipLaunchKernelGGL(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);
+            MPC_CHECK_LAUNCH();
+        }
+        if (L.nfb > 0) {
+            hipLaunchKernelGGL(k_iwe_accum, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
+            MPC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_iwe_overflow, dim3(64), dim3(256), 0, st, BL, iwe_raw, s->H, s->W);
+            MPC_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     const size_t img_bytes = (size_t)L.nimg * s->H * s->W * sizeof(float);
     hipError_t e = hipMemsetAsync(iwe_raw, 0, img_bytes, st);
     if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
@@ -184,6 +485,20 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const mpc_ws_layout L = mpc_layout(s);
+    if (use_tiled(s, L)) {
+        const BinLayout BL = bin_layout(s, L, ws);
+        // the records must come from mpc_event_splat_fwd on this same workspace: the kernel checks
+        // the marker that call left behind and poisons the output with NaN if it is missing
+        if (L.nbb > 0) {
+            hipLaunchKernelGGL(k_lut_accum, dim3(L.nbb), dim3(1024), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
+                               grad_iwe, scal, grad_out, grad_flow_lut, accumulate);
+            MPC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_lut_overflow, dim3(64), dim3(256), 0, st, *s, BL, grad_iwe, scal, grad_out, grad_flow_lut);
+            MPC_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     if (!accumulate) {
         const size_t bytes = (size_t)s->B * s->nb * s->hq * s->wq * s->T * 2 * sizeof(float);
         hipError_t e = hipMemsetAsync(grad_flow_lut, 0, bytes, st);

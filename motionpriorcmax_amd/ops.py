@@ -236,9 +236,9 @@ class FocusCalcFn(torch.autograd.Function):
         ev = _f32c(events.detach())
         tr = _f32c(t_ref.detach().to(dev))
         n = traj.shape[2]
-        shape = make_shape(cfg, B, M, Mp, n)
-        ws = alloc_workspace(shape, dev)
         need_grad = trajectories.requires_grad
+        shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
+        ws = alloc_workspace(shape, dev)
 
         flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
         g_field = None
@@ -295,9 +295,9 @@ class EventFocusFn(torch.autograd.Function):
         lut = _f32c(flow_lut.detach())
         ev = _f32c(events.detach())
         tr = _f32c(t_ref.detach().to(dev))
-        shape = make_shape(cfg, B, M, Mp, 0, K=0)
-        ws = alloc_workspace(shape, dev)
         need_grad = flow_lut.requires_grad
+        shape = make_shape(cfg, B, M, Mp, 0, K=0, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
+        ws = alloc_workspace(shape, dev)
         raw = event_splat_fwd(shape, ev, lut, tr, ws)
         blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
         scal = finalize(shape, 0, 0, 0.0, ws, dev)

@@ -185,6 +185,35 @@ def test_tiled_and_atomic_paths_agree():
     assert _rel_l2(outs[0][2], outs[1][2]) < 1e-5
 
 
+def test_bucket_overflow_spill_path():
+    """All events inside one image strip and one time bin: the per-bucket capacity of the
+    LDS-tiled path overflows and the spill lists (global atomics) must keep the result exact."""
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    dev = _dev()
+    B, M, nb = 1, 40000, 15
+    ev, num_pos = O.synth_events(B, M, (480, 640), nb, seed=2)
+    ev[..., 0] = ev[..., 0] * (20.0 / 479.0) + 3.0          # rows 3..23: one 30-row strip, one LUT strip
+    ev[..., 2] = 0.5 + 0.01 * ev[..., 2]
+    ev[..., 4] = 7
+    g = torch.Generator().manual_seed(4)
+    lut = torch.randn(B, nb, 120, 160, 1, 2, generator=g) * 1.5
+    cfg = dict(image_shape=(480, 640), num_tref=1, num_bins=nb, num_knn=32, smooth_weight=0.0,
+               lut_superpixel_size=4, focus_loss_norm='l2', dist_norm='l2', scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    lo = lut.clone().requires_grad_(True)
+    fo, iwo, rawo = O.FocusLossOracle(**cfg).event_path(ev, lo, torch.tensor([0.41]), num_pos)
+    fo.backward()
+    L = _loss_obj(cfg)
+    lt = lut.to(dev).requires_grad_(True)
+    f, blur, raw = ops.EventFocusFn.apply(lt, ev.to(dev), torch.tensor([0.41], device=dev), L._cfg, num_pos)
+    f.backward()
+    assert abs(f.item() - fo.item()) <= 2e-6 * abs(fo.item())
+    np.testing.assert_allclose(raw.cpu().numpy(), rawo.detach().numpy(), atol=1e-5 * rawo.max().item())
+    assert _rel_l2(lt.grad.cpu().numpy(), lo.grad.numpy()) < 1e-4
+
+
 def test_cpu_tensors_fail_loudly():
     g = load_golden('g3_squeeze_k1')
     L = _loss_obj(g['cfg'])
