@@ -137,6 +137,16 @@ struct Acc {
         }
     }
     __device__ __forceinline__ float2 pos(int j) const { return LDS ? c.lpos[j] : c.spos[j]; }
+    // Visit the candidates of rows [y0,y1] x cells [x0,x1].  (A 4-wide batched-load variant of
+    // this loop measured 30% SLOWER on gfx950 -- 1246 vs 934 us at B=14 -- and was dropped.)
+    template <typename F>
+    __device__ __forceinline__ void for_each(int y0, int y1, int x0, int x1, F f) const {
+        for (int yy = y0; yy <= y1; ++yy) {
+            int js, je;
+            range(yy, x0, x1, js, je);
+            for (int j = js; j < je; ++j) f(j, pos(j));
+        }
+    }
     __device__ __forceinline__ int idx(int j) const { return LDS ? c.lidx[j] : c.sidx[j]; }
     __device__ __forceinline__ float2 flow_ref(int j, int tr, float2 pj) const {
         if (LDS && p.T == 1) return c.lf0[j];
@@ -197,19 +207,14 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
 #pragma unroll
         for (int h = 0; h < KNN_BINS / 2; ++h) s_hist[h][tid] = 0u;
         cnt = 0;
-        for (int yy = y0; yy <= y1; ++yy) {
-            int js, je;
-            A.range(yy, x0, x1, js, je);
-            for (int j = js; j < je; ++j) {
-                const float2 q = A.pos(j);
-                const float d = pair_dist(qy, qx, q.x, q.y, p.l1);
-                if (d < upper) {
-                    const int bin = min((int)(d * scale), KNN_BINS - 1);
-                    atomicAdd(&s_hist[bin >> 1][tid], (bin & 1) ? 0x10000u : 1u);   // private column, fire-and-forget
-                    ++cnt;
-                }
+        A.for_each(y0, y1, x0, x1, [&](int, float2 q) {
+            const float d = pair_dist(qy, qx, q.x, q.y, p.l1);
+            if (d < upper) {
+                const int bin = min((int)(d * scale), KNN_BINS - 1);
+                atomicAdd(&s_hist[bin >> 1][tid], (bin & 1) ? 0x10000u : 1u);   // private column, fire-and-forget
+                ++cnt;
             }
-        }
+        });
         if (cnt >= p.K || whole) break;
         r += 1 + (r >> 2);
     }
@@ -237,27 +242,22 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     const bool do_next0 = p.want_next && (t < p.nb - 1);
     float sy = 0.f, sx = 0.f, sw = 0.f, ny = 0.f, nx = 0.f;
     int m = 0;
-    for (int yy = y0; yy <= y1; ++yy) {
-        int js, je;
-        A.range(yy, x0, x1, js, je);
-        for (int j = js; j < je; ++j) {
-            const float2 pj = A.pos(j);
-            const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
-            if (!(d < upper)) continue;
-            const int bin = min((int)(d * scale), KNN_BINS - 1);
-            if (bin < bstar) {
-                if (fuse) {
-                    const float2 f = A.flow_ref(j, 0, pj);
-                    if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
-                    else { sy += f.x; sx += f.y; }
-                    if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
-                }
-            } else if (bin == bstar) {
-                if (m < KNN_BINS / 4) { s_hist[2 * m][tid] = __float_as_uint(d); s_hist[2 * m + 1][tid] = (unsigned)j; }
-                ++m;
+    A.for_each(y0, y1, x0, x1, [&](int j, float2 pj) {
+        const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+        if (!(d < upper)) return;
+        const int bin = min((int)(d * scale), KNN_BINS - 1);
+        if (bin < bstar) {
+            if (fuse) {
+                const float2 f = A.flow_ref(j, 0, pj);
+                if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
+                else { sy += f.x; sx += f.y; }
+                if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
             }
+        } else if (bin == bstar) {
+            if (m < KNN_BINS / 4) { s_hist[2 * m][tid] = __float_as_uint(d); s_hist[2 * m + 1][tid] = (unsigned)j; }
+            ++m;
         }
-    }
+    });
     float dK = 0.f; int iK = -1;
     bool listed = (m <= KNN_BINS / 4);
     if (listed) {
@@ -822,6 +822,8 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
     float *lnorm = reinterpret_cast<float *>(s_dyn + (size_t)RW * RW * 8);
     float2 *lg = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 12);
     float2 *lgn = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 20);
+    float4 *lq4 = reinterpret_cast<float4 *>(s_dyn + (size_t)RW * RW * 28);
+    const bool fast = use_lds && p.T == 1 && !p.iwd;
     const bool has_next = (gnext != nullptr) && (t < p.nb - 1);
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G * p.T;
@@ -840,6 +842,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
                 if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
             }
             ldK[i] = dk; liK[i] = ik; lnorm[i] = nm; lg[i] = g; lgn[i] = gn;
+            lq4[i] = make_float4(dk, __int_as_float(ik), g.x, g.y);
         }
     }
     // points of the tile: per tile row a contiguous range of the bucketed arrays
@@ -880,6 +883,30 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
             y0 = max(y0, ry0); x0 = max(x0, rx0); y1 = min(y1, ry0 + RW - 1); x1 = min(x1, rx0 + RW - 1);
         }
         float2 an = make_float2(0.f, 0.f);
+        if (fast) {
+            // {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} in one 16-byte LDS read per query cell;
+            // membership is a predicate, not a branch, so the loads of the unrolled body overlap
+            float ay = 0.f, ax = 0.f;
+            for (int cy = y0; cy <= y1; ++cy) {
+                const float dy = ((float)(cy * p.sp) + p.off) - pt.x;
+                const float dy2 = p.l1 ? fabsf(dy) : dy * dy;
+                const float4 *row = lq4 + (cy - ry0) * RW - rx0;
+                const float2 *rown = lgn + (cy - ry0) * RW - rx0;
+#pragma unroll 4
+                for (int cx = x0; cx <= x1; ++cx) {
+                    const float4 e = row[cx];
+                    const float dx = ((float)(cx * p.sp) + p.off) - pt.y;
+                    const float d = dy2 + (p.l1 ? fabsf(dx) : dx * dx);
+                    const bool in = (d < e.x) || (d == e.x && i <= __float_as_int(e.y));
+                    ay += in ? e.z : 0.f;
+                    ax += in ? e.w : 0.f;
+                    if (has_next) { const float2 gq = rown[cx]; an.x += in ? gq.x : 0.f; an.y += in ? gq.y : 0.f; }
+                }
+            }
+            tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
+            tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
+            continue;
+        }
         for (int tr = 0; tr < p.T; ++tr) {
             float ay = 0.f, ax = 0.f;
             for (int cy = y0; cy <= y1; ++cy) {
@@ -1053,7 +1080,7 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         attr_set = true;
     }
     const int RWmax = 16 + 2 * KNN_RQ_MAX;
-    const size_t lds = (size_t)RWmax * RWmax * 28;
+    const size_t lds = (size_t)RWmax * RWmax * 44;
     const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
     hipLaunchKernelGGL(k_knn_bwd_points, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
                        grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a);
