@@ -14,6 +14,9 @@
 #include <stdlib.h>
 
 #define KNN_BINS 32
+#ifndef KNN_BATCH
+#define KNN_BATCH 2   // candidate positions loaded ahead of use in the two hot scans (B=14: 944 -> 874 us; 4: 867)
+#endif
 #define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
 
 struct KnnParams {
@@ -137,16 +140,6 @@ struct Acc {
         }
     }
     __device__ __forceinline__ float2 pos(int j) const { return LDS ? c.lpos[j] : c.spos[j]; }
-    // Visit the candidates of rows [y0,y1] x cells [x0,x1].  (A 4-wide batched-load variant of
-    // this loop measured 30% SLOWER on gfx950 -- 1246 vs 934 us at B=14 -- and was dropped.)
-    template <typename F>
-    __device__ __forceinline__ void for_each(int y0, int y1, int x0, int x1, F f) const {
-        for (int yy = y0; yy <= y1; ++yy) {
-            int js, je;
-            range(yy, x0, x1, js, je);
-            for (int j = js; j < je; ++j) f(j, pos(j));
-        }
-    }
     __device__ __forceinline__ int idx(int j) const { return LDS ? c.lidx[j] : c.sidx[j]; }
     __device__ __forceinline__ float2 flow_ref(int j, int tr, float2 pj) const {
         if (LDS && p.T == 1) return c.lf0[j];
@@ -207,14 +200,24 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
 #pragma unroll
         for (int h = 0; h < KNN_BINS / 2; ++h) s_hist[h][tid] = 0u;
         cnt = 0;
-        A.for_each(y0, y1, x0, x1, [&](int, float2 q) {
-            const float d = pair_dist(qy, qx, q.x, q.y, p.l1);
-            if (d < upper) {
-                const int bin = min((int)(d * scale), KNN_BINS - 1);
-                atomicAdd(&s_hist[bin >> 1][tid], (bin & 1) ? 0x10000u : 1u);   // private column, fire-and-forget
-                ++cnt;
+        for (int yy = y0; yy <= y1; ++yy) {
+            int js, je;
+            A.range(yy, x0, x1, js, je);
+            for (int j = js; j < je; j += KNN_BATCH) {
+                float2 q[KNN_BATCH];
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(min(j + u, je - 1));     // loads first
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) {
+                    const float d = pair_dist(qy, qx, q[u].x, q[u].y, p.l1);
+                    if (j + u < je && d < upper) {
+                        const int bin = min((int)(d * scale), KNN_BINS - 1);
+                        atomicAdd(&s_hist[bin >> 1][tid], (bin & 1) ? 0x10000u : 1u);   // private column, fire-and-forget
+                        ++cnt;
+                    }
+                }
             }
-        });
+        }
         if (cnt >= p.K || whole) break;
         r += 1 + (r >> 2);
     }
@@ -242,22 +245,34 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     const bool do_next0 = p.want_next && (t < p.nb - 1);
     float sy = 0.f, sx = 0.f, sw = 0.f, ny = 0.f, nx = 0.f;
     int m = 0;
-    A.for_each(y0, y1, x0, x1, [&](int j, float2 pj) {
-        const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
-        if (!(d < upper)) return;
-        const int bin = min((int)(d * scale), KNN_BINS - 1);
-        if (bin < bstar) {
-            if (fuse) {
-                const float2 f = A.flow_ref(j, 0, pj);
-                if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
-                else { sy += f.x; sx += f.y; }
-                if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
+    for (int yy = y0; yy <= y1; ++yy) {
+        int js, je;
+        A.range(yy, x0, x1, js, je);
+        for (int j0 = js; j0 < je; j0 += KNN_BATCH) {
+            float2 qq[KNN_BATCH];
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) qq[u] = A.pos(min(j0 + u, je - 1));
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) {
+                const int j = j0 + u;
+                const float2 pj = qq[u];
+                const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                if (j >= je || !(d < upper)) continue;
+                const int bin = min((int)(d * scale), KNN_BINS - 1);
+                if (bin < bstar) {
+                    if (fuse) {
+                        const float2 f = A.flow_ref(j, 0, pj);
+                        if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
+                        else { sy += f.x; sx += f.y; }
+                        if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
+                    }
+                } else if (bin == bstar) {
+                    if (m < KNN_BINS / 4) { s_hist[2 * m][tid] = __float_as_uint(d); s_hist[2 * m + 1][tid] = (unsigned)j; }
+                    ++m;
+                }
             }
-        } else if (bin == bstar) {
-            if (m < KNN_BINS / 4) { s_hist[2 * m][tid] = __float_as_uint(d); s_hist[2 * m + 1][tid] = (unsigned)j; }
-            ++m;
         }
-    });
+    }
     float dK = 0.f; int iK = -1;
     bool listed = (m <= KNN_BINS / 4);
     if (listed) {
@@ -765,6 +780,37 @@ __global__ __launch_bounds__(KNN_TILE_THREADS) void k_knn_query_tile(
     }
 }
 
+// Gather over the query window of one trajectory point (num_tref == 1, 'mean'): one 16-byte LDS read
+// {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} per query cell; membership is a bitwise predicate
+// (no short-circuit branches), so the unrolled body is straight-line code.
+template <bool L1, bool NEXT>
+__device__ __forceinline__ void bwd_window(const float4 *__restrict__ lq4, const float2 *__restrict__ lgn,
+                                           int RW, int ry0, int rx0, int y0, int y1, int x0, int x1,
+                                           int sp, float off, float2 pt, int i, float &ay, float &ax,
+                                           float2 &an) {
+    ay = 0.f; ax = 0.f;
+    const float fsp = (float)sp;
+    for (int cy = y0; cy <= y1; ++cy) {
+        const float dy = ((float)(cy * sp) + off) - pt.x;
+        const float dy2 = L1 ? fabsf(dy) : dy * dy;
+        const float4 *row = lq4 + (cy - ry0) * RW - rx0;
+        const float2 *rown = lgn + (cy - ry0) * RW - rx0;
+        float qx = (float)(x0 * sp) + off;              // exact: small integers, same value as (float)(cx*sp)+off
+#pragma unroll 4
+        for (int cx = x0; cx <= x1; ++cx) {
+            const float4 e = row[cx];
+            const float dx = qx - pt.y;
+            const float d = dy2 + (L1 ? fabsf(dx) : dx * dx);
+            const int lt = d < e.x, eq = d == e.x, le = i <= __float_as_int(e.y);
+            const bool in = (lt | (eq & le)) != 0;
+            ay += in ? e.z : 0.f;
+            ax += in ? e.w : 0.f;
+            if (NEXT) { const float2 gq = rown[cx]; an.x += in ? gq.x : 0.f; an.y += in ? gq.y : 0.f; }
+            qx += fsp;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward, step 1: one thread per bucketed trajectory point of a 16x16 cell tile.  The K-th
 // keys and LUT gradients of the tile and a halo of RQ cells are staged in LDS; each point scans
@@ -884,24 +930,13 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
         }
         float2 an = make_float2(0.f, 0.f);
         if (fast) {
-            // {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} in one 16-byte LDS read per query cell;
-            // membership is a predicate, not a branch, so the loads of the unrolled body overlap
-            float ay = 0.f, ax = 0.f;
-            for (int cy = y0; cy <= y1; ++cy) {
-                const float dy = ((float)(cy * p.sp) + p.off) - pt.x;
-                const float dy2 = p.l1 ? fabsf(dy) : dy * dy;
-                const float4 *row = lq4 + (cy - ry0) * RW - rx0;
-                const float2 *rown = lgn + (cy - ry0) * RW - rx0;
-#pragma unroll 4
-                for (int cx = x0; cx <= x1; ++cx) {
-                    const float4 e = row[cx];
-                    const float dx = ((float)(cx * p.sp) + p.off) - pt.y;
-                    const float d = dy2 + (p.l1 ? fabsf(dx) : dx * dx);
-                    const bool in = (d < e.x) || (d == e.x && i <= __float_as_int(e.y));
-                    ay += in ? e.z : 0.f;
-                    ax += in ? e.w : 0.f;
-                    if (has_next) { const float2 gq = rown[cx]; an.x += in ? gq.x : 0.f; an.y += in ? gq.y : 0.f; }
-                }
+            float ay, ax;
+            if (p.l1) {
+                if (has_next) bwd_window<true, true>(lq4, lgn, RW, ry0, rx0, y0, y1, x0, x1, p.sp, p.off, pt, i, ay, ax, an);
+                else bwd_window<true, false>(lq4, lgn, RW, ry0, rx0, y0, y1, x0, x1, p.sp, p.off, pt, i, ay, ax, an);
+            } else {
+                if (has_next) bwd_window<false, true>(lq4, lgn, RW, ry0, rx0, y0, y1, x0, x1, p.sp, p.off, pt, i, ay, ax, an);
+                else bwd_window<false, false>(lq4, lgn, RW, ry0, rx0, y0, y1, x0, x1, p.sp, p.off, pt, i, ay, ax, an);
             }
             tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
             tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
