@@ -126,12 +126,14 @@ int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C, floa
                  float *scal, void *ws, void *stream);
 
 /* ---- A11: backward of A6-A8 into the LUT.
- * grad_flow_lut[b][bin][iy][ix][tref][:] (+)= grad_out * scal[GCOEF] * w * bilinear-gradient of
- * grad_iwe at the warped position.  If accumulate == 0 the buffer is overwritten, else added to
- * (used to add the event term onto the smoothness term).  grad_out: device scalar or NULL (=1). */
+ * grad_flow_lut[b][bin][iy][ix][tref][:] = grad_out * (scal[GCOEF] * sum over the cell's events of
+ * w * bilinear-gradient of grad_iwe at the warped position  +  add_term[...]).
+ * add_term: same shape as the LUT or NULL (used to fold in the smoothness gradient of
+ * mpc_lut_smooth).  grad_out: device scalar or NULL (= 1).  Must follow mpc_event_splat_fwd on the
+ * same workspace (the LDS-tiled path reuses the records that call left there).                 */
 int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *flow_lut,
                         const float *t_ref, const float *grad_iwe, const float *scal,
-                        const float *grad_out, float *grad_flow_lut, int32_t accumulate,
+                        const float *grad_out, float *grad_flow_lut, const float *add_term,
                         void *ws, void *stream);
 
 /* y[i] = a[0] * x[i] (device scalar a; used to scale the smoothness gradient by grad_out). */

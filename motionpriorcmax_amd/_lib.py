@@ -60,7 +60,7 @@ def lib():
     L.mpc_contrast_fwd.argtypes = [sp, vp, vp, vp, vp, vp]
     L.mpc_lut_smooth.argtypes = [sp, vp, i32, i32, f32, vp, vp, vp]
     L.mpc_finalize.argtypes = [sp, i32, i32, f32, vp, vp, vp]
-    L.mpc_event_splat_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.mpc_event_splat_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_scale.argtypes = [vp, vp, vp, i64, vp]
     for name in EXPORTS[3:]:
         getattr(L, name).restype = ctypes.c_int

@@ -41,7 +41,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     int64_t off = 0;
     L.n_cblocks = mpc_cdiv(s->W, MPC_CT_W) * mpc_cdiv(s->H, MPC_CT_H) * (L.nimg > 0 ? L.nimg : 1);
     L.off_cpart = off; off += mpc_align((int64_t)L.n_cblocks * 2 * sizeof(double));
-    L.n_sblocks_max = mpc_cdiv(s->wq, MPC_ST) * mpc_cdiv(s->hq, MPC_ST) * (s->B > 0 ? s->B : 1) * s->nb * s->T * 2;
+    L.n_sblocks_max = mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H) * (s->B > 0 ? s->B : 1) * s->nb * s->T;
     L.off_spart = off; off += mpc_align((int64_t)L.n_sblocks_max * 2 * sizeof(double));
     L.off_counts = off; off += mpc_align(64 + (int64_t)(L.nimg > 0 ? L.nimg : 1) * sizeof(float));
     const int64_t bt = (int64_t)(s->B > 0 ? s->B : 1) * s->nb;
@@ -54,7 +54,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     const int64_t lds_budget = 150 * 1024;
     L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));
     if (L.strip_rows > s->H) L.strip_rows = s->H;
-    L.cstrip_rows = (int)(lds_budget / ((int64_t)s->wq * 16));
+    L.cstrip_rows = (int)((48 * 1024) / ((int64_t)s->wq * 16));      // ~3 workgroups of the backward per CU
+    if (L.cstrip_rows < 1) L.cstrip_rows = (int)(lds_budget / ((int64_t)s->wq * 16));
     if (L.cstrip_rows > s->hq) L.cstrip_rows = s->hq;
     if (L.strip_rows > 0 && L.cstrip_rows > 0 && s->T == 1 && s->B > 0 && !(s->flags & MPC_F_ATOMIC_PATH)) {
         L.n_strips = mpc_cdiv(s->H, L.strip_rows);

@@ -59,7 +59,8 @@ struct mpc_ws_layout {
 #define MPC_CT_H 32
 #define MPC_CT_W 64
 // smoothness tiles (LUT cells)
-#define MPC_ST 16
+#define MPC_SM_H 16
+#define MPC_SM_W 64
 
 mpc_ws_layout mpc_layout(const mpc_shape *s);
 int mpc_validate_shape(const mpc_shape *s);

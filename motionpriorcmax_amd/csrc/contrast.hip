@@ -197,6 +197,134 @@ __global__ __launch_bounds__(256) void k_contrast_bwd_gm(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// fused forward + adjoint image (gradient magnitude): raw -> blurred, partial sums, Blur^T Sobel^T u.
+// One pass over the raw image (tile + 4-px halo in LDS) instead of two kernels that each stream the
+// whole batch of images through HBM.  Three LDS planes are recycled:
+//   A: raw -> blurred -> gB      B: horizontal blur -> ux      C: uy
+// grid (ceil(W/64), ceil(H/32), nimg), 256 threads
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_contrast_fused(const float *__restrict__ raw,
+                                                        float *__restrict__ blur,
+                                                        float *__restrict__ gimg,
+                                                        double *__restrict__ part, int H, int W,
+                                                        int norm_l2) {
+    constexpr int TH = MPC_CT_H, TW = MPC_CT_W, LH = TH + 8, LW = TW + 8, LP = LW + 1;
+    __shared__ float sA[LH][LP];
+    __shared__ float sB[LH][LP];
+    __shared__ float sC[LH][LP];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t img_off = (size_t)blockIdx.z * H * W;
+    const float *src = raw + img_off;
+    float ka, kc;
+    blur_taps(ka, kc);
+    // local (r, c) <-> image (ty0 - 4 + r, tx0 - 4 + c)
+    {   // all global loads of the tile are issued before the first LDS store (fully unrolled): the
+        // staging loop is otherwise a chain of dependent HBM round trips
+        constexpr int NLD = (LH * LW + 255) / 256;
+        float v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / LW, c = i - r * LW;
+            const int y = ty0 - 4 + r, x = tx0 - 4 + c;
+            v[k] = 0.f;
+            if (i < LH * LW && y >= -1 && y <= H && x >= -1 && x <= W) v[k] = src[(size_t)reflect1(y, H) * W + reflect1(x, W)];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            if (i < LH * LW) { const int r = i / LW, c = i - r * LW; sA[r][c] = v[k]; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < LH * (LW - 2); i += 256) {             // horizontal blur, cols 1..LW-2
+        const int r = i / (LW - 2), c = 1 + (i - r * (LW - 2));
+        sB[r][c] = ka * sA[r][c - 1] + kc * sA[r][c] + ka * sA[r][c + 1];
+    }
+    __syncthreads();
+    for (int i = tid; i < (LH - 2) * (LW - 2); i += 256) {       // blurred, rows 1..LH-2; zero outside the image
+        const int r = 1 + i / (LW - 2), c = 1 + (i % (LW - 2));
+        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
+        float v = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = ka * sB[r - 1][c] + kc * sB[r][c] + ka * sB[r + 1][c];
+        sA[r][c] = v;
+    }
+    __syncthreads();
+    // blurred output + objective on the tile; u = d|grad|/d(dx,dy) on rows 2..LH-3
+    double acc = 0.0;
+    for (int i = tid; i < (LH - 4) * (LW - 4); i += 256) {
+        const int r = 2 + i / (LW - 4), c = 2 + (i % (LW - 4));
+        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
+        float ux = 0.f, uy = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float tl = sA[r - 1][c - 1], tc = sA[r - 1][c], tr = sA[r - 1][c + 1];
+            const float ml = sA[r][c - 1], mr = sA[r][c + 1];
+            const float bl_ = sA[r + 1][c - 1], bc = sA[r + 1][c], br = sA[r + 1][c + 1];
+            const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
+            const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
+            if (norm_l2) {
+                ux = 2.f * dx;
+                uy = 2.f * dy;
+            } else {
+                ux = (dx > 0.f) ? 1.f : ((dx < 0.f) ? -1.f : 0.f);
+                uy = (dy > 0.f) ? 1.f : ((dy < 0.f) ? -1.f : 0.f);
+            }
+            if (r >= 4 && r < 4 + TH && c >= 4 && c < 4 + TW) {   // own pixel
+                blur[img_off + (size_t)y * W + x] = sA[r][c];
+                acc += norm_l2 ? (double)(dx * dx + dy * dy) : (double)(fabsf(dx) + fabsf(dy));
+            }
+        }
+        sB[r][c] = ux;
+        sC[r][c] = uy;
+    }
+    __syncthreads();
+    for (int i = tid; i < (LH - 6) * (LW - 6); i += 256) {       // gB on rows 3..LH-4; zero outside the image
+        const int r = 3 + i / (LW - 6), c = 3 + (i % (LW - 6));
+        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
+        float g = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const float gx = (sB[r + 1][c - 1] - sB[r + 1][c + 1]) + 2.f * (sB[r][c - 1] - sB[r][c + 1]) +
+                             (sB[r - 1][c - 1] - sB[r - 1][c + 1]);
+            const float gy = (sC[r - 1][c + 1] - sC[r + 1][c + 1]) + 2.f * (sC[r - 1][c] - sC[r + 1][c]) +
+                             (sC[r - 1][c - 1] - sC[r + 1][c - 1]);
+            g = gx + gy;
+        }
+        sA[r][c] = g;
+    }
+    __syncthreads();
+    for (int i = tid; i < TH * TW; i += 256) {
+        const int ry = i / TW, cx = i - ry * TW;
+        const int y = ty0 + ry, x = tx0 + cx;
+        if (y < H && x < W) {
+            float a = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int qy = y + dy;
+                if (qy < 0 || qy >= H) continue;
+                const float wy = blurT_w(qy, y, H, ka, kc);
+                float row = 0.f;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int qx = x + dx;
+                    if (qx < 0 || qx >= W) continue;
+                    row += blurT_w(qx, x, W, ka, kc) * sA[ry + 4 + dy][cx + 4 + dx];
+                }
+                a += wy * row;
+            }
+            gimg[img_off + (size_t)y * W + x] = a;
+        }
+    }
+    const double r0 = block_sum_d<256>(acc, s_red);
+    if (tid == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[2 * bid] = r0;
+        part[2 * bid + 1] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward (variance objective): blurred -> Blur^T (x - mean_img)   (unscaled)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_image_means(const double *__restrict__ part,
@@ -252,66 +380,81 @@ __global__ __launch_bounds__(256) void k_contrast_bwd_var(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------
-// smoothness of a flow field stored [nimg][hq][wq][C]: forward partial sums + gradient
-// grid (ceil(wq/16), ceil(hq/16), nimg*C), 256 threads  (one channel per block)
+// smoothness of a flow field stored [nimg][hq][wq][C] (C even: (y,x) pairs): forward partial sums +
+// gradient.  One workgroup = 16 x 64 cells of one channel PAIR (float2 loads), halo in LDS.
+// grid (ceil(wq/64), ceil(hq/16), nimg*C/2), 256 threads
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ field,
                                                     float *__restrict__ gfield,
                                                     double *__restrict__ part, int hq, int wq, int C,
                                                     float gscale /* smooth_weight/(2*count) */) {
-    constexpr int TS = MPC_ST;
-    __shared__ float s_f[TS + 4][TS + 4 + 1];
-    __shared__ float s_vx[TS + 2][TS + 2 + 1];
-    __shared__ float s_vy[TS + 2][TS + 2 + 1];
+    constexpr int TH = MPC_SM_H, TW = MPC_SM_W;
+    __shared__ float2 s_f[TH + 4][TW + 4 + 1];
+    __shared__ float2 s_vx[TH + 2][TW + 2 + 1];
+    __shared__ float2 s_vy[TH + 2][TW + 2 + 1];
     __shared__ double s_red[2][4];
     const int tid = threadIdx.x;
-    const int img = blockIdx.z / C, ch = blockIdx.z - img * C;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
-    const size_t base = (size_t)img * hq * wq * C + ch;
+    const int C2 = C >> 1;
+    const int img = blockIdx.z / C2, cp = blockIdx.z - img * C2;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const size_t base = (size_t)img * hq * wq * C2 + cp;        // in float2 units
+    const float2 *f2 = reinterpret_cast<const float2 *>(field);
     const float eps2 = 1e-3f * 1e-3f;   // charbonnier epsilon ** 2 (loss.py:46,55)
 
-    for (int i = tid; i < (TS + 4) * (TS + 4); i += 256) {
-        const int ly = i / (TS + 4), lx = i - ly * (TS + 4);
+    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
+        const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
         const int y = y0 - 2 + ly, x = x0 - 2 + lx;
-        s_f[ly][lx] = (y >= 0 && y < hq && x >= 0 && x < wq) ? field[base + ((size_t)y * wq + x) * C] : 0.f;
+        s_f[ly][lx] = (y >= 0 && y < hq && x >= 0 && x < wq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     double a0 = 0.0, a1 = 0.0;
-    for (int i = tid; i < (TS + 2) * (TS + 2); i += 256) {
-        const int ly = i / (TS + 2), lx = i - ly * (TS + 2);
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
         const int y = y0 - 1 + ly, x = x0 - 1 + lx;
-        float vx = 0.f, vy = 0.f;
+        float2 vx = make_float2(0.f, 0.f), vy = make_float2(0.f, 0.f);
         if (y >= 0 && y < hq && x >= 0 && x < wq) {
             const int by = ly + 1, bx = lx + 1;
-            const float tl = s_f[by - 1][bx - 1], tc = s_f[by - 1][bx], tr = s_f[by - 1][bx + 1];
-            const float ml = s_f[by][bx - 1], mr = s_f[by][bx + 1];
-            const float bl_ = s_f[by + 1][bx - 1], bc = s_f[by + 1][bx], br = s_f[by + 1][bx + 1];
-            const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
-            const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
-            const float sx = sqrtf(dx * dx + eps2), sy = sqrtf(dy * dy + eps2);
-            vx = dx / sx;
-            vy = dy / sy;
-            if (ly >= 1 && ly <= TS && lx >= 1 && lx <= TS) {   // own cell, not halo
-                a0 += (double)sx;
-                a1 += (double)sy;
+            const float2 tl = s_f[by - 1][bx - 1], tc = s_f[by - 1][bx], tr = s_f[by - 1][bx + 1];
+            const float2 ml = s_f[by][bx - 1], mr = s_f[by][bx + 1];
+            const float2 bl_ = s_f[by + 1][bx - 1], bc = s_f[by + 1][bx], br = s_f[by + 1][bx + 1];
+            const bool own = ly >= 1 && ly <= TH && lx >= 1 && lx <= TW;     // own cell, not halo
+#define MPC_SM_CH(c)                                                                      \
+            {                                                                             \
+                const float dx = (tr.c - tl.c) + 2.f * (mr.c - ml.c) + (br.c - bl_.c);     \
+                const float dy = (bl_.c - tl.c) + 2.f * (bc.c - tc.c) + (br.c - tr.c);     \
+                const float sx = sqrtf(dx * dx + eps2), sy = sqrtf(dy * dy + eps2);        \
+                vx.c = dx / sx;                                                            \
+                vy.c = dy / sy;                                                            \
+                if (own) { a0 += (double)sx; a1 += (double)sy; }                           \
             }
+            MPC_SM_CH(x)
+            MPC_SM_CH(y)
+#undef MPC_SM_CH
         }
         s_vx[ly][lx] = vx;
         s_vy[ly][lx] = vy;
     }
     __syncthreads();
     if (gfield != nullptr) {
-        const int lx = tid & 15, ly = tid >> 4;
-        const int y = y0 + ly, x = x0 + lx;
-        if (y < hq && x < wq) {
-            const int uy_ = ly + 1, ux_ = lx + 1;
-            const float gx = (s_vx[uy_ + 1][ux_ - 1] - s_vx[uy_ + 1][ux_ + 1]) +
-                             2.f * (s_vx[uy_][ux_ - 1] - s_vx[uy_][ux_ + 1]) +
-                             (s_vx[uy_ - 1][ux_ - 1] - s_vx[uy_ - 1][ux_ + 1]);
-            const float gy = (s_vy[uy_ - 1][ux_ + 1] - s_vy[uy_ + 1][ux_ + 1]) +
-                             2.f * (s_vy[uy_ - 1][ux_] - s_vy[uy_ + 1][ux_]) +
-                             (s_vy[uy_ - 1][ux_ - 1] - s_vy[uy_ + 1][ux_ - 1]);
-            gfield[base + ((size_t)y * wq + x) * C] = gscale * (gx + gy);
+        float2 *g2 = reinterpret_cast<float2 *>(gfield);
+        for (int i = tid; i < TH * TW; i += 256) {
+            const int ly = i / TW, lx = i - ly * TW;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y < hq && x < wq) {
+                const int uy_ = ly + 1, ux_ = lx + 1;
+                float2 o;
+#define MPC_SM_G(c)                                                                                        \
+                o.c = gscale * (((s_vx[uy_ + 1][ux_ - 1].c - s_vx[uy_ + 1][ux_ + 1].c) +                    \
+                                 2.f * (s_vx[uy_][ux_ - 1].c - s_vx[uy_][ux_ + 1].c) +                       \
+                                 (s_vx[uy_ - 1][ux_ - 1].c - s_vx[uy_ - 1][ux_ + 1].c)) +                     \
+                                ((s_vy[uy_ - 1][ux_ + 1].c - s_vy[uy_ + 1][ux_ + 1].c) +                     \
+                                 2.f * (s_vy[uy_ - 1][ux_].c - s_vy[uy_ + 1][ux_].c) +                       \
+                                 (s_vy[uy_ - 1][ux_ - 1].c - s_vy[uy_ + 1][ux_ - 1].c)));
+                MPC_SM_G(x)
+                MPC_SM_G(y)
+#undef MPC_SM_G
+                g2[base + ((size_t)y * wq + x) * C2] = o;
+            }
         }
     }
     const double r0 = block_sum_d<256>(a0, s_red[0]);
@@ -326,19 +469,19 @@ __global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ fi
 // ------------------------------------------------------------------------------------------
 // finalize: fp64 reduction of the partials -> device scalars
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(const double *__restrict__ cpart, int n_cblocks,
+__global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ cpart, int n_cblocks,
                                                   int tiles_per_img, int nimg, int HW,
                                                   const double *__restrict__ spart, int n_sblocks,
                                                   double smooth_count, float smooth_weight,
                                                   int variance, float *__restrict__ scal) {
-    __shared__ double s_red[2][4];
+    __shared__ double s_red[2][16];
     __shared__ double s_var;
     const int tid = threadIdx.x;
     double val = 0.0, gcoef = 0.0;
     if (!variance) {
         double a = 0.0;
-        for (int i = tid; i < n_cblocks; i += 256) a += cpart[2 * (size_t)i];
-        const double tot = block_sum_d<256>(a, s_red[0]);
+        for (int i = tid; i < n_cblocks; i += 1024) a += cpart[2 * (size_t)i];
+        const double tot = block_sum_d<1024>(a, s_red[0]);
         const double N = (double)nimg * (double)HW;
         val = tot / N;
         gcoef = -1.0 / (val * val) / N;
@@ -348,12 +491,12 @@ __global__ __launch_bounds__(256) void k_finalize(const double *__restrict__ cpa
         __syncthreads();
         for (int img = 0; img < nimg; ++img) {
             double a = 0.0, b = 0.0;
-            for (int i = tid; i < tiles_per_img; i += 256) {
+            for (int i = tid; i < tiles_per_img; i += 1024) {
                 a += cpart[2 * ((size_t)img * tiles_per_img + i)];
                 b += cpart[2 * ((size_t)img * tiles_per_img + i) + 1];
             }
-            const double s1 = block_sum_d<256>(a, s_red[0]);
-            const double s2 = block_sum_d<256>(b, s_red[1]);
+            const double s1 = block_sum_d<1024>(a, s_red[0]);
+            const double s2 = block_sum_d<1024>(b, s_red[1]);
             if (tid == 0) s_var += (s2 - s1 * s1 / (double)HW) / (double)(HW - 1);
         }
         __syncthreads();
@@ -363,12 +506,12 @@ __global__ __launch_bounds__(256) void k_finalize(const double *__restrict__ cpa
     double smooth = 0.0;
     if (n_sblocks > 0) {
         double a = 0.0, b = 0.0;
-        for (int i = tid; i < n_sblocks; i += 256) {
+        for (int i = tid; i < n_sblocks; i += 1024) {
             a += spart[2 * (size_t)i];
             b += spart[2 * (size_t)i + 1];
         }
-        const double sx = block_sum_d<256>(a, s_red[0]);
-        const double sy = block_sum_d<256>(b, s_red[1]);
+        const double sx = block_sum_d<1024>(a, s_red[0]);
+        const double sy = block_sum_d<1024>(b, s_red[1]);
         smooth = (double)smooth_weight * ((sx / smooth_count + sy / smooth_count) / 2.0);
     }
     if (tid == 0) {
@@ -404,6 +547,11 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     const dim3 grid(mpc_cdiv(s->W, MPC_CT_W), mpc_cdiv(s->H, MPC_CT_H), L.nimg);
     const int variance = (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0;
     const int l2 = (s->flags & MPC_F_NORM_L2) ? 1 : 0;
+    if (grad_iwe && !variance) {
+        hipLaunchKernelGGL(k_contrast_fused, grid, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
+        MPC_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
     MPC_CHECK_LAUNCH();
     if (grad_iwe) {
@@ -426,9 +574,10 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     const mpc_ws_layout L = mpc_layout(s);
-    const dim3 grid(mpc_cdiv(s->wq, MPC_ST), mpc_cdiv(s->hq, MPC_ST), nimg * C);
+    MPC_CHECK_ARG(nimg > 0 && C > 0 && (C % 2) == 0, MPC_E_SHAPE, "field must have an even number of channels");
+    const dim3 grid(mpc_cdiv(s->wq, MPC_SM_W), mpc_cdiv(s->hq, MPC_SM_H), nimg * (C / 2));
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
-    MPC_CHECK_ARG(nimg > 0 && C > 0 && nblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
+    MPC_CHECK_ARG(nblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
     hipStream_t st = (hipStream_t)stream;
     double *spart = (double *)((char *)ws + L.off_spart);
     const double count = (double)nimg * C * s->hq * s->wq;
@@ -448,11 +597,11 @@ extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smo
     int64_t nsblk = 0;
     double count = 1.0;
     if (smooth_nimg > 0) {
-        nsblk = (int64_t)mpc_cdiv(s->wq, MPC_ST) * mpc_cdiv(s->hq, MPC_ST) * smooth_nimg * smooth_C;
+        nsblk = (int64_t)mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H) * smooth_nimg * (smooth_C / 2);
         MPC_CHECK_ARG(nsblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
         count = (double)smooth_nimg * smooth_C * s->hq * s->wq;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream,
                        (const double *)((char *)ws + L.off_cpart), L.n_cblocks, tiles, L.nimg,
                        s->H * s->W, (const double *)((char *)ws + L.off_spart), (int)nsblk, count,
                        smooth_weight, (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0, scal);

@@ -863,32 +863,29 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
     const int RQ = use_lds ? RQ_need : 0;
     const int RW = 16 + 2 * RQ;
     const int ry0 = blockIdx.y * 16 - RQ, rx0 = blockIdx.x * 16 - RQ;
-    float *ldK = reinterpret_cast<float *>(s_dyn);
-    int *liK = reinterpret_cast<int *>(s_dyn + (size_t)RW * RW * 4);
-    float *lnorm = reinterpret_cast<float *>(s_dyn + (size_t)RW * RW * 8);
-    float2 *lg = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 12);
-    float2 *lgn = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 20);
-    float4 *lq4 = reinterpret_cast<float4 *>(s_dyn + (size_t)RW * RW * 28);
+    // LDS: only the fast path (num_tref == 1, 'mean') stages anything: one float4 per query cell
+    // {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} (+ float2 of the flow_to_next gradient)
+    float4 *lq4 = reinterpret_cast<float4 *>(s_dyn);
+    float2 *lgn = reinterpret_cast<float2 *>(s_dyn + (size_t)RW * RW * 16);
     const bool fast = use_lds && p.T == 1 && !p.iwd;
     const bool has_next = (gnext != nullptr) && (t < p.nb - 1);
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G * p.T;
-    if (use_lds) {
+    if (fast) {
         for (int i = tid; i < RW * RW; i += 256) {
             const int rr = i / RW, cc = i - rr * RW;
             const int yy = ry0 + rr, xx = rx0 + cc;
-            float dk = -1.f, nm = 1.f; int ik = -1;
+            float dk = -1.f; int ik = -1;
             float2 g = make_float2(0.f, 0.f), gn = make_float2(0.f, 0.f);
             if (yy >= 0 && yy < p.hq && xx >= 0 && xx < p.wq) {
                 const size_t q = (size_t)bt * p.G + (size_t)yy * p.wq + xx;
                 dk = knn_state[q];
                 ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
-                if (p.iwd) nm = knn_state[2 * BQ + q];
-                if (p.T == 1) g = gl2[(size_t)yy * p.wq + xx];
+                g = gl2[(size_t)yy * p.wq + xx];
                 if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
             }
-            ldK[i] = dk; liK[i] = ik; lnorm[i] = nm; lg[i] = g; lgn[i] = gn;
             lq4[i] = make_float4(dk, __int_as_float(ik), g.x, g.y);
+            if (has_next) lgn[i] = gn;
         }
     }
     // points of the tile: per tile row a contiguous range of the bucketed arrays
@@ -925,7 +922,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
         int x0 = (int)ceilf((pt.y - R - p.off) / (float)p.sp) - 1;
         int x1 = (int)floorf((pt.y + R - p.off) / (float)p.sp) + 1;
         y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, p.hq - 1); x1 = min(x1, p.wq - 1);
-        if (use_lds) {   // the staged region always covers the window (see the note on clamped cells)
+        if (fast) {      // the staged region always covers the window (see the note on clamped cells)
             y0 = max(y0, ry0); x0 = max(x0, rx0); y1 = min(y1, ry0 + RW - 1); x1 = min(x1, rx0 + RW - 1);
         }
         float2 an = make_float2(0.f, 0.f);
@@ -949,26 +946,14 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
                 for (int cx = x0; cx <= x1; ++cx) {
                     const float qx = (float)(cx * p.sp) + p.off;
                     const float d = pair_dist(qy, qx, pt.x, pt.y, p.l1);
-                    float dk, nm; int ik; float2 gq, gnq;
-                    if (use_lds) {
-                        const int li = (cy - ry0) * RW + (cx - rx0);
-                        dk = ldK[li];
-                        if (d > dk) continue;
-                        ik = liK[li];
-                        if (d == dk && i > ik) continue;
-                        nm = lnorm[li];
-                        gq = (p.T == 1) ? lg[li] : gl2[((size_t)cy * p.wq + cx) * p.T + tr];
-                        gnq = lgn[li];
-                    } else {
-                        const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
-                        dk = knn_state[q];
-                        if (d > dk) continue;
-                        ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
-                        if (d == dk && i > ik) continue;
-                        nm = p.iwd ? knn_state[2 * BQ + q] : 1.f;
-                        gq = gl2[((size_t)cy * p.wq + cx) * p.T + tr];
-                        gnq = has_next ? gn2[(size_t)cy * p.wq + cx] : make_float2(0.f, 0.f);
-                    }
+                    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
+                    const float dk = knn_state[q];
+                    if (d > dk) continue;
+                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                    if (d == dk && i > ik) continue;
+                    const float nm = p.iwd ? knn_state[2 * BQ + q] : 1.f;
+                    const float2 gq = gl2[((size_t)cy * p.wq + cx) * p.T + tr];
+                    const float2 gnq = has_next ? gn2[(size_t)cy * p.wq + cx] : make_float2(0.f, 0.f);
                     const float w = p.iwd ? (1.f / (d + 1e-9f)) / nm : invK;
                     ay += w * gq.x; ax += w * gq.y;
                     if (tr == 0 && has_next) { an.x += invK * gnq.x; an.y += invK * gnq.y; }
@@ -1077,7 +1062,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         int RH = r_init + 1;
         if (RH > 16) RH = 16;
         const int RW = 16 + 2 * RH;
-        int cap = (int)(2.0 * dens * RW * RW) + 256;
+        int cap = (int)(1.5 * dens * RW * RW) + 128;      // LDS per workgroup decides occupancy (4 instead of 3 per CU)
         cap = (cap + 63) / 64 * 64;
         const size_t per_pt = 8 + 4 + (s->T == 1 ? 8 : 0) + (p.want_next ? 8 : 0);
         const size_t fixed = (size_t)(KNN_BINS / 2) * 256 * 4 + (size_t)RW * (RW + 1) * 4 + 64;
@@ -1115,7 +1100,7 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         attr_set = true;
     }
     const int RWmax = 16 + 2 * KNN_RQ_MAX;
-    const size_t lds = (size_t)RWmax * RWmax * 44;
+    const size_t lds = (s->T == 1 && !p.iwd) ? (size_t)RWmax * RWmax * (16 + (grad_flow_next ? 8 : 0)) : 0;
     const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
     hipLaunchKernelGGL(k_knn_bwd_points, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
                        grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a);

@@ -186,11 +186,11 @@ def finalize(shape, smooth_nimg, smooth_C, weight, ws, device):
     return scal
 
 
-def event_splat_bwd(shape, events, flow_lut, t_ref, gimg, scal, grad_out, g_lut, accumulate, ws):
+def event_splat_bwd(shape, events, flow_lut, t_ref, gimg, scal, grad_out, g_lut, add_term, ws):
     with _stage('mpc_event_splat_bwd', events.device):
         C.check(C.lib().mpc_event_splat_bwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
                                             _ptr(gimg), _ptr(scal), _ptr(grad_out), _ptr(g_lut),
-                                            1 if accumulate else 0, _ptr(ws), _stream(events.device)),
+                                            _ptr(add_term), _ptr(ws), _stream(events.device)),
                 'mpc_event_splat_bwd')
     return g_lut
 
@@ -269,12 +269,11 @@ class FocusCalcFn(torch.autograd.Function):
         traj, ev, tr, flow_lut, state, gimg, scal, g_field = ctx.saved_tensors
         g = _f32c(g_loss.reshape(1))
         g_next = None
+        g_lut = torch.empty_like(flow_lut)
         if g_field is not None and not cfg.smooth_on_next:
-            g_lut = scale(g_field, g)
-            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, True, ws)
+            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, g_field, ws)   # smoothness folded in
         else:
-            g_lut = torch.empty_like(flow_lut)
-            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, False, ws)
+            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, None, ws)
             if g_field is not None:
                 g_next = scale(g_field, g)
         g_traj = knn_lut_bwd(shape, traj, g_lut, g_next, state, ws)
@@ -312,7 +311,7 @@ class EventFocusFn(torch.autograd.Function):
         ev, tr, lut, gimg, scal = ctx.saved_tensors
         g = _f32c(g_focus.reshape(1))
         g_lut = torch.empty_like(lut)
-        event_splat_bwd(ctx.shape, ev, lut, tr, gimg, scal, g, g_lut, False, ctx.ws)
+        event_splat_bwd(ctx.shape, ev, lut, tr, gimg, scal, g, g_lut, None, ctx.ws)
         return g_lut, None, None, None, None
 
 
