@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void k_splat_bwd_atomic(const mpc_shape s,
 // than fp32 accumulation of the same taps, and integer sums are order independent, so the
 // image is bitwise reproducible from run to run.
 // ==========================================================================================
-#define EV_PER_THREAD 4
+#ifndef EV_PER_THREAD
+#define EV_PER_THREAD 2   // measured at C3: 2 -> 98.6 us, 4 -> 106.9, 8 -> 107.5 (whole forward splat)
+#endif
 #define EV_FIX_SHIFT 30
 #define EV_MARKER 0x6d706331   // 'mpc1': backward records of this workspace are valid
 

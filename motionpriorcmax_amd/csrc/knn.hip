@@ -62,9 +62,13 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
     for (int g = tid; g < p.G; g += 1024) s_cnt[g] = 0;
     __syncthreads();
-    for (int i = tid; i < p.n; i += 1024) {
-        const float2 q = pts[i];
-        atomicAdd(&s_cnt[cell_of(q.x, p.sp, p.hq) * p.wq + cell_of(q.y, p.sp, p.wq)], 1);
+    for (int i0 = tid; i0 < p.n; i0 += 8 * 1024) {          // 8 loads in flight per thread
+        float2 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < p.n) atomicAdd(&s_cnt[cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq)], 1);
     }
     __syncthreads();
     // exclusive scan over the G counters: each thread owns a contiguous chunk
@@ -94,11 +98,19 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     __syncthreads();
     float2 *sp_ = spos + (size_t)bt * p.n;
     int *si_ = sidx + (size_t)bt * p.n;
-    for (int i = tid; i < p.n; i += 1024) {
-        const float2 q = pts[i];
-        const int pos = atomicAdd(&s_cnt[cell_of(q.x, p.sp, p.hq) * p.wq + cell_of(q.y, p.sp, p.wq)], 1);
-        sp_[pos] = q;
-        si_[pos] = i;
+    for (int i0 = tid; i0 < p.n; i0 += 8 * 1024) {
+        float2 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 1024;
+            if (i < p.n) {
+                const int pos = atomicAdd(&s_cnt[cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq)], 1);
+                sp_[pos] = q[u];
+                si_[pos] = i;
+            }
+        }
     }
 }
 
@@ -974,6 +986,20 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
     if (gi >= (size_t)p.B * p.n) return;
     const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
     float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (p.T + p.nb) * p.n;
+    if (p.T == 1) {                               // one pass over the partials
+        float sy = 0.f, sx = 0.f;
+        float2 carry = make_float2(0.f, 0.f);
+#pragma unroll 5
+        for (int t = 0; t < p.nb; ++t) {
+            const float2 g = tmp_g[(size_t)(b * p.nb + t) * p.n + i];
+            const float2 a = tmp_a[(size_t)(b * p.nb + t) * p.n + i];
+            sy += g.x; sx += g.y;
+            g2[(size_t)(1 + t) * p.n + i] = make_float2(-g.x + carry.x - a.x, -g.y + carry.y - a.y);
+            carry = a;
+        }
+        g2[i] = make_float2(sy, sx);
+        return;
+    }
     for (int tr = 0; tr < p.T; ++tr) {
         float sy = 0.f, sx = 0.f;
         for (int t = 0; t < p.nb; ++t) {
@@ -1029,7 +1055,6 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if ((rc = set_max_lds((const void *)k_knn_query_tile, __func__))) return rc;
         attr_set = true;
     }
-    (void)hipMemsetAsync((char *)ws + L.off_counts, 0, 32, st);      // statistics of the query kernel (tests, tuning)
     hipLaunchKernelGGL(k_knn_bucket, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
@@ -1045,6 +1070,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         mode = (e && e[0] == 't' && e[1] == 'i') ? 0 : ((e && e[0] == 'g') ? 2 : 1);
     }
     if (s->T == 1 && !p.iwd && mode == 0) {
+        (void)hipMemsetAsync((char *)ws + L.off_counts, 0, 32, st);   // statistics of the tile kernel (tuning)
         // one ring of slack over the tight radius: a jittered lattice then almost never fails the
         // "K candidates below the ring bound" test; border queries enlarge their own radius
         const int r_base = r_init + 1;

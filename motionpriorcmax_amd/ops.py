@@ -256,10 +256,10 @@ class FocusCalcFn(torch.autograd.Function):
 
         ctx.cfg, ctx.shape = cfg, shape
         ctx.ws = ws
+        ctx.set_materialize_grads(False)      # no zero-filled [B,P,H,W] gradient for the detached outputs
         ctx.save_for_backward(traj, ev, tr, flow_lut, state, gimg, scal, g_field)
-        loss = scal[C.SCAL_LOSS].clone()
-        focus = scal[C.SCAL_FOCUS].clone()
-        smooth = scal[C.SCAL_SMOOTH].clone()
+        out = scal[:3].clone()                # one tiny copy: the outputs must not alias the saved scalars
+        loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
         ctx.mark_non_differentiable(focus, smooth, blur)
         return loss, focus, smooth, blur
 
@@ -267,6 +267,8 @@ class FocusCalcFn(torch.autograd.Function):
     def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
         cfg, shape, ws = ctx.cfg, ctx.shape, ctx.ws
         traj, ev, tr, flow_lut, state, gimg, scal, g_field = ctx.saved_tensors
+        if g_loss is None:
+            return None, None, None, None, None
         g = _f32c(g_loss.reshape(1))
         g_next = None
         g_lut = torch.empty_like(flow_lut)
@@ -301,6 +303,7 @@ class EventFocusFn(torch.autograd.Function):
         blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
         scal = finalize(shape, 0, 0, 0.0, ws, dev)
         ctx.shape, ctx.ws = shape, ws
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(ev, tr, lut, gimg, scal)
         focus = scal[C.SCAL_FOCUS].clone()
         ctx.mark_non_differentiable(blur, raw)
@@ -309,6 +312,8 @@ class EventFocusFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_focus, g_blur, g_raw):
         ev, tr, lut, gimg, scal = ctx.saved_tensors
+        if g_focus is None:
+            return None, None, None, None, None
         g = _f32c(g_focus.reshape(1))
         g_lut = torch.empty_like(lut)
         event_splat_bwd(ctx.shape, ev, lut, tr, gimg, scal, g, g_lut, None, ctx.ws)
