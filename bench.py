@@ -98,6 +98,29 @@ def stage_bytes(B, M, nb, n, T=1, P=2):
     }
 
 
+# kernels behind each C-ABI stage (for the PMC traffic figure)
+STAGE_KERNELS = {
+    'mpc_knn_lut_fwd': ['k_knn_bucket', 'k_knn_query', 'k_knn_query_tile'],
+    'mpc_knn_lut_bwd': ['k_knn_bwd_points', 'k_knn_bwd_combine'],
+    'mpc_event_splat_fwd': ['k_ev_bin', 'k_iwe_accum', 'k_iwe_overflow', 'k_splat_fwd_atomic'],
+    'mpc_event_splat_bwd': ['k_lut_accum', 'k_lut_overflow', 'k_splat_bwd_atomic'],
+    'mpc_contrast_fwd': ['k_contrast_fused', 'k_contrast_fwd', 'k_contrast_bwd_gm', 'k_contrast_bwd_var', 'k_image_means'],
+    'mpc_lut_smooth': ['k_lut_smooth'], 'mpc_finalize': ['k_finalize'], 'mpc_scale': ['k_scale'],
+}
+
+
+def pmc_traffic(workload, stage):
+    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC summary of this workload
+    (profiles/traffic_<workload>.json, made by tools/summarize_pmc.py from separate FETCH_SIZE and
+    WRITE_SIZE passes; gfx950 x2 correction on the read side).  None if no summary is present."""
+    f = os.path.join(ROOT, 'profiles', f'traffic_{workload}.json')
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    tot = sum(d[k]['hbm_bytes_per_launch'] for k in STAGE_KERNELS.get(stage, []) if k in d)
+    return round(tot) if tot > 0 else None
+
+
 def cpu_baseline(wl, budget_s=20.0):
     """The CPU oracle (a restatement of the reference's PyTorch CPU path, `kind: port`) timed on
     the host cores on a bounded sample of the same workload: the event path (warp -> IWE ->
@@ -238,7 +261,7 @@ def main():
     ms_per_step = 1e3 * r['dt'] / r['steps']
     value = r['total_valid'] * r['steps'] / r['dt'] / 1e6
 
-    def roofline_of(res):
+    def roofline_of(res, wname=None):
         wl_ = res['wl']
         sb = stage_bytes(wl_['B'], wl_['M'], wl_['nb'], res['n'])
         per_step = {}
@@ -253,7 +276,8 @@ def main():
         path_b = algorithmic_bytes(wl_['B'], wl_['M'], wl_['nb'])
         return {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(wname, dom) if wname else None,
+            'algorithmic_bytes': int(d['algorithmic_MB'] * 1e6),
             'kernel_us': round(d['us_per_step'], 1),
             'path': {'algorithmic_MB': round(path_b / 1e6, 2), 'gpu_us_per_step': round(gpu_us, 1),
                      'achieved': round(path_b / (gpu_us * 1e-6) / 1e9, 1) if gpu_us > 0 else 0.0,
@@ -272,7 +296,7 @@ def main():
                    'grad_allreduce_MB': 0 if (world == 1 or args.no_grad_allreduce)
                    else round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2)},
         'loss': r['loss'],
-        'roofline': roofline_of(r),
+        'roofline': roofline_of(r, args.workload),
     }
     if rank == 0 and world == 1:
         also = {}

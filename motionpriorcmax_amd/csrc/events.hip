@@ -195,14 +195,26 @@ __device__ __forceinline__ float ev_from_fixed(long long a) {
     return (float)((double)a * (1.0 / (double)(1 << EV_FIX_SHIFT)));
 }
 
-// grid (ceil(M / (256*EV_PER_THREAD)), B), 256 threads, dynamic LDS = (P*NS + nb*NCS) * 2 ints
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Map physical block p to
+// logical block l so that every XCD works on ONE contiguous range of logical blocks: neighbours in
+// that range touch the same LUT slices / adjoint-image rows, which then stay in that XCD's L2
+// instead of being fetched by all eight (speed only; correct for any placement).
+__device__ __forceinline__ int xcd_swizzle(int p, int n) {
+    const int per = (n + 7) >> 3;
+    return (p & 7) * per + (p >> 3);
+}
+
+// grid (ceil(ceil(M / (256*EV_PER_THREAD)) * B / 8) * 8), 256 threads, dynamic LDS = (P*NS + nb*NCS) * 2 ints
 __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayout L,
                                                 const float *__restrict__ events,
                                                 const float *__restrict__ lut,
                                                 const float *__restrict__ t_ref, int want_bwd) {
     extern __shared__ int s_cnt[];          // [nloc] local counts, then [nloc] global bases
     const EvParams p = make_params(s);
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int chunks = (p.M + 256 * EV_PER_THREAD - 1) / (256 * EV_PER_THREAD);
+    const int lblk = xcd_swizzle(blockIdx.x, chunks * p.B);
+    if (lblk >= chunks * p.B) return;
+    const int tid = threadIdx.x, b = lblk / chunks, chunk = lblk - b * chunks;
     const int nf_loc = p.P * L.NS, nb_loc = want_bwd ? p.nb * L.NCS : 0, nloc = nf_loc + nb_loc;
     int *s_base = s_cnt + nloc;
     for (int i = tid; i < nloc; i += 256) s_cnt[i] = 0;
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     int lutidx[EV_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
-        const int i = (blockIdx.x * EV_PER_THREAD + k) * 256 + tid;
+        const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
         f0[k] = f1[k] = bk[k] = -1;
         r0[k] = r1[k] = rb[k] = 0;
         ry[k] = rx[k] = rw[k] = 0.f; aux[k] = 0u; lutidx[k] = 0;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
             }
         }
     }
-    if (want_bwd && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) L.gcount[L.NF + L.NBk + 2] = EV_MARKER;
+    if (want_bwd && lblk == 0 && tid == 0) L.gcount[L.NF + L.NBk + 2] = EV_MARKER;
 }
 
 // taps of one record restricted to rows [row0, row1): calls f(yy, xx, value)
@@ -375,8 +387,13 @@ __global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s,
     extern __shared__ unsigned long long s_acc[];
     const EvParams p = make_params(s);
     const int tid = threadIdx.x;
-    const int g = blockIdx.x;                         // (b*nb + it)*NCS + cstrip
-    const int bt = g / L.NCS, cst = g - bt * L.NCS, b = bt / p.nb;
+    // logical order (sample, LUT strip, bin): the bins of one strip read the same adjoint-image rows
+    const int lg = xcd_swizzle(blockIdx.x, L.NBk);
+    if (lg >= L.NBk) return;
+    const int b = lg / (L.NCS * p.nb), rem = lg - b * (L.NCS * p.nb);
+    const int cst = rem / p.nb, it = rem - cst * p.nb;
+    const int bt = b * p.nb + it;
+    const int g = bt * L.NCS + cst;                   // bucket id: (b*nb + it)*NCS + cstrip
     const int crow0 = cst * L.CSR, crow1 = min(crow0 + L.CSR, p.hq);
     const int ncell = (crow1 - crow0) * p.wq;
     for (int i = tid; i < 2 * ncell; i += EV_LUT_THREADS) s_acc[i] = 0ull;
@@ -469,7 +486,8 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
         hipError_t e0 = hipMemsetAsync(BL.gcount, 0, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st);
         if (e0 != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e0)); return (int)e0; }
         if (s->B > 0 && s->M > 0) {
-            const dim3 grid(mpc_cdiv(s->M, 256 * EV_PER_THREAD), s->B);
+            const int nblk = mpc_cdiv(s->M, 256 * EV_PER_THREAD) * s->B;
+            const dim3 grid(((nblk + 7) / 8) * 8);
             const size_t lds = (size_t)(L.P * L.n_strips + s->nb * L.n_cstrips) * 2 * sizeof(int);
             hipLaunchKernelGGL(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);
             MPC_CHECK_LAUNCH();
@@ -509,7 +527,7 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
         // the records must come from mpc_event_splat_fwd on this same workspace: the kernel checks
         // the marker that call left behind and poisons the output with NaN if it is missing
         if (L.nbb > 0) {
-            hipLaunchKernelGGL(k_lut_accum, dim3(L.nbb), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
+            hipLaunchKernelGGL(k_lut_accum, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
                                grad_iwe, scal, grad_out, grad_flow_lut, add_term);
             MPC_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_lut_overflow, dim3(64), dim3(256), 0, st, *s, BL, grad_iwe, scal, grad_out, grad_flow_lut);
