@@ -467,7 +467,7 @@ static int set_max_lds_ev(const void *fn, const char *who) {
 // ------------------------------------------------------------------------------------------
 extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, const float *flow_lut,
                                    const float *t_ref, float *iwe_raw, void *ws, void *stream) {
-    MPC_CHECK_ARG(s && events && iwe_raw && ws, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(s && iwe_raw && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) || flow_lut, MPC_E_NULL, "flow_lut is null");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
     int rc = mpc_validate_shape(s);
@@ -515,7 +515,7 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
                                    const float *t_ref, const float *grad_iwe, const float *scal,
                                    const float *grad_out, float *grad_flow_lut, const float *add_term,
                                    void *ws, void *stream) {
-    MPC_CHECK_ARG(s && events && flow_lut && grad_iwe && scal && grad_flow_lut && ws, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(s && flow_lut && grad_iwe && scal && grad_flow_lut && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(!(s->flags & MPC_F_NO_WARP), MPC_E_UNSUPPORTED, "no LUT to differentiate with MPC_F_NO_WARP");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
     int rc = mpc_validate_shape(s);

@@ -214,6 +214,85 @@ def test_bucket_overflow_spill_path():
     assert _rel_l2(lt.grad.cpu().numpy(), lo.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize('shape,sp,patch', [((50, 70), 4, 4), ((33, 47), 2, 3), ((64, 96), 8, 4)])
+def test_odd_image_sizes_vs_oracle(shape, sp, patch):
+    """Image sizes that are not multiples of the tile / superpixel / strip sizes, n != Q."""
+    from oracle import focus_oracle as O
+    nb, K, B, M = 4, 5, 2, 6000
+    cfg = dict(image_shape=shape, num_tref=1, num_bins=nb, num_knn=K, smooth_weight=0.01,
+               lut_superpixel_size=sp, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    ev, num_pos = O.synth_events(B, M, shape, nb, seed=17, pad_frac=0.05, num_pos=M // 3)
+    g = torch.Generator().manual_seed(18)
+    coeff = torch.randn(B, 1, 2, *shape, generator=g) * 4.0
+    times = torch.cat((torch.tensor([0.3]), O.bin_mid_times(nb)))
+    traj = O.trajectories_at(coeff, times, O.tile_mask(shape, patch), 1, 'polynomial')
+    to = traj.clone().requires_grad_(True)
+    lo, logo, misco = O.FocusLossOracle(**cfg).calc(to, times, {'events': ev, 'num_pos_events': num_pos})
+    lo.backward()
+    dev = _dev()
+    tg = traj.to(dev).requires_grad_(True)
+    lg, logg, miscg = _loss_obj(cfg).calc(tg, times.to(dev), {'events': ev.to(dev), 'num_pos_events': num_pos})
+    lg.backward()
+    assert abs(lg.item() - lo.item()) <= 1e-5 * abs(lo.item())
+    io = misco['iwes'].numpy()
+    np.testing.assert_allclose(miscg['iwes'].cpu().numpy(), io, rtol=0, atol=1e-5 * max(1.0, np.abs(io).max()))
+    assert _rel_l2(tg.grad.cpu().numpy(), to.grad.numpy()) < 1e-2
+
+
+def test_empty_and_all_padding_windows():
+    """No events at all (M = 0) and windows made only of padding rows: the IWE is zero, the
+    contrast value 0 and the focus loss +inf, exactly as in the reference's arithmetic (1 / 0)."""
+    from oracle import focus_oracle as O
+    shape, nb = (48, 64), 5
+    cfg = dict(image_shape=shape, num_tref=1, num_bins=nb, num_knn=4, smooth_weight=0.003,
+               lut_superpixel_size=4, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    g = torch.Generator().manual_seed(3)
+    coeff = torch.randn(2, 1, 2, *shape, generator=g)
+    times = torch.cat((torch.tensor([0.5]), O.bin_mid_times(nb)))
+    traj = O.trajectories_at(coeff, times, O.tile_mask(shape, 4), 1, 'polynomial')
+    dev = _dev()
+    L = _loss_obj(cfg)
+    for ev, num_pos in ((torch.zeros(2, 0, 6), 0), (torch.zeros(2, 300, 6), 120)):
+        loss, log, misc = L.calc(traj.to(dev), times.to(dev), {'events': ev.to(dev), 'num_pos_events': num_pos})
+        assert torch.isinf(loss).item() and loss.item() > 0
+        assert misc['iwes'].shape == (2, 1, 2, 48, 64) and float(misc['iwes'].abs().max()) == 0.0
+        so = O.FocusLossOracle(**cfg).smooth_loss(O.interpolate_flow(traj[:, :1], traj[:, 1:], shape, 4, 4)[0], None)
+        assert abs(log['smoothness_loss'].item() - so.item()) <= 1e-5 * so.item()
+
+
+def test_single_sample_single_event_and_far_out_of_bounds_flow():
+    """B*T = 1 with one valid event, and a LUT that throws every event far outside the image
+    (all taps masked): finite gradients, zero image."""
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    dev = _dev()
+    shape, nb = (48, 64), 5
+    cfg = dict(image_shape=shape, num_tref=1, num_bins=nb, num_knn=4, smooth_weight=0.0,
+               lut_superpixel_size=4, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=False,
+               mask_image_border=False, polarity_aware_batching=False, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    L = _loss_obj(cfg)
+    ev = torch.zeros(1, 8, 6)
+    ev[0, 3] = torch.tensor([20.25, 30.75, 0.4, 1.0, 2.0, 1.0])
+    lut = torch.zeros(1, nb, 12, 16, 1, 2)
+    lut[0, 2, 5, 7, 0] = torch.tensor([1.5, -2.25])
+    fo, iwo, rawo = O.FocusLossOracle(**cfg).event_path(ev, lut, torch.tensor([0.5]), -1)
+    lt = lut.to(dev).requires_grad_(True)
+    f, blur, raw = ops.EventFocusFn.apply(lt, ev.to(dev), torch.tensor([0.5], device=dev), L._cfg, -1)
+    f.backward()
+    assert abs(f.item() - fo.item()) <= 2e-6 * abs(fo.item())
+    np.testing.assert_allclose(raw.cpu().numpy().reshape(rawo.shape), rawo.numpy(), atol=1e-6)
+    assert torch.isfinite(lt.grad).all() and (lt.grad != 0).sum().item() <= 2
+    far = torch.full((1, nb, 12, 16, 1, 2), 500.0, device=dev)
+    ev2, _ = O.synth_events(1, 500, shape, nb, seed=1)
+    _, _, raw2 = ops.EventFocusFn.apply(far, ev2.to(dev), torch.tensor([0.5], device=dev), L._cfg, -1)
+    assert float(raw2.abs().max()) == 0.0
+
+
 def test_cpu_tensors_fail_loudly():
     g = load_golden('g3_squeeze_k1')
     L = _loss_obj(g['cfg'])
