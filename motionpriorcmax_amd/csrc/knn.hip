@@ -13,7 +13,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#ifndef KNN_BINS
 #define KNN_BINS 32
+#endif
 #ifndef KNN_BATCH
 #define KNN_BATCH 2   // candidate positions loaded ahead of use in the two hot scans (B=14: 944 -> 874 us; 4: 867)
 #endif
@@ -49,9 +51,14 @@ __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float p
 }
 
 // ------------------------------------------------------------------------------------------
-// bucket the points of one (sample, bin) by cell: counting sort in LDS
+// bucket the points of one (sample, bin) by cell: counting sort in LDS.  With CACHED, every thread
+// keeps its (up to KNN_BUCKET_NPT) points in registers: one round of global-load latency for the
+// whole kernel instead of one per point and pass (the kernel has only B*nb workgroups, so it is
+// latency- not bandwidth-limited).  A segmented multi-workgroup variant measured slower (66 vs 48 us).
 // grid B*nb, 1024 threads, dynamic LDS = G * 4 bytes
 // ------------------------------------------------------------------------------------------
+#define KNN_BUCKET_NPT 24
+template <bool CACHED>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start,
                                                      float2 *__restrict__ spos, int *__restrict__ sidx) {
@@ -60,20 +67,30 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     const int tid = threadIdx.x;
     const int bt = blockIdx.x, b = bt / p.nb, t = bt - b * p.nb;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
+    float2 q[CACHED ? KNN_BUCKET_NPT : 1];
+    int qc[CACHED ? KNN_BUCKET_NPT : 1];
+    if (CACHED) {
+#pragma unroll
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
+    }
     for (int g = tid; g < p.G; g += 1024) s_cnt[g] = 0;
     __syncthreads();
-    for (int i0 = tid; i0 < p.n; i0 += 8 * 1024) {          // 8 loads in flight per thread
-        float2 q[8];
+    if (CACHED) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + u * 1024 < p.n) atomicAdd(&s_cnt[cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq)], 1);
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
+            qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
+            if (tid + u * 1024 < p.n) atomicAdd(&s_cnt[qc[u]], 1);
+        }
+    } else {
+        for (int i = tid; i < p.n; i += 1024) {
+            const float2 v = pts[i];
+            atomicAdd(&s_cnt[cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+        }
     }
     __syncthreads();
     // exclusive scan over the G counters: each thread owns a contiguous chunk
     const int chunk = (p.G + 1023) / 1024;
-    const int g0 = tid * chunk, g1 = min(g0 + chunk, p.G);
+    const int g0 = min(tid * chunk, p.G), g1 = min(g0 + chunk, p.G);
     int local = 0;
     for (int g = g0; g < g1; ++g) local += s_cnt[g];
     int incl = local;
@@ -87,29 +104,34 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     int wave_off = 0;
     for (int w = 0; w < (tid >> 6); ++w) wave_off += s_wave[w];
     int run = wave_off + incl - local;
-    int *cs = cell_start + (size_t)bt * (p.G + 1);
     for (int g = g0; g < g1; ++g) {
         const int c = s_cnt[g];
         s_cnt[g] = run;        // becomes the fill cursor of the cell
-        cs[g] = run;
         run += c;
     }
-    if (tid == 1023) cs[p.G] = p.n;
+    __syncthreads();
+    int *cs = cell_start + (size_t)bt * (p.G + 1);
+    for (int g = tid; g < p.G; g += 1024) cs[g] = s_cnt[g];      // coalesced
+    if (tid == 0) cs[p.G] = p.n;
     __syncthreads();
     float2 *sp_ = spos + (size_t)bt * p.n;
     int *si_ = sidx + (size_t)bt * p.n;
-    for (int i0 = tid; i0 < p.n; i0 += 8 * 1024) {
-        float2 q[8];
+    if (CACHED) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 1024;
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
+            const int i = tid + u * 1024;
             if (i < p.n) {
-                const int pos = atomicAdd(&s_cnt[cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq)], 1);
+                const int pos = atomicAdd(&s_cnt[qc[u]], 1);
                 sp_[pos] = q[u];
                 si_[pos] = i;
             }
+        }
+    } else {
+        for (int i = tid; i < p.n; i += 1024) {
+            const float2 v = pts[i];
+            const int pos = atomicAdd(&s_cnt[cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+            sp_[pos] = v;
+            si_[pos] = i;
         }
     }
 }
@@ -1050,12 +1072,16 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent
     if (!attr_set) {
-        if ((rc = set_max_lds((const void *)k_knn_bucket, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<false>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query_tile, __func__))) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_knn_bucket, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
+    if (s->n <= KNN_BUCKET_NPT * 1024)
+        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
+    else
+        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
@@ -1088,7 +1114,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         int RH = r_init + 1;
         if (RH > 16) RH = 16;
         const int RW = 16 + 2 * RH;
-        int cap = (int)(1.5 * dens * RW * RW) + 128;      // LDS per workgroup decides occupancy (4 instead of 3 per CU)
+        int cap = (int)(1.5 * dens * RW * RW) + 128;      // LDS per workgroup decides occupancy (4 per CU; a tighter cap measured no gain)
         cap = (cap + 63) / 64 * 64;
         const size_t per_pt = 8 + 4 + (s->T == 1 ? 8 : 0) + (p.want_next ? 8 : 0);
         const size_t fixed = (size_t)(KNN_BINS / 2) * 256 * 4 + (size_t)RW * (RW + 1) * 4 + 64;
