@@ -188,7 +188,7 @@ struct Acc {
 };
 
 // Returns false if the search needs more rings than the LDS halo holds (LDS variant only).
-template <bool LDS>
+template <bool LDS, bool L1>
 __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int t, int cy, int cx,
                               int r_init, unsigned (*s_hist)[256], float *__restrict__ flow_lut,
                               float *__restrict__ flow_next, float *__restrict__ knn_state,
@@ -221,14 +221,14 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             float dmax = 0.f;
             for (int j = 0; j < p.n; ++j) {
                 const float2 q = c.spos[j];
-                dmax = fmaxf(dmax, pair_dist(qy, qx, q.x, q.y, p.l1));
+                dmax = fmaxf(dmax, pair_dist(qy, qx, q.x, q.y, L1));
             }
             upper = INFINITY;
             scale = dmax > 0.f ? (float)KNN_BINS / dmax : 0.f;
         } else {
             // anything outside the square is at least lb away along one axis
             const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
-            upper = p.l1 ? lb : lb * lb;
+            upper = L1 ? lb : lb * lb;
             scale = (float)KNN_BINS / upper;
         }
 #pragma unroll
@@ -243,7 +243,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                 for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(min(j + u, je - 1));     // loads first
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
-                    const float d = pair_dist(qy, qx, q[u].x, q[u].y, p.l1);
+                    const float d = pair_dist(qy, qx, q[u].x, q[u].y, L1);
                     if (j + u < je && d < upper) {
                         const int bin = min((int)(d * scale), KNN_BINS - 1);
                         atomicAdd(&s_hist[bin >> 1][tid], (bin & 1) ? 0x10000u : 1u);   // private column, fire-and-forget
@@ -290,7 +290,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             for (int u = 0; u < KNN_BATCH; ++u) {
                 const int j = j0 + u;
                 const float2 pj = qq[u];
-                const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                 if (j >= je || !(d < upper)) continue;
                 const int bin = min((int)(d * scale), KNN_BINS - 1);
                 if (bin < bstar) {
@@ -342,7 +342,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                 A.range(yy, x0, x1, js, je);
                 for (int j = js; j < je; ++j) {
                     const float2 pj = A.pos(j);
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                     if (!(d < upper)) continue;
                     if (min((int)(d * scale), KNN_BINS - 1) != bstar) continue;
                     if (d < ld || d > bd) continue;
@@ -376,7 +376,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                 A.range(yy, x0, x1, js, je);
                 for (int j = js; j < je; ++j) {
                     const float2 pj = A.pos(j);
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                     if (d > dK) continue;
                     if (d == dK && A.idx(j) > iK) continue;
                     const float2 f = A.flow_ref(j, tr, pj);
@@ -415,7 +415,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                 A.range(yy, x0, x1, js, je);
                 for (int j = js; j < je; ++j) {
                     const float2 pj = A.pos(j);
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, p.l1);
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                     const int id = A.idx(j);
                     const bool gt_last = (d > pd) || (d == pd && id > pi);
                     const bool lt_best = (d < bd) || (d == bd && id < bi);
@@ -518,8 +518,13 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     float dK = 0.f;
     if (cy < p.hq && cx < p.wq) {
         bool done = false;
-        if (use_lds) done = knn_one_query<true>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
-        if (!done) knn_one_query<false>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+        if (p.l1) {
+            if (use_lds) done = knn_one_query<true, true>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+            if (!done) knn_one_query<false, true>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+        } else {
+            if (use_lds) done = knn_one_query<true, false>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+            if (!done) knn_one_query<false, false>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+        }
     }
     // largest K-th distance of this tile: bounds the backward's search windows
     float m = dK;
@@ -798,7 +803,8 @@ __global__ __launch_bounds__(KNN_TILE_THREADS) void k_knn_query_tile(
         c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
         c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
         c.ry0 = c.rx0 = c.RW = c.RH = 0;
-        knn_one_query<false>(p, c, b, t, cy, cx, r_base, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+        if (p.l1) knn_one_query<false, true>(p, c, b, t, cy, cx, r_base, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+        else knn_one_query<false, false>(p, c, b, t, cy, cx, r_base, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
     }
     // largest K-th distance of this tile: bounds the backward's search windows
     float m = dK;
@@ -1087,6 +1093,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     const double dens = (double)s->n / (double)p.G;
     int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
     if (r_init < 1) r_init = 1;
+    { const char *e = getenv("MPC_KNN_R0"); if (e) r_init += atoi(e); }      // tuning: initial search radius offset
     const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
     // tuning switch (A/B measurements): MPC_KNN_MODE = thread (default) | tile | global.
     // Measured at B=14, 480x640, K=32 (round 1): thread 934 us, global 947 us, tile 2053 us.
