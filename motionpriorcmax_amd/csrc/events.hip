@@ -401,14 +401,25 @@ __global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s,
     const bool valid = L.gcount[L.NF + L.NBk + 2] == EV_MARKER;
     const int n = valid ? min(L.gcount[L.NF + g], L.bcap) : 0;
     const float4 *rec = L.brec + (size_t)g * L.bcap;
-    for (int r = tid; r < n; r += EV_LUT_THREADS) {
-        const float4 e = rec[r];
-        const unsigned a = __float_as_uint(e.w);
-        const int pol = (int)(a >> 31), cell = (int)(a & 0x7fffffffu);
-        float gy, gx;
-        record_grad(e.x, e.y, e.z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy, gx);
-        atomicAdd(&s_acc[2 * cell], (unsigned long long)ev_to_fixed(gy));
-        atomicAdd(&s_acc[2 * cell + 1], (unsigned long long)ev_to_fixed(gx));
+    // four records per thread in flight: their adjoint-image gathers (the latency of this kernel) overlap
+    for (int r0 = tid; r0 < n; r0 += 4 * EV_LUT_THREADS) {
+        float4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = rec[min(r0 + u * EV_LUT_THREADS, n - 1)];
+        float gy[4], gx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pol = (int)(__float_as_uint(e[u].w) >> 31);
+            record_grad(e[u].x, e[u].y, e[u].z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy[u], gx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u * EV_LUT_THREADS < n) {
+                const int cell = (int)(__float_as_uint(e[u].w) & 0x7fffffffu);
+                atomicAdd(&s_acc[2 * cell], (unsigned long long)ev_to_fixed(gy[u]));
+                atomicAdd(&s_acc[2 * cell + 1], (unsigned long long)ev_to_fixed(gx[u]));
+            }
+        }
     }
     __syncthreads();
     const float gout = grad_out ? grad_out[0] : 1.f;
