@@ -1,0 +1,48 @@
+// Microbenchmark: sustained VALU issue rate per SIMD on gfx950 for wave64 code (fma / int / mixed).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+template <int MODE>
+__global__ void k(float *out, int iters) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
+    const float b = 1.0001f, c = 0.5f;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {   // 8 independent fp32 FMAs
+            a0 = fmaf(a0, b, c); a1 = fmaf(a1, b, c); a2 = fmaf(a2, b, c); a3 = fmaf(a3, b, c);
+            a4 = fmaf(a4, b, c); a5 = fmaf(a5, b, c); a6 = fmaf(a6, b, c); a7 = fmaf(a7, b, c);
+        } else if (MODE == 1) {  // 4 fma + 4 int ops
+            a0 = fmaf(a0, b, c); a1 = fmaf(a1, b, c); a2 = fmaf(a2, b, c); a3 = fmaf(a3, b, c);
+            i0 = (i0 * 3) ^ it; i1 = (i1 + i0) & 0xffff; i2 = max(i2, i1) + 1; i3 = (i3 << 1) | (i2 & 1);
+        } else {                 // compare + select chains
+            a0 = a0 > a1 ? a0 * b : a1 + c; a1 = a1 > a2 ? a1 * b : a2 + c; a2 = a2 > a3 ? a2 * b : a3 + c; a3 = a3 > a0 ? a3 * b : a0 + c;
+            a4 = a4 > a5 ? a4 * b : a5 + c; a5 = a5 > a6 ? a5 * b : a6 + c; a6 = a6 > a7 ? a6 * b : a7 + c; a7 = a7 > a4 ? a7 * b : a4 + c;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + i0 + i1 + i2 + i3;
+}
+
+template <int MODE>
+void run(float *d, int waves_per_simd, int ops_per_iter) {
+    const int iters = 20000;
+    const int blocks = 256 * waves_per_simd;       // 256 threads = 4 waves per block = 1 wave per SIMD per block
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double winstr_per_simd = (double)waves_per_simd * iters * ops_per_iter;
+    printf("mode %d  waves/SIMD %d : %.3f ms -> %.2f cycles per wave-instruction per SIMD (2.4 GHz)\n", MODE, waves_per_simd, ms,
+           ms * 1e-3 * 2.4e9 / winstr_per_simd);
+}
+
+int main() {
+    float *d; hipMalloc(&d, 64 << 20);
+    for (int w : {1, 2, 4, 8}) run<0>(d, w, 8);
+    for (int w : {1, 2, 4, 8}) run<1>(d, w, 12);
+    for (int w : {1, 2, 4, 8}) run<2>(d, w, 24);
+    return 0;
+}
