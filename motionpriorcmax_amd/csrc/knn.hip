@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
         __syncthreads();
     }
     const float R = fmaxf(fmaxf(s_R[0], s_R[1]), fmaxf(s_R[2], s_R[3]));
-    const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;
+    const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo of the staged region, in cells
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
     const int RQ = use_lds ? RQ_need : 0;
     const int RW = 16 + 2 * RQ;
@@ -958,10 +958,12 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
         const int g = s_rowg[lo] + (pi - s_rowbase[lo]);
         const float2 pt = sp_[g];
         const int i = si_[g];
-        int y0 = (int)ceilf((pt.x - R - p.off) / (float)p.sp) - 1;
-        int y1 = (int)floorf((pt.x + R - p.off) / (float)p.sp) + 1;
-        int x0 = (int)ceilf((pt.y - R - p.off) / (float)p.sp) - 1;
-        int x1 = (int)floorf((pt.y + R - p.off) / (float)p.sp) + 1;
+        // query cells within reach: |q - p| <= R per axis.  R already carries a 0.01 px + 1e-4 relative
+        // margin, which dominates the rounding of these four expressions, so no extra cell is added.
+        int y0 = (int)ceilf((pt.x - R - p.off) / (float)p.sp);
+        int y1 = (int)floorf((pt.x + R - p.off) / (float)p.sp);
+        int x0 = (int)ceilf((pt.y - R - p.off) / (float)p.sp);
+        int x1 = (int)floorf((pt.y + R - p.off) / (float)p.sp);
         y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, p.hq - 1); x1 = min(x1, p.wq - 1);
         if (fast) {      // the staged region always covers the window (see the note on clamped cells)
             y0 = max(y0, ry0); x0 = max(x0, rx0); y1 = min(y1, ry0 + RW - 1); x1 = min(x1, rx0 + RW - 1);
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
                 else bwd_window<false, false>(lq4, lgn, RW, ry0, rx0, y0, y1, x0, x1, p.sp, p.off, pt, i, ay, ax, an);
             }
             tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
-            tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
+            if (gnext != nullptr) tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
             continue;
         }
         for (int tr = 0; tr < p.T; ++tr) {
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
 // backward, step 2: one thread per (sample, trajectory point): combine the per-bin partials.
 //   d traj(t_ref)[tr] = sum_t g[t][tr];   d traj(t_mid)[t] = -sum_tr g[t][tr] - a[t] + a[t-1]
 __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, const float2 *__restrict__ tmp_g,
-                                                         const float2 *__restrict__ tmp_a,
+                                                         const float2 *__restrict__ tmp_a,   // nullptr: no flow_to_next term
                                                          float *__restrict__ gtraj) {
     const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gi >= (size_t)p.B * p.n) return;
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 #pragma unroll 5
         for (int t = 0; t < p.nb; ++t) {
             const float2 g = tmp_g[(size_t)(b * p.nb + t) * p.n + i];
-            const float2 a = tmp_a[(size_t)(b * p.nb + t) * p.n + i];
+            const float2 a = tmp_a ? tmp_a[(size_t)(b * p.nb + t) * p.n + i] : make_float2(0.f, 0.f);
             sy += g.x; sx += g.y;
             g2[(size_t)(1 + t) * p.n + i] = make_float2(-g.x + carry.x - a.x, -g.y + carry.y - a.y);
             carry = a;
@@ -1166,7 +1168,8 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
                        grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a);
     MPC_CHECK_LAUNCH();
     const int64_t total = (int64_t)s->B * s->n;
-    hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g, tmp_a, grad_traj);
+    hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g,
+                       (grad_flow_next || s->T != 1 || p.iwd) ? tmp_a : nullptr, grad_traj);
     MPC_CHECK_LAUNCH();
     return 0;
 }
