@@ -293,6 +293,31 @@ def test_single_sample_single_event_and_far_out_of_bounds_flow():
     assert float(raw2.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('mode', ['tile', 'global'])
+def test_alternative_knn_kernels_agree_with_goldens(mode):
+    """The point-centric tile kernel and the unstaged per-thread search (MPC_KNN_MODE, read once per
+    process) must produce the same LUT as the default: run a golden stage check in a subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
+        "from conftest import load_golden\n"
+        "from motionpriorcmax_amd import LossFactory, ops\n"
+        "for name in ('g1_allflags', 'g2_config1', 'g5a_dct3_l2'):\n"
+        "    g = load_golden(name); L = LossFactory.get_loss_calculator('FOCUS', g['cfg'])\n"
+        "    t = torch.from_numpy(g['trajectories']).cuda().requires_grad_(True)\n"
+        "    lut, _ = ops.KnnLutFn.apply(t, L._cfg)\n"
+        "    assert np.abs(lut.detach().cpu().numpy() - g['flow_lut']).max() < 1e-5, name\n"
+        "    lut.backward(torch.from_numpy(g['grad_flow_lut']).cuda())\n"
+        "    assert torch.isfinite(t.grad).all()\n"
+        "print('ok')\n")
+    env = dict(os.environ, MPC_KNN_MODE=mode)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
 def test_cpu_tensors_fail_loudly():
     g = load_golden('g3_squeeze_k1')
     L = _loss_obj(g['cfg'])
