@@ -401,10 +401,21 @@ __global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ fi
     const float2 *f2 = reinterpret_cast<const float2 *>(field);
     const float eps2 = 1e-3f * 1e-3f;   // charbonnier epsilon ** 2 (loss.py:46,55)
 
-    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
-        const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
-        const int y = y0 - 2 + ly, x = x0 - 2 + lx;
-        s_f[ly][lx] = (y >= 0 && y < hq && x >= 0 && x < wq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
+    {   // all global loads of the tile before the first LDS store (see k_contrast_fused)
+        constexpr int NLD = ((TH + 4) * (TW + 4) + 255) / 256;
+        float2 v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
+            const int y = y0 - 2 + ly, x = x0 - 2 + lx;
+            v[k] = (i < (TH + 4) * (TW + 4) && y >= 0 && y < hq && x >= 0 && x < wq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + k * 256;
+            if (i < (TH + 4) * (TW + 4)) { const int ly = i / (TW + 4), lx = i - ly * (TW + 4); s_f[ly][lx] = v[k]; }
+        }
     }
     __syncthreads();
     double a0 = 0.0, a1 = 0.0;
