@@ -301,12 +301,19 @@ def main():
     if rank == 0 and world == 1:
         also = {}
         for name in [a for a in args.also.split(',') if a and a != args.workload]:
-            torch.cuda.empty_cache()     # the allocator otherwise frees/reallocates inside the timed steps
-            ra = run_workload(name, max(5, args.steps // 2), 5, False)
-            rf = roofline_of(ra)
-            also[name] = {'value': round(ra['total_valid'] * ra['steps'] / ra['dt'] / 1e6, 3),
-                          'ms_per_step': round(1e3 * ra['dt'] / ra['steps'], 4),
-                          'path_frac': rf['path']['frac'], 'stages_us_per_step': rf['stages_us_per_step']}
+            # each extra workload runs in a fresh child process: the caching allocator of this process
+            # (sized by the main workload) otherwise frees/reallocates inside the child's timed steps
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--steps', str(args.steps),
+                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--also', '']
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                dj = json.loads(r.stdout.strip().splitlines()[-1])
+                also[name] = {'value': dj['value'], 'ms_per_step': dj['ms_per_step'],
+                              'path_frac': dj['roofline']['path']['frac'],
+                              'stages_us_per_step': dj['roofline']['stages_us_per_step']}
+            except Exception as e:      # informational field: never fail the main line
+                also[name] = {'error': repr(e)[:200]}
         out['also'] = also
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)

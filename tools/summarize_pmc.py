@@ -19,7 +19,8 @@ def per_kernel(d, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         if r['Counter_Name'] == counter:
-            agg[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+            name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
+            agg[name].append(float(r['Counter_Value']))
     return agg
 
 
