@@ -214,7 +214,7 @@ def test_bucket_overflow_spill_path():
     assert _rel_l2(lt.grad.cpu().numpy(), lo.grad.numpy()) < 1e-4
 
 
-@pytest.mark.parametrize('shape,sp,patch', [((50, 70), 4, 4), ((33, 47), 2, 3), ((64, 96), 8, 4)])
+@pytest.mark.parametrize('shape,sp,patch', [((50, 70), 4, 4), ((33, 47), 2, 3), ((64, 96), 8, 4), ((45, 63), 3, 3)])
 def test_odd_image_sizes_vs_oracle(shape, sp, patch):
     """Image sizes that are not multiples of the tile / superpixel / strip sizes, n != Q."""
     from oracle import focus_oracle as O
@@ -316,6 +316,50 @@ def test_alternative_knn_kernels_agree_with_goldens(mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def _knn_vs_bruteforce(traj, shape, sp, K, dist_norm='l2', scheme='mean'):
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    cfg = dict(image_shape=shape, num_tref=1, num_bins=traj.shape[1] - 1, num_knn=K, smooth_weight=0.0,
+               lut_superpixel_size=sp, focus_loss_norm='l1', dist_norm=dist_norm, scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme=scheme,
+               smooth_type='on_flow_to_tref')
+    L = _loss_obj(cfg)
+    lut, _ = ops.KnnLutFn.apply(traj.to(_dev()), L._cfg)
+    ref, _ = O.interpolate_flow(traj[:, :1], traj[:, 1:], shape, sp, K, dist_norm, scheme)
+    return lut.cpu().numpy(), ref.numpy()
+
+
+def test_knn_large_k_and_dense_points():
+    """K = 64 (the search square has to grow) and 4 trajectories per LUT cell (patch 2, sp 4)."""
+    from oracle import focus_oracle as O
+    g = torch.Generator().manual_seed(31)
+    times = torch.cat((torch.tensor([0.4]), O.bin_mid_times(3)))
+    coeff = torch.randn(1, 1, 2, 64, 96, generator=g) * 5.0
+    traj = O.trajectories_at(coeff, times, O.tile_mask((64, 96), 4), 1, 'polynomial')
+    got, ref = _knn_vs_bruteforce(traj, (64, 96), 4, 64)
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    traj2 = O.trajectories_at(coeff, times, O.tile_mask((64, 96), 2), 1, 'polynomial')
+    got, ref = _knn_vs_bruteforce(traj2, (64, 96), 4, 16, dist_norm='l1', scheme='iwd')
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+
+
+def test_knn_degenerate_point_sets():
+    """Every trajectory collapsed onto a handful of spots (heavy distance ties, empty cells everywhere
+    else: the whole-grid search path), and trajectories far outside the image."""
+    from oracle import focus_oracle as O
+    g = torch.Generator().manual_seed(32)
+    n, nb = 192, 2
+    base = O.tile_mask((48, 64), 4).nonzero().float()
+    traj = base[None, None].repeat(1, 1 + nb, 1, 1).clone()
+    # bin 0: three clusters with distinct flows; bin 1: everything 500 px outside the image
+    centres = torch.tensor([[5.0, 7.0], [40.0, 50.0], [20.0, 30.0]])
+    traj[0, 1] = centres[torch.arange(n) % 3] + torch.randn(n, 2, generator=g) * 1e-3
+    traj[0, 2] = base + 500.0
+    traj[0, 0] = base + torch.randn(n, 2, generator=g)
+    got, ref = _knn_vs_bruteforce(traj, (48, 64), 4, 8)
+    np.testing.assert_allclose(got, ref, atol=5e-4)      # flows are O(500): 1e-6 relative
 
 
 def test_cpu_tensors_fail_loudly():
