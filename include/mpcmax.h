@@ -139,6 +139,19 @@ int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *fl
 /* y[i] = a[0] * x[i] (device scalar a; used to scale the smoothness gradient by grad_out). */
 int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *stream);
 
+/* ---- next row: voxel-grid builder, reference src/loader/dsec/utils.py:29-77
+ * (VoxelGrid.convert) as called from src/loader/dsec/loader.py:133-139.
+ * xytp   [B][N][4] : x, y, t, p per raw event (p in {0,1}; t increasing within a sample; rows beyond
+ *                    counts[b] are ignored)                        counts [B] int32 (device)
+ * grid   [B][C][H][W] (out, overwritten).  norm: 0 none, 1 'mean_std', 2 'max' (quantile clipping of
+ * the reference is not provided: quantile must be 0, the value used by config/exe/flow_training/dsec.yaml). */
+typedef struct mpc_vox_shape {
+    int32_t B, N, C, H, W, norm;
+} mpc_vox_shape;
+int64_t mpc_voxel_workspace_bytes(const mpc_vox_shape *s);
+int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const int32_t *counts, float *grid,
+                   void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,13 +25,17 @@ SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 
 
 EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_knn_lut_fwd',
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
-           'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale']
+           'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid']
 
 
 class Shape(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in
                 ('B', 'M', 'Mp', 'nb', 'T', 'H', 'W', 'sp', 'hq', 'wq', 'n', 'K')] + \
                [('flags', ctypes.c_uint32)]
+
+
+class VoxShape(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'C', 'H', 'W', 'norm')]
 
 
 _lib = None
@@ -62,8 +66,12 @@ def lib():
     L.mpc_finalize.argtypes = [sp, i32, i32, f32, vp, vp, vp]
     L.mpc_event_splat_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_scale.argtypes = [vp, vp, vp, i64, vp]
+    vsp = ctypes.POINTER(VoxShape)
+    L.mpc_voxel_workspace_bytes.argtypes = [vsp]
+    L.mpc_voxel_grid.argtypes = [vsp, vp, vp, vp, vp, vp]
     for name in EXPORTS[3:]:
         getattr(L, name).restype = ctypes.c_int
+    L.mpc_voxel_workspace_bytes.restype = i64
     if L.mpc_version() != 100:
         raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (100)')
     _lib = L

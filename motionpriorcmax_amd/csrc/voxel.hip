@@ -1,0 +1,311 @@
+// Voxel-grid builder: the network input that the reference's DataLoader workers
+// build on the CPU from the same event window (src/loader/dsec/utils.py:29-77, VoxelGrid.convert):
+// trilinear accumulation of +-1 polarity votes into [C][H][W], then normalisation of the non-zero
+// entries.  Same machinery as the IWE (events.hip): one binning pass appends 16-byte records to
+// per-(sample, channel, row-strip) buckets, one workgroup per bucket accumulates its strip in LDS as
+// Q33.30 fixed point (ds_add_u64) and writes it with plain stores; overflowing buckets spill to a
+// list applied with global atomics.
+//
+// Arithmetic follows the reference op for op: x0 = int(x) (truncation), tap weight
+// value * (1-|xl-x|) * (1-|yl-y|) * (1-|tl-t_norm|) (left to right; value = 2p-1 is +-1, so its sign
+// commutes exactly), t_norm = (C-1) * (t - t[0]) / (t[-1] - t[0]).
+#include "common.h"
+
+#define VOX_FIX_SHIFT 30
+#define VOX_PER_THREAD 2
+
+struct VoxLayout {
+    int SR, NS, NBk, cap;
+    int *gcount;          // [NBk + 8]   (NBk+0: spill count)
+    float4 *rec, *ovf;
+    double *part;         // [B][nblk][4]
+    float *stat;          // [B][4]  mean, 1/std (or 1/max), flag
+    int nstat_blocks;
+};
+
+__device__ __forceinline__ long long vox_to_fixed(float v) {         // |v| < 2^31
+    const float hi = truncf(v);
+    return ((long long)(int)hi << VOX_FIX_SHIFT) + (long long)(int)((v - hi) * (float)(1 << VOX_FIX_SHIFT));
+}
+__device__ __forceinline__ float vox_from_fixed(long long a) {
+    return (float)((double)a * (1.0 / (double)(1 << VOX_FIX_SHIFT)));
+}
+
+// taps of one record restricted to rows [row0, row1): f(yy, xx, value)
+template <typename F>
+__device__ __forceinline__ void vox_taps(float y, float x, float wt, int H, int W, int row0, int row1, F f) {
+    const int y0 = (int)fminf(fmaxf(y, -8.f), (float)H + 8.f), x0 = (int)fminf(fmaxf(x, -8.f), (float)W + 8.f);
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+        const int xx = x0 + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float wx = 1.f - fabsf((float)xx - x);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int yy = y0 + dy;
+            if (yy < row0 || yy >= row1) continue;
+            const float wy = 1.f - fabsf((float)yy - y);
+            f(yy, xx, (wx * wy) * wt);
+        }
+    }
+}
+
+// grid (chunks * B rounded up to 8), 256 threads, dynamic LDS = C*NS*2 ints
+__global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const VoxLayout L,
+                                                 const float4 *__restrict__ ev, const int *__restrict__ counts) {
+    extern __shared__ int s_cnt[];
+    const int chunks = (s.N + 256 * VOX_PER_THREAD - 1) / (256 * VOX_PER_THREAD);
+    const int per = (chunks * s.B + 7) >> 3;
+    const int lblk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-contiguous order
+    if (lblk >= chunks * s.B) return;
+    const int tid = threadIdx.x, b = lblk / chunks, chunk = lblk - b * chunks;
+    const int nloc = s.C * L.NS;
+    int *s_base = s_cnt + nloc;
+    for (int i = tid; i < nloc; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    const int n = min(counts[b], s.N);
+    const float4 *e = ev + (size_t)b * s.N;
+    float t_first = 0.f, t_span = 1.f;
+    if (n > 0) { t_first = e[0].z; t_span = e[n - 1].z - t_first; }
+    float ry[VOX_PER_THREAD], rx[VOX_PER_THREAD], rw[VOX_PER_THREAD][2];
+    int bk[VOX_PER_THREAD][4], rk[VOX_PER_THREAD][4];
+#pragma unroll
+    for (int k = 0; k < VOX_PER_THREAD; ++k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { bk[k][u] = -1; rk[k][u] = 0; }
+        ry[k] = rx[k] = rw[k][0] = rw[k][1] = 0.f;
+        const int i = (chunk * VOX_PER_THREAD + k) * 256 + tid;
+        if (i >= n) continue;
+        const float4 v = e[i];                       // x, y, t, p
+        const float tn = (float)(s.C - 1) * (v.z - t_first) / t_span;       // utils.py:35-36
+        const int t0 = (int)tn;
+        const int y0 = (int)fminf(fmaxf(v.y, -8.f), (float)s.H + 8.f);
+        const float val = 2.f * v.w - 1.f;
+        ry[k] = v.y; rx[k] = v.x;
+        const int x0 = (int)fminf(fmaxf(v.x, -8.f), (float)s.W + 8.f);
+        if (x0 + 1 < 0 || x0 >= s.W) continue;        // no column inside the sensor
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int tl = t0 + dt;
+            if (tl < 0 || tl >= s.C) continue;
+            rw[k][dt] = val * (1.f - fabsf((float)tl - tn));
+            int prev = -1;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yl = y0 + dy;
+                if (yl < 0 || yl >= s.H) continue;
+                const int st = yl / L.SR;
+                if (st == prev) continue;
+                prev = st;
+                const int lb = tl * L.NS + st;
+                bk[k][dt * 2 + dy] = lb;
+                rk[k][dt * 2 + dy] = atomicAdd(&s_cnt[lb], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nloc; i += 256) {
+        const int c = s_cnt[i];
+        s_base[i] = c > 0 ? atomicAdd(&L.gcount[b * nloc + i], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VOX_PER_THREAD; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int lb = bk[k][u];
+            if (lb < 0) continue;
+            const int g = b * nloc + lb;
+            const int slot = s_base[lb] + rk[k][u];
+            const float4 rec = make_float4(ry[k], rx[k], rw[k][u >> 1], __int_as_float(g));
+            if (slot < L.cap) L.rec[(size_t)g * L.cap + slot] = rec;
+            else L.ovf[atomicAdd(&L.gcount[L.NBk], 1)] = rec;
+        }
+}
+
+// grid NBk, 1024 threads, dynamic LDS = SR * W * 8
+__global__ __launch_bounds__(1024) void k_vox_accum(const VoxLayout L, float *__restrict__ grid, int H, int W) {
+    extern __shared__ unsigned long long s_acc[];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x, img = g / L.NS, strip = g - img * L.NS;
+    const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
+    const int npix = (row1 - row0) * W;
+    for (int i = tid; i < npix; i += 1024) s_acc[i] = 0ull;
+    __syncthreads();
+    const int n = min(L.gcount[g], L.cap);
+    const float4 *rec = L.rec + (size_t)g * L.cap;
+    for (int r = tid; r < n; r += 1024) {
+        const float4 e = rec[r];
+        vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) {
+            atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)vox_to_fixed(v));
+        });
+    }
+    __syncthreads();
+    float *dst = grid + ((size_t)img * H + row0) * W;
+    for (int i = tid; i < npix; i += 1024) dst[i] = vox_from_fixed((long long)s_acc[i]);
+}
+
+__global__ __launch_bounds__(256) void k_vox_overflow(const VoxLayout L, float *__restrict__ grid, int H, int W) {
+    const int n = L.gcount[L.NBk];
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        const float4 e = L.ovf[r];
+        const int g = __float_as_int(e.w), img = g / L.NS, strip = g - img * L.NS;
+        const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
+        float *dst = grid + (size_t)img * H * W;
+        vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) { atomicAdd(dst + (size_t)yy * W + xx, v); });
+    }
+}
+
+// per-sample statistics of the non-zero entries: grid (nblk, B), 256 threads -> part[b][blk][4]
+__global__ __launch_bounds__(256) void k_vox_stats(const float *__restrict__ grid, double *__restrict__ part, int64_t per_sample) {
+    __shared__ double s_red[4][4];
+    const float *g = grid + (size_t)blockIdx.y * per_sample;
+    double cnt = 0.0, sum = 0.0, sq = 0.0, mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        if (v != 0.f) { cnt += 1.0; sum += (double)v; sq += (double)v * (double)v; mx = fmax(mx, fabs((double)v)); }
+    }
+    const double r0 = block_sum_d<256>(cnt, s_red[0]);
+    const double r1 = block_sum_d<256>(sum, s_red[1]);
+    const double r2 = block_sum_d<256>(sq, s_red[2]);
+    // max via the same reduction shape
+    double m = mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_red[3][threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *p = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        p[0] = r0; p[1] = r1; p[2] = r2;
+        p[3] = fmax(fmax(s_red[3][0], s_red[3][1]), fmax(s_red[3][2], s_red[3][3]));
+    }
+}
+
+// one workgroup per sample: mean / std of the non-zero entries (unbiased std, torch.std) or max
+__global__ __launch_bounds__(256) void k_vox_finalize(const double *__restrict__ part, float *__restrict__ stat, int nblk, int norm) {
+    __shared__ double s_red[4][4];
+    const int b = blockIdx.x;
+    double cnt = 0.0, sum = 0.0, sq = 0.0, mx = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        const double *p = part + ((size_t)b * nblk + i) * 4;
+        cnt += p[0]; sum += p[1]; sq += p[2]; mx = fmax(mx, p[3]);
+    }
+    const double n = block_sum_d<256>(cnt, s_red[0]);
+    const double s1 = block_sum_d<256>(sum, s_red[1]);
+    const double s2 = block_sum_d<256>(sq, s_red[2]);
+    double m = mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0) s_red[3][threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(s_red[3][0], s_red[3][1]), fmax(s_red[3][2], s_red[3][3]));
+        float sub = 0.f, mul = 1.f;
+        if (norm == 1 && n > 0.0) {                      // utils.py:61-69
+            const double mean = s1 / n;
+            const double var = n > 1.0 ? (s2 - n * mean * mean) / (n - 1.0) : NAN;
+            const double sd = sqrt(var);
+            sub = (float)mean;
+            mul = (sd > 0.0) ? (float)(1.0 / sd) : 1.f;   // std == 0, or NaN for a single entry: only subtract (utils.py:66-69)
+        } else if (norm == 2 && m > 0.0) {               // utils.py:70-73
+            mul = (float)(1.0 / m);
+        }
+        stat[b * 4 + 0] = sub;
+        stat[b * 4 + 1] = mul;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vox_norm(float *__restrict__ grid, const float *__restrict__ stat, int64_t per_sample, int norm) {
+    const int b = blockIdx.y;
+    const float sub = stat[b * 4 + 0], mul = stat[b * 4 + 1];
+    float *g = grid + (size_t)b * per_sample;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        if (norm == 1) { if (v != 0.f) g[i] = (v - sub) * mul; }
+        else g[i] = v * mul;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static int vox_validate(const mpc_vox_shape *s) {
+    MPC_CHECK_ARG(s->B >= 0 && s->N >= 0 && s->C >= 1 && s->H >= 1 && s->W >= 1, MPC_E_SHAPE, "bad voxel-grid shape");
+    MPC_CHECK_ARG(s->norm >= 0 && s->norm <= 2, MPC_E_SHAPE, "norm must be 0 (none), 1 (mean_std) or 2 (max)");
+    MPC_CHECK_ARG((int64_t)s->W * 8 <= 150 * 1024, MPC_E_UNSUPPORTED, "sensor too wide for one LDS strip row");
+    MPC_CHECK_ARG((int64_t)s->B * s->C * s->H * s->W < (1LL << 31), MPC_E_UNSUPPORTED, "voxel grid too large");
+    return 0;
+}
+
+struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_part, off_stat, total; };
+
+static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
+    VoxHostLayout h;
+    VoxLayout &L = h.L;
+    L.SR = (int)((150 * 1024) / ((int64_t)s->W * 8));
+    if (L.SR > s->H) L.SR = s->H;
+    L.NS = mpc_cdiv(s->H, L.SR);
+    L.SR = mpc_cdiv(s->H, L.NS);
+    L.NBk = s->B * s->C * L.NS;
+    int64_t cap = 4 * ((2 * (int64_t)s->N + (int64_t)s->C * L.NS - 1) / ((int64_t)s->C * L.NS));
+    if (cap < 4096) cap = 4096;
+    if (cap > 2 * (int64_t)s->N) cap = 2 * (int64_t)s->N;
+    L.cap = (int)(cap > 0 ? cap : 1);
+    L.nstat_blocks = 256;
+    int64_t off = 0;
+    h.off_count = off; off += mpc_align((int64_t)(L.NBk + 8) * 4);
+    h.off_rec = off;   off += mpc_align((int64_t)L.NBk * L.cap * 16);
+    h.off_ovf = off;   off += mpc_align((int64_t)4 * s->B * s->N * 16 + 16);
+    h.off_part = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * L.nstat_blocks * 4 * 8);
+    h.off_stat = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 4 * 4);
+    h.total = off;
+    char *w = (char *)ws;
+    L.gcount = (int *)(w + h.off_count);
+    L.rec = (float4 *)(w + h.off_rec);
+    L.ovf = (float4 *)(w + h.off_ovf);
+    L.part = (double *)(w + h.off_part);
+    L.stat = (float *)(w + h.off_stat);
+    return h;
+}
+
+extern "C" int64_t mpc_voxel_workspace_bytes(const mpc_vox_shape *s) {
+    if (!s) { mpc_set_error("mpc_voxel_workspace_bytes: null shape"); return MPC_E_NULL; }
+    int rc = vox_validate(s);
+    if (rc) return rc;
+    return vox_layout(s, nullptr).total;
+}
+
+extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const int32_t *counts, float *grid,
+                              void *ws, void *stream) {
+    MPC_CHECK_ARG(s && counts && grid && ws && (xytp || s->N == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    int rc = vox_validate(s);
+    if (rc) return rc;
+    if (s->B == 0) return 0;
+    const VoxHostLayout h = vox_layout(s, ws);
+    const VoxLayout &L = h.L;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_vox_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipError_t e0 = hipMemsetAsync(L.gcount, 0, (size_t)(L.NBk + 8) * 4, st);
+    if (e0 != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e0)); return (int)e0; }
+    if (s->N > 0) {
+        const int nblk = mpc_cdiv(s->N, 256 * VOX_PER_THREAD) * s->B;
+        hipLaunchKernelGGL(k_vox_bin, dim3(((nblk + 7) / 8) * 8), dim3(256), (size_t)s->C * L.NS * 2 * sizeof(int), st,
+                           *s, L, reinterpret_cast<const float4 *>(xytp), counts);
+        MPC_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_vox_accum, dim3(L.NBk), dim3(1024), (size_t)L.SR * s->W * 8, st, L, grid, s->H, s->W);
+    MPC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_vox_overflow, dim3(64), dim3(256), 0, st, L, grid, s->H, s->W);
+    MPC_CHECK_LAUNCH();
+    if (s->norm != 0) {
+        const int64_t per_sample = (int64_t)s->C * s->H * s->W;
+        hipLaunchKernelGGL(k_vox_stats, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.part, per_sample);
+        hipLaunchKernelGGL(k_vox_finalize, dim3(s->B), dim3(256), 0, st, L.part, L.stat, L.nstat_blocks, s->norm);
+        hipLaunchKernelGGL(k_vox_norm, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.stat, per_sample, s->norm);
+        MPC_CHECK_LAUNCH();
+    }
+    return 0;
+}
