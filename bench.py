@@ -314,6 +314,33 @@ def main():
                               'stages_us_per_step': dj['roofline']['stages_us_per_step']}
             except Exception as e:      # informational field: never fail the main line
                 also[name] = {'error': repr(e)[:200]}
+        # next row 8f-2: voxel-grid builder on the same window shape (network input; not part of `value`)
+        try:
+            from motionpriorcmax_amd.utils import voxel_grids
+            from oracle import voxel_oracle as VO
+            Bv, Nv, vshape = wl['B'], wl['M'], (wl['nb'], H, W)
+            xs = [torch.stack(VO.synth_raw_events(Nv, vshape, seed=900 + b), -1) for b in range(Bv)]
+            evv = torch.stack(xs).to(dev)
+            cntv = torch.full((Bv,), Nv, dtype=torch.int32, device=dev)
+            for _ in range(3):
+                voxel_grids(evv, cntv, vshape, 'mean_std')
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                voxel_grids(evv, cntv, vshape, 'mean_std')
+            torch.cuda.synchronize()
+            tv = (time.perf_counter() - t0) / 10
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            x, y, t, p = (xs[0][:, k] for k in range(4))
+            t0 = time.perf_counter()
+            VO.voxel_grid(x, y, t, p, vshape, 'mean_std')
+            tc = time.perf_counter() - t0
+            also['voxel_grid'] = {'ms_per_batch': round(1e3 * tv, 4), 'value': round(Bv * Nv / tv / 1e6, 1),
+                                  'unit': 'Mevents/s', 'batch': Bv, 'events_per_sample': Nv,
+                                  'algorithmic_MB': round((16 * Bv * Nv + 4 * Bv * wl['nb'] * H * W) / 1e6, 1),
+                                  'cpu_oracle_Mevents_per_s': round(Nv / tc / 1e6, 3)}
+        except Exception as e:
+            also['voxel_grid'] = {'error': repr(e)[:200]}
         out['also'] = also
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)
