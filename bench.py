@@ -104,7 +104,7 @@ STAGE_KERNELS = {
     'mpc_knn_lut_bwd': ['k_knn_bwd_points', 'k_knn_bwd_combine'],
     'mpc_event_splat_fwd': ['k_ev_bin', 'k_iwe_accum', 'k_iwe_overflow', 'k_splat_fwd_atomic'],
     'mpc_event_splat_bwd': ['k_lut_accum', 'k_lut_overflow', 'k_splat_bwd_atomic'],
-    'mpc_contrast_fwd': ['k_contrast_fused', 'k_contrast_fwd', 'k_contrast_bwd_gm', 'k_contrast_bwd_var', 'k_image_means'],
+    'mpc_contrast_fwd': ['k_contrast_fused', 'k_contrast_fwd', 'k_contrast_bwd_var', 'k_image_means'],
     'mpc_lut_smooth': ['k_lut_smooth'], 'mpc_finalize': ['k_finalize'], 'mpc_scale': ['k_scale'],
 }
 

@@ -95,9 +95,7 @@ __global__ __launch_bounds__(256) void k_contrast_fwd(const float *__restrict__ 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward (gradient magnitude): blurred -> Blur^T Sobel^T u   (unscaled)
-// ------------------------------------------------------------------------------------------
+// weight of a raw coordinate in a blurred one (adjoint of the reflect-padded 3-tap blur)
 __device__ __forceinline__ float blurT_w(int q, int y, int n, float ka, float kc) {
     // weight of raw coordinate y in blurred coordinate q (both inside [0,n)), reflect padding
     const int d = y - q;
@@ -105,95 +103,6 @@ __device__ __forceinline__ float blurT_w(int q, int y, int n, float ka, float kc
     if (q == 0 && y == 1) w += ka;
     if (q == n - 1 && y == n - 2) w += ka;
     return w;
-}
-
-__global__ __launch_bounds__(256) void k_contrast_bwd_gm(const float *__restrict__ blur,
-                                                         float *__restrict__ gimg, int H, int W,
-                                                         int norm_l2) {
-    constexpr int TH = MPC_CT_H, TW = MPC_CT_W;
-    __shared__ float s_bl[TH + 6][TW + 6 + 1];
-    __shared__ float s_ux[TH + 4][TW + 4 + 1];
-    __shared__ float s_uy[TH + 4][TW + 4 + 1];
-    __shared__ float s_gb[TH + 2][TW + 2 + 1];
-    const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const size_t img_off = (size_t)blockIdx.z * H * W;
-    const float *src = blur + img_off;
-    float ka, kc;
-    blur_taps(ka, kc);
-
-    for (int i = tid; i < (TH + 6) * (TW + 6); i += 256) {
-        const int ly = i / (TW + 6), lx = i - ly * (TW + 6);
-        const int y = ty0 - 3 + ly, x = tx0 - 3 + lx;
-        s_bl[ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
-    }
-    __syncthreads();
-    // u = d|grad|/d(dx,dy) on rows ty0-2.., zero outside the image
-    for (int i = tid; i < (TH + 4) * (TW + 4); i += 256) {
-        const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
-        const int y = ty0 - 2 + ly, x = tx0 - 2 + lx;
-        float ux = 0.f, uy = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const int by = ly + 1, bx = lx + 1;
-            const float tl = s_bl[by - 1][bx - 1], tc = s_bl[by - 1][bx], tr = s_bl[by - 1][bx + 1];
-            const float ml = s_bl[by][bx - 1], mr = s_bl[by][bx + 1];
-            const float bl_ = s_bl[by + 1][bx - 1], bc = s_bl[by + 1][bx], br = s_bl[by + 1][bx + 1];
-            const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
-            const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
-            if (norm_l2) {
-                ux = 2.f * dx;
-                uy = 2.f * dy;
-            } else {
-                ux = (dx > 0.f) ? 1.f : ((dx < 0.f) ? -1.f : 0.f);
-                uy = (dy > 0.f) ? 1.f : ((dy < 0.f) ? -1.f : 0.f);
-            }
-        }
-        s_ux[ly][lx] = ux;
-        s_uy[ly][lx] = uy;
-    }
-    __syncthreads();
-    // gB[p] = sum_d Kx(d) ux[p-d] + Ky(d) uy[p-d]   (adjoint of zero-padded correlation)
-    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
-        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
-        const int y = ty0 - 1 + ly, x = tx0 - 1 + lx;
-        float g = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const int uy_ = ly + 1, ux_ = lx + 1;
-            // Kx(dy,dx) = sm(dy)*sx(dx), sx=(-1,0,1), sm=(1,2,1); contribution Kx(d)*ux[p-d]
-            // p-d with dx=+1 is column ux_-1 (weight +1), dx=-1 is column ux_+1 (weight -1)
-            const float gx = (s_ux[uy_ + 1][ux_ - 1] - s_ux[uy_ + 1][ux_ + 1]) +
-                             2.f * (s_ux[uy_][ux_ - 1] - s_ux[uy_][ux_ + 1]) +
-                             (s_ux[uy_ - 1][ux_ - 1] - s_ux[uy_ - 1][ux_ + 1]);
-            const float gy = (s_uy[uy_ - 1][ux_ + 1] - s_uy[uy_ + 1][ux_ + 1]) +
-                             2.f * (s_uy[uy_ - 1][ux_] - s_uy[uy_ + 1][ux_]) +
-                             (s_uy[uy_ - 1][ux_ - 1] - s_uy[uy_ + 1][ux_ - 1]);
-            g = gx + gy;
-        }
-        s_gb[ly][lx] = g;
-    }
-    __syncthreads();
-    const int cx = tid & 63;
-    for (int ry = tid >> 6; ry < TH; ry += 4) {
-        const int y = ty0 + ry, x = tx0 + cx;
-        if (y < H && x < W) {
-            float acc = 0.f;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int qy = y + dy;
-                if (qy < 0 || qy >= H) continue;
-                const float wy = blurT_w(qy, y, H, ka, kc);
-                float row = 0.f;
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int qx = x + dx;
-                    if (qx < 0 || qx >= W) continue;
-                    row += blurT_w(qx, x, W, ka, kc) * s_gb[ry + 1 + dy][cx + 1 + dx];
-                }
-                acc += wy * row;
-            }
-            gimg[img_off + (size_t)y * W + x] = acc;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -565,10 +474,8 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     }
     hipLaunchKernelGGL(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
     MPC_CHECK_LAUNCH();
-    if (grad_iwe) {
-        if (!variance) {
-            hipLaunchKernelGGL(k_contrast_bwd_gm, grid, dim3(256), 0, st, iwe_blur, grad_iwe, s->H, s->W, l2);
-        } else {
+    if (grad_iwe) {      // variance objective: the adjoint needs the image means first
+        {
             float *means = (float *)((char *)ws + L.off_counts) + 8;   // nimg floats after the counters
             hipLaunchKernelGGL(k_image_means, dim3(L.nimg), dim3(256), 0, st, cpart, means,
                                (int)(grid.x * grid.y), s->H * s->W);
