@@ -58,6 +58,7 @@ struct mpc_ws_layout {
 // contrast tiles
 #define MPC_CT_H 32
 #define MPC_CT_W 64
+#define MPC_CF_TW 56   // fused kernel: tile + 2*4 halo columns = 64 = one wavefront row
 // smoothness tiles (LUT cells)
 #define MPC_SM_H 16
 #define MPC_SM_W 64

@@ -110,123 +110,128 @@ __device__ __forceinline__ float blurT_w(int q, int y, int n, float ka, float kc
 // One pass over the raw image (tile + 4-px halo in LDS) instead of two kernels that each stream the
 // whole batch of images through HBM.  Three LDS planes are recycled:
 //   A: raw -> blurred -> gB      B: horizontal blur -> ux      C: uy
-// grid (ceil(W/64), ceil(H/32), nimg), 256 threads
+// Tile = 32 rows x 56 columns, so that tile + halo is exactly 64 columns: thread (tx, ty) of the
+// 64 x 4 workgroup owns local column tx and rows ty, ty+4, ...; a wavefront is one row, column tests
+// are hoisted out of the row loops, and there is no integer division in the kernel.
+// grid (ceil(W/56), ceil(H/32), nimg), 256 threads
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_contrast_fused(const float *__restrict__ raw,
                                                         float *__restrict__ blur,
                                                         float *__restrict__ gimg,
                                                         double *__restrict__ part, int H, int W,
                                                         int norm_l2) {
-    constexpr int TH = MPC_CT_H, TW = MPC_CT_W, LH = TH + 8, LW = TW + 8, LP = LW + 1;
+    constexpr int TH = MPC_CT_H, TW = MPC_CF_TW, LH = TH + 8, LW = TW + 8, LP = LW + 1;
+    static_assert(LW == 64, "one local column per lane");
     __shared__ float sA[LH][LP];
     __shared__ float sB[LH][LP];
     __shared__ float sC[LH][LP];
     __shared__ double s_red[4];
-    const int tid = threadIdx.x;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;      // local column, first local row
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const size_t img_off = (size_t)blockIdx.z * H * W;
     const float *src = raw + img_off;
     float ka, kc;
     blur_taps(ka, kc);
     // local (r, c) <-> image (ty0 - 4 + r, tx0 - 4 + c)
-    {   // all global loads of the tile are issued before the first LDS store (fully unrolled): the
-        // staging loop is otherwise a chain of dependent HBM round trips
-        constexpr int NLD = (LH * LW + 255) / 256;
-        float v[NLD];
+    const int x = tx0 - 4 + c;
+    const bool xin = x >= 0 && x < W;
+    const int xr = (x >= -1 && x <= W) ? reflect1(x, W) : -1;
+    {   // P0: stage raw (reflect ring at coordinates -1 and H / W); all loads first
+        float v[LH / 4];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + k * 256;
-            const int r = i / LW, c = i - r * LW;
-            const int y = ty0 - 4 + r, x = tx0 - 4 + c;
-            v[k] = 0.f;
-            if (i < LH * LW && y >= -1 && y <= H && x >= -1 && x <= W) v[k] = src[(size_t)reflect1(y, H) * W + reflect1(x, W)];
+        for (int i = 0; i < LH / 4; ++i) {
+            const int y = ty0 - 4 + rl + 4 * i;
+            v[i] = (xr >= 0 && y >= -1 && y <= H) ? src[(size_t)reflect1(y, H) * W + xr] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + k * 256;
-            if (i < LH * LW) { const int r = i / LW, c = i - r * LW; sA[r][c] = v[k]; }
+        for (int i = 0; i < LH / 4; ++i) sA[rl + 4 * i][c] = v[i];
+    }
+    __syncthreads();
+    const bool c1 = c >= 1 && c <= LW - 2, c2 = c >= 2 && c <= LW - 3, c3 = c >= 3 && c <= LW - 4;
+    // P1: horizontal blur, columns 1 .. LW-2
+    if (c1)
+#pragma unroll
+        for (int i = 0; i < LH / 4; ++i) { const int r = rl + 4 * i; sB[r][c] = ka * sA[r][c - 1] + kc * sA[r][c] + ka * sA[r][c + 1]; }
+    __syncthreads();
+    // P2: vertical blur, rows 1 .. LH-2; zero outside the image (Sobel pads with zeros)
+    if (c1)
+#pragma unroll
+        for (int i = 0; i < LH / 4; ++i) {
+            const int r = rl + 4 * i, y = ty0 - 4 + r;
+            if (r >= 1 && r <= LH - 2)
+                sA[r][c] = (xin && y >= 0 && y < H) ? ka * sB[r - 1][c] + kc * sB[r][c] + ka * sB[r + 1][c] : 0.f;
         }
-    }
     __syncthreads();
-    for (int i = tid; i < LH * (LW - 2); i += 256) {             // horizontal blur, cols 1..LW-2
-        const int r = i / (LW - 2), c = 1 + (i - r * (LW - 2));
-        sB[r][c] = ka * sA[r][c - 1] + kc * sA[r][c] + ka * sA[r][c + 1];
-    }
-    __syncthreads();
-    for (int i = tid; i < (LH - 2) * (LW - 2); i += 256) {       // blurred, rows 1..LH-2; zero outside the image
-        const int r = 1 + i / (LW - 2), c = 1 + (i % (LW - 2));
-        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
-        float v = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) v = ka * sB[r - 1][c] + kc * sB[r][c] + ka * sB[r + 1][c];
-        sA[r][c] = v;
-    }
-    __syncthreads();
-    // blurred output + objective on the tile; u = d|grad|/d(dx,dy) on rows 2..LH-3
+    // P3: Sobel on rows/cols 2 .. L-3: u = d|grad|/d(dx,dy); own pixels: blurred output + objective
     double acc = 0.0;
-    for (int i = tid; i < (LH - 4) * (LW - 4); i += 256) {
-        const int r = 2 + i / (LW - 4), c = 2 + (i % (LW - 4));
-        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
-        float ux = 0.f, uy = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const float tl = sA[r - 1][c - 1], tc = sA[r - 1][c], tr = sA[r - 1][c + 1];
-            const float ml = sA[r][c - 1], mr = sA[r][c + 1];
-            const float bl_ = sA[r + 1][c - 1], bc = sA[r + 1][c], br = sA[r + 1][c + 1];
-            const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
-            const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
-            if (norm_l2) {
-                ux = 2.f * dx;
-                uy = 2.f * dy;
-            } else {
-                ux = (dx > 0.f) ? 1.f : ((dx < 0.f) ? -1.f : 0.f);
-                uy = (dy > 0.f) ? 1.f : ((dy < 0.f) ? -1.f : 0.f);
+    const bool own_col = c >= 4 && c < 4 + TW;
+    if (c2)
+#pragma unroll
+        for (int i = 0; i < LH / 4; ++i) {
+            const int r = rl + 4 * i, y = ty0 - 4 + r;
+            if (r < 2 || r > LH - 3) continue;
+            float ux = 0.f, uy = 0.f;
+            if (xin && y >= 0 && y < H) {
+                const float tl = sA[r - 1][c - 1], tc = sA[r - 1][c], tr = sA[r - 1][c + 1];
+                const float ml = sA[r][c - 1], mr = sA[r][c + 1];
+                const float bl_ = sA[r + 1][c - 1], bc = sA[r + 1][c], br = sA[r + 1][c + 1];
+                const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
+                const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
+                if (norm_l2) {
+                    ux = 2.f * dx;
+                    uy = 2.f * dy;
+                } else {
+                    ux = (dx > 0.f) ? 1.f : ((dx < 0.f) ? -1.f : 0.f);
+                    uy = (dy > 0.f) ? 1.f : ((dy < 0.f) ? -1.f : 0.f);
+                }
+                if (own_col && r >= 4 && r < 4 + TH) {
+                    blur[img_off + (size_t)y * W + x] = sA[r][c];
+                    acc += norm_l2 ? (double)(dx * dx + dy * dy) : (double)(fabsf(dx) + fabsf(dy));
+                }
             }
-            if (r >= 4 && r < 4 + TH && c >= 4 && c < 4 + TW) {   // own pixel
-                blur[img_off + (size_t)y * W + x] = sA[r][c];
-                acc += norm_l2 ? (double)(dx * dx + dy * dy) : (double)(fabsf(dx) + fabsf(dy));
+            sB[r][c] = ux;
+            sC[r][c] = uy;
+        }
+    __syncthreads();
+    // P4: gB on rows/cols 3 .. L-4; zero outside the image
+    if (c3)
+#pragma unroll
+        for (int i = 0; i < LH / 4; ++i) {
+            const int r = rl + 4 * i, y = ty0 - 4 + r;
+            if (r < 3 || r > LH - 4) continue;
+            float g = 0.f;
+            if (xin && y >= 0 && y < H) {
+                const float gx = (sB[r + 1][c - 1] - sB[r + 1][c + 1]) + 2.f * (sB[r][c - 1] - sB[r][c + 1]) +
+                                 (sB[r - 1][c - 1] - sB[r - 1][c + 1]);
+                const float gy = (sC[r - 1][c + 1] - sC[r + 1][c + 1]) + 2.f * (sC[r - 1][c] - sC[r + 1][c]) +
+                                 (sC[r - 1][c - 1] - sC[r + 1][c - 1]);
+                g = gx + gy;
             }
+            sA[r][c] = g;
         }
-        sB[r][c] = ux;
-        sC[r][c] = uy;
-    }
     __syncthreads();
-    for (int i = tid; i < (LH - 6) * (LW - 6); i += 256) {       // gB on rows 3..LH-4; zero outside the image
-        const int r = 3 + i / (LW - 6), c = 3 + (i % (LW - 6));
-        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
-        float g = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const float gx = (sB[r + 1][c - 1] - sB[r + 1][c + 1]) + 2.f * (sB[r][c - 1] - sB[r][c + 1]) +
-                             (sB[r - 1][c - 1] - sB[r - 1][c + 1]);
-            const float gy = (sC[r - 1][c + 1] - sC[r + 1][c + 1]) + 2.f * (sC[r - 1][c] - sC[r + 1][c]) +
-                             (sC[r - 1][c - 1] - sC[r + 1][c - 1]);
-            g = gx + gy;
-        }
-        sA[r][c] = g;
-    }
-    __syncthreads();
-    for (int i = tid; i < TH * TW; i += 256) {
-        const int ry = i / TW, cx = i - ry * TW;
-        const int y = ty0 + ry, x = tx0 + cx;
-        if (y < H && x < W) {
+    // P5: adjoint of the blur for own pixels (column weights hoisted out of the row loop)
+    if (own_col && x < W) {
+        float wx[3];
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) wx[d + 1] = (x + d >= 0 && x + d < W) ? blurT_w(x + d, x, W, ka, kc) : 0.f;
+#pragma unroll
+        for (int i = 0; i < TH / 4; ++i) {
+            const int r = 4 + rl + 4 * i, y = ty0 - 4 + r;
+            if (y >= H) break;
             float a = 0.f;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int qy = y + dy;
+            for (int d = -1; d <= 1; ++d) {
+                const int qy = y + d;
                 if (qy < 0 || qy >= H) continue;
                 const float wy = blurT_w(qy, y, H, ka, kc);
-                float row = 0.f;
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int qx = x + dx;
-                    if (qx < 0 || qx >= W) continue;
-                    row += blurT_w(qx, x, W, ka, kc) * sA[ry + 4 + dy][cx + 4 + dx];
-                }
-                a += wy * row;
+                a += wy * (wx[0] * sA[r + d][c - 1] + wx[1] * sA[r + d][c] + wx[2] * sA[r + d][c + 1]);
             }
             gimg[img_off + (size_t)y * W + x] = a;
         }
     }
     const double r0 = block_sum_d<256>(acc, s_red);
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         part[2 * bid] = r0;
         part[2 * bid + 1] = 0.0;
@@ -468,9 +473,14 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     const int variance = (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0;
     const int l2 = (s->flags & MPC_F_NORM_L2) ? 1 : 0;
     if (grad_iwe && !variance) {
-        hipLaunchKernelGGL(k_contrast_fused, grid, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
+        const dim3 gridf(mpc_cdiv(s->W, MPC_CF_TW), mpc_cdiv(s->H, MPC_CT_H), L.nimg);
+        hipLaunchKernelGGL(k_contrast_fused, gridf, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
         MPC_CHECK_LAUNCH();
         return 0;
+    }
+    {   // the unfused tiling has fewer workgroups than the partial-sum array: clear the rest
+        hipError_t e = hipMemsetAsync(cpart, 0, (size_t)L.n_cblocks * 2 * sizeof(double), st);
+        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
     }
     hipLaunchKernelGGL(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
     MPC_CHECK_LAUNCH();
