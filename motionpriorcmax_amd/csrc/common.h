@@ -61,7 +61,7 @@ struct mpc_ws_layout {
 #define MPC_CF_TW 56   // fused kernel: tile + 2*4 halo columns = 64 = one wavefront row
 // smoothness tiles (LUT cells)
 #define MPC_SM_H 16
-#define MPC_SM_W 64
+#define MPC_SM_W 60   // + 2*2 halo cells = 64 = one wavefront row
 
 mpc_ws_layout mpc_layout(const mpc_shape *s);
 int mpc_validate_shape(const mpc_shape *s);

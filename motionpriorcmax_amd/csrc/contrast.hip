@@ -295,96 +295,94 @@ __global__ __launch_bounds__(256) void k_contrast_bwd_var(const float *__restric
 
 // ------------------------------------------------------------------------------------------
 // smoothness of a flow field stored [nimg][hq][wq][C] (C even: (y,x) pairs): forward partial sums +
-// gradient.  One workgroup = 16 x 64 cells of one channel PAIR (float2 loads), halo in LDS.
-// grid (ceil(wq/64), ceil(hq/16), nimg*C/2), 256 threads
+// gradient.  One workgroup = 16 x 60 cells of one channel PAIR (float2 loads); tile + 2-cell halo is
+// exactly 64 columns, one per lane (same mapping as k_contrast_fused: no index division).
+// grid (ceil(wq/60), ceil(hq/16), nimg*C/2), 256 threads
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ field,
                                                     float *__restrict__ gfield,
                                                     double *__restrict__ part, int hq, int wq, int C,
                                                     float gscale /* smooth_weight/(2*count) */) {
-    constexpr int TH = MPC_SM_H, TW = MPC_SM_W;
-    __shared__ float2 s_f[TH + 4][TW + 4 + 1];
-    __shared__ float2 s_vx[TH + 2][TW + 2 + 1];
-    __shared__ float2 s_vy[TH + 2][TW + 2 + 1];
+    constexpr int TH = MPC_SM_H, TW = MPC_SM_W, LH = TH + 4, LW = TW + 4, LP = LW + 1;
+    static_assert(LW == 64, "one local column per lane");
+    __shared__ float2 s_f[LH][LP];
+    __shared__ float2 s_vx[LH][LP];
+    __shared__ float2 s_vy[LH][LP];
     __shared__ double s_red[2][4];
-    const int tid = threadIdx.x;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int C2 = C >> 1;
     const int img = blockIdx.z / C2, cp = blockIdx.z - img * C2;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const size_t base = (size_t)img * hq * wq * C2 + cp;        // in float2 units
     const float2 *f2 = reinterpret_cast<const float2 *>(field);
     const float eps2 = 1e-3f * 1e-3f;   // charbonnier epsilon ** 2 (loss.py:46,55)
-
-    {   // all global loads of the tile before the first LDS store (see k_contrast_fused)
-        constexpr int NLD = ((TH + 4) * (TW + 4) + 255) / 256;
-        float2 v[NLD];
+    // local (r, c) <-> cell (y0 - 2 + r, x0 - 2 + c)
+    const int x = x0 - 2 + c;
+    const bool xin = x >= 0 && x < wq;
+    {
+        float2 v[LH / 4];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + k * 256;
-            const int ly = i / (TW + 4), lx = i - ly * (TW + 4);
-            const int y = y0 - 2 + ly, x = x0 - 2 + lx;
-            v[k] = (i < (TH + 4) * (TW + 4) && y >= 0 && y < hq && x >= 0 && x < wq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
+        for (int i = 0; i < LH / 4; ++i) {
+            const int y = y0 - 2 + rl + 4 * i;
+            v[i] = (xin && y >= 0 && y < hq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
         }
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = tid + k * 256;
-            if (i < (TH + 4) * (TW + 4)) { const int ly = i / (TW + 4), lx = i - ly * (TW + 4); s_f[ly][lx] = v[k]; }
-        }
+        for (int i = 0; i < LH / 4; ++i) s_f[rl + 4 * i][c] = v[i];
     }
     __syncthreads();
     double a0 = 0.0, a1 = 0.0;
-    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
-        const int ly = i / (TW + 2), lx = i - ly * (TW + 2);
-        const int y = y0 - 1 + ly, x = x0 - 1 + lx;
-        float2 vx = make_float2(0.f, 0.f), vy = make_float2(0.f, 0.f);
-        if (y >= 0 && y < hq && x >= 0 && x < wq) {
-            const int by = ly + 1, bx = lx + 1;
-            const float2 tl = s_f[by - 1][bx - 1], tc = s_f[by - 1][bx], tr = s_f[by - 1][bx + 1];
-            const float2 ml = s_f[by][bx - 1], mr = s_f[by][bx + 1];
-            const float2 bl_ = s_f[by + 1][bx - 1], bc = s_f[by + 1][bx], br = s_f[by + 1][bx + 1];
-            const bool own = ly >= 1 && ly <= TH && lx >= 1 && lx <= TW;     // own cell, not halo
-#define MPC_SM_CH(c)                                                                      \
-            {                                                                             \
-                const float dx = (tr.c - tl.c) + 2.f * (mr.c - ml.c) + (br.c - bl_.c);     \
-                const float dy = (bl_.c - tl.c) + 2.f * (bc.c - tc.c) + (br.c - tr.c);     \
-                const float sx = sqrtf(dx * dx + eps2), sy = sqrtf(dy * dy + eps2);        \
-                vx.c = dx / sx;                                                            \
-                vy.c = dy / sy;                                                            \
-                if (own) { a0 += (double)sx; a1 += (double)sy; }                           \
-            }
-            MPC_SM_CH(x)
-            MPC_SM_CH(y)
+    const bool own_col = c >= 2 && c < 2 + TW;
+    if (c >= 1 && c <= LW - 2)
+#pragma unroll
+        for (int i = 0; i < LH / 4; ++i) {
+            const int r = rl + 4 * i, y = y0 - 2 + r;
+            if (r < 1 || r > LH - 2) continue;
+            float2 vx = make_float2(0.f, 0.f), vy = make_float2(0.f, 0.f);
+            if (xin && y >= 0 && y < hq) {
+                const float2 tl = s_f[r - 1][c - 1], tc = s_f[r - 1][c], tr = s_f[r - 1][c + 1];
+                const float2 ml = s_f[r][c - 1], mr = s_f[r][c + 1];
+                const float2 bl_ = s_f[r + 1][c - 1], bc = s_f[r + 1][c], br = s_f[r + 1][c + 1];
+                const bool own = own_col && r >= 2 && r < 2 + TH;
+#define MPC_SM_CH(ch)                                                                       \
+                {                                                                           \
+                    const float dx = (tr.ch - tl.ch) + 2.f * (mr.ch - ml.ch) + (br.ch - bl_.ch); \
+                    const float dy = (bl_.ch - tl.ch) + 2.f * (bc.ch - tc.ch) + (br.ch - tr.ch); \
+                    const float sx = sqrtf(dx * dx + eps2), sy = sqrtf(dy * dy + eps2);      \
+                    vx.ch = dx / sx;                                                         \
+                    vy.ch = dy / sy;                                                         \
+                    if (own) { a0 += (double)sx; a1 += (double)sy; }                         \
+                }
+                MPC_SM_CH(x)
+                MPC_SM_CH(y)
 #undef MPC_SM_CH
-        }
-        s_vx[ly][lx] = vx;
-        s_vy[ly][lx] = vy;
-    }
-    __syncthreads();
-    if (gfield != nullptr) {
-        float2 *g2 = reinterpret_cast<float2 *>(gfield);
-        for (int i = tid; i < TH * TW; i += 256) {
-            const int ly = i / TW, lx = i - ly * TW;
-            const int y = y0 + ly, x = x0 + lx;
-            if (y < hq && x < wq) {
-                const int uy_ = ly + 1, ux_ = lx + 1;
-                float2 o;
-#define MPC_SM_G(c)                                                                                        \
-                o.c = gscale * (((s_vx[uy_ + 1][ux_ - 1].c - s_vx[uy_ + 1][ux_ + 1].c) +                    \
-                                 2.f * (s_vx[uy_][ux_ - 1].c - s_vx[uy_][ux_ + 1].c) +                       \
-                                 (s_vx[uy_ - 1][ux_ - 1].c - s_vx[uy_ - 1][ux_ + 1].c)) +                     \
-                                ((s_vy[uy_ - 1][ux_ + 1].c - s_vy[uy_ + 1][ux_ + 1].c) +                     \
-                                 2.f * (s_vy[uy_ - 1][ux_].c - s_vy[uy_ + 1][ux_].c) +                       \
-                                 (s_vy[uy_ - 1][ux_ - 1].c - s_vy[uy_ + 1][ux_ - 1].c)));
-                MPC_SM_G(x)
-                MPC_SM_G(y)
-#undef MPC_SM_G
-                g2[base + ((size_t)y * wq + x) * C2] = o;
             }
+            s_vx[r][c] = vx;
+            s_vy[r][c] = vy;
+        }
+    __syncthreads();
+    if (gfield != nullptr && own_col && x < wq) {
+        float2 *g2 = reinterpret_cast<float2 *>(gfield);
+#pragma unroll
+        for (int i = 0; i < TH / 4; ++i) {
+            const int r = 2 + rl + 4 * i, y = y0 - 2 + r;
+            if (y >= hq) break;
+            float2 o;
+#define MPC_SM_G(ch)                                                                                 \
+            o.ch = gscale * (((s_vx[r + 1][c - 1].ch - s_vx[r + 1][c + 1].ch) +                       \
+                              2.f * (s_vx[r][c - 1].ch - s_vx[r][c + 1].ch) +                          \
+                              (s_vx[r - 1][c - 1].ch - s_vx[r - 1][c + 1].ch)) +                        \
+                             ((s_vy[r - 1][c + 1].ch - s_vy[r + 1][c + 1].ch) +                        \
+                              2.f * (s_vy[r - 1][c].ch - s_vy[r + 1][c].ch) +                          \
+                              (s_vy[r - 1][c - 1].ch - s_vy[r + 1][c - 1].ch)));
+            MPC_SM_G(x)
+            MPC_SM_G(y)
+#undef MPC_SM_G
+            g2[base + ((size_t)y * wq + x) * C2] = o;
         }
     }
     const double r0 = block_sum_d<256>(a0, s_red[0]);
     const double r1 = block_sum_d<256>(a1, s_red[1]);
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         part[2 * bid] = r0;
         part[2 * bid + 1] = r1;
