@@ -16,6 +16,7 @@ struct Warped {
     int lut;           // index of the LUT cell (b,bin,iy,ix) -> element offset / (2T) ... see below
     float fy, fx;      // fractional parts
     int y0, x0;        // top-left tap
+    int it, iy, ix;    // time bin and LUT cell of the (unwarped) event
 };
 
 __device__ __forceinline__ EvParams make_params(const mpc_shape s) {
@@ -43,6 +44,7 @@ __device__ __forceinline__ bool warp_event(const EvParams &p, const float e[6], 
         it = min(max(it, 0), p.nb - 1);
         iy = min(max(iy, 0), p.hq - 1);
         ix = min(max(ix, 0), p.wq - 1);
+        o.it = it; o.iy = iy; o.ix = ix;
         o.lut = (((b * p.nb + it) * p.hq + iy) * p.wq + ix) * p.T + tr;
         const float2 f = reinterpret_cast<const float2 *>(lut)[o.lut];
         y = f.x + e[0];
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     for (int i = tid; i < nloc; i += 256) s_cnt[i] = 0;
     __syncthreads();
     const float tref = (p.flags & MPC_F_SCALE_BY_DT) ? t_ref[0] : 0.f;
+    const float inv_SR = 1.f / (float)L.SR, inv_CSR = 1.f / (float)L.CSR;
 
     float ry[EV_PER_THREAD], rx[EV_PER_THREAD], rw[EV_PER_THREAD];
     int f0[EV_PER_THREAD], f1[EV_PER_THREAD], bk[EV_PER_THREAD];     // local bucket ids (-1: none)
@@ -242,18 +245,16 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
         if (!xin || !(yin0 || yin1)) continue;            // no tap inside the image
         const int pol = (p.P == 2 && i >= p.Mp) ? 1 : 0;
         ry[k] = o.y; rx[k] = o.x; rw[k] = o.w;
-        const int s0 = yin0 ? o.y0 / L.SR : -1, s1 = yin1 ? (o.y0 + 1) / L.SR : -1;
+        // strip = row / SR without an integer division: (row + 0.5) / SR is at least 0.5 / SR away from an
+        // integer, far more than the rounding of the float product, so the truncation is exact
+        const int s0 = yin0 ? (int)(((float)o.y0 + 0.5f) * inv_SR) : -1, s1 = yin1 ? (int)(((float)o.y0 + 1.5f) * inv_SR) : -1;
         if (s0 >= 0) { f0[k] = pol * L.NS + s0; r0[k] = atomicAdd(&s_cnt[f0[k]], 1); }
         if (s1 >= 0 && s1 != s0) { f1[k] = pol * L.NS + s1; r1[k] = atomicAdd(&s_cnt[f1[k]], 1); }
         if (want_bwd && o.lut >= 0) {
-            // o.lut = ((b*nb + it)*hq + iy)*wq + ix   (T == 1)
-            const int cell = o.lut - (b * p.nb) * p.hq * p.wq;
-            const int it = cell / (p.hq * p.wq), rem = cell - it * p.hq * p.wq;
-            const int iy = rem / p.wq;
-            const int cst = iy / L.CSR;
-            bk[k] = nf_loc + it * L.NCS + cst;
+            const int cst = (int)(((float)o.iy + 0.5f) * inv_CSR);
+            bk[k] = nf_loc + o.it * L.NCS + cst;
             rb[k] = atomicAdd(&s_cnt[bk[k]], 1);
-            aux[k] = ((unsigned)pol << 31) | (unsigned)(rem - cst * L.CSR * p.wq);
+            aux[k] = ((unsigned)pol << 31) | (unsigned)((o.iy - cst * L.CSR) * p.wq + o.ix);
             lutidx[k] = o.lut;
         }
     }

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const Vo
     const float4 *e = ev + (size_t)b * s.N;
     float t_first = 0.f, t_span = 1.f;
     if (n > 0) { t_first = e[0].z; t_span = e[n - 1].z - t_first; }
+    const float inv_SR = 1.f / (float)L.SR;
     float ry[VOX_PER_THREAD], rx[VOX_PER_THREAD], rw[VOX_PER_THREAD][2];
     int bk[VOX_PER_THREAD][4], rk[VOX_PER_THREAD][4];
 #pragma unroll
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const Vo
             for (int dy = 0; dy < 2; ++dy) {
                 const int yl = y0 + dy;
                 if (yl < 0 || yl >= s.H) continue;
-                const int st = yl / L.SR;
+                const int st = (int)(((float)yl + 0.5f) * inv_SR);     // exact, see k_ev_bin
                 if (st == prev) continue;
                 prev = st;
                 const int lb = tl * L.NS + st;
