@@ -343,6 +343,30 @@ def main():
                                   'cpu_oracle_Mevents_per_s': round(Nv / tc / 1e6, 3)}
         except Exception as e:
             also['voxel_grid'] = {'error': repr(e)[:200]}
+        # next row 8f-1: event ingest (raw window -> padded [B,M,6] tensor) on the same window shape
+        try:
+            from motionpriorcmax_amd.utils import ingest_events
+            from oracle import ingest_oracle as IO
+            Bi, Ni = wl['B'], wl['M']
+            raws = [IO.synth_raw(Ni, H, W, seed=950 + b) for b in range(Bi)]
+            tx = [torch.from_numpy(__import__('numpy').stack([r[k] for r in raws])).to(dev) for k in range(4)]
+            cnti = torch.full((Bi,), Ni, dtype=torch.int32)
+            for _ in range(3):
+                ingest_events(tx[0], tx[1], tx[2], tx[3], cnti, (H, W), wl['nb'])
+            tis = []
+            for _ in range(11):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ingest_events(tx[0], tx[1], tx[2], tx[3], cnti, (H, W), wl['nb'])
+                torch.cuda.synchronize(); tis.append(time.perf_counter() - t0)
+            ti = sorted(tis)[len(tis) // 2]
+            t0 = time.perf_counter()
+            IO.collate([IO.sample_events(*r, H, W, wl['nb']) for r in raws[:2]])
+            tci = (time.perf_counter() - t0) / 2
+            also['event_ingest'] = {'ms_per_batch': round(1e3 * ti, 4), 'value': round(Bi * Ni / ti / 1e6, 1), 'unit': 'Mevents/s',
+                                    'batch': Bi, 'events_per_sample': Ni, 'algorithmic_MB': round((20 + 24) * Bi * Ni / 1e6, 1),
+                                    'cpu_oracle_Mevents_per_s': round(Ni / tci / 1e6, 2), 'note': 'includes the 2-integer host read that sizes the output'}
+        except Exception as e:
+            also['event_ingest'] = {'error': repr(e)[:200]}
         out['also'] = also
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)

@@ -152,6 +152,23 @@ int64_t mpc_voxel_workspace_bytes(const mpc_vox_shape *s);
 int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const int32_t *counts, float *grid,
                    void *ws, void *stream);
 
+/* ---- next row: event ingest, reference src/loader/dsec/loader.py:152-167 (time
+ * normalisation, bin index, in-image filter, polarity split) + :360-415 (pad_events, sequence_collate_fn).
+ * x, y, p [B][N] float32, t_us [B][N] int64 (increasing within a sample), counts [B] int32 (device).
+ * mpc_ingest_count  -> out_max[2] (device): largest number of valid positive / negative events of a sample;
+ *                      the caller reads them to size `events`  = [B][max_pos + max_neg][6]
+ * mpc_ingest_scatter-> events (zero padded, valid flag in column 5, positive block first) and, if xytp is
+ *                      not NULL, [B][N][4] = (x, y, t, p) as loader.py:135-138 hands them to the voxel grid. */
+typedef struct mpc_ingest_shape {
+    int32_t B, N, H, W, nb;
+} mpc_ingest_shape;
+int64_t mpc_ingest_workspace_bytes(const mpc_ingest_shape *s);
+int mpc_ingest_count(const mpc_ingest_shape *s, const float *x, const float *y, const int64_t *t_us,
+                     const float *p, const int32_t *counts, int32_t *out_max, void *ws, void *stream);
+int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, const float *y, const int64_t *t_us,
+                       const float *p, const int32_t *counts, int32_t max_pos, int32_t max_neg,
+                       float *events, float *xytp, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

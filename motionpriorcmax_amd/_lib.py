@@ -25,7 +25,8 @@ SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 
 
 EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_knn_lut_fwd',
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
-           'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid']
+           'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
+           'mpc_ingest_scatter']
 
 
 class Shape(ctypes.Structure):
@@ -36,6 +37,10 @@ class Shape(ctypes.Structure):
 
 class VoxShape(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'C', 'H', 'W', 'norm')]
+
+
+class IngestShape(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'H', 'W', 'nb')]
 
 
 _lib = None
@@ -72,6 +77,11 @@ def lib():
     for name in EXPORTS[3:]:
         getattr(L, name).restype = ctypes.c_int
     L.mpc_voxel_workspace_bytes.restype = i64
+    isp = ctypes.POINTER(IngestShape)
+    L.mpc_ingest_workspace_bytes.argtypes = [isp]
+    L.mpc_ingest_workspace_bytes.restype = i64
+    L.mpc_ingest_count.argtypes = [isp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_ingest_scatter.argtypes = [isp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     if L.mpc_version() != 100:
         raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (100)')
     _lib = L

@@ -1,0 +1,255 @@
+// Event ingest: raw window (x, y, t_us, p per event, ragged batch) -> the padded
+// [B][M][6] event tensor the loss consumes, built on the GPU.
+//   per-sample half : reference src/loader/dsec/loader.py:152-167 (time normalisation by min/max in
+//                     float64, bin = clip(searchsorted(linspace(0,1,nb+1), t) - 1, 0), in-image filter,
+//                     positive / negative split, cast to float32)
+//   collate half    : loader.py:360-415 (pad_events + sequence_collate_fn: zero rows with valid = 0,
+//                     positive block padded to the batch maximum, then the negative block)
+// Three passes: per-chunk counts and time extrema -> per-sample scan (chunk offsets, totals, batch
+// maxima) -> stable scatter (order inside each block is the input order, as boolean masking gives).
+// The caller reads the two batch maxima to size the output (the only host round trip of ingest).
+#include "common.h"
+
+#define ING_CHUNK 1024          // events per workgroup (256 threads x 4 consecutive events)
+
+struct IngLayout {
+    int nchunks;
+    int *chunk_cnt;             // [B][nchunks][2]  valid positives / negatives per chunk
+    long long *chunk_t;         // [B][nchunks][2]  min / max timestamp per chunk
+    int *chunk_off;             // [B][nchunks][2]  exclusive offsets
+    long long *tminmax;         // [B][2]
+    int *totals;                // [B][2]
+};
+
+__device__ __forceinline__ int classify(float x, float y, float p, int H, int W) {
+    // 1: positive row, 2: negative row, 0: dropped   (loader.py:160-165; comparisons on the float32 values)
+    const bool in = (0.f <= y) && (y < (float)H) && (0.f <= x) && (x < (float)W);
+    if (!in) return 0;
+    return p == 1.f ? 1 : (p == 0.f ? 2 : 0);
+}
+
+// grid (nchunks, B), 256 threads
+__global__ __launch_bounds__(256) void k_ingest_count(const mpc_ingest_shape s, const IngLayout L,
+                                                      const float *__restrict__ x, const float *__restrict__ y,
+                                                      const long long *__restrict__ t, const float *__restrict__ p,
+                                                      const int *__restrict__ counts) {
+    __shared__ int s_c[2][4];
+    __shared__ long long s_t[2][4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int n = min(counts[b], s.N);
+    const size_t base = (size_t)b * s.N;
+    int cp = 0, cn = 0;
+    long long tmin = 0x7fffffffffffffffLL, tmax = -0x7fffffffffffffffLL - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = chunk * ING_CHUNK + tid * 4 + k;
+        if (i < n) {
+            const int c = classify(x[base + i], y[base + i], p[base + i], s.H, s.W);
+            cp += c == 1; cn += c == 2;
+            const long long tv = t[base + i];       // extrema over ALL events of the window (loader.py:152)
+            tmin = tv < tmin ? tv : tmin; tmax = tv > tmax ? tv : tmax;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cp += __shfl_down(cp, o, 64); cn += __shfl_down(cn, o, 64);
+        const long long a = __shfl_down(tmin, o, 64), c2 = __shfl_down(tmax, o, 64);
+        tmin = a < tmin ? a : tmin; tmax = c2 > tmax ? c2 : tmax;
+    }
+    if ((tid & 63) == 0) { s_c[0][tid >> 6] = cp; s_c[1][tid >> 6] = cn; s_t[0][tid >> 6] = tmin; s_t[1][tid >> 6] = tmax; }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t o = ((size_t)b * L.nchunks + chunk) * 2;
+        L.chunk_cnt[o] = s_c[0][0] + s_c[0][1] + s_c[0][2] + s_c[0][3];
+        L.chunk_cnt[o + 1] = s_c[1][0] + s_c[1][1] + s_c[1][2] + s_c[1][3];
+        long long a = s_t[0][0], c2 = s_t[1][0];
+        for (int w = 1; w < 4; ++w) { a = s_t[0][w] < a ? s_t[0][w] : a; c2 = s_t[1][w] > c2 ? s_t[1][w] : c2; }
+        L.chunk_t[o] = a; L.chunk_t[o + 1] = c2;
+    }
+}
+
+// grid B, 256 threads: exclusive scan over the chunks of one sample
+__global__ __launch_bounds__(256) void k_ingest_scan(const IngLayout L, int *__restrict__ out_max) {
+    __shared__ int s_run[2];
+    __shared__ int s_part[2][256];
+    __shared__ long long s_t[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { s_run[0] = 0; s_run[1] = 0; }
+    long long tmin = 0x7fffffffffffffffLL, tmax = -0x7fffffffffffffffLL - 1;
+    __syncthreads();
+    for (int c0 = 0; c0 < L.nchunks; c0 += 256) {
+        const int c = c0 + tid;
+        int vp = 0, vn = 0;
+        if (c < L.nchunks) {
+            const size_t o = ((size_t)b * L.nchunks + c) * 2;
+            vp = L.chunk_cnt[o]; vn = L.chunk_cnt[o + 1];
+            const long long a = L.chunk_t[o], c2 = L.chunk_t[o + 1];
+            tmin = a < tmin ? a : tmin; tmax = c2 > tmax ? c2 : tmax;
+        }
+        s_part[0][tid] = vp; s_part[1][tid] = vn;
+        __syncthreads();
+        if (tid < 2) {                      // serial scan of <= 256 values per polarity: tiny
+            int run = s_run[tid];
+            for (int k = 0; k < 256; ++k) { const int v = s_part[tid][k]; s_part[tid][k] = run; run += v; }
+            s_run[tid] = run;
+        }
+        __syncthreads();
+        if (c < L.nchunks) {
+            const size_t o = ((size_t)b * L.nchunks + c) * 2;
+            L.chunk_off[o] = s_part[0][tid]; L.chunk_off[o + 1] = s_part[1][tid];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_down(tmin, o, 64), c2 = __shfl_down(tmax, o, 64);
+        tmin = a < tmin ? a : tmin; tmax = c2 > tmax ? c2 : tmax;
+    }
+    if ((tid & 63) == 0) { s_t[0][tid >> 6] = tmin; s_t[1][tid >> 6] = tmax; }
+    __syncthreads();
+    if (tid == 0) {
+        long long a = s_t[0][0], c2 = s_t[1][0];
+        for (int w = 1; w < 4; ++w) { a = s_t[0][w] < a ? s_t[0][w] : a; c2 = s_t[1][w] > c2 ? s_t[1][w] : c2; }
+        L.tminmax[b * 2] = a; L.tminmax[b * 2 + 1] = c2;
+        L.totals[b * 2] = s_run[0]; L.totals[b * 2 + 1] = s_run[1];
+        atomicMax(&out_max[0], s_run[0]);
+        atomicMax(&out_max[1], s_run[1]);
+    }
+}
+
+__device__ __forceinline__ int bin_index(double tn, int nb) {
+    // np.searchsorted(np.linspace(0, 1, nb + 1), tn, side='left') - 1, clipped at 0.
+    // linspace: e_i = i * (1.0 / nb) in float64, e_nb = 1.0 exactly.
+    const double step = 1.0 / (double)nb;
+    int i = (int)ceil(tn * (double)nb);
+    i = i < 0 ? 0 : (i > nb ? nb : i);
+    auto edge = [&](int k) { return k >= nb ? 1.0 : (double)k * step; };
+    while (i > 0 && edge(i - 1) >= tn) --i;
+    while (i < nb && edge(i) < tn) ++i;
+    if (i == nb && edge(nb) < tn) i = nb + 1;          // tn > 1 cannot happen after min/max normalisation
+    return i - 1 < 0 ? 0 : i - 1;
+}
+
+// grid (nchunks, B), 256 threads.  Thread t owns 4 consecutive events, so ranks follow the input order.
+__global__ __launch_bounds__(256) void k_ingest_scatter(const mpc_ingest_shape s, const IngLayout L,
+                                                        const float *__restrict__ x, const float *__restrict__ y,
+                                                        const long long *__restrict__ t, const float *__restrict__ p,
+                                                        const int *__restrict__ counts, int max_pos, int max_neg,
+                                                        float *__restrict__ events, float *__restrict__ xytp) {
+    __shared__ int s_w[2][4];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int n = min(counts[b], s.N);
+    const size_t base = (size_t)b * s.N;
+    const long long tmin = L.tminmax[b * 2], tmax = L.tminmax[b * 2 + 1];
+    const double span = (double)(tmax - tmin);
+    int cls[4], lp = 0, ln = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = chunk * ING_CHUNK + tid * 4 + k;
+        cls[k] = (i < n) ? classify(x[base + i], y[base + i], p[base + i], s.H, s.W) : 0;
+        lp += cls[k] == 1; ln += cls[k] == 2;
+    }
+    // exclusive scan of (lp, ln) over the workgroup
+    int ip = lp, in_ = ln;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int a = __shfl_up(ip, o, 64), c2 = __shfl_up(in_, o, 64);
+        if ((tid & 63) >= o) { ip += a; in_ += c2; }
+    }
+    if ((tid & 63) == 63) { s_w[0][tid >> 6] = ip; s_w[1][tid >> 6] = in_; }
+    __syncthreads();
+    int wp = 0, wn = 0;
+    for (int w = 0; w < (tid >> 6); ++w) { wp += s_w[0][w]; wn += s_w[1][w]; }
+    const size_t co = ((size_t)b * L.nchunks + chunk) * 2;
+    int rp = L.chunk_off[co] + wp + ip - lp;
+    int rn = L.chunk_off[co + 1] + wn + in_ - ln;
+    const int M = max_pos + max_neg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = chunk * ING_CHUNK + tid * 4 + k;
+        if (i >= n) continue;
+        const long long tv = t[base + i];
+        if (xytp != nullptr) {
+            // loader.py:135-138: t = (t - t[0]).astype(float32); t = t / t[-1]   (t increasing)
+            const float tf = (float)(tv - tmin) / (float)(tmax - tmin);
+            reinterpret_cast<float4 *>(xytp)[base + i] = make_float4(x[base + i], y[base + i], tf, p[base + i]);
+        }
+        if (cls[k] == 0) continue;
+        const double tn = (double)(tv - tmin) / span;                       // loader.py:152 (float64)
+        const int row = cls[k] == 1 ? rp++ : max_pos + rn++;
+        float *e = events + ((size_t)b * M + row) * 6;
+        e[0] = y[base + i]; e[1] = x[base + i]; e[2] = (float)tn; e[3] = p[base + i];
+        e[4] = (float)bin_index(tn, s.nb); e[5] = 1.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static int ing_validate(const mpc_ingest_shape *s) {
+    MPC_CHECK_ARG(s->B >= 0 && s->N >= 0 && s->H >= 1 && s->W >= 1 && s->nb >= 1, MPC_E_SHAPE, "bad ingest shape");
+    MPC_CHECK_ARG((int64_t)s->B * s->N < (1LL << 31), MPC_E_UNSUPPORTED, "too many events");
+    return 0;
+}
+
+struct IngHost { IngLayout L; int64_t total; };
+
+static IngHost ing_layout(const mpc_ingest_shape *s, void *ws) {
+    IngHost h;
+    const int B = s->B > 0 ? s->B : 1;
+    h.L.nchunks = mpc_cdiv(s->N > 0 ? s->N : 1, ING_CHUNK);
+    const int64_t nc = (int64_t)B * h.L.nchunks;
+    int64_t off = 0;
+    char *w = (char *)ws;
+    h.L.chunk_t = (long long *)(w + off);  off += mpc_align(nc * 2 * 8);
+    h.L.tminmax = (long long *)(w + off);  off += mpc_align((int64_t)B * 2 * 8);
+    h.L.chunk_cnt = (int *)(w + off);      off += mpc_align(nc * 2 * 4);
+    h.L.chunk_off = (int *)(w + off);      off += mpc_align(nc * 2 * 4);
+    h.L.totals = (int *)(w + off);         off += mpc_align((int64_t)B * 2 * 4);
+    h.total = off;
+    return h;
+}
+
+extern "C" int64_t mpc_ingest_workspace_bytes(const mpc_ingest_shape *s) {
+    if (!s) { mpc_set_error("mpc_ingest_workspace_bytes: null shape"); return MPC_E_NULL; }
+    int rc = ing_validate(s);
+    if (rc) return rc;
+    return ing_layout(s, nullptr).total;
+}
+
+extern "C" int mpc_ingest_count(const mpc_ingest_shape *s, const float *x, const float *y, const int64_t *t_us,
+                                const float *p, const int32_t *counts, int32_t *out_max, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && counts && out_max && ws && ((x && y && t_us && p) || s->N == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    int rc = ing_validate(s);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out_max, 0, 2 * sizeof(int32_t), st);
+    if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+    if (s->B == 0) return 0;
+    const IngLayout L = ing_layout(s, ws).L;
+    hipLaunchKernelGGL(k_ingest_count, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
+                       reinterpret_cast<const long long *>(t_us), p, counts);
+    hipLaunchKernelGGL(k_ingest_scan, dim3(s->B), dim3(256), 0, st, L, out_max);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, const float *y, const int64_t *t_us,
+                                  const float *p, const int32_t *counts, int32_t max_pos, int32_t max_neg,
+                                  float *events, float *xytp, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && counts && ws && ((x && y && t_us && p) || s->N == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(max_pos >= 0 && max_neg >= 0 && (events || max_pos + max_neg == 0 || s->B == 0), MPC_E_NULL, "events is null");
+    int rc = ing_validate(s);
+    if (rc) return rc;
+    if (s->B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)max_pos + max_neg;
+    if (M > 0) {
+        hipError_t e = hipMemsetAsync(events, 0, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows
+        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+    }
+    if (s->N == 0) return 0;
+    const IngLayout L = ing_layout(s, ws).L;
+    hipLaunchKernelGGL(k_ingest_scatter, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
+                       reinterpret_cast<const long long *>(t_us), p, counts, max_pos, max_neg, events, xytp);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,37 @@
+"""Event ingest on the GPU: raw windows -> the padded [B, M, 6] event tensor and
+`num_pos_events` that `FocusLoss.calc` consumes, and (optionally) the (x, y, t, p) rows for the
+voxel-grid builder.  Mirrors reference src/loader/dsec/loader.py:152-167 + 360-415; numerics in
+libmpcmax.so (csrc/ingest.hip)."""
+import ctypes
+
+import torch
+
+from .. import _lib as C
+from ..ops import _ptr, _require_gpu, _stream
+
+
+def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input=False):
+    """x, y, p: [B, N] float32; t_us: [B, N] int64 (increasing per sample); counts: [B] valid lengths.
+    Returns {'events': [B, M, 6], 'num_pos_events': int, 'xytp': [B, N, 4] or None}.
+    One host round trip (two integers) sizes the output, as the reference's CPU collate does."""
+    _require_gpu(x, 'x')
+    dev = x.device
+    B, N = x.shape
+    x = x.float().contiguous(); y = y.float().contiguous(); p = p.float().contiguous()
+    t_us = t_us.to(torch.int64).contiguous()
+    cnt = counts.to(device=dev, dtype=torch.int32).contiguous()
+    shape = C.IngestShape(B=B, N=N, H=int(image_shape[0]), W=int(image_shape[1]), nb=int(num_bins))
+    nbytes = C.lib().mpc_ingest_workspace_bytes(ctypes.byref(shape))
+    if nbytes < 0:
+        C.check(int(nbytes), 'mpc_ingest_workspace_bytes')
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    out_max = torch.empty(2, dtype=torch.int32, device=dev)
+    st = _stream(dev)
+    C.check(C.lib().mpc_ingest_count(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
+                                     _ptr(out_max), _ptr(ws), st), 'mpc_ingest_count')
+    max_pos, max_neg = (int(v) for v in out_max.tolist())          # the collate's host decision
+    events = torch.empty((B, max_pos + max_neg, 6), dtype=torch.float32, device=dev)
+    xytp = torch.empty((B, N, 4), dtype=torch.float32, device=dev) if want_voxel_input else None
+    C.check(C.lib().mpc_ingest_scatter(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
+                                       max_pos, max_neg, _ptr(events), _ptr(xytp), _ptr(ws), st), 'mpc_ingest_scatter')
+    return {'events': events, 'num_pos_events': max_pos, 'xytp': xytp}

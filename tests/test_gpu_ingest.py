@@ -1,0 +1,56 @@
+"""Event ingest (next row 8f-1): HIP path vs the reference's collate golden and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from test_ingest_oracle import load_ingest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x, y, t, p, counts, H, W, nb, voxel=False):
+    from motionpriorcmax_amd.utils import ingest_events
+    dev = torch.device('cuda:0')
+    return ingest_events(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(t).to(dev),
+                         torch.from_numpy(p).to(dev), torch.from_numpy(counts), (H, W), nb, want_voxel_input=voxel)
+
+
+def test_ingest_golden_collate():
+    g = load_ingest()
+    out = _run(g['x'], g['y'], g['t'], g['p'], g['counts'], int(g['H']), int(g['W']), int(g['nb']))
+    assert out['num_pos_events'] == int(g['num_pos_events'])
+    np.testing.assert_array_equal(out['events'].cpu().numpy(), g['events'])
+
+
+def test_ingest_full_size_ragged_vs_oracle_and_feeds_the_loss():
+    """DSEC-size windows of different length (one empty), bit-exact against the oracle; the result is
+    accepted by FocusLoss.calc and the voxel rows by the voxel-grid builder."""
+    from motionpriorcmax_amd import LossFactory
+    from motionpriorcmax_amd.utils import voxel_grids
+    from oracle import focus_oracle as O
+    from oracle import ingest_oracle as I
+    H, W, nb = 480, 640, 15
+    ns = [200000, 120000, 0, 64]
+    N = max(ns)
+    raws = [I.synth_raw(n, H, W, seed=70 + b) if n else None for b, n in enumerate(ns)]
+    pad = lambda k, dt: np.stack([np.concatenate((r[k], np.zeros(N - len(r[k]), dt))) if r else np.zeros(N, dt) for r in raws])
+    x, y, t, p = pad(0, 'float32'), pad(1, 'float32'), pad(2, 'int64'), pad(3, 'float32')
+    out = _run(x, y, t, p, np.array(ns, dtype=np.int32), H, W, nb, voxel=True)
+    empty = (np.zeros((0, 5), np.float32), np.zeros((0, 5), np.float32))
+    ref, num_pos = I.collate([I.sample_events(*r, H, W, nb) if r else empty for r in raws])
+    assert out['num_pos_events'] == num_pos
+    np.testing.assert_array_equal(out['events'].cpu().numpy(), ref)
+    np.testing.assert_array_equal(out['xytp'][0].cpu().numpy(), I.voxel_input(*raws[0]))
+    # downstream: the loss and the voxel grid take it as is
+    cfg = dict(image_shape=(H, W), num_tref=1, num_bins=nb, num_knn=32, smooth_weight=0.003,
+               lut_superpixel_size=4, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    g = torch.Generator().manual_seed(1)
+    times = torch.cat((torch.tensor([0.41]), O.bin_mid_times(nb)))
+    traj = O.trajectories_at(torch.randn(len(ns), 1, 2, H, W, generator=g), times, O.tile_mask((H, W), 4), 1, 'polynomial')
+    loss, _, misc = LossFactory.get_loss_calculator('FOCUS', cfg).calc(
+        traj.cuda(), times.cuda(), {'events': out['events'], 'num_pos_events': out['num_pos_events']})
+    assert torch.isfinite(loss).item() and misc['iwes'].shape == (len(ns), 1, 2, H, W)
+    vox = voxel_grids(out['xytp'][:2], torch.tensor(ns[:2], dtype=torch.int32), (nb, H, W), 'mean_std')
+    assert torch.isfinite(vox).all()
