@@ -59,12 +59,8 @@ def synth_inputs(wl, seed, B=None):
     mask = utils.get_optical_flow_tile_mask((H, W), PATCH)
     if wl is WORKLOADS['C4']:
         # Bezier control points N(0, 2^2) per tile, (x, y) channel order (bezier.py / polynomial.py:60-61)
-        params = torch.randn(B, 2, k, H // PATCH, W // PATCH, generator=g) * 2.0
-        bm = utils.bernstein_basis(times.numpy(), k)                       # [n_t, k]
-        flow = torch.einsum('bdphw,tp->btdhw', params, bm)                 # [B, n_t, 2(x,y), h, w]
-        pos = torch.nonzero(mask).float()
-        disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), -1).reshape(B, len(times), -1, 2)
-        traj = disp + pos[None, None]
+        params = torch.randn(B, 2 * k, H // PATCH, W // PATCH, generator=g) * 2.0
+        traj, _ = utils.trajectories_from_bezier(params, times, PATCH, (H, W))
     else:
         sigma = 3.0 if k == 1 else 1.0
         coeff = torch.randn(B, 1, 2 * k, H, W, generator=g) * sigma
@@ -367,6 +363,37 @@ def main():
                                     'cpu_oracle_Mevents_per_s': round(Ni / tci / 1e6, 2), 'note': 'includes the 2-integer host read that sizes the output'}
         except Exception as e:
             also['event_ingest'] = {'error': repr(e)[:200]}
+        # next row 8f-3: dense flow from tile trajectories + flow metrics at the DSEC validation shape
+        try:
+            from motionpriorcmax_amd.utils import dense_flow_from_traj, calculate_flow_error, get_optical_flow_tile_mask
+            from oracle import flow_oracle as FO
+            Bf = wl['B']
+            pixf = torch.nonzero(get_optical_flow_tile_mask((H, W), 4)).to(dev)
+            tff = torch.randn(Bf, pixf.shape[0], 2, device=dev)
+            gtf, prf, emf, _ = FO.synth_flow_case(Bf, H, W, seed=77, with_scale=False)
+            gtf, prf, emf = gtf.to(dev), prf.to(dev), emf.to(dev)
+
+            def med(fn, reps=11):
+                for _ in range(3):
+                    fn()
+                ts_ = []
+                for _ in range(reps):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize(); ts_.append(time.perf_counter() - t0)
+                return sorted(ts_)[len(ts_) // 2]
+            td = med(lambda: dense_flow_from_traj(tff, pixf, 4, (H, W)))
+            te = med(lambda: calculate_flow_error(gtf, prf, emf))
+            t0 = time.perf_counter()
+            FO.calculate_flow_error(gtf[:1].cpu(), prf[:1].cpu(), emf[:1].cpu())
+            tce = time.perf_counter() - t0
+            also['dense_flow'] = {'ms_per_batch': round(1e3 * td, 4), 'batch': Bf,
+                                  'algorithmic_MB': round(Bf * 2 * 4 * (H * W + 2 * (H // 4) * (W // 4)) / 1e6, 2)}
+            also['flow_error'] = {'ms_per_batch': round(1e3 * te, 4), 'batch': Bf,
+                                  'algorithmic_MB': round(Bf * H * W * 17 / 1e6, 2),
+                                  'cpu_oracle_ms_per_sample': round(1e3 * tce, 2)}
+        except Exception as e:
+            also['dense_flow'] = {'error': repr(e)[:200]}
         out['also'] = also
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)

@@ -169,6 +169,27 @@ int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, const float *y
                        const float *p, const int32_t *counts, int32_t max_pos, int32_t max_neg,
                        float *events, float *xytp, void *ws, void *stream);
 
+/* ---- next row: dense flow from tile trajectories and flow error metrics.
+ * mpc_dense_flow = reference src/utils/flow.py:12-16 (dense_flow_from_traj): list_to_grid
+ *   (src/utils/trajectories.py:54-76) at pixel_positions // patch, then the anti-aliased bicubic resize
+ *   of src/utils/flow.py:9-10 to H x W.
+ *   traj_flow [B][n][C], pixel_positions [n][2] int64 (y, x)
+ *   patch_flow [B][C][H/patch][W/patch] (out), dense [B][C][H][W] (out)
+ * mpc_flow_error = reference src/utils/flow.py:18-70 (calculate_flow_error).
+ *   flow_gt, flow_pred [B][2][H][W]; event_mask [B][H][W] bytes (non-zero = true) or NULL;
+ *   time_scale [B] or NULL; out[5] (device) = EPE, 1PE, 2PE, 3PE, AE (degrees). */
+typedef struct mpc_flow_shape {
+    int32_t B, C, n, patch, H, W;
+} mpc_flow_shape;
+int mpc_dense_flow(const mpc_flow_shape *s, const float *traj_flow, const int64_t *pixel_positions,
+                   float *patch_flow, float *dense, void *stream);
+typedef struct mpc_err_shape {
+    int32_t B, H, W;
+} mpc_err_shape;
+int64_t mpc_flow_error_workspace_bytes(const mpc_err_shape *s);
+int mpc_flow_error(const mpc_err_shape *s, const float *flow_gt, const float *flow_pred,
+                   const uint8_t *event_mask, const float *time_scale, float *out, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

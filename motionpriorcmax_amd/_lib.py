@@ -26,7 +26,7 @@ SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 
 EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_knn_lut_fwd',
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
-           'mpc_ingest_scatter']
+           'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error']
 
 
 class Shape(ctypes.Structure):
@@ -41,6 +41,14 @@ class VoxShape(ctypes.Structure):
 
 class IngestShape(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'H', 'W', 'nb')]
+
+
+class FlowShape(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'C', 'n', 'patch', 'H', 'W')]
+
+
+class ErrShape(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'H', 'W')]
 
 
 _lib = None
@@ -82,6 +90,10 @@ def lib():
     L.mpc_ingest_workspace_bytes.restype = i64
     L.mpc_ingest_count.argtypes = [isp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_ingest_scatter.argtypes = [isp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.mpc_dense_flow.argtypes = [ctypes.POINTER(FlowShape), vp, vp, vp, vp, vp]
+    L.mpc_flow_error_workspace_bytes.argtypes = [ctypes.POINTER(ErrShape)]
+    L.mpc_flow_error_workspace_bytes.restype = i64
+    L.mpc_flow_error.argtypes = [ctypes.POINTER(ErrShape), vp, vp, vp, vp, vp, vp, vp]
     if L.mpc_version() != 100:
         raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (100)')
     _lib = L

@@ -34,3 +34,28 @@ def bernstein_basis(times, degree):
         i = d_idx + 1
         out[:, d_idx] = math.comb(degree, i) * (1 - t) ** (degree - i) * t ** i
     return torch.from_numpy(out).float()
+
+
+def trajectories_from_bezier(params, times, tile_size, image_shape, scale=1.0):
+    """RAFT-spline adapter: sample Bezier flow curves at the tile centres as `trajectories`
+    for `FocusLoss.calc`.
+
+    params [B, 2*d, h, w] with h = H // tile_size, w = W // tile_size, viewed [B, 2, d, h, w] with dim 1 in
+    (x, y) order (reference src/models/raft_spline/curves/base.py:88-89, polynomial.py:60-61); the flow at time
+    t is `CurveBase.get_flow_from_reference(t)` = sum_i B_i(t) P_i (bezier.py:92-113), which is zero at the
+    anchor t = 0.  Returns (trajectories [B, n_t, n, 2] in (y, x) pixel coordinates, pixel_positions [n, 2]) with
+    the tile centres of `get_optical_flow_tile_mask` as start points -- the layout `calc` expects
+    (focus.py:66-72).  `scale` multiplies the flow (8.0 if the curve lives on RAFT's 1/8 grid units).
+    Differentiable w.r.t. `params` (plain torch: 2*d*n_t multiply-adds per tile)."""
+    from .trajectories import get_optical_flow_tile_mask
+    B, c2, h, w = params.shape
+    H, W = (int(v) for v in image_shape)
+    assert c2 % 2 == 0 and h == H // tile_size and w == W // tile_size, (params.shape, image_shape, tile_size)
+    d = c2 // 2
+    t = times.detach().cpu().numpy() if torch.is_tensor(times) else times
+    bm = bernstein_basis(t, d).to(params.device, params.dtype)                       # [n_t, d]
+    flow = torch.einsum('bcdhw,td->btchw', params.view(B, 2, d, h, w), bm) * scale  # [B, n_t, (x, y), h, w]
+    pos = torch.nonzero(get_optical_flow_tile_mask((H, W), tile_size))
+    assert pos.shape[0] == h * w, 'image shape must be a multiple of the tile size'
+    disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), dim=-1).reshape(B, bm.shape[0], h * w, 2)
+    return disp + pos.to(params.device, params.dtype)[None, None], pos

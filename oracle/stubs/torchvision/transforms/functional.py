@@ -1,5 +1,7 @@
 """torchvision.transforms.functional.gaussian_blur restated from its documented algorithm
-(reference call site: src/utils/event_image_converter.py:175).  Third-party stand-in."""
+(reference call site: src/utils/event_image_converter.py:175), and `resize` for float tensors, which
+torchvision forwards to torch.nn.functional.interpolate (reference call site: src/utils/flow.py:9-10).
+Third-party stand-in."""
 import torch
 import torch.nn.functional as F
 
@@ -22,5 +24,12 @@ def gaussian_blur(img, kernel_size, sigma=None):
     return F.conv2d(x, k2.expand(C, 1, *k2.shape), groups=C)
 
 
-def resize(*a, **k):
-    raise NotImplementedError
+def resize(img, size, interpolation=None, max_size=None, antialias=True):
+    """Float tensors [..., C, H, W]: interpolate(size, mode, align_corners=False, antialias), no clamping."""
+    mode = getattr(interpolation, 'value', interpolation) or 'bilinear'
+    lead = img.shape[:-3]
+    x = img.reshape((-1,) + tuple(img.shape[-3:]))
+    ac = False if mode in ('bilinear', 'bicubic') else None
+    aa = bool(antialias) and mode in ('bilinear', 'bicubic')
+    y = F.interpolate(x, size=list(size), mode=mode, align_corners=ac, antialias=aa)
+    return y.reshape(lead + tuple(y.shape[-3:]))

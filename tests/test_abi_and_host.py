@@ -116,3 +116,22 @@ def test_bernstein_basis_matches_reference():
     bm = utils.bernstein_basis(g['timestamps'], 10)
     p = torch.from_numpy(g['params']).view(2, 2, 10, 6, 8)
     np.testing.assert_allclose(torch.einsum('bdphw,tp->tbdhw', p, bm).numpy(), g['flows'], atol=1e-5)
+
+
+def test_bezier_adapter_matches_reference_curves():
+    """8f-4: trajectories sampled from Bezier curves = tile centres + the reference's
+    `get_flow_from_reference` (g6, (x, y) channel order swapped to (y, x)); gradient reaches the parameters."""
+    from motionpriorcmax_amd import utils
+    g = load_golden('g6_bezier10')
+    params = torch.from_numpy(g['params']).requires_grad_(True)          # [2, 20, 6, 8]
+    traj, pos = utils.trajectories_from_bezier(params, g['timestamps'], 4, (24, 32))
+    assert traj.shape == (2, 6, 48, 2) and pos.shape == (48, 2)
+    assert pos[0].tolist() == [2, 2] and pos[-1].tolist() == [22, 30]
+    flows = torch.from_numpy(g['flows'])                                 # [n_t, B, 2 (x, y), h, w]
+    disp = (traj - pos.float()[None, None]).reshape(2, 6, 6, 8, 2)
+    np.testing.assert_allclose(disp[..., 0].detach().numpy(), flows[:, :, 1].permute(1, 0, 2, 3).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(disp[..., 1].detach().numpy(), flows[:, :, 0].permute(1, 0, 2, 3).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(disp[:, 0].detach().numpy(), 0.0, atol=0)            # anchor t = 0
+    np.testing.assert_allclose(disp[:, -1, ..., 1].detach().numpy(), g['flow_t1'][:, 0], rtol=1e-6, atol=1e-6)
+    traj.sum().backward()
+    assert params.grad is not None and float(params.grad.abs().sum()) > 0
