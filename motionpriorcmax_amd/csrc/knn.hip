@@ -19,6 +19,8 @@
 #ifndef KNN_BATCH
 #define KNN_BATCH 2   // candidate positions loaded ahead of use in the two hot scans (B=14: 944 -> 874 us; 4: 867)
 #endif
+#define KNN_HW (KNN_BINS / 4)   // histogram words per query: four 8-bit bins per word
+#define KNN_LIST KNN_HW          // {candidate slot, trajectory index} pairs kept in a (dead) histogram column
 #define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
 
 struct KnnParams {
@@ -150,10 +152,10 @@ struct QueryCtx {
     const int *sidx;
     const float2 *traj_b;   // trajectories of this sample: [T+nb][n]
     // LDS
-    const int *lcs;         // [RW][RW+1]
+    const unsigned short *lcs;   // [RW][RW+1]  (staged offsets < cap <= 65535)
     const float2 *lpos;
-    const int *lidx;
-    const float2 *lf0;      // flow to t_ref (T == 1 only)
+    const unsigned short *lidx;  // trajectory index (n < 65536)
+    const float2 *lf0;      // flow to t_ref (T == 1 and staged), else null
     const float2 *lf1;      // flow to the next bin (want_next only)
     int ry0, rx0, RW, RH;
 };
@@ -165,7 +167,7 @@ struct Acc {
     int t;
     __device__ __forceinline__ void range(int yy, int x0, int x1, int &js, int &je) const {
         if (LDS) {
-            const int *row = c.lcs + (yy - c.ry0) * (c.RW + 1);
+            const unsigned short *row = c.lcs + (yy - c.ry0) * (c.RW + 1);
             js = row[x0 - c.rx0];
             je = row[x1 + 1 - c.rx0];
         } else {
@@ -176,7 +178,7 @@ struct Acc {
     __device__ __forceinline__ float2 pos(int j) const { return LDS ? c.lpos[j] : c.spos[j]; }
     __device__ __forceinline__ int idx(int j) const { return LDS ? c.lidx[j] : c.sidx[j]; }
     __device__ __forceinline__ float2 flow_ref(int j, int tr, float2 pj) const {
-        if (LDS && p.T == 1) return c.lf0[j];
+        if (LDS && c.lf0 != nullptr) return c.lf0[j];
         const float2 a = c.traj_b[(size_t)tr * p.n + idx(j)];
         return make_float2(a.x - pj.x, a.y - pj.y);          // traj(t_ref) - traj(t_mid)
     }
@@ -232,7 +234,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             scale = (float)KNN_BINS / upper;
         }
 #pragma unroll
-        for (int h = 0; h < KNN_BINS / 2; ++h) s_hist[h][tid] = 0u;
+        for (int h = 0; h < KNN_HW; ++h) s_hist[h][tid] = 0u;
         cnt = 0;
         for (int yy = y0; yy <= y1; ++yy) {
             int js, je;
@@ -248,7 +250,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                     const float d = pair_dist(qy, qx, q[u].x, q[u].y, L1);
                     const int in = (j + u < je) & (d < upper);
                     const int bin = min((int)(fminf(d, upper) * scale), KNN_BINS - 1);
-                    atomicAdd(&s_hist[bin >> 1][tid], in ? ((bin & 1) ? 0x10000u : 1u) : 0u);   // private column
+                    atomicAdd(&s_hist[bin >> 2][tid], in ? (1u << ((bin << 3) & 31)) : 0u);   // private column
                     cnt += in;
                 }
             }
@@ -258,17 +260,28 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     }
     // ---- 2. bin holding the K-th smallest ----------------------------------------------------
     int bstar = KNN_BINS - 1, before = 0;
-    {
+    if (cnt > 255) {
+        // an 8-bit bin may have wrapped (dense clusters, K > 255): treat every candidate as one bin,
+        // which sends the selection to the repeated-minimum path below
+        scale = 0.f; bstar = 0;
+    } else {
+        // word holding the K-th smallest (v_sad_u8 sums the four 8-bit bins of a word), then the bin inside it
         int cum = 0;
+        unsigned wstar = 0u;
         bool found = false;
 #pragma unroll
-        for (int h = 0; h < KNN_BINS / 2; ++h) {
+        for (int h = 0; h < KNN_HW; ++h) {
             const unsigned wv = s_hist[h][tid];
-            const int c0 = (int)(wv & 0xffffu), c1 = (int)(wv >> 16);
-            if (!found && cum + c0 >= p.K) { bstar = 2 * h; before = cum; found = true; }
-            cum += c0;
-            if (!found && cum + c1 >= p.K) { bstar = 2 * h + 1; before = cum; found = true; }
-            cum += c1;
+            const int nc = (int)__builtin_amdgcn_sad_u8(wv, 0u, (unsigned)cum);
+            if (!found && nc >= p.K) { bstar = 4 * h; before = cum; wstar = wv; found = true; }
+            cum = nc;
+        }
+        if (found) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ck = (int)((wstar >> (8 * k)) & 0xffu);
+                if (before + ck < p.K) { before += ck; ++bstar; } else break;
+            }
         }
     }
     // ---- 3. second scan: sum the flows of the bins below bstar (num_tref == 1), and list the
@@ -302,29 +315,58 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                         if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
                     }
                 } else if (bin == bstar) {
-                    if (m < KNN_BINS / 4) { s_hist[2 * m][tid] = __float_as_uint(d); s_hist[2 * m + 1][tid] = (unsigned)j; }
+                    if (m < KNN_LIST) s_hist[m][tid] = ((unsigned)j << 16) | (unsigned)A.idx(j);
                     ++m;
                 }
             }
         }
     }
     float dK = 0.f; int iK = -1;
-    bool listed = (m <= KNN_BINS / 4);
-    if (listed) {
-        // rank the <= 8 listed keys by (distance, index); the first `need` of them are neighbours
+    bool listed = (m <= KNN_LIST);
+    if (m <= 4) {
+        // the usual case: rank up to four keys by (distance, index) in registers, straight-line
+        float dd[4]; int ii[4], jj[4]; float2 pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned w = s_hist[u][tid];
+            const bool valid = u < m;
+            jj[u] = valid ? (int)(w >> 16) : 0;
+            ii[u] = valid ? (int)(w & 0xffffu) : 0x7fffffff;
+            pp[u] = A.pos(jj[u]);
+            dd[u] = valid ? pair_dist(qy, qx, pp[u].x, pp[u].y, L1) : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int rank = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e != u) rank += ((dd[e] < dd[u]) | ((dd[e] == dd[u]) & (ii[e] < ii[u]))) ? 1 : 0;
+            if (u < m && rank < need) {
+                if (fuse) {
+                    const float2 f = A.flow_ref(jj[u], 0, pp[u]);
+                    if (p.iwd) { const float w = 1.f / (dd[u] + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
+                    else { sy += f.x; sx += f.y; }
+                    if (do_next0) { const float2 g = A.flow_next(jj[u], pp[u]); ny += g.x; nx += g.y; }
+                }
+                if (rank == need - 1) { dK = dd[u]; iK = ii[u]; }
+            }
+        }
+    } else if (listed) {
+        // rank the listed keys by (distance, index); the first `need` of them are neighbours
         for (int a = 0; a < m; ++a) {
-            const float da = __uint_as_float(s_hist[2 * a][tid]);
-            const int ja = (int)s_hist[2 * a + 1][tid];
-            const int ia = A.idx(ja);
+            const unsigned wa = s_hist[a][tid];
+            const int ja = (int)(wa >> 16), ia = (int)(wa & 0xffffu);
+            const float2 pj = A.pos(ja);
+            const float da = pair_dist(qy, qx, pj.x, pj.y, L1);
             int rank = 0;
             for (int e = 0; e < m; ++e) {
-                const float de = __uint_as_float(s_hist[2 * e][tid]);
-                const int ie = A.idx((int)s_hist[2 * e + 1][tid]);
-                rank += (de < da || (de == da && ie < ia)) ? 1 : 0;
+                const unsigned we = s_hist[e][tid];
+                const float2 pe = A.pos((int)(we >> 16));
+                const float de = pair_dist(qy, qx, pe.x, pe.y, L1);
+                rank += (de < da || (de == da && (int)(we & 0xffffu) < ia)) ? 1 : 0;
             }
             if (rank < need) {
                 if (fuse) {
-                    const float2 pj = A.pos(ja);
                     const float2 f = A.flow_ref(ja, 0, pj);
                     if (p.iwd) { const float w = 1.f / (da + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
                     else { sy += f.x; sx += f.y; }
@@ -440,7 +482,7 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
                                                    float *__restrict__ knn_state,
                                                    int *__restrict__ idx_out,
                                                    float *__restrict__ tile_dkmax, int r_init, int RH,
-                                                   int cap) {
+                                                   int cap, int stage_flow) {
     extern __shared__ unsigned char s_dyn[];
     __shared__ float s_maxf[4];
     __shared__ int s_rowbase[64 + 1];   // RW <= 48
@@ -451,12 +493,13 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     const int RW = 16 + 2 * RH;
     // dynamic LDS carve-up (all sizes multiples of 16 bytes)
     unsigned (*s_hist)[256] = reinterpret_cast<unsigned (*)[256]>(s_dyn);
-    size_t o = (size_t)(KNN_BINS / 2) * 256 * 4;
+    size_t o = (size_t)KNN_HW * 256 * 4;
     float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
-    float2 *lf0 = reinterpret_cast<float2 *>(s_dyn + o); o += (p.T == 1) ? (size_t)cap * 8 : 0;
+    const bool st_f0 = (p.T == 1) && stage_flow;
+    float2 *lf0 = st_f0 ? reinterpret_cast<float2 *>(s_dyn + o) : nullptr; o += st_f0 ? (size_t)cap * 8 : 0;
     float2 *lf1 = reinterpret_cast<float2 *>(s_dyn + o); o += p.want_next ? (size_t)cap * 8 : 0;
-    int *lidx = reinterpret_cast<int *>(s_dyn + o); o += (size_t)cap * 4;
-    int *lcs = reinterpret_cast<int *>(s_dyn + o);
+    unsigned short *lidx = reinterpret_cast<unsigned short *>(s_dyn + o); o += (size_t)cap * 2;
+    unsigned short *lcs = reinterpret_cast<unsigned short *>(s_dyn + o);
 
     QueryCtx c;
     c.cs = cell_start + (size_t)bt * (p.G + 1);
@@ -496,7 +539,7 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
                 const int xx = min(max(c.rx0 + cc, xlo), xhi + 1);
                 v += c.cs[yy * p.wq + xx] - s_rowg[rr];
             }
-            lcs[i] = v;
+            lcs[i] = (unsigned short)v;
         }
         const float2 *tref0 = c.traj_b;                                   // T == 1: the reference time
         const float2 *tnext = c.traj_b + (size_t)(p.T + t + 1) * p.n;     // next bin (if any)
@@ -508,8 +551,8 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
             const float2 pj = c.spos[g];
             const int id = c.sidx[g];
             lpos[i] = pj;
-            lidx[i] = id;
-            if (p.T == 1) { const float2 a = tref0[id]; lf0[i] = make_float2(a.x - pj.x, a.y - pj.y); }
+            lidx[i] = (unsigned short)id;
+            if (st_f0) { const float2 a = tref0[id]; lf0[i] = make_float2(a.x - pj.x, a.y - pj.y); }
             if (has_next) { const float2 a = tnext[id]; lf1[i] = make_float2(a.x - pj.x, a.y - pj.y); }
         }
     }
@@ -536,289 +579,6 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     if (tid == 0)
         tile_dkmax[((size_t)bt * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
             fmaxf(fmaxf(s_maxf[0], s_maxf[1]), fmaxf(s_maxf[2], s_maxf[3]));
-}
-
-// ------------------------------------------------------------------------------------------
-// query, point-centric form ('mean' scheme, num_tref == 1): the regular side of the problem is
-// the QUERY lattice, so the loops run over the staged points and, for each point, over the
-// query cells of the tile within reach of the point's home cell -- near-uniform trip counts
-// instead of the per-query divergence of the search above.  Per query the workgroup keeps in LDS:
-// its search radius (larger next to the image border, where the neighbourhood is clipped), a
-// 32-bin distance histogram, the flow sums of all points in bins below the bin of the K-th
-// smallest, and a short list of the keys inside that bin, from which the owning thread picks the
-// remaining neighbours exactly.  All LDS accumulation is INTEGER: ds_add_u32 for the histogram
-// and Q33.30 fixed point with ds_add_u64 for the flow sums (measured on gfx950: ds_add_f32 takes
-// ~193 cycles per wave-instruction against 6-12 for the integer forms, profiles/
-// r01_ubench_lds_atomics.txt); integer sums also make the LUT bitwise reproducible.
-// Queries the fixed budget cannot serve (too few candidates, list overflow) finish in the
-// per-thread search above.
-// grid (ceil(wq/16), ceil(hq/16), B*nb), KNN_TILE_THREADS threads, dynamic LDS
-// ------------------------------------------------------------------------------------------
-#define KNN_LCAP 8
-#define KNN_TILE_THREADS 512
-#define KNN_FIX_SHIFT 30
-
-__device__ __forceinline__ long long to_fixed(float v) {
-    // exact split: integer part + fraction, |v| < 2^31
-    const float hi = truncf(v);
-    const float lo = v - hi;
-    return ((long long)(int)hi << KNN_FIX_SHIFT) + (long long)(int)(lo * (float)(1 << KNN_FIX_SHIFT));
-}
-__device__ __forceinline__ float from_fixed(long long a) {
-    return (float)((double)a * (1.0 / (double)(1 << KNN_FIX_SHIFT)));
-}
-
-__global__ __launch_bounds__(KNN_TILE_THREADS) void k_knn_query_tile(
-    const KnnParams p, const float *__restrict__ traj, const int *__restrict__ cell_start,
-    const float2 *__restrict__ spos, const int *__restrict__ sidx, float *__restrict__ flow_lut,
-    float *__restrict__ flow_next, float *__restrict__ knn_state, int *__restrict__ idx_out,
-    float *__restrict__ tile_dkmax, int r_base, int RH_MAX, int cap, int *__restrict__ dbg) {
-    constexpr int NT = KNN_TILE_THREADS;
-    extern __shared__ unsigned char s_dyn[];
-    __shared__ float s_maxf[NT / 64];
-    __shared__ int s_maxi[NT / 64];
-    __shared__ int s_rowbase[80 + 1];
-    __shared__ int s_rowg[80];
-    __shared__ int s_flag;
-    const int tid = threadIdx.x;
-    const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
-    const int ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
-    const int ty1 = min(ty0 + 15, p.hq - 1), tx1 = min(tx0 + 15, p.wq - 1);
-    // LDS carve-up
-    unsigned (*s_hist)[256] = reinterpret_cast<unsigned (*)[256]>(s_dyn);
-    // the key list reuses the histogram storage (the histogram is dead once bstar is known)
-    float (*l_ld)[256] = reinterpret_cast<float (*)[256]>(s_dyn);
-    int (*l_li)[256] = reinterpret_cast<int (*)[256]>(s_dyn + KNN_LCAP * 256 * 4);
-    size_t o = (size_t)(KNN_BINS / 2) * 256 * 4;
-    unsigned long long (*l_acc)[256] = reinterpret_cast<unsigned long long (*)[256]>(s_dyn + o); o += 4 * 256 * 8;
-    float4 *l_par = reinterpret_cast<float4 *>(s_dyn + o); o += 256 * 16;   // {upper, scale, r_q, bstar}
-    int *l_cnt = reinterpret_cast<int *>(s_dyn + o); o += 256 * 4;
-    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
-    float2 *lf0 = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
-    float2 *lf1 = reinterpret_cast<float2 *>(s_dyn + o); o += p.want_next ? (size_t)cap * 8 : 0;
-    int *lidx = reinterpret_cast<int *>(s_dyn + o);
-
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
-    const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
-    const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
-    const bool has_next = p.want_next && (t < p.nb - 1);
-    const bool qthread = tid < 256;                           // threads that own a query
-    const int cy = ty0 + ((tid & 255) >> 4), cx = tx0 + (tid & 15);
-    const bool active = qthread && cy < p.hq && cx < p.wq;
-
-    // ---- per-query search radius: r_base inside the image, larger where the square is clipped ----
-    int rq = 0;
-    float q_upper = 0.f, q_scale = 0.f;
-    if (active) {
-        const int want = (2 * r_base + 1) * (2 * r_base + 1);
-        rq = r_base;
-        for (;;) {
-            const int hh = min(cy + rq, p.hq - 1) - max(cy - rq, 0) + 1;
-            const int ww = min(cx + rq, p.wq - 1) - max(cx - rq, 0) + 1;
-            if (hh * ww >= want || rq >= RH_MAX || (hh == p.hq && ww == p.wq)) break;
-            ++rq;
-        }
-        const float lb = ((float)rq + 0.5f) * (float)p.sp - KNN_SLACK;
-        q_upper = p.l1 ? lb : lb * lb;
-        q_scale = (float)KNN_BINS / q_upper;
-    }
-    if (qthread) l_par[tid] = make_float4(q_upper, q_scale, active ? (float)rq : -1.f, -1.f);
-    int rmax = rq;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) rmax = max(rmax, __shfl_down(rmax, o2, 64));
-    if ((tid & 63) == 0) s_maxi[tid >> 6] = rmax;
-    __syncthreads();
-    rmax = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) rmax = max(rmax, s_maxi[w]);
-
-    // ---- stage the points of (tile +- rmax rings) ---------------------------------------------
-    const int RW = 16 + 2 * rmax;
-    const int ry0 = ty0 - rmax, rx0 = tx0 - rmax;
-    const int xlo = max(rx0, 0), xhi = min(rx0 + RW - 1, p.wq - 1);
-    if (tid < RW) {
-        const int yy = ry0 + tid;
-        int gs = 0, ge = 0;
-        if (yy >= 0 && yy < p.hq) { gs = cs[yy * p.wq + xlo]; ge = cs[yy * p.wq + xhi + 1]; }
-        s_rowg[tid] = gs;
-        s_rowbase[tid + 1] = ge - gs;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        s_rowbase[0] = 0;
-        for (int rr = 0; rr < RW; ++rr) { const int c = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + c; run += c; }
-        s_flag = (run <= cap) ? 1 : 0;
-    }
-    __syncthreads();
-    const int total = s_rowbase[RW];
-    const bool staged = s_flag != 0;
-    bool fallback = active && !staged;
-    float dK = 0.f;
-
-    if (staged) {
-        for (int i = tid; i < total; i += NT) {
-            int lo = 0, hi = RW;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= i) lo = mid; else hi = mid; }
-            const int g = s_rowg[lo] + (i - s_rowbase[lo]);
-            const float2 pj = sp_[g];
-            const int id = si_[g];
-            lpos[i] = pj;
-            lidx[i] = id;
-            const float2 a = traj_b[id];                                   // t_ref row (T == 1)
-            lf0[i] = make_float2(a.x - pj.x, a.y - pj.y);
-            if (has_next) { const float2 a2 = traj_b[(size_t)(p.T + t + 1) * p.n + id]; lf1[i] = make_float2(a2.x - pj.x, a2.y - pj.y); }
-        }
-        if (qthread) {
-#pragma unroll
-            for (int h = 0; h < KNN_BINS / 2; ++h) s_hist[h][tid] = 0u;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) l_acc[a][tid] = 0ull;
-            l_cnt[tid] = 0;
-        }
-        __syncthreads();
-        // ---- pass 1: distance histograms ---------------------------------------------------
-        for (int i = tid; i < total; i += NT) {
-            const float2 pj = lpos[i];
-            const int hy = cell_of(pj.x, p.sp, p.hq), hx = cell_of(pj.y, p.sp, p.wq);
-            const int ya = max(hy - rmax, ty0), yb = min(hy + rmax, ty1);
-            const int xa = max(hx - rmax, tx0), xb = min(hx + rmax, tx1);
-            for (int yy = ya; yy <= yb; ++yy) {
-                const float dy = ((float)(yy * p.sp) + p.off) - pj.x;
-                const float dy2 = p.l1 ? fabsf(dy) : dy * dy;
-                const int ady = abs(yy - hy);
-                for (int xx = xa; xx <= xb; ++xx) {
-                    const int ql = (yy - ty0) * 16 + (xx - tx0);
-                    const float4 par = l_par[ql];
-                    const float dx = ((float)(xx * p.sp) + p.off) - pj.y;
-                    const float d = dy2 + (p.l1 ? fabsf(dx) : dx * dx);
-                    const int bin = min((int)(d * par.y), KNN_BINS - 1);
-                    if ((float)max(ady, abs(xx - hx)) <= par.z && d < par.x)
-                        atomicAdd(&s_hist[bin >> 1][ql], (bin & 1) ? 0x10000u : 1u);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- bin of the K-th smallest, per query --------------------------------------------
-        int bstar = -1, need = 0;
-        if (active) {
-            int cum = 0;
-            bool found = false;
-#pragma unroll
-            for (int h = 0; h < KNN_BINS / 2; ++h) {
-                const unsigned wv = s_hist[h][tid];
-                const int c0 = (int)(wv & 0xffffu), c1 = (int)(wv >> 16);
-                if (!found && cum + c0 >= p.K) { bstar = 2 * h; need = p.K - cum; found = true; }
-                cum += c0;
-                if (!found && cum + c1 >= p.K) { bstar = 2 * h + 1; need = p.K - cum; found = true; }
-                cum += c1;
-            }
-            if (!found) { fallback = true; atomicAdd(&dbg[3], 1); }   // fewer than K candidates below the ring bound
-            l_par[tid].w = (float)bstar;
-        }
-        __syncthreads();                          // histograms are dead from here on (list aliases them)
-        // ---- pass 2: sum the flows below that bin, list the keys inside it ------------------
-        for (int i = tid; i < total; i += NT) {
-            const float2 pj = lpos[i];
-            const float2 f = lf0[i];
-            const long long fy_fix = to_fixed(f.x), fx_fix = to_fixed(f.y);
-            long long ny_fix = 0, nx_fix = 0;
-            if (has_next) { const float2 fn = lf1[i]; ny_fix = to_fixed(fn.x); nx_fix = to_fixed(fn.y); }
-            const int hy = cell_of(pj.x, p.sp, p.hq), hx = cell_of(pj.y, p.sp, p.wq);
-            const int ya = max(hy - rmax, ty0), yb = min(hy + rmax, ty1);
-            const int xa = max(hx - rmax, tx0), xb = min(hx + rmax, tx1);
-            for (int yy = ya; yy <= yb; ++yy) {
-                const float dy = ((float)(yy * p.sp) + p.off) - pj.x;
-                const float dy2 = p.l1 ? fabsf(dy) : dy * dy;
-                const int ady = abs(yy - hy);
-                for (int xx = xa; xx <= xb; ++xx) {
-                    const int ql = (yy - ty0) * 16 + (xx - tx0);
-                    const float4 par = l_par[ql];
-                    const float dx = ((float)(xx * p.sp) + p.off) - pj.y;
-                    const float d = dy2 + (p.l1 ? fabsf(dx) : dx * dx);
-                    if (!((float)max(ady, abs(xx - hx)) <= par.z && d < par.x)) continue;
-                    const float fb = (float)min((int)(d * par.y), KNN_BINS - 1);
-                    if (fb < par.w) {
-                        atomicAdd(&l_acc[0][ql], (unsigned long long)fy_fix);
-                        atomicAdd(&l_acc[1][ql], (unsigned long long)fx_fix);
-                        if (has_next) {
-                            atomicAdd(&l_acc[2][ql], (unsigned long long)ny_fix);
-                            atomicAdd(&l_acc[3][ql], (unsigned long long)nx_fix);
-                        }
-                    } else if (fb == par.w) {
-                        const int slot = atomicAdd(&l_cnt[ql], 1);
-                        if (slot < KNN_LCAP) { l_ld[slot][ql] = d; l_li[slot][ql] = i; }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- finish per query: the `need` smallest (distance, index) keys of the list ----------
-        if (active && !fallback) {
-            const int m = l_cnt[tid];
-            if (m > KNN_LCAP) {
-                fallback = true;
-                atomicAdd(&dbg[2], 1);
-            } else {
-                long long sy = (long long)l_acc[0][tid], sx = (long long)l_acc[1][tid];
-                long long ny = (long long)l_acc[2][tid], nx = (long long)l_acc[3][tid];
-                float kd = 0.f; int ki = -1;
-                for (int a = 0; a < m; ++a) {
-                    const float da = l_ld[a][tid]; const int la = l_li[a][tid]; const int ia = lidx[la];
-                    int rank = 0;
-                    for (int c = 0; c < m; ++c) {
-                        const float dc = l_ld[c][tid]; const int ic = lidx[l_li[c][tid]];
-                        rank += (dc < da || (dc == da && ic < ia)) ? 1 : 0;
-                    }
-                    if (rank < need) {
-                        const float2 f = lf0[la];
-                        sy += to_fixed(f.x); sx += to_fixed(f.y);
-                        if (has_next) { const float2 fn = lf1[la]; ny += to_fixed(fn.x); nx += to_fixed(fn.y); }
-                        if (rank == need - 1) { kd = da; ki = ia; }
-                    }
-                }
-                const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
-                const size_t BQ = (size_t)p.B * p.nb * p.G;
-                float2 ov;
-                ov.x = from_fixed(sy) / (float)p.K;
-                ov.y = from_fixed(sx) / (float)p.K;
-                reinterpret_cast<float2 *>(flow_lut)[q] = ov;
-                if (has_next) {
-                    float2 on; on.x = from_fixed(ny) / (float)p.K; on.y = from_fixed(nx) / (float)p.K;
-                    reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
-                }
-                knn_state[q] = kd;
-                reinterpret_cast<int *>(knn_state)[BQ + q] = ki;
-                knn_state[2 * BQ + q] = 0.f;
-                dK = kd;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- queries the tile pass could not serve, and the optional sorted index output ------------
-    if (!staged && tid == 0) atomicAdd(&dbg[1], 1);
-    if (active && (fallback || idx_out != nullptr)) {
-        if (fallback) atomicAdd(&dbg[0], 1);
-        QueryCtx c;
-        c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
-        c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
-        c.ry0 = c.rx0 = c.RW = c.RH = 0;
-        if (p.l1) knn_one_query<false, true>(p, c, b, t, cy, cx, r_base, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
-        else knn_one_query<false, false>(p, c, b, t, cy, cx, r_base, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
-    }
-    // largest K-th distance of this tile: bounds the backward's search windows
-    float m = dK;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_down(m, o2, 64));
-    if ((tid & 63) == 0) s_maxf[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-        float mm = 0.f;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) mm = fmaxf(mm, s_maxf[w]);
-        tile_dkmax[((size_t)bt * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mm;
-    }
 }
 
 // Gather over the query window of one trajectory point (num_tref == 1, 'mean'): one 16-byte LDS read
@@ -1084,7 +844,6 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bucket<false>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_query_tile, __func__))) return rc;
         attr_set = true;
     }
     if (s->n <= KNN_BUCKET_NPT * 1024)
@@ -1098,44 +857,42 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     if (r_init < 1) r_init = 1;
     { const char *e = getenv("MPC_KNN_R0"); if (e) r_init += atoi(e); }      // tuning: initial search radius offset
     const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
-    // tuning switch (A/B measurements): MPC_KNN_MODE = thread (default) | tile | global.
-    // Measured at B=14, 480x640, K=32 (round 1): thread 934 us, global 947 us, tile 2053 us.
-    static int mode = -1;
+    // tuning switch (A/B measurements): MPC_KNN_MODE = thread (default) | global (nothing staged in LDS)
+    static int mode = -1, want_blocks = 0, want_stage = -1;
     if (mode < 0) {
         const char *e = getenv("MPC_KNN_MODE");
-        mode = (e && e[0] == 't' && e[1] == 'i') ? 0 : ((e && e[0] == 'g') ? 2 : 1);
+        mode = (e && e[0] == 'g') ? 2 : 1;
+        if ((e = getenv("MPC_KNN_BLOCKS"))) want_blocks = atoi(e);
+        if ((e = getenv("MPC_KNN_STAGE_FLOW"))) want_stage = atoi(e);
     }
-    if (s->T == 1 && !p.iwd && mode == 0) {
-        (void)hipMemsetAsync((char *)ws + L.off_counts, 0, 32, st);   // statistics of the tile kernel (tuning)
-        // one ring of slack over the tight radius: a jittered lattice then almost never fails the
-        // "K candidates below the ring bound" test; border queries enlarge their own radius
-        const int r_base = r_init + 1;
-        int RH = 2 * r_base;                      // a corner query sees a quarter of its square
-        if (RH > 32) RH = 32;
-        const size_t per_pt = 8 + 8 + 4 + (p.want_next ? 8 : 0);
-        const size_t fixed = (size_t)(KNN_BINS / 2) * 256 * 4 + 4 * 256 * 8 + 256 * 16 + 256 * 4 + 64;
-        const size_t budget = 52 * 1024;
-        int cap = (int)((budget - fixed) / per_pt / 64 * 64);
-        if (cap < 64) cap = 64;
-        const size_t lds = fixed + per_pt * cap;
-        hipLaunchKernelGGL(k_knn_query_tile, grid, dim3(KNN_TILE_THREADS), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                           flow_next, knn_state, idx_out, tile_dkmax, r_base, RH, cap, (int *)((char *)ws + L.off_counts));
-    } else {
-        int RH = r_init + 1;
-        if (RH > 16) RH = 16;
-        const int RW = 16 + 2 * RH;
-        int cap = (int)(1.5 * dens * RW * RW) + 128;      // LDS per workgroup decides occupancy (4 per CU; a tighter cap measured no gain)
-        cap = (cap + 63) / 64 * 64;
-        const size_t per_pt = 8 + 4 + (s->T == 1 ? 8 : 0) + (p.want_next ? 8 : 0);
-        const size_t fixed = (size_t)(KNN_BINS / 2) * 256 * 4 + (size_t)RW * (RW + 1) * 4 + 64;
-        const size_t budget = 64 * 1024;
-        if (fixed + per_pt * cap > budget) cap = (int)((budget - fixed) / per_pt / 64 * 64);
-        if (cap < 64) cap = 64;
-        if (mode == 2) cap = 0;                    // nothing staged: every query searches the global arrays
-        const size_t lds = fixed + per_pt * cap;
-        hipLaunchKernelGGL(k_knn_query, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap);
+    int RH = r_init + 1;
+    if (RH > 16) RH = 16;
+    const int RW = 16 + 2 * RH;
+    // LDS per workgroup decides how many of them a CU holds, and the kernel is latency bound: measured at C3
+    // 2 / 3 / 4 workgroups per CU = 1180 / 850 / 685 us.  The staging capacity is what is left of the
+    // per-workgroup share after the histogram columns, provided it still holds 1.3x the mean region.
+    const int stage_flow = (want_stage >= 0) ? want_stage : 1;
+    const size_t per_pt = 8 + 2 + ((s->T == 1 && stage_flow) ? 8 : 0) + (p.want_next ? 8 : 0);
+    const size_t fixed = (size_t)KNN_HW * 256 * 4 + (size_t)RW * (RW + 1) * 2 + 64;
+    const double mean_pts = dens * RW * RW;
+    int cap = 0;
+    for (int blocks = want_blocks > 0 ? want_blocks : 8; blocks >= 1; --blocks) {
+        const size_t share = (size_t)160 * 1024 / blocks;
+        const size_t budget = (share > 64 * 1024 ? 64 * 1024 : share) - 1024;      // static LDS + allocation granule
+        if (budget <= fixed) continue;
+        int c = (int)((budget - fixed) / per_pt / 64 * 64);
+        if (c > 65472) c = 65472;                                                  // 16-bit staged offsets
+        if (c >= (int)(1.3 * mean_pts) + 64 || blocks == 1 || want_blocks > 0) {
+            const int full = ((int)(1.5 * mean_pts) + 128 + 63) / 64 * 64;
+            cap = (blocks == 1 && c > full) ? full : c;
+            break;
+        }
     }
+    if (cap < 64) cap = 64;
+    if (mode == 2) cap = 0;                    // nothing staged: every query searches the global arrays
+    const size_t lds = fixed + per_pt * cap;
+    hipLaunchKernelGGL(k_knn_query, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+                       flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow);
     MPC_CHECK_LAUNCH();
     return 0;
 }

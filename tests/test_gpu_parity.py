@@ -293,10 +293,11 @@ def test_single_sample_single_event_and_far_out_of_bounds_flow():
     assert float(raw2.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('mode', ['tile', 'global'])
-def test_alternative_knn_kernels_agree_with_goldens(mode):
-    """The point-centric tile kernel and the unstaged per-thread search (MPC_KNN_MODE, read once per
-    process) must produce the same LUT as the default: run a golden stage check in a subprocess."""
+@pytest.mark.parametrize('env', [{'MPC_KNN_MODE': 'global'}, {'MPC_KNN_STAGE_FLOW': '0'}, {'MPC_KNN_BLOCKS': '8'}])
+def test_alternative_knn_kernels_agree_with_goldens(env):
+    """The unstaged per-thread search, the variant that gathers the flows from global memory and a tiny LDS
+    staging capacity (tiles that overflow it finish on the global arrays) -- tuning switches read once per
+    process -- must produce the same LUT as the default: run a golden stage check in a subprocess."""
     import os
     import subprocess
     import sys
@@ -312,7 +313,7 @@ def test_alternative_knn_kernels_agree_with_goldens(mode):
         "    lut.backward(torch.from_numpy(g['grad_flow_lut']).cuda())\n"
         "    assert torch.isfinite(t.grad).all()\n"
         "print('ok')\n")
-    env = dict(os.environ, MPC_KNN_MODE=mode)
+    env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
