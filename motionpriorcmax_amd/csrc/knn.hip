@@ -190,9 +190,9 @@ struct Acc {
 };
 
 // Returns false if the search needs more rings than the LDS halo holds (LDS variant only).
-template <bool LDS, bool L1>
+template <bool LDS, bool L1, int NT>
 __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int t, int cy, int cx,
-                              int r_init, unsigned (*s_hist)[256], float *__restrict__ flow_lut,
+                              int r_init, unsigned (*s_hist)[NT], float *__restrict__ flow_lut,
                               float *__restrict__ flow_next, float *__restrict__ knn_state,
                               int *__restrict__ idx_out, float &dK_out) {
     const Acc<LDS> A{p, c, t};
@@ -249,7 +249,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                     // instruction issue, and exec-mask branches cost more than the spare LDS atomic)
                     const float d = pair_dist(qy, qx, q[u].x, q[u].y, L1);
                     const int in = (j + u < je) & (d < upper);
-                    const int bin = min((int)(fminf(d, upper) * scale), KNN_BINS - 1);
+                    const int bin = min((int)(d * scale), KNN_BINS - 1);     // d < upper <= FLT_MAX wherever `in` holds
                     atomicAdd(&s_hist[bin >> 2][tid], in ? (1u << ((bin << 3) & 31)) : 0u);   // private column
                     cnt += in;
                 }
@@ -292,6 +292,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     const bool fuse = (p.T == 1);
     const bool do_next0 = p.want_next && (t < p.nb - 1);
     float sy = 0.f, sx = 0.f, sw = 0.f, ny = 0.f, nx = 0.f;
+    const float fb = (float)bstar, fb1 = (bstar == KNN_BINS - 1) ? INFINITY : (float)(bstar + 1);
     int m = 0;
     for (int yy = y0; yy <= y1; ++yy) {
         int js, je;
@@ -306,15 +307,15 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                 const float2 pj = qq[u];
                 const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                 if (j >= je || !(d < upper)) continue;      // (a predicated form of this scan measured slower: 751 vs 673 us)
-                const int bin = min((int)(d * scale), KNN_BINS - 1);
-                if (bin < bstar) {
+                const float ds = d * scale;                 // bin = min(floor(ds), KNN_BINS - 1)
+                if (ds < fb) {
                     if (fuse) {
                         const float2 f = A.flow_ref(j, 0, pj);
                         if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
                         else { sy += f.x; sx += f.y; }
                         if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
                     }
-                } else if (bin == bstar) {
+                } else if (ds < fb1) {
                     if (m < KNN_LIST) s_hist[m][tid] = ((unsigned)j << 16) | (unsigned)A.idx(j);
                     ++m;
                 }
@@ -473,7 +474,8 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const float *__restrict__ traj,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float *__restrict__ traj,
                                                    const int *__restrict__ cell_start,
                                                    const float2 *__restrict__ spos,
                                                    const int *__restrict__ sidx,
@@ -484,16 +486,17 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
                                                    float *__restrict__ tile_dkmax, int r_init, int RH,
                                                    int cap, int stage_flow) {
     extern __shared__ unsigned char s_dyn[];
-    __shared__ float s_maxf[4];
+    __shared__ float s_maxf[NT / 64];
     __shared__ int s_rowbase[64 + 1];   // RW <= 48
     __shared__ int s_rowg[64];
     __shared__ int s_use_lds;
     const int tid = threadIdx.x;
     const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
-    const int RW = 16 + 2 * RH;
+    constexpr int TY = NT / 16;                 // query rows per workgroup (16 columns)
+    const int RW = 16 + 2 * RH, RWY = TY + 2 * RH;
     // dynamic LDS carve-up (all sizes multiples of 16 bytes)
-    unsigned (*s_hist)[256] = reinterpret_cast<unsigned (*)[256]>(s_dyn);
-    size_t o = (size_t)KNN_HW * 256 * 4;
+    unsigned (*s_hist)[NT] = reinterpret_cast<unsigned (*)[NT]>(s_dyn);
+    size_t o = (size_t)KNN_HW * NT * 4;
     float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)cap * 8;
     const bool st_f0 = (p.T == 1) && stage_flow;
     float2 *lf0 = st_f0 ? reinterpret_cast<float2 *>(s_dyn + o) : nullptr; o += st_f0 ? (size_t)cap * 8 : 0;
@@ -508,12 +511,12 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     c.lcs = lcs; c.lpos = lpos; c.lidx = lidx; c.lf0 = lf0; c.lf1 = lf1;
     c.RW = RW; c.RH = RH;
-    c.ry0 = blockIdx.y * 16 - RH;
+    c.ry0 = blockIdx.y * TY - RH;
     c.rx0 = blockIdx.x * 16 - RH;
 
     // ---- stage the region (tile + RH rings) ---------------------------------------------------
     const int xlo = max(c.rx0, 0), xhi = min(c.rx0 + RW - 1, p.wq - 1);
-    if (tid < RW) {
+    if (tid < RWY) {
         const int yy = c.ry0 + tid;
         int gs = 0, ge = 0;
         if (yy >= 0 && yy < p.hq) { gs = c.cs[yy * p.wq + xlo]; ge = c.cs[yy * p.wq + xhi + 1]; }
@@ -524,14 +527,14 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     if (tid == 0) {
         int run = 0;
         s_rowbase[0] = 0;
-        for (int rr = 0; rr < RW; ++rr) { const int cnt = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + cnt; run += cnt; }
+        for (int rr = 0; rr < RWY; ++rr) { const int cnt = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + cnt; run += cnt; }
         s_use_lds = (run <= cap) ? 1 : 0;
     }
     __syncthreads();
     const bool use_lds = s_use_lds != 0;
     if (use_lds) {
-        const int total = s_rowbase[RW];
-        for (int i = tid; i < RW * (RW + 1); i += 256) {
+        const int total = s_rowbase[RWY];
+        for (int i = tid; i < RWY * (RW + 1); i += NT) {
             const int rr = i / (RW + 1), cc = i - rr * (RW + 1);
             const int yy = c.ry0 + rr;
             int v = s_rowbase[rr];
@@ -544,8 +547,8 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
         const float2 *tref0 = c.traj_b;                                   // T == 1: the reference time
         const float2 *tnext = c.traj_b + (size_t)(p.T + t + 1) * p.n;     // next bin (if any)
         const bool has_next = p.want_next && (t < p.nb - 1);
-        for (int i = tid; i < total; i += 256) {
-            int lo = 0, hi = RW;             // row rr with s_rowbase[rr] <= i < s_rowbase[rr+1]
+        for (int i = tid; i < total; i += NT) {
+            int lo = 0, hi = RWY;             // row rr with s_rowbase[rr] <= i < s_rowbase[rr+1]
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= i) lo = mid; else hi = mid; }
             const int g = s_rowg[lo] + (i - s_rowbase[lo]);
             const float2 pj = c.spos[g];
@@ -558,16 +561,16 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     }
     __syncthreads();
 
-    const int cy = blockIdx.y * 16 + (tid >> 4), cx = blockIdx.x * 16 + (tid & 15);
+    const int cy = blockIdx.y * TY + (tid >> 4), cx = blockIdx.x * 16 + (tid & 15);
     float dK = 0.f;
     if (cy < p.hq && cx < p.wq) {
         bool done = false;
         if (p.l1) {
-            if (use_lds) done = knn_one_query<true, true>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
-            if (!done) knn_one_query<false, true>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+            if (use_lds) done = knn_one_query<true, true, NT>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+            if (!done) knn_one_query<false, true, NT>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
         } else {
-            if (use_lds) done = knn_one_query<true, false>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
-            if (!done) knn_one_query<false, false>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+            if (use_lds) done = knn_one_query<true, false, NT>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
+            if (!done) knn_one_query<false, false, NT>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
         }
     }
     // largest K-th distance of this tile: bounds the backward's search windows
@@ -576,9 +579,16 @@ __global__ __launch_bounds__(256) void k_knn_query(const KnnParams p, const floa
     for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_down(m, o2, 64));
     if ((tid & 63) == 0) s_maxf[tid >> 6] = m;
     __syncthreads();
-    if (tid == 0)
-        tile_dkmax[((size_t)bt * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
-            fmaxf(fmaxf(s_maxf[0], s_maxf[1]), fmaxf(s_maxf[2], s_maxf[3]));
+    // one maximum per 16x16 query tile (= 4 wavefronts), the granularity the backward works at
+    const int gy16 = (p.hq + 15) >> 4;
+    if ((tid & 255) == 0) {
+        const int ty16 = blockIdx.y * (TY / 16) + (tid >> 8);
+        if (ty16 < gy16) {
+            const int w0 = tid >> 6;
+            tile_dkmax[((size_t)bt * gy16 + ty16) * gridDim.x + blockIdx.x] =
+                fmaxf(fmaxf(s_maxf[w0], s_maxf[w0 + 1]), fmaxf(s_maxf[w0 + 2], s_maxf[w0 + 3]));
+        }
+    }
 }
 
 // Gather over the query window of one trajectory point (num_tref == 1, 'mean'): one 16-byte LDS read
@@ -843,7 +853,8 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     if (!attr_set) {
         if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bucket<false>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_query, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_query<256>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
         attr_set = true;
     }
     if (s->n <= KNN_BUCKET_NPT * 1024)
@@ -856,43 +867,58 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
     if (r_init < 1) r_init = 1;
     { const char *e = getenv("MPC_KNN_R0"); if (e) r_init += atoi(e); }      // tuning: initial search radius offset
-    const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
     // tuning switch (A/B measurements): MPC_KNN_MODE = thread (default) | global (nothing staged in LDS)
-    static int mode = -1, want_blocks = 0, want_stage = -1;
+    static int mode = -1, want_blocks = 0, want_stage = -1, want_nt = 0;
     if (mode < 0) {
         const char *e = getenv("MPC_KNN_MODE");
         mode = (e && e[0] == 'g') ? 2 : 1;
         if ((e = getenv("MPC_KNN_BLOCKS"))) want_blocks = atoi(e);
         if ((e = getenv("MPC_KNN_STAGE_FLOW"))) want_stage = atoi(e);
+        if ((e = getenv("MPC_KNN_NT"))) want_nt = atoi(e);
     }
     int RH = r_init + 1;
     if (RH > 16) RH = 16;
     const int RW = 16 + 2 * RH;
-    // LDS per workgroup decides how many of them a CU holds, and the kernel is latency bound: measured at C3
-    // 2 / 3 / 4 workgroups per CU = 1180 / 850 / 685 us.  The staging capacity is what is left of the
-    // per-workgroup share after the histogram columns, provided it still holds 1.3x the mean region.
+    // LDS per workgroup decides how many wavefronts a CU holds, and the kernel is latency bound: measured at
+    // C3 with 256-thread workgroups, 2 / 3 / 4 / 6 per CU = 1180 / 850 / 685 / 550 us.  The staging capacity is
+    // what is left of the per-workgroup share after the histogram columns, provided it still holds 1.25x the
+    // mean region; 16x32-query workgroups (512 threads) carry less halo per query and are used when they
+    // reach more wavefronts per CU.
     const int stage_flow = (want_stage >= 0) ? want_stage : 1;
     const size_t per_pt = 8 + 2 + ((s->T == 1 && stage_flow) ? 8 : 0) + (p.want_next ? 8 : 0);
-    const size_t fixed = (size_t)KNN_HW * 256 * 4 + (size_t)RW * (RW + 1) * 2 + 64;
-    const double mean_pts = dens * RW * RW;
-    int cap = 0;
-    for (int blocks = want_blocks > 0 ? want_blocks : 8; blocks >= 1; --blocks) {
-        const size_t share = (size_t)160 * 1024 / blocks;
-        const size_t budget = (share > 64 * 1024 ? 64 * 1024 : share) - 1024;      // static LDS + allocation granule
-        if (budget <= fixed) continue;
-        int c = (int)((budget - fixed) / per_pt / 64 * 64);
-        if (c > 65472) c = 65472;                                                  // 16-bit staged offsets
-        if (c >= (int)(1.3 * mean_pts) + 64 || blocks == 1 || want_blocks > 0) {
-            const int full = ((int)(1.5 * mean_pts) + 128 + 63) / 64 * 64;
-            cap = (blocks == 1 && c > full) ? full : c;
-            break;
+    int best_nt = 256, best_cap = 64, best_waves = 0;
+    for (int nt = 256; nt <= 512; nt *= 2) {
+        if (want_nt > 0 && nt != want_nt) continue;
+        if (nt == 512 && s->hq <= 16 && want_nt == 0) continue;
+        const int RWY = nt / 16 + 2 * RH;
+        const size_t fixed = (size_t)KNN_HW * nt * 4 + (size_t)RWY * (RW + 1) * 2 + 64;
+        const double mean_pts = dens * RW * RWY;
+        for (int blocks = want_blocks > 0 ? want_blocks : 2048 / nt; blocks >= 1; --blocks) {
+            const size_t share = (size_t)160 * 1024 / blocks;
+            const size_t budget = (share > 64 * 1024 ? 64 * 1024 : share) - 1024;  // static LDS + allocation granule
+            if (budget <= fixed) continue;
+            int c = (int)((budget - fixed) / per_pt / 64 * 64);
+            if (c > 65472) c = 65472;                                              // 16-bit staged offsets
+            if (c >= (int)(1.25 * mean_pts) + 64 || blocks == 1 || want_blocks > 0) {
+                const int full = ((int)(1.5 * mean_pts) + 128 + 63) / 64 * 64;
+                if (blocks == 1 && c > full) c = full;
+                if (c < 64) c = 64;
+                if (blocks * nt / 64 > best_waves) { best_waves = blocks * nt / 64; best_nt = nt; best_cap = c; }
+                break;
+            }
         }
     }
-    if (cap < 64) cap = 64;
+    int cap = best_cap;
     if (mode == 2) cap = 0;                    // nothing staged: every query searches the global arrays
-    const size_t lds = fixed + per_pt * cap;
-    hipLaunchKernelGGL(k_knn_query, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                       flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow);
+    const int RWYb = best_nt / 16 + 2 * RH;
+    const size_t lds = (size_t)KNN_HW * best_nt * 4 + (size_t)RWYb * (RW + 1) * 2 + 64 + per_pt * cap;
+    const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, best_nt / 16), s->B * s->nb);
+    if (best_nt == 512)
+        hipLaunchKernelGGL(k_knn_query<512>, grid, dim3(512), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow);
+    else
+        hipLaunchKernelGGL(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow);
     MPC_CHECK_LAUNCH();
     return 0;
 }
