@@ -42,6 +42,7 @@ struct mpc_ws_layout {
     int64_t off_sidx;        // int32  [B*nb][n]
     int64_t off_knn_tmp_g;   // float2 [B*nb][n][T]  backward partials
     int64_t off_knn_tmp_a;   // float2 [B*nb][n]
+    int64_t off_knn_reach;   // float  [B*nb][ceil(hq/16)][ceil(wq/16)]  backward search reach per 16x16 tile
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, spill counters, marker
     int64_t off_frec;        // float4 [nfb][fcap]

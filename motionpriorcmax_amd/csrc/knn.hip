@@ -236,13 +236,21 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
 #pragma unroll
         for (int h = 0; h < KNN_HW; ++h) s_hist[h][tid] = 0u;
         cnt = 0;
+        // software pipeline: the candidate positions of the next step and the cell range of the next row are
+        // requested before the current ones are consumed (the wavefront otherwise parks on every LDS round trip)
+        int njs, nje;
+        A.range(y0, x0, x1, njs, nje);
         for (int yy = y0; yy <= y1; ++yy) {
-            int js, je;
-            A.range(yy, x0, x1, js, je);
-            for (int j = js; j < je; j += KNN_BATCH) {
-                float2 q[KNN_BATCH];
+            const int js = njs, je = nje;
+            A.range(min(yy + 1, y1), x0, x1, njs, nje);
+            if (js >= je) continue;
+            float2 q[KNN_BATCH];
 #pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(min(j + u, je - 1));     // loads first
+            for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(min(js + u, je - 1));
+            for (int j = js; j < je; j += KNN_BATCH) {
+                float2 nq[KNN_BATCH];
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) nq[u] = A.pos(min(j + KNN_BATCH + u, je - 1));
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
                     // predicated, not branched: an out-of-range candidate adds 0 (the kernel is bound by
@@ -253,6 +261,8 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                     atomicAdd(&s_hist[bin >> 2][tid], in ? (1u << ((bin << 3) & 31)) : 0u);   // private column
                     cnt += in;
                 }
+#pragma unroll
+                for (int u = 0; u < KNN_BATCH; ++u) q[u] = nq[u];
             }
         }
         if (cnt >= p.K || whole) break;
@@ -294,17 +304,23 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     float sy = 0.f, sx = 0.f, sw = 0.f, ny = 0.f, nx = 0.f;
     const float fb = (float)bstar, fb1 = (bstar == KNN_BINS - 1) ? INFINITY : (float)(bstar + 1);
     int m = 0;
+    int njs, nje;
+    A.range(y0, x0, x1, njs, nje);
     for (int yy = y0; yy <= y1; ++yy) {
-        int js, je;
-        A.range(yy, x0, x1, js, je);
-        for (int j0 = js; j0 < je; j0 += KNN_BATCH) {
-            float2 qq[KNN_BATCH];
+        const int js = njs, je = nje;
+        A.range(min(yy + 1, y1), x0, x1, njs, nje);
+        if (js >= je) continue;
+        float2 qq[KNN_BATCH];
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) qq[u] = A.pos(min(j0 + u, je - 1));
+        for (int u = 0; u < KNN_BATCH; ++u) qq[u] = A.pos(min(js + u, je - 1));
+        for (int j0 = js; j0 < je; j0 += KNN_BATCH) {
+            float2 cur[KNN_BATCH];
+#pragma unroll
+            for (int u = 0; u < KNN_BATCH; ++u) { cur[u] = qq[u]; qq[u] = A.pos(min(j0 + KNN_BATCH + u, je - 1)); }
 #pragma unroll
             for (int u = 0; u < KNN_BATCH; ++u) {
                 const int j = j0 + u;
-                const float2 pj = qq[u];
+                const float2 pj = cur[u];
                 const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                 if (j >= je || !(d < upper)) continue;      // (a predicated form of this scan measured slower: 751 vs 673 us)
                 const float ds = d * scale;                 // bin = min(floor(ds), KNN_BINS - 1)
@@ -484,14 +500,21 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
                                                    float *__restrict__ knn_state,
                                                    int *__restrict__ idx_out,
                                                    float *__restrict__ tile_dkmax, int r_init, int RH,
-                                                   int cap, int stage_flow) {
+                                                   int cap, int stage_flow, int gx, int gy) {
     extern __shared__ unsigned char s_dyn[];
     __shared__ float s_maxf[NT / 64];
     __shared__ int s_rowbase[64 + 1];   // RW <= 48
     __shared__ int s_rowg[64];
     __shared__ int s_use_lds;
     const int tid = threadIdx.x;
-    const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
+    // 1-D grid, XCD-contiguous: the tiles of one (sample, bin) run on one XCD, whose L2 then serves the
+    // halo points that neighbouring tiles stage again
+    const int nblk = gx * gy * p.B * p.nb;
+    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (lblk >= nblk) return;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
     constexpr int TY = NT / 16;                 // query rows per workgroup (16 columns)
     const int RW = 16 + 2 * RH, RWY = TY + 2 * RH;
     // dynamic LDS carve-up (all sizes multiples of 16 bytes)
@@ -511,8 +534,8 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
     c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     c.lcs = lcs; c.lpos = lpos; c.lidx = lidx; c.lf0 = lf0; c.lf1 = lf1;
     c.RW = RW; c.RH = RH;
-    c.ry0 = blockIdx.y * TY - RH;
-    c.rx0 = blockIdx.x * 16 - RH;
+    c.ry0 = by_ * TY - RH;
+    c.rx0 = bx_ * 16 - RH;
 
     // ---- stage the region (tile + RH rings) ---------------------------------------------------
     const int xlo = max(c.rx0, 0), xhi = min(c.rx0 + RW - 1, p.wq - 1);
@@ -561,7 +584,7 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
     }
     __syncthreads();
 
-    const int cy = blockIdx.y * TY + (tid >> 4), cx = blockIdx.x * 16 + (tid & 15);
+    const int cy = by_ * TY + (tid >> 4), cx = bx_ * 16 + (tid & 15);
     float dK = 0.f;
     if (cy < p.hq && cx < p.wq) {
         bool done = false;
@@ -582,10 +605,10 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
     // one maximum per 16x16 query tile (= 4 wavefronts), the granularity the backward works at
     const int gy16 = (p.hq + 15) >> 4;
     if ((tid & 255) == 0) {
-        const int ty16 = blockIdx.y * (TY / 16) + (tid >> 8);
+        const int ty16 = by_ * (TY / 16) + (tid >> 8);
         if (ty16 < gy16) {
             const int w0 = tid >> 6;
-            tile_dkmax[((size_t)bt * gy16 + ty16) * gridDim.x + blockIdx.x] =
+            tile_dkmax[((size_t)bt * gy16 + ty16) * gx + bx_] =
                 fmaxf(fmaxf(s_maxf[w0], s_maxf[w0 + 1]), fmaxf(s_maxf[w0 + 2], s_maxf[w0 + 3]));
         }
     }
@@ -623,57 +646,99 @@ __device__ __forceinline__ void bwd_window(const float4 *__restrict__ lq4, const
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, step 1: one thread per bucketed trajectory point of a 16x16 cell tile.  The K-th
+// backward, step 0: search reach of the points of every 16x16 cell tile = the largest K-th distance
+// among the tiles whose queries can reach into the tile at all (Chebyshev gap between the tile's cell
+// area and their query centres).  One thread per tile; grid (ceil(tiles/256), B*nb).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_knn_reach(const KnnParams p, const float *__restrict__ tile_dkmax,
+                                                   float *__restrict__ reach) {
+    const int ntx = (p.wq + 15) >> 4, nty = (p.hq + 15) >> 4;
+    const int tile = blockIdx.x * 256 + threadIdx.x, bt = blockIdx.y;
+    if (tile >= ntx * nty) return;
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    const float ay0 = (float)(ty * 16 * p.sp) - 0.5f, ay1 = (float)(min(ty * 16 + 16, p.hq) * p.sp) - 0.5f;
+    const float ax0 = (float)(tx * 16 * p.sp) - 0.5f, ax1 = (float)(min(tx * 16 + 16, p.wq) * p.sp) - 0.5f;
+    float r = 0.f;
+    for (int tb = 0; tb < ntx * nty; ++tb) {
+        const int by = tb / ntx, bx = tb - by * ntx;
+        const float dk = tile_dkmax[(size_t)bt * ntx * nty + tb];
+        const float lin = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
+        const float qy0 = (float)(by * 16 * p.sp) + p.off, qy1 = (float)((min(by * 16 + 16, p.hq) - 1) * p.sp) + p.off;
+        const float qx0 = (float)(bx * 16 * p.sp) + p.off, qx1 = (float)((min(bx * 16 + 16, p.wq) - 1) * p.sp) + p.off;
+        const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
+        const float gx = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
+        if (lin >= fmaxf(gy, gx)) r = fmaxf(r, lin);
+    }
+    reach[(size_t)bt * ntx * nty + tile] = r;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, step 1: one thread per bucketed trajectory point of a TS x TS cell tile.  The K-th
 // keys and LUT gradients of the tile and a halo of RQ cells are staged in LDS; each point scans
-// the query cells within the largest K-th distance of its (sample, bin) and gathers the gradient
-// of every cell that has the point among its K nearest.  Writes per-(bin, point) partials.
-// grid (ceil(wq/16), ceil(hq/16), B*nb), 256 threads, dynamic LDS
+// the query cells within the reach of its 16x16 tile and gathers the gradient of every cell that
+// has the point among its K nearest.  Writes per-(bin, point) partials.
+// The kernel is a chain of short dependent phases (reach -> region -> points -> window), so large
+// workgroups (TS = 32: 1024 threads, 4 points' worth of window work per phase) amortise the chain:
+// measured at C3, 16x16 tiles 210 us of which only ~70 us is the window loop.
+// grid (ceil(wq/TS), ceil(hq/TS), B*nb), TS*TS threads, dynamic LDS
 // ------------------------------------------------------------------------------------------
 #define KNN_RQ_MAX 7
-__global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const int *__restrict__ cell_start,
-                                                        const float2 *__restrict__ spos,
-                                                        const int *__restrict__ sidx,
-                                                        const float *__restrict__ glut,
-                                                        const float *__restrict__ gnext,
-                                                        const float *__restrict__ knn_state,
-                                                        const float *__restrict__ tile_dkmax,
-                                                        float2 *__restrict__ tmp_g,   // [B*nb][n][T]
-                                                        float2 *__restrict__ tmp_a) { // [B*nb][n]
+template <int TS>
+__global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, const int *__restrict__ cell_start,
+                                                            const float2 *__restrict__ spos,
+                                                            const int *__restrict__ sidx,
+                                                            const float *__restrict__ glut,
+                                                            const float *__restrict__ gnext,
+                                                            const float *__restrict__ knn_state,
+                                                            const float *__restrict__ reach,
+                                                            float2 *__restrict__ tmp_g,   // [B*nb][n][T]
+                                                            float2 *__restrict__ tmp_a,   // [B*nb][n]
+                                                            int gx, int gy) {
+    constexpr int NT = TS * TS, SUB = TS / 16;
     extern __shared__ unsigned char s_dyn[];
-    __shared__ int s_rowbase[17];
-    __shared__ int s_rowg[16];
+    __shared__ int s_rowbase[TS + 1];
+    __shared__ int s_rowg[TS];
+    __shared__ float s_Rsub[SUB * SUB];
     const int tid = threadIdx.x;
-    const int bt = blockIdx.z, b = bt / p.nb, t = bt - b * p.nb;
+    // 1-D grid, XCD-contiguous: the gx*gy tiles of one (sample, bin) run on one XCD, so the halo cells that
+    // neighbouring tiles stage again are found in that XCD's L2
+    const int nblk = gx * gy * p.B * p.nb;
+    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (lblk >= nblk) return;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    // Reach of this tile's points: the largest K-th distance among the tiles whose queries can
-    // reach into this tile at all (Chebyshev gap between our cell areas and their query centres).
-    __shared__ float s_R[4];
-    {
-        const int ntx = gridDim.x, nty = gridDim.y;
-        const float ay0 = (float)(blockIdx.y * 16 * p.sp) - 0.5f, ay1 = (float)(min(blockIdx.y * 16 + 16, (unsigned)p.hq) * p.sp) - 0.5f;
-        const float ax0 = (float)(blockIdx.x * 16 * p.sp) - 0.5f, ax1 = (float)(min(blockIdx.x * 16 + 16, (unsigned)p.wq) * p.sp) - 0.5f;
-        float rloc = 0.f;
-        for (int tb = tid; tb < ntx * nty; tb += 256) {
-            const int by = tb / ntx, bx = tb - by * ntx;
-            const float dk = tile_dkmax[(size_t)bt * ntx * nty + tb];
-            const float lin = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
-            const float qy0 = (float)(by * 16 * p.sp) + p.off, qy1 = (float)((min(by * 16 + 16, p.hq) - 1) * p.sp) + p.off;
-            const float qx0 = (float)(bx * 16 * p.sp) + p.off, qx1 = (float)((min(bx * 16 + 16, p.wq) - 1) * p.sp) + p.off;
-            const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
-            const float gx = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
-            if (lin >= fmaxf(gy, gx)) rloc = fmaxf(rloc, lin);
-        }
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) rloc = fmaxf(rloc, __shfl_down(rloc, o2, 64));
-        if ((tid & 63) == 0) s_R[tid >> 6] = rloc;
-        __syncthreads();
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    // phase 1 (independent loads): reach of the 16x16 sub-tiles; per tile row the contiguous range of
+    // the bucketed arrays, turned into a running offset by a wavefront scan
+    if (tid < SUB * SUB) {
+        const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+        const int ty = by_ * SUB + tid / SUB, tx = bx_ * SUB + tid % SUB;
+        s_Rsub[tid] = (ty < gy16 && tx < gx16) ? reach[((size_t)bt * gy16 + ty) * gx16 + tx] : 0.f;
     }
-    const float R = fmaxf(fmaxf(s_R[0], s_R[1]), fmaxf(s_R[2], s_R[3]));
+    if (tid < 64) {
+        int gs = 0, ge = 0;
+        const int yy = by_ * TS + tid;
+        if (tid < TS && yy < p.hq) {
+            const int xa = bx_ * TS, xb = min(xa + TS, p.wq);
+            gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
+        }
+        int run = ge - gs;                               // inclusive scan over the lanes
+#pragma unroll
+        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
+        if (tid < TS) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
+        if (tid == 0) s_rowbase[0] = 0;
+    }
+    __syncthreads();
+    float R = s_Rsub[0];
+#pragma unroll
+    for (int k = 1; k < SUB * SUB; ++k) R = fmaxf(R, s_Rsub[k]);
     const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo of the staged region, in cells
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
     const int RQ = use_lds ? RQ_need : 0;
-    const int RW = 16 + 2 * RQ;
-    const int ry0 = blockIdx.y * 16 - RQ, rx0 = blockIdx.x * 16 - RQ;
+    const int RW = TS + 2 * RQ;
+    const int ry0 = by_ * TS - RQ, rx0 = bx_ * TS - RQ;
     // LDS: only the fast path (num_tref == 1, 'mean') stages anything: one float4 per query cell
     // {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} (+ float2 of the flow_to_next gradient)
     float4 *lq4 = reinterpret_cast<float4 *>(s_dyn);
@@ -683,7 +748,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G * p.T;
     if (fast) {
-        for (int i = tid; i < RW * RW; i += 256) {
+        for (int i = tid; i < RW * RW; i += NT) {
             const int rr = i / RW, cc = i - rr * RW;
             const int yy = ry0 + rr, xx = rx0 + cc;
             float dk = -1.f; int ik = -1;
@@ -699,35 +764,18 @@ __global__ __launch_bounds__(256) void k_knn_bwd_points(const KnnParams p, const
             if (has_next) lgn[i] = gn;
         }
     }
-    // points of the tile: per tile row a contiguous range of the bucketed arrays
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
-    if (tid < 16) {
-        const int yy = blockIdx.y * 16 + tid;
-        int gs = 0, ge = 0;
-        if (yy < p.hq) {
-            const int xa = blockIdx.x * 16, xb = min(xa + 16, p.wq);
-            gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
-        }
-        s_rowg[tid] = gs;
-        s_rowbase[tid + 1] = ge - gs;
-    }
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        s_rowbase[0] = 0;
-        for (int rr = 0; rr < 16; ++rr) { const int c = s_rowbase[rr + 1]; s_rowbase[rr + 1] = run + c; run += c; }
-    }
-    __syncthreads();
-    const int total = s_rowbase[16];
+    const int total = s_rowbase[TS];
     const float invK = 1.f / (float)p.K;
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const int *si_ = sidx + (size_t)bt * p.n;
-    for (int pi = tid; pi < total; pi += 256) {
-        int lo = 0, hi = 16;
+    for (int pi = tid; pi < total; pi += NT) {
+        int lo = 0, hi = TS;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
         const int g = s_rowg[lo] + (pi - s_rowbase[lo]);
         const float2 pt = sp_[g];
         const int i = si_[g];
+        if (SUB > 1) R = s_Rsub[(lo >> 4) * SUB + ((cell_of(pt.y, p.sp, p.wq) - bx_ * TS) >> 4)];
         // query cells within reach: |q - p| <= R per axis.  R already carries a 0.01 px + 1e-4 relative
         // margin, which dominates the rounding of these four expressions, so no extra cell is added.
         int y0 = (int)ceilf((pt.x - R - p.off) / (float)p.sp);
@@ -912,13 +960,14 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     if (mode == 2) cap = 0;                    // nothing staged: every query searches the global arrays
     const int RWYb = best_nt / 16 + 2 * RH;
     const size_t lds = (size_t)KNN_HW * best_nt * 4 + (size_t)RWYb * (RW + 1) * 2 + 64 + per_pt * cap;
-    const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, best_nt / 16), s->B * s->nb);
+    const int gx = mpc_cdiv(s->wq, 16), gy = mpc_cdiv(s->hq, best_nt / 16);
+    const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
     if (best_nt == 512)
         hipLaunchKernelGGL(k_knn_query<512>, grid, dim3(512), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow);
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
     else
         hipLaunchKernelGGL(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow);
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
     MPC_CHECK_LAUNCH();
     return 0;
 }
@@ -939,16 +988,32 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     float2 *tmp_g = (float2 *)((char *)ws + L.off_knn_tmp_g);
     float2 *tmp_a = (float2 *)((char *)ws + L.off_knn_tmp_a);
     const float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
+    float *reach = (float *)((char *)ws + L.off_knn_reach);
     static bool attr_set = false;
+    static int want_ts = 0;
     if (!attr_set) {
-        if ((rc = set_max_lds((const void *)k_knn_bwd_points, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_points<16>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_points<32>, __func__))) return rc;
+        const char *e = getenv("MPC_KNN_BWD_TS");                    // tuning: 16 or 32
+        if (e) want_ts = atoi(e);
         attr_set = true;
     }
-    const int RWmax = 16 + 2 * KNN_RQ_MAX;
+    const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
+    hipLaunchKernelGGL(k_knn_reach, dim3(mpc_cdiv(ntiles, 256), s->B * s->nb), dim3(256), 0, st, p, tile_dkmax, reach);
+    MPC_CHECK_LAUNCH();
+    // (32x32-cell tiles with 1024 threads measured slower at C3: 296 vs 229 us)
+    int ts = 16;
+    if (want_ts == 16 || want_ts == 32) ts = want_ts;
+    const int RWmax = ts + 2 * KNN_RQ_MAX;
     const size_t lds = (s->T == 1 && !p.iwd) ? (size_t)RWmax * RWmax * (16 + (grad_flow_next ? 8 : 0)) : 0;
-    const dim3 grid(mpc_cdiv(s->wq, 16), mpc_cdiv(s->hq, 16), s->B * s->nb);
-    hipLaunchKernelGGL(k_knn_bwd_points, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
-                       grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a);
+    const int gx = mpc_cdiv(s->wq, ts), gy = mpc_cdiv(s->hq, ts);
+    const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
+    if (ts == 32)
+        hipLaunchKernelGGL(k_knn_bwd_points<32>, grid, dim3(1024), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
+                           grad_flow_next, knn_state, reach, tmp_g, tmp_a, gx, gy);
+    else
+        hipLaunchKernelGGL(k_knn_bwd_points<16>, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
+                           grad_flow_next, knn_state, reach, tmp_g, tmp_a, gx, gy);
     MPC_CHECK_LAUNCH();
     const int64_t total = (int64_t)s->B * s->n;
     hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g,

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from motionpriorcmax_amd import ops, LossFactory, _lib as C
+if os.environ.get('MPC_AB_LIB'):          # A/B timing of two builds on the same box
+    C.LIB_PATH = os.path.abspath(os.environ['MPC_AB_LIB'])
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 wl = dict(bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else 'C3'])
@@ -15,7 +17,7 @@ cfg = L._cfg
 trajd = traj.to(dev)
 shape = ops.make_shape(cfg, B, 0, 0, traj.shape[2])
 ws = ops.alloc_workspace(shape, dev)
-for it in range(4):
+for it in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lut, nxt, state, _ = ops.knn_lut_fwd(cfg, shape, trajd, ws)
     torch.cuda.synchronize(); t1 = time.perf_counter()
