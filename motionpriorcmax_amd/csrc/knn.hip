@@ -648,28 +648,35 @@ __device__ __forceinline__ void bwd_window(const float4 *__restrict__ lq4, const
 // ------------------------------------------------------------------------------------------
 // backward, step 0: search reach of the points of every 16x16 cell tile = the largest K-th distance
 // among the tiles whose queries can reach into the tile at all (Chebyshev gap between the tile's cell
-// area and their query centres).  One thread per tile; grid (ceil(tiles/256), B*nb).
+// area and their query centres).  One workgroup per (sample, bin), the tile maxima staged in LDS.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_knn_reach(const KnnParams p, const float *__restrict__ tile_dkmax,
                                                    float *__restrict__ reach) {
-    const int ntx = (p.wq + 15) >> 4, nty = (p.hq + 15) >> 4;
-    const int tile = blockIdx.x * 256 + threadIdx.x, bt = blockIdx.y;
-    if (tile >= ntx * nty) return;
-    const int ty = tile / ntx, tx = tile - ty * ntx;
-    const float ay0 = (float)(ty * 16 * p.sp) - 0.5f, ay1 = (float)(min(ty * 16 + 16, p.hq) * p.sp) - 0.5f;
-    const float ax0 = (float)(tx * 16 * p.sp) - 0.5f, ax1 = (float)(min(tx * 16 + 16, p.wq) * p.sp) - 0.5f;
-    float r = 0.f;
-    for (int tb = 0; tb < ntx * nty; ++tb) {
-        const int by = tb / ntx, bx = tb - by * ntx;
-        const float dk = tile_dkmax[(size_t)bt * ntx * nty + tb];
-        const float lin = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
-        const float qy0 = (float)(by * 16 * p.sp) + p.off, qy1 = (float)((min(by * 16 + 16, p.hq) - 1) * p.sp) + p.off;
-        const float qx0 = (float)(bx * 16 * p.sp) + p.off, qx1 = (float)((min(bx * 16 + 16, p.wq) - 1) * p.sp) + p.off;
-        const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
-        const float gx = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
-        if (lin >= fmaxf(gy, gx)) r = fmaxf(r, lin);
+    extern __shared__ float s_lin[];          // linear K-th distance bound of every tile of this (sample, bin)
+    const int ntx = (p.wq + 15) >> 4, nty = (p.hq + 15) >> 4, nt = ntx * nty;
+    const int bt = blockIdx.x;
+    for (int tb = threadIdx.x; tb < nt; tb += 256) {
+        const float dk = tile_dkmax[(size_t)bt * nt + tb];
+        s_lin[tb] = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
     }
-    reach[(size_t)bt * ntx * nty + tile] = r;
+    __syncthreads();
+    for (int tile = threadIdx.x; tile < nt; tile += 256) {
+        const int ty = tile / ntx, tx = tile - ty * ntx;
+        const float ay0 = (float)(ty * 16 * p.sp) - 0.5f, ay1 = (float)(min(ty * 16 + 16, p.hq) * p.sp) - 0.5f;
+        const float ax0 = (float)(tx * 16 * p.sp) - 0.5f, ax1 = (float)(min(tx * 16 + 16, p.wq) * p.sp) - 0.5f;
+        float r = 0.f;
+        for (int by = 0; by < nty; ++by) {
+            const float qy0 = (float)(by * 16 * p.sp) + p.off, qy1 = (float)((min(by * 16 + 16, p.hq) - 1) * p.sp) + p.off;
+            const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
+            for (int bx = 0; bx < ntx; ++bx) {
+                const float lin = s_lin[by * ntx + bx];
+                const float qx0 = (float)(bx * 16 * p.sp) + p.off, qx1 = (float)((min(bx * 16 + 16, p.wq) - 1) * p.sp) + p.off;
+                const float gx = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
+                if (lin >= fmaxf(gy, gx)) r = fmaxf(r, lin);
+            }
+        }
+        reach[(size_t)bt * nt + tile] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     }
     __syncthreads();
     const int total = s_rowbase[TS];
-    const float invK = 1.f / (float)p.K;
+    const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const int *si_ = sidx + (size_t)bt * p.n;
     for (int pi = tid; pi < total; pi += NT) {
@@ -778,10 +785,11 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
         if (SUB > 1) R = s_Rsub[(lo >> 4) * SUB + ((cell_of(pt.y, p.sp, p.wq) - bx_ * TS) >> 4)];
         // query cells within reach: |q - p| <= R per axis.  R already carries a 0.01 px + 1e-4 relative
         // margin, which dominates the rounding of these four expressions, so no extra cell is added.
-        int y0 = (int)ceilf((pt.x - R - p.off) / (float)p.sp);
-        int y1 = (int)floorf((pt.x + R - p.off) / (float)p.sp);
-        int x0 = (int)ceilf((pt.y - R - p.off) / (float)p.sp);
-        int x1 = (int)floorf((pt.y + R - p.off) / (float)p.sp);
+        // (a reciprocal multiply instead of four divisions: its 1e-7 relative error is far inside that margin too)
+        int y0 = (int)ceilf((pt.x - R - p.off) * inv_sp);
+        int y1 = (int)floorf((pt.x + R - p.off) * inv_sp);
+        int x0 = (int)ceilf((pt.y - R - p.off) * inv_sp);
+        int x1 = (int)floorf((pt.y + R - p.off) * inv_sp);
         y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, p.hq - 1); x1 = min(x1, p.wq - 1);
         if (fast) {      // the staged region always covers the window (see the note on clamped cells)
             y0 = max(y0, ry0); x0 = max(x0, rx0); y1 = min(y1, ry0 + RW - 1); x1 = min(x1, rx0 + RW - 1);
@@ -999,7 +1007,7 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         attr_set = true;
     }
     const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
-    hipLaunchKernelGGL(k_knn_reach, dim3(mpc_cdiv(ntiles, 256), s->B * s->nb), dim3(256), 0, st, p, tile_dkmax, reach);
+    hipLaunchKernelGGL(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);
     MPC_CHECK_LAUNCH();
     // (32x32-cell tiles with 1024 threads measured slower at C3: 296 vs 229 us)
     int ts = 16;
