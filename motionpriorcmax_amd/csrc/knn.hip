@@ -882,6 +882,31 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
+// Tuning switches for A/B measurements, read once per process from the environment (defaults in brackets):
+//   MPC_KNN_MODE=global     nothing staged in LDS, every query searches the global arrays     [thread]
+//   MPC_KNN_BLOCKS=<n>      force the LDS share of the query kernel to n workgroups per CU    [largest that fits]
+//   MPC_KNN_STAGE_FLOW=0    gather the flows from global memory instead of staging them       [1]
+//   MPC_KNN_NT=256|512      query workgroup size (16x16 or 16x32 queries)                     [by occupancy]
+//   MPC_KNN_R0=<d>          offset of the initial search radius                               [0]
+//   MPC_KNN_BWD_TS=16|32    tile side of the backward gather                                  [16]
+struct KnnTuning {
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts;
+};
+static const KnnTuning &knn_tuning() {
+    static const KnnTuning t = [] {
+        KnnTuning v{0, 0, 1, 0, 0, 16};
+        const char *e;
+        if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
+        if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
+        if ((e = getenv("MPC_KNN_STAGE_FLOW"))) v.stage_flow = atoi(e) != 0;
+        if ((e = getenv("MPC_KNN_NT"))) v.nt = atoi(e);
+        if ((e = getenv("MPC_KNN_R0"))) v.r0 = atoi(e);
+        if ((e = getenv("MPC_KNN_BWD_TS"))) v.bwd_ts = atoi(e) == 32 ? 32 : 16;
+        return v;
+    }();
+    return t;
+}
+
 static int set_max_lds(const void *fn, const char *who) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) { mpc_set_error("%s: %s", who, hipGetErrorString(e)); return (int)e; }
@@ -921,17 +946,10 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
     int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
+    const KnnTuning &tune = knn_tuning();
+    r_init += tune.r0;
     if (r_init < 1) r_init = 1;
-    { const char *e = getenv("MPC_KNN_R0"); if (e) r_init += atoi(e); }      // tuning: initial search radius offset
-    // tuning switch (A/B measurements): MPC_KNN_MODE = thread (default) | global (nothing staged in LDS)
-    static int mode = -1, want_blocks = 0, want_stage = -1, want_nt = 0;
-    if (mode < 0) {
-        const char *e = getenv("MPC_KNN_MODE");
-        mode = (e && e[0] == 'g') ? 2 : 1;
-        if ((e = getenv("MPC_KNN_BLOCKS"))) want_blocks = atoi(e);
-        if ((e = getenv("MPC_KNN_STAGE_FLOW"))) want_stage = atoi(e);
-        if ((e = getenv("MPC_KNN_NT"))) want_nt = atoi(e);
-    }
+    const int want_blocks = tune.blocks, want_nt = tune.nt;
     int RH = r_init + 1;
     if (RH > 16) RH = 16;
     const int RW = 16 + 2 * RH;
@@ -940,7 +958,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     // what is left of the per-workgroup share after the histogram columns, provided it still holds 1.25x the
     // mean region; 16x32-query workgroups (512 threads) carry less halo per query and are used when they
     // reach more wavefronts per CU.
-    const int stage_flow = (want_stage >= 0) ? want_stage : 1;
+    const int stage_flow = tune.stage_flow;
     const size_t per_pt = 8 + 2 + ((s->T == 1 && stage_flow) ? 8 : 0) + (p.want_next ? 8 : 0);
     int best_nt = 256, best_cap = 64, best_waves = 0;
     for (int nt = 256; nt <= 512; nt *= 2) {
@@ -965,7 +983,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         }
     }
     int cap = best_cap;
-    if (mode == 2) cap = 0;                    // nothing staged: every query searches the global arrays
+    if (tune.global_mode) cap = 0;             // nothing staged: every query searches the global arrays
     const int RWYb = best_nt / 16 + 2 * RH;
     const size_t lds = (size_t)KNN_HW * best_nt * 4 + (size_t)RWYb * (RW + 1) * 2 + 64 + per_pt * cap;
     const int gx = mpc_cdiv(s->wq, 16), gy = mpc_cdiv(s->hq, best_nt / 16);
@@ -998,20 +1016,16 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     const float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     float *reach = (float *)((char *)ws + L.off_knn_reach);
     static bool attr_set = false;
-    static int want_ts = 0;
     if (!attr_set) {
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<16>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<32>, __func__))) return rc;
-        const char *e = getenv("MPC_KNN_BWD_TS");                    // tuning: 16 or 32
-        if (e) want_ts = atoi(e);
         attr_set = true;
     }
     const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
     hipLaunchKernelGGL(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);
     MPC_CHECK_LAUNCH();
     // (32x32-cell tiles with 1024 threads measured slower at C3: 296 vs 229 us)
-    int ts = 16;
-    if (want_ts == 16 || want_ts == 32) ts = want_ts;
+    const int ts = knn_tuning().bwd_ts;
     const int RWmax = ts + 2 * KNN_RQ_MAX;
     const size_t lds = (s->T == 1 && !p.iwd) ? (size_t)RWmax * RWmax * (16 + (grad_flow_next ? 8 : 0)) : 0;
     const int gx = mpc_cdiv(s->wq, ts), gy = mpc_cdiv(s->hq, ts);

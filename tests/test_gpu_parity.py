@@ -293,30 +293,24 @@ def test_single_sample_single_event_and_far_out_of_bounds_flow():
     assert float(raw2.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('env', [{'MPC_KNN_MODE': 'global'}, {'MPC_KNN_STAGE_FLOW': '0'}, {'MPC_KNN_BLOCKS': '8'}])
+@pytest.mark.parametrize('env', [{'MPC_KNN_MODE': 'global'}, {'MPC_KNN_STAGE_FLOW': '0'}, {'MPC_KNN_BLOCKS': '8'},
+                                 {'MPC_KNN_NT': '512', 'MPC_KNN_BWD_TS': '32'}])
 def test_alternative_knn_kernels_agree_with_goldens(env):
-    """The unstaged per-thread search, the variant that gathers the flows from global memory and a tiny LDS
-    staging capacity (tiles that overflow it finish on the global arrays) -- tuning switches read once per
-    process -- must produce the same LUT as the default: run a golden stage check in a subprocess."""
+    """The unstaged per-thread search, the variant that gathers the flows from global memory, a tiny LDS
+    staging capacity (tiles that overflow it finish on the global arrays) and the larger workgroup shapes --
+    tuning switches read once per process -- must pass the same parity tests as the default: the golden,
+    odd-size and brute-force KNN tests of this file are re-run in a subprocess with the switch set."""
     import os
     import subprocess
     import sys
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, 'tests'); sys.path.insert(0, '.')\n"
-        "from conftest import load_golden\n"
-        "from motionpriorcmax_amd import LossFactory, ops\n"
-        "for name in ('g1_allflags', 'g2_config1', 'g5a_dct3_l2'):\n"
-        "    g = load_golden(name); L = LossFactory.get_loss_calculator('FOCUS', g['cfg'])\n"
-        "    t = torch.from_numpy(g['trajectories']).cuda().requires_grad_(True)\n"
-        "    lut, _ = ops.KnnLutFn.apply(t, L._cfg)\n"
-        "    assert np.abs(lut.detach().cpu().numpy() - g['flow_lut']).max() < 1e-5, name\n"
-        "    lut.backward(torch.from_numpy(g['grad_flow_lut']).cuda())\n"
-        "    assert torch.isfinite(t.grad).all()\n"
-        "print('ok')\n")
-    env = dict(os.environ, **env)
+    if os.environ.get('MPC_ALT_KNN_CHILD'):
+        pytest.skip('already inside the child run')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+    sel = 'golden_full_calc or golden_stages or odd_image_sizes or knn_large_k or knn_degenerate or full_size_knn'
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-x', '-q', '-m', 'gpu', '-k', sel],
+                       cwd=root, env=dict(os.environ, MPC_ALT_KNN_CHILD='1', **env), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
 
 
 def _knn_vs_bruteforce(traj, shape, sp, K, dist_norm='l2', scheme='mean'):
