@@ -96,8 +96,8 @@ def stage_bytes(B, M, nb, n, T=1, P=2):
 
 # kernels behind each C-ABI stage (for the PMC traffic figure)
 STAGE_KERNELS = {
-    'mpc_knn_lut_fwd': ['k_knn_bucket', 'k_knn_query', 'k_knn_query_tile'],
-    'mpc_knn_lut_bwd': ['k_knn_bwd_points', 'k_knn_bwd_combine'],
+    'mpc_knn_lut_fwd': ['k_knn_bucket', 'k_knn_query'],
+    'mpc_knn_lut_bwd': ['k_knn_reach', 'k_knn_bwd_points', 'k_knn_bwd_combine'],
     'mpc_event_splat_fwd': ['k_ev_bin', 'k_iwe_accum', 'k_iwe_overflow', 'k_splat_fwd_atomic'],
     'mpc_event_splat_bwd': ['k_lut_accum', 'k_lut_overflow', 'k_splat_bwd_atomic'],
     'mpc_contrast_fwd': ['k_contrast_fused', 'k_contrast_fwd', 'k_contrast_bwd_var', 'k_image_means'],
@@ -257,6 +257,14 @@ def main():
     ms_per_step = 1e3 * r['dt'] / r['steps']
     value = r['total_valid'] * r['steps'] / r['dt'] / 1e6
 
+    def event_path_roofline(per_step, wl_):
+        """the event path alone (A6-A11 with the LUT given) against the HBM roofline."""
+        names = ('mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_event_splat_bwd', 'mpc_finalize')
+        us = sum(per_step[k]['us_per_step'] for k in names if k in per_step)
+        b = algorithmic_bytes(wl_['B'], wl_['M'], wl_['nb'])
+        return {'us_per_step': round(us, 1), 'achieved': round(b / (us * 1e-6) / 1e9, 1) if us > 0 else 0.0,
+                'frac': round(b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else 0.0}
+
     def roofline_of(res, wname=None):
         wl_ = res['wl']
         sb = stage_bytes(wl_['B'], wl_['M'], wl_['nb'], res['n'])
@@ -274,7 +282,8 @@ def main():
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(wname, dom) if wname else None,
             'algorithmic_bytes': int(d['algorithmic_MB'] * 1e6),
-            'kernel_us': round(d['us_per_step'], 1),
+            'kernel_us': round(d['us_per_step'], 1), 'kernels_in_stage': STAGE_KERNELS.get(dom, []),
+            'event_path': event_path_roofline(per_step, wl_),
             'path': {'algorithmic_MB': round(path_b / 1e6, 2), 'gpu_us_per_step': round(gpu_us, 1),
                      'achieved': round(path_b / (gpu_us * 1e-6) / 1e9, 1) if gpu_us > 0 else 0.0,
                      'frac': round(path_b / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if gpu_us > 0 else 0.0},
