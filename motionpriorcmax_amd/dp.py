@@ -40,10 +40,13 @@ class GradAllReducer:
     messages beat DDP's default 25 MB buckets.  `start()` enqueues the all-reduces on a side
     stream (after the producer stream's current work), `wait()` makes the consumer stream wait."""
 
-    def __init__(self, numel: int = UNET_GRAD_NUMEL, n_buckets: int = 4, device=None, group=None):
+    def __init__(self, numel: int = UNET_GRAD_NUMEL, n_buckets: int = 4, device=None, group=None,
+                 force_collective: bool = False):
         self.device = torch.device(device) if device is not None else torch.device('cpu')
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collective: issue the all-reduce even in a group of one (exercises the RCCL path on a 1-GPU box)
+        self.skip = (self.world == 1) and not (force_collective and dist.is_initialized())
         self.flat = torch.zeros(numel, dtype=torch.float32, device=self.device)
         self.bounds = bucket_bounds(numel, n_buckets)
         self.is_cuda = self.device.type == 'cuda'
@@ -51,7 +54,7 @@ class GradAllReducer:
         self._works = []
 
     def start(self):
-        if self.world == 1:
+        if self.skip:
             return
         if self.is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -69,7 +72,7 @@ class GradAllReducer:
                                                    group=self.group, async_op=True))
 
     def wait(self):
-        if self.world == 1:
+        if self.skip:
             return
         if self.is_cuda:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
@@ -80,17 +83,17 @@ class GradAllReducer:
             self.flat.mul_(1.0 / self.world)
 
 
-def max_over_ranks(value: float, device=None) -> float:
+def max_over_ranks(value: float, device=None, force_collective: bool = False) -> float:
     """MAX of a host float over all ranks (step-time reduction of the benchmark)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def sum_over_ranks(value: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def sum_over_ranks(value: float, device=None, force_collective: bool = False) -> float:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
