@@ -6,6 +6,7 @@
 #include "../../include/mpcmax.h"
 
 #define MPC_WAVE 64
+#define MPC_KNN_LDS_SORT_CELLS (150 * 1024 / 4)   // largest LUT grid the single-workgroup LDS counting sort holds
 
 void mpc_set_error(const char *fmt, ...);
 
@@ -42,6 +43,7 @@ struct mpc_ws_layout {
     int64_t off_sidx;        // int32  [B*nb][n]
     int64_t off_knn_tmp_g;   // float2 [B*nb][n][T]  backward partials
     int64_t off_knn_tmp_a;   // float2 [B*nb][n]
+    int64_t off_knn_cursor;  // int32  [B*nb][G]  fill cursors of the global-memory bucket sort (only when G*4 B exceeds the LDS sort)
     int64_t off_knn_reach;   // float  [B*nb][ceil(hq/16)][ceil(wq/16)]  backward search reach per 16x16 tile
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, spill counters, marker

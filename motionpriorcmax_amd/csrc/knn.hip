@@ -138,6 +138,81 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     }
 }
 
+// LUT grids beyond the LDS sort (G > 38 400 cells, e.g. 1280x720 at superpixel 4): the same counting sort with
+// the counters in global memory, as three launches (count / scan / scatter) and a fourth that orders the
+// points of every cell by trajectory index, so that the bucket order -- and with it the fp32 summation order
+// of the LUT -- does not depend on the order the atomics happened to execute in.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, const float *__restrict__ traj,
+                                                          int *__restrict__ cursor) {
+    const int bt = blockIdx.y, b = bt / p.nb, t = bt - b * p.nb;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const float2 v = reinterpret_cast<const float2 *>(traj)[((size_t)b * (p.T + p.nb) + p.T + t) * p.n + i];
+    atomicAdd(&cursor[(size_t)bt * p.G + cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+}
+
+// grid B*nb, 1024 threads
+__global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
+                                                          int *__restrict__ cell_start) {
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, bt = blockIdx.x;
+    int *cur = cursor + (size_t)bt * p.G;
+    int *cs = cell_start + (size_t)bt * (p.G + 1);
+    const int chunk = (p.G + 1023) / 1024;
+    const int g0 = min(tid * chunk, p.G), g1 = min(g0 + chunk, p.G);
+    int local = 0;
+    for (int g = g0; g < g1; ++g) local += cur[g];
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (tid >> 6); ++w) run += s_wave[w];
+    for (int g = g0; g < g1; ++g) {
+        const int c = cur[g];
+        cur[g] = run;           // becomes the fill cursor of the cell
+        cs[g] = run;
+        run += c;
+    }
+    if (tid == 0) cs[p.G] = p.n;
+}
+
+__global__ __launch_bounds__(256) void k_knn_bucket_scatter(const KnnParams p, const float *__restrict__ traj,
+                                                            int *__restrict__ cursor,
+                                                            float2 *__restrict__ spos, int *__restrict__ sidx) {
+    const int bt = blockIdx.y, b = bt / p.nb, t = bt - b * p.nb;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const float2 v = reinterpret_cast<const float2 *>(traj)[((size_t)b * (p.T + p.nb) + p.T + t) * p.n + i];
+    const int pos = atomicAdd(&cursor[(size_t)bt * p.G + cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+    spos[(size_t)bt * p.n + pos] = v;
+    sidx[(size_t)bt * p.n + pos] = i;
+}
+
+// one thread per cell: insertion sort of its (few) points by trajectory index
+__global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, const int *__restrict__ cell_start,
+                                                          float2 *__restrict__ spos, int *__restrict__ sidx) {
+    const int bt = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= p.G) return;
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    float2 *sp_ = spos + (size_t)bt * p.n;
+    int *si_ = sidx + (size_t)bt * p.n;
+    const int a = cs[g], e = cs[g + 1];
+    for (int i = a + 1; i < e; ++i) {
+        const int key = si_[i];
+        const float2 v = sp_[i];
+        int j = i - 1;
+        while (j >= a && si_[j] > key) { si_[j + 1] = si_[j]; sp_[j + 1] = sp_[j]; --j; }
+        si_[j + 1] = key; sp_[j + 1] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // query: one thread per LUT cell; 16x16 cells per workgroup.  The candidate points of the tile
 // and a halo of RH cell rings are staged in LDS (positions, indices, flows), so the selection
@@ -922,7 +997,6 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     MPC_CHECK_ARG(s->n >= s->K && s->K >= 1, MPC_E_SHAPE, "need 1 <= K <= n");
     MPC_CHECK_ARG(s->n < 65536, MPC_E_UNSUPPORTED, "more than 65535 trajectories per sample");
     const KnnParams p = knn_params(s);
-    MPC_CHECK_ARG((size_t)p.G * 4 <= 150 * 1024, MPC_E_UNSUPPORTED, "LUT grid too large for the LDS counting sort");
     if (s->B == 0) return 0;
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
@@ -938,7 +1012,16 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
         attr_set = true;
     }
-    if (s->n <= KNN_BUCKET_NPT * 1024)
+    if (p.G > MPC_KNN_LDS_SORT_CELLS) {
+        int *cursor = (int *)((char *)ws + L.off_knn_cursor);
+        hipError_t e = hipMemsetAsync(cursor, 0, (size_t)s->B * s->nb * p.G * sizeof(int), st);
+        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
+        hipLaunchKernelGGL(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
+        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start);
+        hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
+        hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
+    } else if (s->n <= KNN_BUCKET_NPT * 1024)
         hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
     else
         hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);

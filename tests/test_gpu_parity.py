@@ -471,6 +471,60 @@ def test_full_size_knn_against_bruteforce_sample():
         assert (got - f).abs().max().item() < 1e-5
 
 
+def test_hd_sensor_1280x720_large_lut_grid():
+    """1280x720 (57 600 LUT cells: beyond the single-workgroup LDS counting sort, so the points are bucketed
+    by the global-memory sort): the LUT equals a brute-force K-nearest mean on a sample of cells, the result
+    is bitwise reproducible from run to run, the KNN backward matches autograd through the brute-force
+    neighbour sets, and the full loss runs with a finite gradient."""
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    dev = _dev()
+    shape = (720, 1280)
+    g = torch.Generator().manual_seed(33)
+    coeff = torch.randn(1, 1, 2, *shape, generator=g) * 3.0
+    nb = 5
+    times = torch.cat((torch.tensor([0.41]), O.bin_mid_times(nb)))
+    traj = O.trajectories_at(coeff, times, O.tile_mask(shape, 4), 1, 'polynomial').to(dev)
+    cfg = dict(image_shape=shape, num_tref=1, num_bins=nb, num_knn=32, smooth_weight=0.003,
+               lut_superpixel_size=4, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True,
+               mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    L = _loss_obj(cfg)
+    tr = traj.clone().requires_grad_(True)
+    lut, _ = ops.KnnLutFn.apply(tr, L._cfg)
+    lut2, _ = ops.KnnLutFn.apply(traj, L._cfg)
+    assert torch.equal(lut.detach(), lut2)
+    grid, hq, wq = O.lut_grid_points(shape, 4)
+    assert hq * wq == 57600
+    sel = torch.randperm(hq * wq, generator=g)[:384]
+    q = grid[sel].to(dev)
+    gsel = torch.randn(nb, 384, 2, generator=g).to(dev)
+    tref = traj.clone().requires_grad_(True)
+    ref_terms = []
+    for t in range(nb):
+        pts = tref[0, 1 + t]
+        d = ((q[:, None, :] - pts.detach()[None, :, :]) ** 2).sum(-1)
+        idx = torch.sort(d, dim=1, stable=True).indices[:, :32]
+        f = (tref[0, 0] - pts)[idx].mean(1)
+        got = lut[0, t].reshape(-1, 2)[sel.to(dev)]
+        assert (got.detach() - f.detach()).abs().max().item() < 1e-5
+        ref_terms.append((f * gsel[t]).sum())
+    torch.stack(ref_terms).sum().backward()
+    gl = torch.zeros_like(lut)
+    glv = gl[0].reshape(nb, -1, 2)
+    glv[:, sel.to(dev)] = gsel
+    lut.backward(gl)
+    assert _rel_l2(tr.grad.cpu().numpy(), tref.grad.cpu().numpy()) < 1e-5
+    # whole loss on this sensor size
+    ev, num_pos = O.synth_events(1, 100000, shape, nb, seed=9)
+    t2 = traj.clone().requires_grad_(True)
+    loss, _, misc = L.calc(t2, times.to(dev), {'events': ev.to(dev), 'num_pos_events': num_pos})
+    loss.backward()
+    assert torch.isfinite(loss).item() and torch.isfinite(t2.grad).all().item() and float(t2.grad.abs().sum()) > 0
+    assert misc['iwes'].shape == (1, 1, 2, 720, 1280)
+    assert abs(float(misc['iwes'].sum()) - 0.0) > 1.0
+
+
 def test_contrast_maximisation_recovers_a_known_flow():
     """Beyond parity: optimising a constant flow with the loss' own gradient (Adam, from zero) collapses
     the events of points moving at (6, -9) px per window back onto the points: the recovered flow is the

@@ -3,7 +3,9 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from motionpriorcmax_amd import ops, LossFactory
+from motionpriorcmax_amd import ops, LossFactory, _lib as C
+if os.environ.get('MPC_AB_LIB'):          # A/B timing of two builds on the same box
+    C.LIB_PATH = os.path.abspath(os.environ['MPC_AB_LIB'])
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 wl = dict(bench.WORKLOADS['C3']); wl['B'] = B
