@@ -51,7 +51,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(int32_t));
     L.off_knn_tmp_g = off;  off += mpc_align(bt * (int64_t)s->n * s->T * 2 * sizeof(float));
     L.off_knn_tmp_a = off;  off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
-    L.off_knn_cursor = off; off += (L.G > MPC_KNN_LDS_SORT_CELLS) ? mpc_align(bt * (int64_t)L.G * sizeof(int32_t)) : 0;
+    const bool big_sort = L.G > MPC_KNN_LDS_SORT_CELLS || (int64_t)L.G * 4 + ((int64_t)s->n + 1) / 2 * 4 > 150 * 1024;
+    L.off_knn_cursor = off; off += big_sort ? mpc_align(bt * (int64_t)L.G * sizeof(int32_t)) : 0;
     L.off_knn_reach = off;  off += mpc_align(bt * (int64_t)mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16) * sizeof(float));
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;

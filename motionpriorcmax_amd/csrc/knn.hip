@@ -54,10 +54,10 @@ __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float p
 
 // ------------------------------------------------------------------------------------------
 // bucket the points of one (sample, bin) by cell: counting sort in LDS.  With CACHED, every thread
-// keeps its (up to KNN_BUCKET_NPT) points in registers: one round of global-load latency for the
+// keeps the cells of its (up to KNN_BUCKET_NPT) points in registers: one round of global-load latency for the
 // whole kernel instead of one per point and pass (the kernel has only B*nb workgroups, so it is
 // latency- not bandwidth-limited).  A segmented multi-workgroup variant measured slower (66 vs 48 us).
-// grid B*nb, 1024 threads, dynamic LDS = G * 4 bytes
+// grid B*nb, 1024 threads, dynamic LDS = G * 4 + n * 2 bytes
 // ------------------------------------------------------------------------------------------
 #define KNN_BUCKET_NPT 24
 template <bool CACHED>
@@ -69,20 +69,20 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     const int tid = threadIdx.x;
     const int bt = blockIdx.x, b = bt / p.nb, t = bt - b * p.nb;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
-    float2 q[CACHED ? KNN_BUCKET_NPT : 1];
     int qc[CACHED ? KNN_BUCKET_NPT : 1];
     if (CACHED) {
+        float2 q[KNN_BUCKET_NPT];
 #pragma unroll
         for (int u = 0; u < KNN_BUCKET_NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
+#pragma unroll
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u) qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
     }
     for (int g = tid; g < p.G; g += 1024) s_cnt[g] = 0;
     __syncthreads();
     if (CACHED) {
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
-            qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u)
             if (tid + u * 1024 < p.n) atomicAdd(&s_cnt[qc[u]], 1);
-        }
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
@@ -118,26 +118,42 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     __syncthreads();
     float2 *sp_ = spos + (size_t)bt * p.n;
     int *si_ = sidx + (size_t)bt * p.n;
+    // scatter the INDICES into LDS first: the slots inside a cell are handed out in the order the LDS atomics
+    // happen to execute, so the (few) points of every cell are then ordered by trajectory index -- the bucket
+    // order, and with it the fp32 summation order of the LUT, is the same in every run -- and only then are
+    // the bucketed arrays written, with coalesced stores and the positions gathered by index.
+    unsigned short *l_idx = reinterpret_cast<unsigned short *>(s_cnt + p.G);
     if (CACHED) {
 #pragma unroll
         for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
             const int i = tid + u * 1024;
-            if (i < p.n) {
-                const int pos = atomicAdd(&s_cnt[qc[u]], 1);
-                sp_[pos] = q[u];
-                si_[pos] = i;
-            }
+            if (i < p.n) l_idx[atomicAdd(&s_cnt[qc[u]], 1)] = (unsigned short)i;
         }
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
-            const int pos = atomicAdd(&s_cnt[cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
-            sp_[pos] = v;
-            si_[pos] = i;
+            l_idx[atomicAdd(&s_cnt[cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1)] = (unsigned short)i;
         }
+    }
+    __syncthreads();
+    for (int g = tid; g < p.G; g += 1024) {          // s_cnt[g] is now the END of cell g
+        const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0;
+        for (int i = a + 1; i < e; ++i) {
+            const unsigned short key = l_idx[i];
+            int j = i - 1;
+            while (j >= a && l_idx[j] > key) { l_idx[j + 1] = l_idx[j]; --j; }
+            l_idx[j + 1] = key;
+        }
+    }
+    __syncthreads();
+    for (int sl = tid; sl < p.n; sl += 1024) {
+        const int i = l_idx[sl];
+        si_[sl] = i;
+        sp_[sl] = pts[i];
     }
 }
 
+// ------------------------------------------------------------------------------------------
 // LUT grids beyond the LDS sort (G > 38 400 cells, e.g. 1280x720 at superpixel 4): the same counting sort with
 // the counters in global memory, as three launches (count / scan / scatter) and a fourth that orders the
 // points of every cell by trajectory index, so that the bucket order -- and with it the fp32 summation order
@@ -1012,7 +1028,8 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
         attr_set = true;
     }
-    if (p.G > MPC_KNN_LDS_SORT_CELLS) {
+    const size_t sort_lds = (size_t)p.G * 4 + (size_t)((s->n + 1) / 2 * 2) * 2;
+    if (p.G > MPC_KNN_LDS_SORT_CELLS || sort_lds > 150 * 1024) {
         int *cursor = (int *)((char *)ws + L.off_knn_cursor);
         hipError_t e = hipMemsetAsync(cursor, 0, (size_t)s->B * s->nb * p.G * sizeof(int), st);
         if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
@@ -1022,9 +1039,9 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
     } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
+        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx);
     else
-        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb), dim3(1024), (size_t)p.G * 4, st, p, traj, cell_start, spos, sidx);
+        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;

@@ -525,6 +525,30 @@ def test_hd_sensor_1280x720_large_lut_grid():
     assert abs(float(misc['iwes'].sum()) - 0.0) > 1.0
 
 
+def test_loss_and_gradient_are_bitwise_reproducible():
+    """Run to run, on the same inputs: LUT, IWEs, loss and the gradient are identical bit for bit (integer
+    LDS accumulation in the event path, index-ordered buckets in the KNN, no floating-point atomics)."""
+    from oracle import focus_oracle as O
+    dev = _dev()
+    B, M, nb = 2, 60000, 15
+    ev, num_pos, _ = _full_size_inputs(B=B, M=M, nb=nb, seed=13)
+    coeff = torch.randn(B, 1, 6, 480, 640, generator=torch.Generator().manual_seed(14))
+    times = torch.cat((torch.tensor([0.41]), O.bin_mid_times(nb)))
+    traj = O.trajectories_at(coeff, times, O.tile_mask((480, 640), 4), 3, 'polynomial')
+    L = _loss_obj(dict(image_shape=(480, 640), num_tref=1, num_bins=nb, num_knn=32, smooth_weight=0.003,
+                       lut_superpixel_size=4, focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True,
+                       mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+                       smooth_type='on_flow_to_tref'))
+    outs = []
+    for _ in range(3):
+        t = traj.to(dev).requires_grad_(True)
+        loss, _, misc = L.calc(t, times.to(dev), {'events': ev.to(dev), 'num_pos_events': num_pos})
+        loss.backward()
+        outs.append((loss.detach().clone(), misc['iwes'].clone(), t.grad.clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
 def test_contrast_maximisation_recovers_a_known_flow():
     """Beyond parity: optimising a constant flow with the loss' own gradient (Adam, from zero) collapses
     the events of points moving at (6, -9) px per window back onto the points: the recovered flow is the
