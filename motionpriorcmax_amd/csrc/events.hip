@@ -206,12 +206,43 @@ __device__ __forceinline__ int xcd_swizzle(int p, int n) {
     return (p & 7) * per + (p >> 3);
 }
 
+#define EV_STAGE 1152      // records of one workgroup laid out in LDS before they are written (>= 2.25 per event)
+
+// one record into slot `slot` of local bucket `lb` (forward buckets first, then backward ones), or into the
+// spill list of its kind when the bucket is full
+__device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, int b, int nf_loc, int lb, int slot,
+                                        float4 rec) {
+    if (lb < nf_loc) {
+        const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
+        if (slot < L.fcap) L.frec[(size_t)g * L.fcap + slot] = rec;
+        else {
+            // spill: the strip id rides in the sign-free high bits of the image id
+            const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 0], 1);
+            rec.w = __int_as_float(((lb % L.NS) << 20) | __float_as_int(rec.w));
+            L.fovf[ov] = rec;
+        }
+    } else {
+        const int gb = b * p.nb * L.NCS + (lb - nf_loc);
+        if (slot < L.bcap) L.brec[(size_t)gb * L.bcap + slot] = rec;
+        else {
+            // spill: the record carries the cell offset inside its LUT strip; the list wants the LUT index
+            const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 1], 1);
+            const unsigned aux = __float_as_uint(rec.w);
+            const int it = (lb - nf_loc) / L.NCS, cst = (lb - nf_loc) - it * L.NCS;
+            const unsigned lutidx = (unsigned)((b * p.nb + it) * (p.hq * p.wq) + cst * L.CSR * p.wq) + (aux & 0x7fffffffu);
+            rec.w = __uint_as_float((aux & 0x80000000u) | lutidx);
+            L.bovf[ov] = rec;
+        }
+    }
+}
+
 // grid (ceil(ceil(M / (256*EV_PER_THREAD)) * B / 8) * 8), 256 threads, dynamic LDS = (P*NS + nb*NCS) * 2 ints
 __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayout L,
                                                 const float *__restrict__ events,
                                                 const float *__restrict__ lut,
                                                 const float *__restrict__ t_ref, int want_bwd) {
-    extern __shared__ int s_cnt[];          // [nloc] local counts, then [nloc] global bases
+    extern __shared__ int s_cnt[];          // [nloc] local counts, [nloc] global bases, [nloc+1] local offsets, ids, records
+    __shared__ int s_wsum[4];
     const EvParams p = make_params(s);
     const int chunks = (p.M + 256 * EV_PER_THREAD - 1) / (256 * EV_PER_THREAD);
     const int lblk = xcd_swizzle(blockIdx.x, chunks * p.B);
@@ -219,6 +250,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     const int tid = threadIdx.x, b = lblk / chunks, chunk = lblk - b * chunks;
     const int nf_loc = p.P * L.NS, nb_loc = want_bwd ? p.nb * L.NCS : 0, nloc = nf_loc + nb_loc;
     int *s_base = s_cnt + nloc;
+    const int stage_off = ((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3;     // in ints; 16-byte aligned record area
     for (int i = tid; i < nloc; i += 256) s_cnt[i] = 0;
     __syncthreads();
     const float tref = (p.flags & MPC_F_SCALE_BY_DT) ? t_ref[0] : 0.f;
@@ -228,13 +260,12 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     int f0[EV_PER_THREAD], f1[EV_PER_THREAD], bk[EV_PER_THREAD];     // local bucket ids (-1: none)
     int r0[EV_PER_THREAD], r1[EV_PER_THREAD], rb[EV_PER_THREAD];     // ranks inside the block
     unsigned aux[EV_PER_THREAD];
-    int lutidx[EV_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
         const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
         f0[k] = f1[k] = bk[k] = -1;
         r0[k] = r1[k] = rb[k] = 0;
-        ry[k] = rx[k] = rw[k] = 0.f; aux[k] = 0u; lutidx[k] = 0;
+        ry[k] = rx[k] = rw[k] = 0.f; aux[k] = 0u;
         if (i >= p.M) continue;
         float e[6];
         load_event(events, (size_t)b * p.M + i, e);
@@ -255,7 +286,6 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
             bk[k] = nf_loc + o.it * L.NCS + cst;
             rb[k] = atomicAdd(&s_cnt[bk[k]], 1);
             aux[k] = ((unsigned)pol << 31) | (unsigned)((o.iy - cst * L.CSR) * p.wq + o.ix);
-            lutidx[k] = o.lut;
         }
     }
     __syncthreads();
@@ -267,10 +297,32 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
         else g = L.NF + b * p.nb * L.NCS + (i - nf_loc);
         s_base[i] = c > 0 ? atomicAdd(&L.gcount[g], c) : 0;
     }
+    // Local exclusive prefix of the counts: the records are first laid out in LDS bucket by bucket and then
+    // written out in that order, so that neighbouring lanes store to neighbouring slots of the same bucket
+    // (a 64-lane store touches a few runs of 16-byte records instead of 64 separate cache lines; the kernel
+    // was bound by the issue of scattered stores: SQ_WAIT_INST_ANY 46 % of the wave cycles).
+    int *s_loc = s_base + nloc;                              // [nloc + 1]
+    unsigned short *s_bid = reinterpret_cast<unsigned short *>(s_loc + nloc + 1);     // [EV_STAGE]
+    float4 *s_rec = reinterpret_cast<float4 *>(s_cnt + stage_off);                     // [EV_STAGE]
+    {
+        const int per = (nloc + 255) >> 8;
+        const int i0 = min(tid * per, nloc), i1 = min(i0 + per, nloc);
+        int local = 0;
+        for (int i = i0; i < i1; ++i) local += s_cnt[i];
+        int incl = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += v; }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        int run = incl - local;
+        for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
+        for (int i = i0; i < i1; ++i) { s_loc[i] = run; run += s_cnt[i]; }
+        if (tid == 255) s_loc[nloc] = run;
+    }
     __syncthreads();
+    const int total = s_loc[nloc];
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
-        const int pol = (int)(aux[k] >> 31);
         if (f0[k] >= 0 || f1[k] >= 0) {
             const int polf = (f0[k] >= 0 ? f0[k] : f1[k]) / L.NS;
             const float4 rec = make_float4(ry[k], rx[k], rw[k], __int_as_float(b * p.P + polf));
@@ -278,25 +330,22 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
             for (int h = 0; h < 2; ++h) {
                 const int lb = h ? f1[k] : f0[k];
                 if (lb < 0) continue;
-                const int slot = s_base[lb] + (h ? r1[k] : r0[k]);
-                const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
-                if (slot < L.fcap) L.frec[(size_t)g * L.fcap + slot] = rec;
-                else {
-                    // spill: the strip id rides in the sign-free high bits of the image id
-                    const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 0], 1);
-                    L.fovf[ov] = make_float4(ry[k], rx[k], rw[k], __int_as_float(((lb % L.NS) << 20) | (b * p.P + polf)));
-                }
+                const int at = s_loc[lb] + (h ? r1[k] : r0[k]);
+                if (at < EV_STAGE) { s_rec[at] = rec; s_bid[at] = (unsigned short)lb; }
+                else ev_emit(p, L, b, nf_loc, lb, s_base[lb] + (h ? r1[k] : r0[k]), rec);
             }
         }
         if (bk[k] >= 0) {
-            const int slot = s_base[bk[k]] + rb[k];
-            const int g = L.NF + b * p.nb * L.NCS + (bk[k] - nf_loc);
-            if (slot < L.bcap) L.brec[(size_t)(g - L.NF) * L.bcap + slot] = make_float4(ry[k], rx[k], rw[k], __uint_as_float(aux[k]));
-            else {
-                const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 1], 1);
-                L.bovf[ov] = make_float4(ry[k], rx[k], rw[k], __uint_as_float(((unsigned)pol << 31) | (unsigned)lutidx[k]));
-            }
+            const float4 rec = make_float4(ry[k], rx[k], rw[k], __uint_as_float(aux[k]));
+            const int at = s_loc[bk[k]] + rb[k];
+            if (at < EV_STAGE) { s_rec[at] = rec; s_bid[at] = (unsigned short)bk[k]; }
+            else ev_emit(p, L, b, nf_loc, bk[k], s_base[bk[k]] + rb[k], rec);
         }
+    }
+    __syncthreads();
+    for (int r = tid; r < min(total, EV_STAGE); r += 256) {
+        const int lb = s_bid[r];
+        ev_emit(p, L, b, nf_loc, lb, s_base[lb] + (r - s_loc[lb]), s_rec[r]);
     }
     if (want_bwd && lblk == 0 && tid == 0) L.gcount[L.NF + L.NBk + 2] = EV_MARKER;
 }
@@ -500,7 +549,8 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
         if (s->B > 0 && s->M > 0) {
             const int nblk = mpc_cdiv(s->M, 256 * EV_PER_THREAD) * s->B;
             const dim3 grid(((nblk + 7) / 8) * 8);
-            const size_t lds = (size_t)(L.P * L.n_strips + s->nb * L.n_cstrips) * 2 * sizeof(int);
+            const int nloc = L.P * L.n_strips + s->nb * L.n_cstrips;
+            const size_t lds = (size_t)(((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3) * sizeof(int) + (size_t)EV_STAGE * 16;
             hipLaunchKernelGGL(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);
             MPC_CHECK_LAUNCH();
         }
