@@ -337,11 +337,11 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             if (js >= je) continue;
             float2 q[KNN_BATCH];
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(min(js + u, je - 1));
+            for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(js + u);      // reads past the row are masked below
             for (int j = js; j < je; j += KNN_BATCH) {
                 float2 nq[KNN_BATCH];
 #pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) nq[u] = A.pos(min(j + KNN_BATCH + u, je - 1));
+                for (int u = 0; u < KNN_BATCH; ++u) nq[u] = A.pos(j + KNN_BATCH + u);
 #pragma unroll
                 for (int u = 0; u < KNN_BATCH; ++u) {
                     // predicated, not branched: an out-of-range candidate adds 0 (the kernel is bound by
@@ -349,7 +349,9 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                     const float d = pair_dist(qy, qx, q[u].x, q[u].y, L1);
                     const int in = (j + u < je) & (d < upper);
                     const int bin = min((int)(d * scale), KNN_BINS - 1);     // d < upper <= FLT_MAX wherever `in` holds
-                    atomicAdd(&s_hist[bin >> 2][tid], in ? (1u << ((bin << 3) & 31)) : 0u);   // private column
+                    // word (bin >> 2) of the private column: byte offset (bin & 0x1c) * NT, one AND + one shift-add
+                    unsigned *hw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(&s_hist[0][tid]) + (bin & 0x1c) * NT);
+                    atomicAdd(hw, in ? (1u << ((bin << 3) & 31)) : 0u);
                     cnt += in;
                 }
 #pragma unroll
@@ -403,11 +405,11 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
         if (js >= je) continue;
         float2 qq[KNN_BATCH];
 #pragma unroll
-        for (int u = 0; u < KNN_BATCH; ++u) qq[u] = A.pos(min(js + u, je - 1));
+        for (int u = 0; u < KNN_BATCH; ++u) qq[u] = A.pos(js + u);
         for (int j0 = js; j0 < je; j0 += KNN_BATCH) {
             float2 cur[KNN_BATCH];
 #pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) { cur[u] = qq[u]; qq[u] = A.pos(min(j0 + KNN_BATCH + u, je - 1)); }
+            for (int u = 0; u < KNN_BATCH; ++u) { cur[u] = qq[u]; qq[u] = A.pos(j0 + KNN_BATCH + u); }
 #pragma unroll
             for (int u = 0; u < KNN_BATCH; ++u) {
                 const int j = j0 + u;
