@@ -186,8 +186,10 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='C3', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-grad-allreduce', action='store_true',
-                    help='N>1: skip the overlapped 124 MB network-gradient all-reduce')
+    ap.add_argument('--grad-allreduce', action='store_true',
+                    help='N>1: put the overlapped 124 MB network-gradient all-reduce inside the main timed loop '
+                         '(default: the loss path alone is timed -- it has no data-path collective -- and the '
+                         'variant with the all-reduce is timed in a second loop and reported beside it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--also', default='C2,C4', help='extra workloads reported in the "also" field (N=1 only)')
     args = ap.parse_args()
@@ -206,7 +208,7 @@ def main():
 
     from motionpriorcmax_amd import LossFactory, ops, dp
 
-    def run_workload(name, steps, warmup, with_comm):
+    def run_workload(name, steps, warmup, with_comm, instrument=True):
         wl = WORKLOADS[name]
         ev, num_pos, traj, times = synth_inputs(wl, seed=1000 * rank + 1)
         L = LossFactory.get_loss_calculator('FOCUS', loss_config(wl))
@@ -225,34 +227,52 @@ def main():
                 reducer.start()      # this step's network gradient; overlaps the next step's loss
             return loss
 
+        # set-up, not part of the W warm-up steps: bring the caching allocator to its steady state (the
+        # per-step workspaces are first hipMalloc'ed over several steps) and the device out of its idle clocks
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
         for _ in range(warmup):
             step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            last = step()
-        if reducer is not None:
-            reducer.wait()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
+        # EXACTLY `steps` steps per timed block, each block bracketed by barrier + synchronize and reduced with
+        # MAX over ranks; three consecutive blocks, the MEDIAN one is reported (a fresh box showed one-off host
+        # stalls of ~15 ms that land in one block); all block times go into the JSON line
+        blocks = []
+        for _ in range(3):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                last = step()
+            if reducer is not None:
+                reducer.wait()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            blocks.append(dp.max_over_ranks(time.perf_counter() - t0, dev))
+        dt = sorted(blocks)[1]
         total_valid = dp.sum_over_ranks(valid_local, dev)
 
         # instrumented pass: HIP events around every C-ABI call, on the stream they launch on
-        ops.STAGE_TIMER = ops.StageTimer()
-        for _ in range(steps):
-            loss, _, _ = L.calc(trajd, times_d, batch)
-            loss.backward()
-            trajd.grad = None
-        stages = ops.STAGE_TIMER.summary()
-        ops.STAGE_TIMER = None
-        return dict(wl=wl, dt=dt, steps=steps, total_valid=total_valid, stages=stages,
+        stages = {}
+        if instrument:
+            ops.STAGE_TIMER = ops.StageTimer()
+            for _ in range(steps):
+                loss, _, _ = L.calc(trajd, times_d, batch)
+                loss.backward()
+                trajd.grad = None
+            stages = ops.STAGE_TIMER.summary()
+            ops.STAGE_TIMER = None
+        return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages,
                     loss=float(last.item()), n=traj.shape[2])
 
-    r = run_workload(args.workload, args.steps, args.warmup, not args.no_grad_allreduce)
+    r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
+    r_comm = None
+    if world > 1 and not args.grad_allreduce:
+        # the data-parallel training step's one real exchange: the same steps with the averaged
+        # network gradient (UNet-sized, 124 MB fp32) all-reduced over RCCL on a side stream, overlapping the next loss
+        r_comm = run_workload(args.workload, args.steps, args.warmup, True, instrument=False)
     wl = r['wl']
     ms_per_step = 1e3 * r['dt'] / r['steps']
     value = r['total_valid'] * r['steps'] / r['dt'] / 1e6
@@ -293,16 +313,22 @@ def main():
     out = {
         'metric': 'Mevents/s through CMax loss fwd+bwd, DSEC 480x640',
         'value': round(value, 3), 'unit': 'Mevents/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'blocks_ms_per_step': [round(1e3 * x / r['steps'], 4) for x in r['blocks']], 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f"{args.workload}: {wl['desc']}", 'batch_per_gpu': wl['B'],
                    'global_batch': wl['B'] * world, 'events_per_sample': wl['M'], 'num_bins': wl['nb'],
                    'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
-                   'grad_allreduce_MB': 0 if (world == 1 or args.no_grad_allreduce)
-                   else round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2)},
+                   'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
         'loss': r['loss'],
         'roofline': roofline_of(r, args.workload),
     }
+    if r_comm is not None:
+        out['dp_with_grad_allreduce'] = {
+            'value': round(r_comm['total_valid'] * r_comm['steps'] / r_comm['dt'] / 1e6, 3), 'unit': 'Mevents/s',
+            'ms_per_step': round(1e3 * r_comm['dt'] / r_comm['steps'], 4),
+            'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2),
+            'note': 'same steps with the 124 MB network-gradient all-reduce (RCCL, 4 buckets, side stream) overlapping the next loss'}
     if rank == 0 and world == 1:
         also = {}
         for name in [a for a in args.also.split(',') if a and a != args.workload]:
