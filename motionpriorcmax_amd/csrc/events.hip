@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
                                                 const float *__restrict__ events,
                                                 const float *__restrict__ lut,
                                                 const float *__restrict__ t_ref, int want_bwd) {
-    extern __shared__ int s_cnt[];          // [nloc] local counts, [nloc] global bases, [nloc+1] local offsets, ids, records
+    extern __shared__ __align__(16) int s_cnt[];          // [nloc] local counts, [nloc] global bases, [nloc+1] local offsets, ids, records
     __shared__ int s_wsum[4];
     const EvParams p = make_params(s);
     const int chunks = (p.M + 256 * EV_PER_THREAD - 1) / (256 * EV_PER_THREAD);

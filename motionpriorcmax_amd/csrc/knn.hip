@@ -594,7 +594,7 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
                                                    int *__restrict__ idx_out,
                                                    float *__restrict__ tile_dkmax, int r_init, int RH,
                                                    int cap, int stage_flow, int gx, int gy) {
-    extern __shared__ unsigned char s_dyn[];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ float s_maxf[NT / 64];
     __shared__ int s_rowbase[64 + 1];   // RW <= 48
     __shared__ int s_rowg[64];
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
                                                             float2 *__restrict__ tmp_a,   // [B*nb][n]
                                                             int gx, int gy) {
     constexpr int NT = TS * TS, SUB = TS / 16;
-    extern __shared__ unsigned char s_dyn[];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_rowbase[TS + 1];
     __shared__ int s_rowg[TS];
     __shared__ float s_Rsub[SUB * SUB];
