@@ -27,12 +27,3 @@ for it in range(8):
     gt = ops.knn_lut_bwd(shape, trajd, g, gn, state, ws)
     torch.cuda.synchronize(); t3 = time.perf_counter()
     print(f'fwd {1e6*(t1-t0):.0f} us  bwd {1e6*(t3-t2):.0f} us')
-lay_off = None
-# counters live at off_counts: find by scanning is not possible from python; re-derive: they are the first
-# 8 int32 after the two partial-sum regions.  Expose through a tiny helper instead:
-n_c = ((640 + 63) // 64) * ((480 + 31) // 32) * (B * 2)
-n_s = ((160 + 15) // 16) * ((120 + 15) // 16) * B * wl['nb'] * 2
-al = lambda x: (x + 255) // 256 * 256
-off = al(n_c * 16) + al(n_s * 16)
-print('dbg [fallback queries, unstaged tiles, list overflows, not found]:', ws[off:off + 32].view(torch.int32).tolist()[:4],
-      'of', B * wl['nb'] * 19200, 'queries')
