@@ -55,44 +55,61 @@ __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float p
 // ------------------------------------------------------------------------------------------
 // bucket the points of one (sample, bin) by cell: counting sort in LDS.  With CACHED, every thread
 // keeps the cells of its (up to KNN_BUCKET_NPT) points in registers: one round of global-load latency for the
-// whole kernel instead of one per point and pass (the kernel has only B*nb workgroups, so it is
-// latency- not bandwidth-limited).  A segmented multi-workgroup variant measured slower (66 vs 48 us).
-// grid B*nb, 1024 threads, dynamic LDS = G * 4 + n * 2 bytes
+// whole kernel instead of one per point and pass.  The kernel is latency- not bandwidth-limited, so the cell
+// rows of a (sample, bin) are split over S workgroups: each reads all n points, counts those below its row
+// range (its base offset in the bucketed arrays) and sorts the ones inside it -- no exchange between them.
+// grid B*nb*S, 1024 threads, dynamic LDS = ceil(hq/S)*wq * 4 + n * 2 bytes
 // ------------------------------------------------------------------------------------------
 #define KNN_BUCKET_NPT 24
 template <bool CACHED>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start,
-                                                     float2 *__restrict__ spos, int *__restrict__ sidx) {
+                                                     float2 *__restrict__ spos, int *__restrict__ sidx, int S) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
+    __shared__ int s_low[16];
     const int tid = threadIdx.x;
-    const int bt = blockIdx.x, b = bt / p.nb, t = bt - b * p.nb;
+    const int bt = blockIdx.x / S, part = blockIdx.x - bt * S, b = bt / p.nb, t = bt - b * p.nb;
+    const int rows_per = (p.hq + S - 1) / S;
+    const int g_lo = min(part * rows_per, p.hq) * p.wq, g_hi = min((part + 1) * rows_per, p.hq) * p.wq, Gp = g_hi - g_lo;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
     int qc[CACHED ? KNN_BUCKET_NPT : 1];
+    int below = 0;                                  // points of this thread in cells before the range
     if (CACHED) {
         float2 q[KNN_BUCKET_NPT];
 #pragma unroll
         for (int u = 0; u < KNN_BUCKET_NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u) qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
+            qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
+            if (tid + u * 1024 >= p.n) qc[u] = 0x7fffffff;          // not a point
+            below += qc[u] < g_lo;
+        }
     }
-    for (int g = tid; g < p.G; g += 1024) s_cnt[g] = 0;
+    for (int g = tid; g < Gp; g += 1024) s_cnt[g] = 0;
     __syncthreads();
     if (CACHED) {
 #pragma unroll
         for (int u = 0; u < KNN_BUCKET_NPT; ++u)
-            if (tid + u * 1024 < p.n) atomicAdd(&s_cnt[qc[u]], 1);
+            if (qc[u] >= g_lo && qc[u] < g_hi) atomicAdd(&s_cnt[qc[u] - g_lo], 1);
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
-            atomicAdd(&s_cnt[cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+            const int c = cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq);
+            below += c < g_lo;
+            if (c >= g_lo && c < g_hi) atomicAdd(&s_cnt[c - g_lo], 1);
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_down(below, o, 64);
+    if ((tid & 63) == 0) s_low[tid >> 6] = below;
     __syncthreads();
-    // exclusive scan over the G counters: each thread owns a contiguous chunk
-    const int chunk = (p.G + 1023) / 1024;
-    const int g0 = min(tid * chunk, p.G), g1 = min(g0 + chunk, p.G);
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) base += s_low[w];
+    // exclusive scan over the Gp counters: each thread owns a contiguous chunk
+    const int chunk = (Gp + 1023) / 1024;
+    const int g0 = min(tid * chunk, Gp), g1 = min(g0 + chunk, Gp);
     int local = 0;
     for (int g = g0; g < g1; ++g) local += s_cnt[g];
     int incl = local;
@@ -108,35 +125,34 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     int run = wave_off + incl - local;
     for (int g = g0; g < g1; ++g) {
         const int c = s_cnt[g];
-        s_cnt[g] = run;        // becomes the fill cursor of the cell
+        s_cnt[g] = run;        // becomes the fill cursor of the cell (local to the range)
         run += c;
     }
     __syncthreads();
     int *cs = cell_start + (size_t)bt * (p.G + 1);
-    for (int g = tid; g < p.G; g += 1024) cs[g] = s_cnt[g];      // coalesced
-    if (tid == 0) cs[p.G] = p.n;
+    for (int g = tid; g < Gp; g += 1024) cs[g_lo + g] = base + s_cnt[g];      // coalesced
+    if (tid == 0 && part == S - 1) cs[p.G] = p.n;
     __syncthreads();
-    float2 *sp_ = spos + (size_t)bt * p.n;
-    int *si_ = sidx + (size_t)bt * p.n;
+    float2 *sp_ = spos + (size_t)bt * p.n + base;
+    int *si_ = sidx + (size_t)bt * p.n + base;
     // scatter the INDICES into LDS first: the slots inside a cell are handed out in the order the LDS atomics
     // happen to execute, so the (few) points of every cell are then ordered by trajectory index -- the bucket
     // order, and with it the fp32 summation order of the LUT, is the same in every run -- and only then are
     // the bucketed arrays written, with coalesced stores and the positions gathered by index.
-    unsigned short *l_idx = reinterpret_cast<unsigned short *>(s_cnt + p.G);
+    unsigned short *l_idx = reinterpret_cast<unsigned short *>(s_cnt + Gp);
     if (CACHED) {
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
-            const int i = tid + u * 1024;
-            if (i < p.n) l_idx[atomicAdd(&s_cnt[qc[u]], 1)] = (unsigned short)i;
-        }
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u)
+            if (qc[u] >= g_lo && qc[u] < g_hi) l_idx[atomicAdd(&s_cnt[qc[u] - g_lo], 1)] = (unsigned short)(tid + u * 1024);
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
-            l_idx[atomicAdd(&s_cnt[cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1)] = (unsigned short)i;
+            const int c = cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq);
+            if (c >= g_lo && c < g_hi) l_idx[atomicAdd(&s_cnt[c - g_lo], 1)] = (unsigned short)i;
         }
     }
     __syncthreads();
-    for (int g = tid; g < p.G; g += 1024) {          // s_cnt[g] is now the END of cell g
+    for (int g = tid; g < Gp; g += 1024) {          // s_cnt[g] is now the END of cell g
         const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0;
         for (int i = a + 1; i < e; ++i) {
             const unsigned short key = l_idx[i];
@@ -146,7 +162,8 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         }
     }
     __syncthreads();
-    for (int sl = tid; sl < p.n; sl += 1024) {
+    const int own = Gp > 0 ? s_cnt[Gp - 1] : 0;
+    for (int sl = tid; sl < own; sl += 1024) {
         const int i = l_idx[sl];
         si_[sl] = i;
         sp_[sl] = pts[i];
@@ -1030,7 +1047,14 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
         attr_set = true;
     }
-    const size_t sort_lds = (size_t)p.G * 4 + (size_t)((s->n + 1) / 2 * 2) * 2;
+    // workgroups per (sample, bin) of the LDS sort: as many as keep the launch within one workgroup per CU
+    // (measured at C3: 210 workgroups 39 us, split three ways 68 us; at B = 1: 15 workgroups 33 us, split
+    // eight ways 19 us)
+    int S = 256 / (s->B * s->nb);
+    if (S > 8) S = 8;
+    if (S > s->hq) S = s->hq;
+    if (S < 1) S = 1;
+    const size_t sort_lds = (size_t)((s->hq + S - 1) / S) * s->wq * 4 + (size_t)((s->n + 1) / 2 * 2) * 2;
     if (p.G > MPC_KNN_LDS_SORT_CELLS || sort_lds > 150 * 1024) {
         int *cursor = (int *)((char *)ws + L.off_knn_cursor);
         hipError_t e = hipMemsetAsync(cursor, 0, (size_t)s->B * s->nb * p.G * sizeof(int), st);
@@ -1041,9 +1065,9 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
     } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx);
+        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S);
     else
-        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx);
+        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
