@@ -265,7 +265,7 @@ struct QueryCtx {
     const unsigned short *lidx;  // trajectory index (n < 65536)
     const float2 *lf0;      // flow to t_ref (T == 1 and staged), else null
     const float2 *lf1;      // flow to the next bin (want_next only)
-    int ry0, rx0, RW, RH;
+    int ry0, rx0, RW, RWY, RH;   // staged region: cell rows [ry0, ry0+RWY), columns [rx0, rx0+RW); RH = halo
 };
 
 template <bool LDS>
@@ -321,9 +321,12 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     float upper, scale;
     bool whole;
     for (;;) {
-        if (LDS && r > c.RH) return false;
         y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
         x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
+        // the LDS variant serves any square that lies inside the staged region: next to the image border a
+        // grown square is wider than the halo but, clipped, still inside the tile (otherwise such queries finish
+        // on the global arrays, one dependent L2 round trip per step: the tail of small launches)
+        if (LDS && (y0 < c.ry0 || y1 >= c.ry0 + c.RWY || x0 < c.rx0 || x1 >= c.rx0 + c.RW)) return false;
         whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
         if (whole) {
             if (LDS) return false;
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
     c.sidx = sidx + (size_t)bt * p.n;
     c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     c.lcs = lcs; c.lpos = lpos; c.lidx = lidx; c.lf0 = lf0; c.lf1 = lf1;
-    c.RW = RW; c.RH = RH;
+    c.RW = RW; c.RWY = RWY; c.RH = RH;
     c.ry0 = by_ * TY - RH;
     c.rx0 = bx_ * 16 - RH;
 
