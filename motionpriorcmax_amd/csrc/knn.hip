@@ -505,8 +505,49 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
                 if (rank == need - 1) { dK = da; iK = ia; }
             }
         }
+    } else if (m <= 2 * KNN_LIST) {
+        // The bin holds more keys than the packed list (a tight cluster; one workgroup in a thousand at C3, but
+        // it used to cost `need` + 1 further scans and was the tail of small launches): collect the slots once
+        // more as 16-bit entries in the same column, then rank them by (distance, index) as above.
+        int mm = 0;
+        for (int yy = y0; yy <= y1; ++yy) {
+            int js, je;
+            A.range(yy, x0, x1, js, je);
+            for (int j = js; j < je; ++j) {
+                const float2 pj = A.pos(j);
+                const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                if (!(d < upper)) continue;
+                const float ds = d * scale;
+                if (ds < fb || !(ds < fb1)) continue;
+                reinterpret_cast<unsigned short *>(&s_hist[mm >> 1][tid])[mm & 1] = (unsigned short)j;
+                ++mm;
+            }
+        }
+        for (int a = 0; a < mm; ++a) {
+            const int ja = (int)reinterpret_cast<const unsigned short *>(&s_hist[a >> 1][tid])[a & 1];
+            const int ia = A.idx(ja);
+            const float2 pj = A.pos(ja);
+            const float da = pair_dist(qy, qx, pj.x, pj.y, L1);
+            int rank = 0;
+            for (int e = 0; e < mm; ++e) {
+                const int je = (int)reinterpret_cast<const unsigned short *>(&s_hist[e >> 1][tid])[e & 1];
+                const float2 pe = A.pos(je);
+                const float de = pair_dist(qy, qx, pe.x, pe.y, L1);
+                rank += (de < da || (de == da && A.idx(je) < ia)) ? 1 : 0;
+            }
+            if (rank < need) {
+                if (fuse) {
+                    const float2 f = A.flow_ref(ja, 0, pj);
+                    if (p.iwd) { const float w = 1.f / (da + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
+                    else { sy += f.x; sx += f.y; }
+                    if (do_next0) { const float2 g = A.flow_next(ja, pj); ny += g.x; nx += g.y; }
+                }
+                if (rank == need - 1) { dK = da; iK = ia; }
+            }
+        }
+        listed = true;
     } else {
-        // more keys in the bin than the list holds (heavy ties): select by repeated minimum
+        // far more keys in the bin than any list holds (heavy ties): select by repeated minimum
         float ld = -1.f; int li = -1;
         for (int it = 0; it < need; ++it) {
             float bd = INFINITY; int bi = 0x7fffffff;

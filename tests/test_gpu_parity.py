@@ -357,6 +357,44 @@ def test_knn_degenerate_point_sets():
     np.testing.assert_allclose(got, ref, atol=5e-4)      # flows are O(500): 1e-6 relative
 
 
+@pytest.mark.parametrize('ring', [12, 40])
+def test_knn_many_keys_in_the_kth_bin(ring):
+    """A thin annulus of `ring` points around one query with the K-th neighbour inside it: more keys in the
+    histogram bin of the K-th smallest than the packed 8-entry list holds.  12 -> the 16-entry re-collection
+    path, 40 -> selection by repeated minimum.  Checked against brute force over the whole LUT, forward and
+    (through the saved K-th keys) backward."""
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    shape, sp, K = (64, 96), 4, 26
+    g = torch.Generator().manual_seed(50 + ring)
+    base = O.tile_mask(shape, 4).nonzero().float()                      # 384 lattice points
+    q0 = torch.tensor([8 * sp + sp / 2 - 0.5, 12 * sp + sp / 2 - 0.5])  # centre of LUT cell (8, 12)
+    near = q0 + (torch.rand(20, 2, generator=g) - 0.5)                  # 20 points within 0.7 px
+    ang = torch.rand(ring, generator=g) * 6.2831853
+    rad = 9.0 + (torch.rand(ring, generator=g) - 0.5) * 0.02            # d^2 in 81 +- 0.2: one bin
+    annulus = q0 + torch.stack((rad * torch.sin(ang), rad * torch.cos(ang)), -1)
+    far = base[((base - q0).norm(dim=1) > 14.0)]                        # lattice elsewhere
+    pts = torch.cat((near, annulus, far))
+    n = pts.shape[0]
+    traj = torch.zeros(1, 2, n, 2)
+    traj[0, 1] = pts
+    traj[0, 0] = pts + torch.randn(n, 2, generator=g) * 3.0
+    got, ref = _knn_vs_bruteforce(traj, shape, sp, K)
+    np.testing.assert_allclose(got, ref, atol=2e-5)
+    # backward through the same neighbour sets
+    L = _loss_obj(dict(image_shape=shape, num_tref=1, num_bins=1, num_knn=K, smooth_weight=0.0, lut_superpixel_size=sp,
+                       focus_loss_norm='l1', dist_norm='l2', scale_iwe_by_dt=True, mask_image_border=True,
+                       polarity_aware_batching=True, interpolation_scheme='mean', smooth_type='on_flow_to_tref'))
+    t = traj.to(_dev()).requires_grad_(True)
+    lut, _ = ops.KnnLutFn.apply(t, L._cfg)
+    gl = torch.randn(lut.shape, generator=g).to(_dev())
+    lut.backward(gl)
+    tr = traj.clone().requires_grad_(True)
+    lref, _ = O.interpolate_flow(tr[:, :1], tr[:, 1:], shape, sp, K, 'l2', 'mean')
+    lref.backward(gl.cpu())
+    assert _rel_l2(t.grad.cpu().numpy(), tr.grad.numpy()) < 1e-5
+
+
 def test_cpu_tensors_fail_loudly():
     g = load_golden('g3_squeeze_k1')
     L = _loss_obj(g['cfg'])
