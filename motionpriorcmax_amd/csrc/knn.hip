@@ -1043,12 +1043,13 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_NT=256|512      query workgroup size (16x16 or 16x32 queries)                     [by occupancy]
 //   MPC_KNN_R0=<d>          offset of the initial search radius                               [0]
 //   MPC_KNN_BWD_TS=16|32    tile side of the backward gather                                  [16]
+//   MPC_KNN_HALO=<h>        rings staged beyond the initial radius by the query kernel        [1]
 struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts;
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -1056,6 +1057,7 @@ static const KnnTuning &knn_tuning() {
         if ((e = getenv("MPC_KNN_NT"))) v.nt = atoi(e);
         if ((e = getenv("MPC_KNN_R0"))) v.r0 = atoi(e);
         if ((e = getenv("MPC_KNN_BWD_TS"))) v.bwd_ts = atoi(e) == 32 ? 32 : 16;
+        if ((e = getenv("MPC_KNN_HALO"))) v.halo = atoi(e);
         return v;
     }();
     return t;
@@ -1120,7 +1122,7 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     r_init += tune.r0;
     if (r_init < 1) r_init = 1;
     const int want_blocks = tune.blocks, want_nt = tune.nt;
-    int RH = r_init + 1;
+    int RH = r_init + (tune.halo > 0 ? tune.halo : 1);     // halo of the staged region: one ring of slack by default
     if (RH > 16) RH = 16;
     const int RW = 16 + 2 * RH;
     // LDS per workgroup decides how many wavefronts a CU holds, and the kernel is latency bound: measured at
