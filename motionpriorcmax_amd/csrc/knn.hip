@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void k_knn_reach(const KnnParams p, const floa
 // measured at C3, 16x16 tiles 210 us of which only ~70 us is the window loop.
 // grid (ceil(wq/TS), ceil(hq/TS), B*nb), TS*TS threads, dynamic LDS
 // ------------------------------------------------------------------------------------------
-#define KNN_RQ_MAX 7
+#define KNN_RQ_MAX 9   // largest staged halo (cells); tiles whose reach needs more read the global arrays (7 -> 9: the 1 % of such tiles at C3 took 47 us each against 12, and were the whole duration of a B = 1 launch)
 template <int TS>
 __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, const int *__restrict__ cell_start,
                                                             const float2 *__restrict__ spos,
