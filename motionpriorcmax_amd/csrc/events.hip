@@ -408,19 +408,19 @@ __device__ __forceinline__ void record_grad(float y, float x, float w, const flo
     const int y0 = (int)fminf(fmaxf(y0f, -4.f), (float)H + 4.f), x0 = (int)fminf(fmaxf(x0f, -4.f), (float)W + 4.f);
     const bool r0 = y0 >= 0 && y0 < H, r1 = y0 + 1 >= 0 && y0 + 1 < H;
     const bool c0 = x0 >= 0 && x0 < W, c1 = x0 + 1 >= 0 && x0 + 1 < W;
-    float g00, g01, g10, g11;
-    if (c0 && c1) {
-        // the two taps of a row are adjacent: one 8-byte (4-byte aligned) gather per row instead of two
-        // 4-byte ones halves the number of cache sectors this kernel pulls through L2
-        const pair4 a = r0 ? *reinterpret_cast<const pair4 *>(g + (size_t)y0 * W + x0) : pair4{0.f, 0.f};
-        const pair4 b = r1 ? *reinterpret_cast<const pair4 *>(g + (size_t)(y0 + 1) * W + x0) : pair4{0.f, 0.f};
-        g00 = a.x; g01 = a.y; g10 = b.x; g11 = b.y;
-    } else {
-        g00 = (r0 && c0) ? g[(size_t)y0 * W + x0] : 0.f;
-        g10 = (r1 && c0) ? g[(size_t)(y0 + 1) * W + x0] : 0.f;
-        g01 = (r0 && c1) ? g[(size_t)y0 * W + x0 + 1] : 0.f;
-        g11 = (r1 && c1) ? g[(size_t)(y0 + 1) * W + x0 + 1] : 0.f;
-    }
+    // Branch-free: two unconditional 8-byte (4-byte aligned) gathers at clamped coordinates, the taps picked
+    // and masked afterwards.  With branches around the loads the compiler could not start the gathers of the
+    // four records a thread has in flight together: four dependent L2 round trips instead of one (measured:
+    // 13.7 us of the 16.5 us a workgroup of k_lut_accum lives).
+    const int xa = min(max(x0, 0), W - 2);
+    const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    const pair4 a = *reinterpret_cast<const pair4 *>(g + (size_t)ya * W + xa);
+    const pair4 b = *reinterpret_cast<const pair4 *>(g + (size_t)yb * W + xa);
+    const bool lo = (xa == x0);                 // column x0 is the first element of the pair
+    const float g00 = (r0 && c0) ? (lo ? a.x : a.y) : 0.f;
+    const float g01 = (r0 && c1) ? (lo ? a.y : a.x) : 0.f;
+    const float g10 = (r1 && c0) ? (lo ? b.x : b.y) : 0.f;
+    const float g11 = (r1 && c1) ? (lo ? b.y : b.x) : 0.f;
     gy = w * ((1.f - fx) * (g10 - g00) + fx * (g11 - g01));
     gx = w * ((1.f - fy) * (g01 - g00) + fy * (g11 - g10));
 }
