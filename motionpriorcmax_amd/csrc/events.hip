@@ -260,17 +260,29 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     int f0[EV_PER_THREAD], f1[EV_PER_THREAD], bk[EV_PER_THREAD];     // local bucket ids (-1: none)
     int r0[EV_PER_THREAD], r1[EV_PER_THREAD], rb[EV_PER_THREAD];     // ranks inside the block
     unsigned aux[EV_PER_THREAD];
+    // the rows of a thread are requested together, then their LUT gathers, and only then does the bucket logic
+    // (with its branches and LDS atomics) run: two dependent memory round trips per workgroup instead of four
+    float ev[EV_PER_THREAD][6];
+    Warped wo[EV_PER_THREAD];
+    bool live[EV_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < EV_PER_THREAD; ++k) {
+        const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
+        load_event(events, (size_t)b * p.M + min(i, p.M - 1), ev[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < EV_PER_THREAD; ++k) {
+        const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
+        live[k] = warp_event(p, ev[k], b, 0, lut, tref, wo[k]) && (i < p.M);
+    }
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
         const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
         f0[k] = f1[k] = bk[k] = -1;
         r0[k] = r1[k] = rb[k] = 0;
         ry[k] = rx[k] = rw[k] = 0.f; aux[k] = 0u;
-        if (i >= p.M) continue;
-        float e[6];
-        load_event(events, (size_t)b * p.M + i, e);
-        Warped o;
-        if (!warp_event(p, e, b, 0, lut, tref, o)) continue;
+        if (!live[k]) continue;
+        const Warped &o = wo[k];
         const bool xin = (o.x0 + 1 >= 0) && (o.x0 < p.W);
         const bool yin0 = o.y0 >= 0 && o.y0 < p.H, yin1 = o.y0 + 1 >= 0 && o.y0 + 1 < p.H;
         if (!xin || !(yin0 || yin1)) continue;            // no tap inside the image
