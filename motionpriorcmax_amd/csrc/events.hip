@@ -206,7 +206,9 @@ __device__ __forceinline__ int xcd_swizzle(int p, int n) {
     return (p & 7) * per + (p >> 3);
 }
 
+#ifndef EV_STAGE
 #define EV_STAGE 1152      // records of one workgroup laid out in LDS before they are written (>= 2.25 per event)
+#endif
 
 // one record into slot `slot` of local bucket `lb` (forward buckets first, then backward ones), or into the
 // spill list of its kind when the bucket is full
