@@ -78,7 +78,9 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     if (CACHED) {
         float2 q[KNN_BUCKET_NPT];
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : tid]; }
+        // (slots beyond n read point 0, which always exists: n >= K >= 1; reading pts[tid] there ran past the end
+        // of the trajectory tensor for the last (sample, bin) whenever n < 1024)
+        for (int u = 0; u < KNN_BUCKET_NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : 0]; }
 #pragma unroll
         for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
             qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
