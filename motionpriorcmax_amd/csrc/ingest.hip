@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void k_ingest_scan(const IngLayout L, int *__r
 __device__ __forceinline__ int bin_index(double tn, int nb) {
     // np.searchsorted(np.linspace(0, 1, nb + 1), tn, side='left') - 1, clipped at 0.
     // linspace: e_i = i * (1.0 / nb) in float64, e_nb = 1.0 exactly.
+    if (tn != tn) return nb;      // a window of one event: 0/0 time; numpy sorts NaN last (searchsorted -> nb + 1)
     const double step = 1.0 / (double)nb;
     int i = (int)ceil(tn * (double)nb);
     i = i < 0 ? 0 : (i > nb ? nb : i);

@@ -54,3 +54,21 @@ def test_ingest_full_size_ragged_vs_oracle_and_feeds_the_loss():
     assert torch.isfinite(loss).item() and misc['iwes'].shape == (len(ns), 1, 2, H, W)
     vox = voxel_grids(out['xytp'][:2], torch.tensor(ns[:2], dtype=torch.int32), (nb, H, W), 'mean_std')
     assert torch.isfinite(vox).all()
+
+
+def test_ingest_single_event_window_matches_numpy():
+    """A window of ONE event normalises its time as 0/0: the reference's numpy arithmetic gives t = NaN and
+    bin = num_bins (NaN sorts last); the kernel reproduces that instead of inventing a value."""
+    from oracle import ingest_oracle as I
+    H, W, nb = 40, 56, 5
+    ns = [1, 7]
+    raws = [I.synth_raw(n, H, W, seed=90 + b, spill=0.0) for b, n in enumerate(ns)]
+    N = max(ns)
+    pad = lambda k, dt: np.stack([np.concatenate((r[k], np.zeros(N - len(r[k]), dt))) for r in raws])
+    out = _run(pad(0, 'float32'), pad(1, 'float32'), pad(2, 'int64'), pad(3, 'float32'), np.array(ns, dtype=np.int32), H, W, nb)
+    with np.errstate(invalid='ignore'):
+        ref, num_pos = I.collate([I.sample_events(*r, H, W, nb) for r in raws])
+    assert out['num_pos_events'] == num_pos
+    got = out['events'].cpu().numpy()
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert np.isnan(got[0, :, 2]).sum() == 1 and (got[0][np.isnan(got[0, :, 2])][:, 4] == nb).all()
