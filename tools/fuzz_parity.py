@@ -42,18 +42,21 @@ def main():
             cfg['smooth_type'] = 'on_flow_to_next'
         if nb == 1:
             cfg['smooth_type'] = 'on_flow_to_tref'
+        if rng.random() < 0.15:
+            cfg['loss_type'] = 'variance'
         mask = O.tile_mask((H, W), patch)
         n = int(mask.sum())
         cfg['num_knn'] = K = max(1, min(n, rng.choice([1, 4, 8, 32, 48])))
         seed = rng.randrange(1 << 30)
         g = torch.Generator().manual_seed(seed)
-        ev, num_pos = O.synth_events(B, M, (H, W), nb, seed=seed, pad_frac=rng.choice([0.0, 0.05]))
+        np_choice = rng.choice([None, None, 0, M])          # polarity blocks: balanced, all negative, all positive
+        ev, num_pos = O.synth_events(B, M, (H, W), nb, seed=seed, pad_frac=rng.choice([0.0, 0.05]), num_pos=np_choice)
         coeff = torch.randn(B, 1, 2, H, W, generator=g) * sigma
         t_ref = torch.tensor([rng.random()]) if T == 1 else torch.linspace(0, 1, T)
         times = torch.cat((t_ref, O.bin_mid_times(nb)))
         traj = O.trajectories_at(coeff, times, mask, 1, 'polynomial')
         tag = f'case {case}: {H}x{W} sp{sp} patch{patch} B{B} nb{nb} M{M} K{K} T{T} sigma{sigma} ' + \
-              ' '.join(f'{k}={cfg[k]}' for k in ('focus_loss_norm', 'dist_norm', 'interpolation_scheme', 'smooth_type',
+              f"Mp{num_pos} {cfg.get('loss_type', 'gradmag')} " + ' '.join(f'{k}={cfg[k]}' for k in ('focus_loss_norm', 'dist_norm', 'interpolation_scheme', 'smooth_type',
                                                  'scale_iwe_by_dt', 'mask_image_border', 'polarity_aware_batching'))
         if os.environ.get('FUZZ_VERBOSE'):
             print(tag, flush=True)
