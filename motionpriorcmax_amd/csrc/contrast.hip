@@ -347,9 +347,12 @@ __global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ fi
                 {                                                                           \
                     const float dx = (tr.ch - tl.ch) + 2.f * (mr.ch - ml.ch) + (br.ch - bl_.ch); \
                     const float dy = (bl_.ch - tl.ch) + 2.f * (bc.ch - tc.ch) + (br.ch - tr.ch); \
-                    const float sx = sqrtf(dx * dx + eps2), sy = sqrtf(dy * dy + eps2);      \
-                    vx.ch = dx / sx;                                                         \
-                    vy.ch = dy / sy;                                                         \
+                    /* hardware sqrt and reciprocal (1 ulp each) instead of the correctly rounded sequences:  \
+                       the charbonnier terms and their derivatives dx / sqrt(dx^2 + eps^2) move by ~1e-7      \
+                       relative, far inside the 1e-5 tolerance, and this kernel is VALU bound */            \
+                    const float sx = __builtin_amdgcn_sqrtf(dx * dx + eps2), sy = __builtin_amdgcn_sqrtf(dy * dy + eps2); \
+                    vx.ch = dx * __builtin_amdgcn_rcpf(sx);                                  \
+                    vy.ch = dy * __builtin_amdgcn_rcpf(sy);                                  \
                     if (own) { a0 += (double)sx; a1 += (double)sy; }                         \
                 }
                 MPC_SM_CH(x)
