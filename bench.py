@@ -199,11 +199,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the CMax path has no CPU fallback')
-    dev = torch.device('cuda', local_rank)
+    # MPC_BENCH_BACKEND=gloo: debugging aid for boxes with fewer GPUs than ranks -- the ranks share cuda:0 and the
+    # collectives (barriers, timing reductions, the gradient all-reduce) run over gloo on host tensors, so the
+    # multi-rank control flow can be exercised on a 1-GPU box.  The measured configuration is always RCCL.
+    backend = os.environ.get('MPC_BENCH_BACKEND', 'nccl')
+    dev = torch.device('cuda', local_rank if backend == 'nccl' else 0)
     torch.cuda.set_device(dev)
+    comm_dev = dev if backend == 'nccl' else torch.device('cpu')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from motionpriorcmax_amd import LossFactory, ops, dp
@@ -216,7 +224,7 @@ def main():
         trajd = traj.to(dev).requires_grad_(True)
         batch = {'events': evd, 'num_pos_events': num_pos}
         valid_local = float(ev[..., 5].sum())
-        reducer = dp.GradAllReducer(device=dev) if (with_comm and world > 1) else None
+        reducer = dp.GradAllReducer(device=comm_dev) if (with_comm and world > 1) else None
 
         def step():
             loss, _, _ = L.calc(trajd, times_d, batch)
@@ -250,9 +258,9 @@ def main():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
-            blocks.append(dp.max_over_ranks(time.perf_counter() - t0, dev))
+            blocks.append(dp.max_over_ranks(time.perf_counter() - t0, comm_dev))
         dt = sorted(blocks)[1]
-        total_valid = dp.sum_over_ranks(valid_local, dev)
+        total_valid = dp.sum_over_ranks(valid_local, comm_dev)
 
         # instrumented pass: HIP events around every C-ABI call, on the stream they launch on
         stages = {}
