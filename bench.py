@@ -191,6 +191,7 @@ def main():
                          '(default: the loss path alone is timed -- it has no data-path collective -- and the '
                          'variant with the all-reduce is timed in a second loop and reported beside it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hip-graph', action='store_true', help='skip the HIP-graph replay timing reported beside the eager one')
     ap.add_argument('--also', default='C2,C4', help='extra workloads reported in the "also" field (N=1 only)')
     args = ap.parse_args()
 
@@ -272,7 +273,44 @@ def main():
                 trajd.grad = None
             stages = ops.STAGE_TIMER.summary()
             ops.STAGE_TIMER = None
-        return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages,
+        # the same step captured once into a HIP graph and replayed (static shapes; N = 1 only): what the host-side
+        # launch overhead of the eager path costs -- reported beside the eager number, never as `value`
+        graph_ms = None
+        if world == 1 and instrument and not args.no_hip_graph:
+            try:
+                if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+                    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    # a fresh leaf: the gradient-accumulation node of `trajd` belongs to the default stream, which
+                    # must not take part in a capture
+                    tg = trajd.detach().clone().requires_grad_(True)
+                    for _ in range(2):
+                        lg, _, _ = L.calc(tg, times_d, batch)
+                        lg.backward()
+                        tg.grad = None
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    lg, _, _ = L.calc(tg, times_d, batch)
+                    lg.backward()
+                for _ in range(3):
+                    gr.replay()
+                gts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        gr.replay()
+                    torch.cuda.synchronize()
+                    gts.append(time.perf_counter() - t0)
+                graph_ms = 1e3 * sorted(gts)[1] / steps
+                del gr, lg, tg
+            except Exception as e:      # informational
+                graph_ms = repr(e)[:120]
+        return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, graph_ms=graph_ms,
                     loss=float(last.item()), n=traj.shape[2])
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
@@ -331,6 +369,11 @@ def main():
         'loss': r['loss'],
         'roofline': roofline_of(r, args.workload),
     }
+    if isinstance(r.get('graph_ms'), float):
+        out['hip_graph'] = {'ms_per_step': round(r['graph_ms'], 4), 'value': round(r['total_valid'] / (r['graph_ms'] * 1e-3) / 1e6, 3),
+                            'unit': 'Mevents/s', 'note': 'calc + backward captured once (torch.cuda.CUDAGraph) and replayed'}
+    elif r.get('graph_ms') is not None:
+        out['hip_graph'] = {'error': r['graph_ms']}
     if r_comm is not None:
         out['dp_with_grad_allreduce'] = {
             'value': round(r_comm['total_valid'] * r_comm['steps'] / r_comm['dt'] / 1e6, 3), 'unit': 'Mevents/s',
@@ -349,6 +392,7 @@ def main():
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 dj = json.loads(r.stdout.strip().splitlines()[-1])
                 also[name] = {'value': dj['value'], 'ms_per_step': dj['ms_per_step'],
+                              'hip_graph_ms_per_step': dj.get('hip_graph', {}).get('ms_per_step'),
                               'path_frac': dj['roofline']['path']['frac'],
                               'stages_us_per_step': dj['roofline']['stages_us_per_step']}
             except Exception as e:      # informational field: never fail the main line

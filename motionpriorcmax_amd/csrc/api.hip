@@ -15,6 +15,33 @@ void mpc_set_error(const char *fmt, ...) {
 extern "C" int mpc_version(void) { return MPC_VERSION; }
 extern "C" const char *mpc_last_error_string(void) { return g_err; }
 
+__global__ __launch_bounds__(256) void k_zero_words(unsigned *__restrict__ p, size_t n) {
+    // up to 3 head words bring the pointer to 16-byte alignment, then 16-byte stores, then up to 3 tail words
+    size_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2;
+    if (head > n) head = n;
+    const size_t n4 = (n - head) >> 2;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) p[threadIdx.x] = 0u;
+        const size_t t0 = head + (n4 << 2);
+        if (t0 + threadIdx.x < n) p[t0 + threadIdx.x] = 0u;
+    }
+}
+
+int mpc_zero_async(void *ptr, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return 0;
+    if ((bytes & 3) || (reinterpret_cast<uintptr_t>(ptr) & 3)) { mpc_set_error("mpc_zero_async: unaligned"); return MPC_E_SHAPE; }
+    const size_t n = bytes >> 2;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned *)ptr, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mpc_set_error("mpc_zero_async: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 int mpc_validate_shape(const mpc_shape *s) {
     MPC_CHECK_ARG(s->B >= 0 && s->M >= 0 && s->Mp >= 0 && s->Mp <= s->M, MPC_E_SHAPE, "bad B/M/Mp");
     MPC_CHECK_ARG(s->nb >= 1 && s->T >= 1, MPC_E_SHAPE, "need num_bins >= 1 and num_tref >= 1");

@@ -9,6 +9,9 @@
 #define MPC_KNN_LDS_SORT_CELLS (150 * 1024 / 4)   // largest LUT grid the single-workgroup LDS counting sort holds
 
 void mpc_set_error(const char *fmt, ...);
+// Zero `bytes` bytes (a multiple of 4, 4-byte aligned) on `stream` with a kernel.  Used instead of hipMemsetAsync:
+// memset NODES made repeated replays of a captured HIP graph fault on ROCm 7.2 (tools/graph_probe2.py).
+int mpc_zero_async(void *ptr, size_t bytes, hipStream_t stream);
 
 #define MPC_CHECK_ARG(cond, code, msg)                                   \
     do {                                                                 \

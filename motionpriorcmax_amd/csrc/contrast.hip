@@ -480,8 +480,8 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
         return 0;
     }
     {   // the unfused tiling has fewer workgroups than the partial-sum array: clear the rest
-        hipError_t e = hipMemsetAsync(cpart, 0, (size_t)L.n_cblocks * 2 * sizeof(double), st);
-        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        const int e = mpc_zero_async(cpart, (size_t)L.n_cblocks * 2 * sizeof(double), st);
+        if (e) return e;
     }
     hipLaunchKernelGGL(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
     MPC_CHECK_LAUNCH();

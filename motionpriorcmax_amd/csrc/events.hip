@@ -567,8 +567,7 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
         }
         const BinLayout BL = bin_layout(s, L, ws);
         const int want_bwd = (s->flags & (MPC_F_NO_WARP | MPC_F_NO_BWD_RECORDS)) ? 0 : 1;
-        hipError_t e0 = hipMemsetAsync(BL.gcount, 0, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st);
-        if (e0 != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e0)); return (int)e0; }
+        if ((rc = mpc_zero_async(BL.gcount, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st))) return rc;
         if (s->B > 0 && s->M > 0) {
             const int nblk = mpc_cdiv(s->M, 256 * EV_PER_THREAD) * s->B;
             const dim3 grid(((nblk + 7) / 8) * 8);
@@ -586,8 +585,8 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
         return 0;
     }
     const size_t img_bytes = (size_t)L.nimg * s->H * s->W * sizeof(float);
-    hipError_t e = hipMemsetAsync(iwe_raw, 0, img_bytes, st);
-    if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+    const int e = mpc_zero_async(iwe_raw, img_bytes, st);
+    if (e) return e;
     const int64_t total = (int64_t)s->B * s->M;
     if (total == 0) return 0;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -626,8 +625,8 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
             rc = grad_out ? mpc_scale(add_term, grad_out, grad_flow_lut, cnt, stream) : (int)hipMemcpyAsync(grad_flow_lut, add_term, cnt * sizeof(float), hipMemcpyDeviceToDevice, st);
             if (rc) return rc;
         } else {
-            hipError_t e = hipMemsetAsync(grad_flow_lut, 0, cnt * sizeof(float), st);
-            if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+            const int e = mpc_zero_async(grad_flow_lut, cnt * sizeof(float), st);
+            if (e) return e;
         }
     }
     const int64_t total = (int64_t)s->B * s->M;

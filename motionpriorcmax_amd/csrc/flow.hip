@@ -97,8 +97,8 @@ extern "C" int mpc_dense_flow(const mpc_flow_shape *s, const float *traj_flow, c
     MPC_CHECK_ARG(s->n == 0 || (traj_flow && pixel_positions), -1, "null argument");
     hipStream_t st = (hipStream_t)stream;
     const int hp = s->H / s->patch, wp = s->W / s->patch;
-    hipError_t e = hipMemsetAsync(patch_flow, 0, sizeof(float) * (size_t)s->B * s->C * hp * wp, st);
-    if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+    const int e = mpc_zero_async(patch_flow, sizeof(float) * (size_t)s->B * s->C * hp * wp, st);
+    if (e) return e;
     const long long total = (long long)s->B * s->n * s->C;
     if (total > 0)
         hipLaunchKernelGGL(k_list_to_grid, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, *s, traj_flow,

@@ -222,8 +222,8 @@ extern "C" int mpc_ingest_count(const mpc_ingest_shape *s, const float *x, const
     int rc = ing_validate(s);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out_max, 0, 2 * sizeof(int32_t), st);
-    if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+    const int e = mpc_zero_async(out_max, 2 * sizeof(int32_t), st);
+    if (e) return e;
     if (s->B == 0) return 0;
     const IngLayout L = ing_layout(s, ws).L;
     hipLaunchKernelGGL(k_ingest_count, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
@@ -244,8 +244,8 @@ extern "C" int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, con
     hipStream_t st = (hipStream_t)stream;
     const int64_t M = (int64_t)max_pos + max_neg;
     if (M > 0) {
-        hipError_t e = hipMemsetAsync(events, 0, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows
-        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        const int e = mpc_zero_async(events, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows
+        if (e) return e;
     }
     if (s->N == 0) return 0;
     const IngLayout L = ing_layout(s, ws).L;

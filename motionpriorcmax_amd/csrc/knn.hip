@@ -1105,8 +1105,8 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     const size_t sort_lds = (size_t)((s->hq + S - 1) / S) * s->wq * 4 + (size_t)((s->n + 1) / 2 * 2) * 2;
     if (p.G > MPC_KNN_LDS_SORT_CELLS || sort_lds > 150 * 1024) {
         int *cursor = (int *)((char *)ws + L.off_knn_cursor);
-        hipError_t e = hipMemsetAsync(cursor, 0, (size_t)s->B * s->nb * p.G * sizeof(int), st);
-        if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        const int e = mpc_zero_async(cursor, (size_t)s->B * s->nb * p.G * sizeof(int), st);
+        if (e) return e;
         const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
         hipLaunchKernelGGL(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
         hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start);

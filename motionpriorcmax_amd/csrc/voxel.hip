@@ -289,8 +289,8 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
         if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipError_t e0 = hipMemsetAsync(L.gcount, 0, (size_t)(L.NBk + 8) * 4, st);
-    if (e0 != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e0)); return (int)e0; }
+    const int e0 = mpc_zero_async(L.gcount, (size_t)(L.NBk + 8) * 4, st);
+    if (e0) return e0;
     if (s->N > 0) {
         const int nblk = mpc_cdiv(s->N, 256 * VOX_PER_THREAD) * s->B;
         hipLaunchKernelGGL(k_vox_bin, dim3(((nblk + 7) / 8) * 8), dim3(256), (size_t)s->C * L.NS * 2 * sizeof(int), st,

@@ -21,6 +21,15 @@ torch.cuda.current_stream().wait_stream(s)
 torch.cuda.synchronize()
 ref_grad = t.grad.clone(); ref_loss = float(loss)
 print('eager ok', ref_loss, flush=True)
+from motionpriorcmax_amd import ops
+if os.environ.get('STAGE'):
+    ops.STAGE_TIMER = ops.StageTimer()
+    for _ in range(3):
+        loss, _, _ = L.calc(t, td, batch); loss.backward(); t.grad = None
+    st = ops.STAGE_TIMER.summary(); ops.STAGE_TIMER = None
+    print('stage timer pass done', flush=True)
+if os.environ.get('NOWARN'):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 g = torch.cuda.CUDAGraph()
 t.grad = None
 with torch.cuda.graph(g):
