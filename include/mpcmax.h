@@ -13,7 +13,11 @@
  *  - `ws` is a caller-provided scratch buffer of at least mpc_workspace_bytes() bytes; its
  *    content carries state from a *_fwd call to the matching *_bwd call;
  *  - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
- *    synchronising; there is no global mutable state (the last-error string is thread local);
+ *    synchronising or allocating; the work consists of kernel launches only (no memset / memcpy nodes), so a
+ *    sequence of calls can be captured into a HIP graph and replayed;
+ *  - no mutable global state takes part in a result: the last-error string is thread local, and the only
+ *    process-wide state is one-time, idempotent set-up (raising the dynamic-LDS limit of the kernels, tuning
+ *    switches read once from the environment, listed in csrc/knn.hip);
  *  - return value: 0 ok, >0 a hipError_t, <0 an argument error (MPC_E_*).  No C++ exception
  *    crosses the ABI.
  *
