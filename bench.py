@@ -350,7 +350,9 @@ def main():
         path_b = algorithmic_bytes(wl_['B'], wl_['M'], wl_['nb'])
         return {
             'bound': 'hbm', 'kernel': DOMINANT_KERNEL.get(dom, dom), 'stage': dom,
-            'note': 'HIP events bracket the C-ABI stage (all kernels_in_stage); the rocprofv3 summary in profiles/ splits it',
+            'note': 'HIP events bracket the C-ABI stage (all kernels_in_stage); the rocprofv3 summary in profiles/ splits it'
+                    + ('; this kernel is VALU-issue bound (exact K-nearest selection, ~3.2k VALU per 64 queries, VALU busy ~77 %: '
+                       'DESIGN.md section 4), the HBM fraction is reported as measured' if dom.startswith('mpc_knn') else ''),
             'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(wname, dom) if wname else None,
             'algorithmic_bytes': int(d['algorithmic_MB'] * 1e6),
