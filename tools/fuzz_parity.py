@@ -29,7 +29,7 @@ def main():
         W = rng.randrange(24, 180)
         B = rng.choice([1, 1, 2, 3])
         nb = rng.choice([1, 3, 5, 15])
-        M = rng.choice([0, 1, 50, 2000, 20000])
+        M = rng.choice([0, 1, 50, 2000, 20000, 20000])
         sigma = rng.choice([0.0, 0.5, 3.0, 12.0])
         T = rng.choice([1, 1, 1, 2])
         cfg = dict(image_shape=(H, W), num_tref=T, num_bins=nb, num_knn=1, smooth_weight=rng.choice([0.0, 0.003, 0.06]),
@@ -51,11 +51,19 @@ def main():
         g = torch.Generator().manual_seed(seed)
         np_choice = rng.choice([None, None, 0, M])          # polarity blocks: balanced, all negative, all positive
         ev, num_pos = O.synth_events(B, M, (H, W), nb, seed=seed, pad_frac=rng.choice([0.0, 0.05]), num_pos=np_choice)
+        dist_kind = rng.choice(['uniform', 'uniform', 'band', 'spot'])
+        if dist_kind != 'uniform' and M > 0:
+            # concentrated events: one image strip / LUT strip receives (almost) everything -> bucket overflow, spill lists
+            y0c, x0c = rng.random() * (H - 2), rng.random() * (W - 2)
+            rows = ev[..., 5] > 0
+            ev[..., 0] = torch.where(rows, y0c + torch.rand(ev.shape[:2], generator=g) * 1.5, ev[..., 0])
+            if dist_kind == 'spot':
+                ev[..., 1] = torch.where(rows, x0c + torch.rand(ev.shape[:2], generator=g) * 1.5, ev[..., 1])
         coeff = torch.randn(B, 1, 2, H, W, generator=g) * sigma
         t_ref = torch.tensor([rng.random()]) if T == 1 else torch.linspace(0, 1, T)
         times = torch.cat((t_ref, O.bin_mid_times(nb)))
         traj = O.trajectories_at(coeff, times, mask, 1, 'polynomial')
-        tag = f'case {case}: {H}x{W} sp{sp} patch{patch} B{B} nb{nb} M{M} K{K} T{T} sigma{sigma} ' + \
+        tag = f'case {case}: {dist_kind} {H}x{W} sp{sp} patch{patch} B{B} nb{nb} M{M} K{K} T{T} sigma{sigma} ' + \
               f"Mp{num_pos} {cfg.get('loss_type', 'gradmag')} " + ' '.join(f'{k}={cfg[k]}' for k in ('focus_loss_norm', 'dist_norm', 'interpolation_scheme', 'smooth_type',
                                                  'scale_iwe_by_dt', 'mask_image_border', 'polarity_aware_batching'))
         if os.environ.get('FUZZ_VERBOSE'):
