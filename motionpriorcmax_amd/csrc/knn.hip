@@ -249,11 +249,14 @@ __global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, con
 }
 
 // ------------------------------------------------------------------------------------------
-// query: one thread per LUT cell; 16x16 cells per workgroup.  The candidate points of the tile
-// and a halo of RH cell rings are staged in LDS (positions, indices, flows), so the selection
-// passes never leave the CU; a thread that needs a larger radius (or a workgroup whose region
-// overflows the LDS budget) finishes on the global arrays with the same code.
-// grid (ceil(wq/16), ceil(hq/16), B*nb), 256 threads, dynamic LDS
+// query: one thread per LUT cell; 16 x (NT/16) cells per workgroup (NT = 256 or 512).  The candidate
+// points of the tile and a halo of RH cell rings are staged in LDS (positions, 16-bit offsets and indices,
+// flows), so the selection passes never leave the CU; a thread that needs a square outside the staged
+// region (or a workgroup whose region overflows the staging capacity) finishes on the global arrays
+// with the same code.  Per thread: a private column of 8 LDS words = 32 histogram bins of 8 bits, later
+// reused for the short list of keys inside the K-th bin.
+// 1-D grid of gx*gy*B*nb workgroups in XCD-contiguous order, NT threads, dynamic LDS sized by the launcher
+// so that as many workgroups as possible fit a CU (the kernel is latency bound below ~24 wavefronts per CU)
 // ------------------------------------------------------------------------------------------
 struct QueryCtx {
     // global
