@@ -184,6 +184,79 @@ def cpu_baseline(wl, budget_s=20.0):
     }
 
 
+def _in_rank_env():
+    """True inside a rank started by torch.distributed.run (which exports RANK and WORLD_SIZE)."""
+    return 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: this process becomes the PARENT of the run,
+    as `scripts/flow_training.py:125-128` fans out from one command (`devices=args.gpus`).  It starts N fresh ranks
+    (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one per GPU, rendezvous on 127.0.0.1),
+    relays rank 0's JSON line and exits non-zero if any rank fails.  The parent never touches the GPU (no
+    torch.cuda call other than device_count(), which does not initialise HIP), so nothing is re-exec'ed from a
+    process that holds the device."""
+    import subprocess
+    dry = os.environ.get('MPC_BENCH_DRYRUN') == '1'
+    shared_gpu = os.environ.get('MPC_BENCH_BACKEND', 'nccl') != 'nccl'
+    if not dry and not shared_gpu:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(r.stdout[-4000:])
+        raise SystemExit(r.returncode if r.returncode != 0 else 1)
+    print(lines[0])
+    raise SystemExit(0)
+
+
+def dry_run(args, rank, world):
+    """MPC_BENCH_DRYRUN=1: the launch and timing CONTROL FLOW only (rank fan-out, process group, barriers, MAX/SUM
+    over ranks, rank-0-only line) on CPU over gloo with an empty step -- what tests/test_bench_launch.py checks in
+    the GPU-less container.  No kernel runs: `value` is 0 and the line says so."""
+    from motionpriorcmax_amd import dp
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    blocks = []
+    for _ in range(3):
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(1e-4)
+        if world > 1:
+            dist.barrier()
+        blocks.append(dp.max_over_ranks(time.perf_counter() - t0))
+    ranks = dp.sum_over_ranks(1.0)
+    if rank == 0:
+        wl = WORKLOADS[args.workload]
+        print(json.dumps({'metric': 'Mevents/s through CMax loss fwd+bwd, DSEC 480x640', 'value': 0.0, 'unit': 'Mevents/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(1e3 * sorted(blocks)[1] / args.steps, 4), 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'none (dry run)', 'dry_run': True,
+                          'ranks_counted': int(ranks), 'rccl_ranks': 0,
+                          'config': {'workload': args.workload, 'global_batch': wl['B'] * world, 'parallelism': f'dp{world}'}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -199,9 +272,18 @@ def main():
     ap.add_argument('--also', default='C2,C4', help='extra workloads reported in the "also" field (N=1 only)')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and not _in_rank_env():
+        launch_ranks(args, sys.argv[1:])          # does not return
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` '
+                         f'(it launches its own ranks) or under torch.distributed.run with --nproc-per-node N')
+    if os.environ.get('MPC_BENCH_DRYRUN') == '1':
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the CMax path has no CPU fallback')
     # MPC_BENCH_BACKEND=gloo: debugging aid for boxes with fewer GPUs than ranks -- the ranks share cuda:0 and the
@@ -217,7 +299,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    rccl_ranks = (dist.get_world_size() if world > 1 else 1) if backend == 'nccl' else 0     # ranks in the RCCL group
 
     from motionpriorcmax_amd import LossFactory, ops, dp
 
@@ -374,6 +456,7 @@ def main():
                    'global_batch': wl['B'] * world, 'events_per_sample': wl['M'], 'num_bins': wl['nb'],
                    'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
+        'rccl_ranks': rccl_ranks,
         'loss': r['loss'],
         'roofline': roofline_of(r, args.workload),
     }

@@ -56,13 +56,14 @@ def test_bench_two_ranks_control_flow_over_gloo():
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MPC_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29731', 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'C2']
+    # plain `python bench.py --gpus 2`: the parent launches the two ranks itself and relays rank 0's line
+    env = {k: v for k, v in env.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--workload', 'C2']
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-1500:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2 and d['value'] > 0
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 0 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2 and d['value'] > 0
     assert len(d['blocks_ms_per_step']) == 3
     assert d['dp_with_grad_allreduce']['grad_allreduce_MB'] > 100 and d['dp_with_grad_allreduce']['value'] > 0
