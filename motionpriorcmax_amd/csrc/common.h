@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/mpcmax.h"
 
 #define MPC_WAVE 64
@@ -29,6 +30,16 @@ int mpc_zero_async(void *ptr, size_t bytes, hipStream_t stream);
             return (int)e__;                                             \
         }                                                                \
     } while (0)
+
+// One-time, idempotent set-up that is PER DEVICE (raising the dynamic-LDS cap of a kernel): one bit per HIP device.
+// need() is true until mark() ran for the current device; two threads (forward and autograd thread) may both run the
+// set-up, which is harmless because it is idempotent -- the flag itself is atomic.
+struct mpc_device_once {
+    std::atomic<uint64_t> done{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool need() const { return !((done.load(std::memory_order_acquire) >> dev()) & 1ull); }
+    void mark() { done.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 static inline int64_t mpc_align(int64_t x, int64_t a = 256) { return (x + a - 1) / a * a; }
 static inline int mpc_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

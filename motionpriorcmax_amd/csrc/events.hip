@@ -396,9 +396,16 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (r0 + u * 1024 >= n) continue;
-            record_taps(e[u].x, e[u].y, e[u].z, H, W, row0, row1, [&](int yy, int xx, float v) {
-                atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed_small(v));
-            });
+            // |tap| <= (1 + 1e-6)^2 |w|: the one-conversion form is exact below 2, any other weight (create_iwe(weight=
+            // tensor), a weighted `valid` column; event_image_converter.py:45-74 accepts any) takes the hi/lo split
+            if (fabsf(e[u].z) <= 1.5f)
+                record_taps(e[u].x, e[u].y, e[u].z, H, W, row0, row1, [&](int yy, int xx, float v) {
+                    atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed_small(v));
+                });
+            else
+                record_taps(e[u].x, e[u].y, e[u].z, H, W, row0, row1, [&](int yy, int xx, float v) {
+                    atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed(v));
+                });
         }
     }
     __syncthreads();
@@ -559,11 +566,11 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
     if (use_tiled(s, L)) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
+        if (attr_once.need()) {
             if ((rc = set_max_lds_ev((const void *)k_iwe_accum, __func__))) return rc;
             if ((rc = set_max_lds_ev((const void *)k_lut_accum, __func__))) return rc;
-            attr_set = true;
+            attr_once.mark();
         }
         const BinLayout BL = bin_layout(s, L, ws);
         const int want_bwd = (s->flags & (MPC_F_NO_WARP | MPC_F_NO_BWD_RECORDS)) ? 0 : 1;

@@ -1090,13 +1090,13 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     float2 *spos = (float2 *)((char *)ws + L.off_spos);
     int *sidx = (int *)((char *)ws + L.off_sidx);
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
-    static bool attr_set = false;   // raising the dynamic-LDS cap is idempotent
-    if (!attr_set) {
+    static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
+    if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bucket<false>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query<256>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
-        attr_set = true;
+        attr_once.mark();
     }
     // workgroups per (sample, bin) of the LDS sort: as many as keep the launch within one workgroup per CU
     // (measured at C3: 210 workgroups 39 us, split three ways 68 us; at B = 1: 15 workgroups 33 us, split
@@ -1192,11 +1192,11 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     float2 *tmp_a = (float2 *)((char *)ws + L.off_knn_tmp_a);
     const float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     float *reach = (float *)((char *)ws + L.off_knn_reach);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
+    if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<16>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<32>, __func__))) return rc;
-        attr_set = true;
+        attr_once.mark();
     }
     const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
     hipLaunchKernelGGL(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);

@@ -283,11 +283,11 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
     const VoxHostLayout h = vox_layout(s, ws);
     const VoxLayout &L = h.L;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute((const void *)k_vox_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
+        attr_once.mark();
     }
     const int e0 = mpc_zero_async(L.gcount, (size_t)(L.NBk + 8) * 4, st);
     if (e0) return e0;

@@ -75,6 +75,10 @@ class _stage:
         self.name, self.device = name, device
 
     def __enter__(self):
+        # the library launches on the CURRENT HIP device: make the tensors' device current for the call (tensors on
+        # cuda:1 while cuda:0 is current would otherwise launch in the wrong device context)
+        self.guard = torch.cuda.device(self.device)
+        self.guard.__enter__()
         if STAGE_TIMER is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
@@ -84,6 +88,7 @@ class _stage:
         if STAGE_TIMER is not None:
             self.b.record(torch.cuda.current_stream(self.device))
             STAGE_TIMER.records.setdefault(self.name, []).append((self.a, self.b))
+        self.guard.__exit__(*exc)
         return False
 
 

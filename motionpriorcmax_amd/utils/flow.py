@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from .. import _lib as C
-from ..ops import _ptr, _require_gpu, _stream
+from ..ops import _ptr, _require_gpu, _stage, _stream
 
 
 def dense_flow_from_traj(traj_flow, pixel_positions, patch_size, image_shape):
@@ -22,8 +22,9 @@ def dense_flow_from_traj(traj_flow, pixel_positions, patch_size, image_shape):
     shape = C.FlowShape(B=B, C=Cn, n=n, patch=int(patch_size), H=h, W=w)
     patch = torch.empty((B, Cn, h // int(patch_size), w // int(patch_size)), dtype=torch.float32, device=tf.device)
     dense = torch.empty((B, Cn, h, w), dtype=torch.float32, device=tf.device)
-    C.check(C.lib().mpc_dense_flow(ctypes.byref(shape), _ptr(tf), _ptr(pix), _ptr(patch), _ptr(dense),
-                                   _stream(tf.device)), 'mpc_dense_flow')
+    with _stage('mpc_dense_flow', tf.device):
+        C.check(C.lib().mpc_dense_flow(ctypes.byref(shape), _ptr(tf), _ptr(pix), _ptr(patch), _ptr(dense),
+                                       _stream(tf.device)), 'mpc_dense_flow')
     return dense, patch
 
 
@@ -46,8 +47,9 @@ def calculate_flow_error(flow_gt, flow_pred, event_mask=None, time_scale=None) -
         C.check(int(nbytes), 'mpc_flow_error_workspace_bytes')
     ws = torch.empty(int(nbytes), dtype=torch.uint8, device=gt.device)
     out = torch.empty(5, dtype=torch.float32, device=gt.device)
-    C.check(C.lib().mpc_flow_error(ctypes.byref(shape), _ptr(gt), _ptr(pr), _ptr(em), _ptr(ts), _ptr(out), _ptr(ws),
-                                   _stream(gt.device)), 'mpc_flow_error')
+    with _stage('mpc_flow_error', gt.device):
+        C.check(C.lib().mpc_flow_error(ctypes.byref(shape), _ptr(gt), _ptr(pr), _ptr(em), _ptr(ts), _ptr(out), _ptr(ws),
+                                       _stream(gt.device)), 'mpc_flow_error')
     return {k: out[i] for i, k in enumerate(('EPE', '1PE', '2PE', '3PE', 'AE'))}
 
 

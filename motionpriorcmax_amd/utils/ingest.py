@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from .. import _lib as C
-from ..ops import _ptr, _require_gpu, _stream
+from ..ops import _ptr, _require_gpu, _stream, _stage
 
 
 def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input=False):
@@ -27,11 +27,13 @@ def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input
     ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
     out_max = torch.empty(2, dtype=torch.int32, device=dev)
     st = _stream(dev)
-    C.check(C.lib().mpc_ingest_count(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
-                                     _ptr(out_max), _ptr(ws), st), 'mpc_ingest_count')
+    with _stage('mpc_ingest_count', dev):
+        C.check(C.lib().mpc_ingest_count(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
+                                         _ptr(out_max), _ptr(ws), st), 'mpc_ingest_count')
     max_pos, max_neg = (int(v) for v in out_max.tolist())          # the collate's host decision
     events = torch.empty((B, max_pos + max_neg, 6), dtype=torch.float32, device=dev)
     xytp = torch.empty((B, N, 4), dtype=torch.float32, device=dev) if want_voxel_input else None
-    C.check(C.lib().mpc_ingest_scatter(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
-                                       max_pos, max_neg, _ptr(events), _ptr(xytp), _ptr(ws), st), 'mpc_ingest_scatter')
+    with _stage('mpc_ingest_scatter', dev):
+        C.check(C.lib().mpc_ingest_scatter(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
+                                           max_pos, max_neg, _ptr(events), _ptr(xytp), _ptr(ws), st), 'mpc_ingest_scatter')
     return {'events': events, 'num_pos_events': max_pos, 'xytp': xytp}

@@ -7,7 +7,7 @@ import ctypes
 import torch
 
 from .. import _lib as C
-from ..ops import _ptr, _require_gpu, _stream
+from ..ops import _ptr, _require_gpu, _stream, _stage
 
 
 def voxel_grids(xytp: torch.Tensor, counts: torch.Tensor, input_size, norm_type='mean_std') -> torch.Tensor:
@@ -25,8 +25,9 @@ def voxel_grids(xytp: torch.Tensor, counts: torch.Tensor, input_size, norm_type=
         C.check(int(nbytes), 'mpc_voxel_workspace_bytes')
     ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=ev.device)
     grid = torch.empty((B, Cn, H, W), dtype=torch.float32, device=ev.device)
-    C.check(C.lib().mpc_voxel_grid(ctypes.byref(shape), _ptr(ev), _ptr(cnt), _ptr(grid), _ptr(ws), _stream(ev.device)),
-            'mpc_voxel_grid')
+    with _stage('mpc_voxel_grid', ev.device):
+        C.check(C.lib().mpc_voxel_grid(ctypes.byref(shape), _ptr(ev), _ptr(cnt), _ptr(grid), _ptr(ws), _stream(ev.device)),
+                'mpc_voxel_grid')
     return grid
 
 
