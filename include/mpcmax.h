@@ -97,6 +97,13 @@ int64_t mpc_workspace_bytes(const mpc_shape *s);
 int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                     float *knn_state, int32_t *idx_out, void *ws, void *stream);
 
+/* Diagnostics: byte offset, inside the workspace, of the list of queries that mpc_knn_lut_fwd's strip kernel handed to
+ * its per-query fallback: int32 count, then count entries (query id = ((b*nb + bin)*hq + cy)*wq + cx in the low 30 bits,
+ * reason in the top 2: 0 fewer than K candidates inside the first search square, 1 more candidate slots than the
+ * fast path holds, 2 more keys at the K-th distance level than it ranks, 3 staging overflow).  Read it after
+ * mpc_knn_lut_fwd (tests assert that the fast path serves nearly all queries of the benchmark shapes). */
+int64_t mpc_knn_fail_list_offset(const mpc_shape *s);
+
 /* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants,
  * focus.py:157-163).  grad_flow_next may be NULL.  grad_traj [B][T+nb][n][2] is overwritten. */
 int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,

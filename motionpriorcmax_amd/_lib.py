@@ -26,7 +26,8 @@ SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 
 EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_knn_lut_fwd',
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
-           'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error']
+           'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
+           'mpc_knn_fail_list_offset']
 
 
 class Shape(ctypes.Structure):
@@ -71,6 +72,7 @@ def lib():
     L.mpc_last_error_string.argtypes = []
     L.mpc_workspace_bytes.restype = i64
     L.mpc_workspace_bytes.argtypes = [sp]
+    L.mpc_knn_fail_list_offset.argtypes = [sp]
     L.mpc_knn_lut_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_knn_lut_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_event_splat_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp]
@@ -85,6 +87,7 @@ def lib():
     for name in EXPORTS[3:]:
         getattr(L, name).restype = ctypes.c_int
     L.mpc_voxel_workspace_bytes.restype = i64
+    L.mpc_knn_fail_list_offset.restype = i64
     isp = ctypes.POINTER(IngestShape)
     L.mpc_ingest_workspace_bytes.argtypes = [isp]
     L.mpc_ingest_workspace_bytes.restype = i64

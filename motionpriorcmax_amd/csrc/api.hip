@@ -81,6 +81,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     const bool big_sort = L.G > MPC_KNN_LDS_SORT_CELLS || (int64_t)L.G * 4 + ((int64_t)s->n + 1) / 2 * 4 > 150 * 1024;
     L.off_knn_cursor = off; off += big_sort ? mpc_align(bt * (int64_t)L.G * sizeof(int32_t)) : 0;
     L.off_knn_reach = off;  off += mpc_align(bt * (int64_t)mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16) * sizeof(float));
+    L.off_knn_fail = off;   off += mpc_align((1 + bt * (int64_t)L.G) * sizeof(int32_t));
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;
     L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));
@@ -114,6 +115,13 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     }
     L.total = off;
     return L;
+}
+
+extern "C" int64_t mpc_knn_fail_list_offset(const mpc_shape *s) {
+    if (!s) { mpc_set_error("mpc_knn_fail_list_offset: null shape"); return MPC_E_NULL; }
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    return mpc_layout(s).off_knn_fail;
 }
 
 extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {

@@ -59,6 +59,7 @@ struct mpc_ws_layout {
     int64_t off_knn_tmp_a;   // float2 [B*nb][n]
     int64_t off_knn_cursor;  // int32  [B*nb][G]  fill cursors of the global-memory bucket sort (only when G*4 B exceeds the LDS sort)
     int64_t off_knn_reach;   // float  [B*nb][ceil(hq/16)][ceil(wq/16)]  backward search reach per 16x16 tile
+    int64_t off_knn_fail;    // int32  [1 + B*nb*G]  queries handed from the strip kernel to the fallback kernel
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, spill counters, marker
     int64_t off_frec;        // float4 [nfb][fcap]

@@ -10,47 +10,9 @@
 // result is the exact K-nearest set; ties resolve to the lowest index.
 // No index tensor is materialised: the backward re-derives membership from the saved K-th key.
 #include "common.h"
-#include <math.h>
+#include "knn_device.h"
 #include <stdlib.h>
 
-#ifndef KNN_BINS
-#define KNN_BINS 32
-#endif
-#ifndef KNN_BATCH
-#define KNN_BATCH 2   // candidate positions loaded ahead of use in the two hot scans (B=14: 944 -> 874 us; 4: 867)
-#endif
-#define KNN_HW (KNN_BINS / 4)   // histogram words per query: four 8-bit bins per word
-#define KNN_LIST KNN_HW          // {candidate slot, trajectory index} pairs kept in a (dead) histogram column
-#define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
-
-struct KnnParams {
-    int B, nb, T, n, hq, wq, sp, K, G;
-    int l1, iwd, want_next;
-    float off;   // sp/2 - 0.5 : centre of cell 0 (focus.py:117)
-};
-
-static KnnParams knn_params(const mpc_shape *s) {
-    KnnParams p;
-    p.B = s->B; p.nb = s->nb; p.T = s->T; p.n = s->n; p.hq = s->hq; p.wq = s->wq; p.sp = s->sp;
-    p.K = s->K; p.G = s->hq * s->wq;
-    p.l1 = (s->flags & MPC_F_DIST_L1) ? 1 : 0;
-    p.iwd = ((s->flags & MPC_F_SCHEME_IWD) && s->K > 1) ? 1 : 0;   // focus.py:145-147: K == 1 is a plain gather
-    p.want_next = (s->flags & MPC_F_WANT_NEXT) ? 1 : 0;
-    p.off = (float)s->sp / 2.f - 0.5f;
-    return p;
-}
-
-__device__ __forceinline__ int cell_of(float v, int sp, int ncell) {
-    // cells are centred on the query points: cell c covers [c*sp - 0.5, (c+1)*sp - 0.5)
-    const float c = floorf((v + 0.5f) / (float)sp);
-    return (int)fminf(fmaxf(c, 0.f), (float)(ncell - 1));
-}
-
-__device__ __forceinline__ float pair_dist(float qy, float qx, float py, float px, int l1) {
-    // focus.py:132-135: (grid - traj) ** 2 summed over (y, x), or abs
-    const float dy = qy - py, dx = qx - px;
-    return l1 ? (fabsf(dy) + fabsf(dx)) : (dy * dy + dx * dx);
-}
 
 // ------------------------------------------------------------------------------------------
 // bucket the points of one (sample, bin) by cell: counting sort in LDS.  With CACHED, every thread
@@ -64,12 +26,17 @@ __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float p
 template <bool CACHED>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start,
-                                                     float2 *__restrict__ spos, int *__restrict__ sidx, int S) {
+                                                     float2 *__restrict__ spos, int *__restrict__ sidx, int S,
+                                                     float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
     __shared__ int s_low[16];
     const int tid = threadIdx.x;
     const int bt = blockIdx.x / S, part = blockIdx.x - bt * S, b = bt / p.nb, t = bt - b * p.nb;
+    // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
+    // atomicMax and its fallback list is appended to (knn_strip.hip)
+    if (part == 0) for (int i = tid; i < ntiles; i += 1024) tile_dkmax[(size_t)bt * ntiles + i] = 0.f;
+    if (blockIdx.x == 0 && tid == 0) fail[0] = 0;
     const int rows_per = (p.hq + S - 1) / S;
     const int g_lo = min(part * rows_per, p.hq) * p.wq, g_hi = min((part + 1) * rows_per, p.hq) * p.wq, Gp = g_hi - g_lo;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
@@ -189,9 +156,12 @@ __global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, con
 
 // grid B*nb, 1024 threads
 __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
-                                                          int *__restrict__ cell_start) {
+                                                          int *__restrict__ cell_start,
+                                                          float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, bt = blockIdx.x;
+    for (int i = tid; i < ntiles; i += 1024) tile_dkmax[(size_t)bt * ntiles + i] = 0.f;       // (see k_knn_bucket)
+    if (bt == 0 && tid == 0) fail[0] = 0;
     int *cur = cursor + (size_t)bt * p.G;
     int *cs = cell_start + (size_t)bt * (p.G + 1);
     const int chunk = (p.G + 1023) / 1024;
@@ -248,406 +218,6 @@ __global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, con
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// query: one thread per LUT cell; 16 x (NT/16) cells per workgroup (NT = 256 or 512).  The candidate
-// points of the tile and a halo of RH cell rings are staged in LDS (positions, 16-bit offsets and indices,
-// flows), so the selection passes never leave the CU; a thread that needs a square outside the staged
-// region (or a workgroup whose region overflows the staging capacity) finishes on the global arrays
-// with the same code.  Per thread: a private column of 8 LDS words = 32 histogram bins of 8 bits, later
-// reused for the short list of keys inside the K-th bin.
-// 1-D grid of gx*gy*B*nb workgroups in XCD-contiguous order, NT threads, dynamic LDS sized by the launcher
-// so that as many workgroups as possible fit a CU (the kernel is latency bound below ~24 wavefronts per CU)
-// ------------------------------------------------------------------------------------------
-struct QueryCtx {
-    // global
-    const int *cs;          // cell_start of this (sample, bin)
-    const float2 *spos;
-    const int *sidx;
-    const float2 *traj_b;   // trajectories of this sample: [T+nb][n]
-    // LDS
-    const unsigned short *lcs;   // [RW][RW+1]  (staged offsets < cap <= 65535)
-    const float2 *lpos;
-    const unsigned short *lidx;  // trajectory index (n < 65536)
-    const float2 *lf0;      // flow to t_ref (T == 1 and staged), else null
-    const float2 *lf1;      // flow to the next bin (want_next only)
-    int ry0, rx0, RW, RWY, RH;   // staged region: cell rows [ry0, ry0+RWY), columns [rx0, rx0+RW); RH = halo
-};
-
-template <bool LDS>
-struct Acc {
-    const KnnParams &p;
-    const QueryCtx &c;
-    int t;
-    __device__ __forceinline__ void range(int yy, int x0, int x1, int &js, int &je) const {
-        if (LDS) {
-            const unsigned short *row = c.lcs + (yy - c.ry0) * (c.RW + 1);
-            js = row[x0 - c.rx0];
-            je = row[x1 + 1 - c.rx0];
-        } else {
-            js = c.cs[yy * p.wq + x0];
-            je = c.cs[yy * p.wq + x1 + 1];
-        }
-    }
-    __device__ __forceinline__ float2 pos(int j) const { return LDS ? c.lpos[j] : c.spos[j]; }
-    __device__ __forceinline__ int idx(int j) const { return LDS ? c.lidx[j] : c.sidx[j]; }
-    __device__ __forceinline__ float2 flow_ref(int j, int tr, float2 pj) const {
-        if (LDS && c.lf0 != nullptr) return c.lf0[j];
-        const float2 a = c.traj_b[(size_t)tr * p.n + idx(j)];
-        return make_float2(a.x - pj.x, a.y - pj.y);          // traj(t_ref) - traj(t_mid)
-    }
-    __device__ __forceinline__ float2 flow_next(int j, float2 pj) const {
-        if (LDS) return c.lf1[j];
-        const float2 a = c.traj_b[(size_t)(p.T + t + 1) * p.n + idx(j)];
-        return make_float2(a.x - pj.x, a.y - pj.y);          // traj(t_mid[i+1]) - traj(t_mid[i])
-    }
-};
-
-// Returns false if the search needs more rings than the LDS halo holds (LDS variant only).
-template <bool LDS, bool L1, int NT>
-__device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int t, int cy, int cx,
-                              int r_init, unsigned (*s_hist)[NT], float *__restrict__ flow_lut,
-                              float *__restrict__ flow_next, float *__restrict__ knn_state,
-                              int *__restrict__ idx_out, float &dK_out) {
-    const Acc<LDS> A{p, c, t};
-    const int tid = threadIdx.x;
-    const int bt = b * p.nb + t;
-    const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-    // ---- 1. grow the search square until K candidates are provably the nearest ---------------
-    int r = r_init, y0, y1, x0, x1, cnt;
-    {   // next to the image border the square is clipped: start with one of the same cell count
-        const int want = (2 * r_init + 1) * (2 * r_init + 1);
-        for (;;) {
-            const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
-            const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
-            if (hh * ww >= want || (hh == p.hq && ww == p.wq) || (LDS && r >= c.RH)) break;
-            ++r;
-        }
-    }
-    float upper, scale;
-    bool whole;
-    for (;;) {
-        y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
-        x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
-        // the LDS variant serves any square that lies inside the staged region: next to the image border a
-        // grown square is wider than the halo but, clipped, still inside the tile (otherwise such queries finish
-        // on the global arrays, one dependent L2 round trip per step: the tail of small launches)
-        if (LDS && (y0 < c.ry0 || y1 >= c.ry0 + c.RWY || x0 < c.rx0 || x1 >= c.rx0 + c.RW)) return false;
-        whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
-        if (whole) {
-            if (LDS) return false;
-            // every point is a candidate: range of the histogram = largest distance
-            float dmax = 0.f;
-            for (int j = 0; j < p.n; ++j) {
-                const float2 q = c.spos[j];
-                dmax = fmaxf(dmax, pair_dist(qy, qx, q.x, q.y, L1));
-            }
-            upper = INFINITY;
-            scale = dmax > 0.f ? (float)KNN_BINS / dmax : 0.f;
-        } else {
-            // anything outside the square is at least lb away along one axis
-            const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
-            upper = L1 ? lb : lb * lb;
-            scale = (float)KNN_BINS / upper;
-        }
-#pragma unroll
-        for (int h = 0; h < KNN_HW; ++h) s_hist[h][tid] = 0u;
-        cnt = 0;
-        // software pipeline: the candidate positions of the next step and the cell range of the next row are
-        // requested before the current ones are consumed (the wavefront otherwise parks on every LDS round trip)
-        int njs, nje;
-        A.range(y0, x0, x1, njs, nje);
-        for (int yy = y0; yy <= y1; ++yy) {
-            const int js = njs, je = nje;
-            A.range(min(yy + 1, y1), x0, x1, njs, nje);
-            if (js >= je) continue;
-            float2 q[KNN_BATCH];
-#pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) q[u] = A.pos(js + u);      // reads past the row are masked below
-            for (int j = js; j < je; j += KNN_BATCH) {
-                float2 nq[KNN_BATCH];
-#pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) nq[u] = A.pos(j + KNN_BATCH + u);
-#pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) {
-                    // predicated, not branched: an out-of-range candidate adds 0 (the kernel is bound by
-                    // instruction issue, and exec-mask branches cost more than the spare LDS atomic)
-                    const float d = pair_dist(qy, qx, q[u].x, q[u].y, L1);
-                    const int in = (j + u < je) & (d < upper);
-                    const int bin = min((int)(d * scale), KNN_BINS - 1);     // d < upper <= FLT_MAX wherever `in` holds
-                    // word (bin >> 2) of the private column: byte offset (bin & 0x1c) * NT, one AND + one shift-add
-                    unsigned *hw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(&s_hist[0][tid]) + (bin & 0x1c) * NT);
-                    atomicAdd(hw, in ? (1u << ((bin << 3) & 31)) : 0u);
-                    cnt += in;
-                }
-#pragma unroll
-                for (int u = 0; u < KNN_BATCH; ++u) q[u] = nq[u];
-            }
-        }
-        if (cnt >= p.K || whole) break;
-        r += 1 + (r >> 2);
-    }
-    // ---- 2. bin holding the K-th smallest ----------------------------------------------------
-    int bstar = KNN_BINS - 1, before = 0;
-    if (cnt > 255) {
-        // an 8-bit bin may have wrapped (dense clusters, K > 255): treat every candidate as one bin,
-        // which sends the selection to the repeated-minimum path below
-        scale = 0.f; bstar = 0;
-    } else {
-        // word holding the K-th smallest (v_sad_u8 sums the four 8-bit bins of a word), then the bin inside it
-        int cum = 0;
-        unsigned wstar = 0u;
-        bool found = false;
-#pragma unroll
-        for (int h = 0; h < KNN_HW; ++h) {
-            const unsigned wv = s_hist[h][tid];
-            const int nc = (int)__builtin_amdgcn_sad_u8(wv, 0u, (unsigned)cum);
-            if (!found && nc >= p.K) { bstar = 4 * h; before = cum; wstar = wv; found = true; }
-            cum = nc;
-        }
-        if (found) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int ck = (int)((wstar >> (8 * k)) & 0xffu);
-                if (before + ck < p.K) { before += ck; ++bstar; } else break;
-            }
-        }
-    }
-    // ---- 3. second scan: sum the flows of the bins below bstar (num_tref == 1), and list the
-    //         keys inside bstar in the thread's (now dead) histogram column -----------------------
-    const int need = p.K - before;
-    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
-    const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const bool fuse = (p.T == 1);
-    const bool do_next0 = p.want_next && (t < p.nb - 1);
-    float sy = 0.f, sx = 0.f, sw = 0.f, ny = 0.f, nx = 0.f;
-    const float fb = (float)bstar, fb1 = (bstar == KNN_BINS - 1) ? INFINITY : (float)(bstar + 1);
-    int m = 0;
-    int njs, nje;
-    A.range(y0, x0, x1, njs, nje);
-    for (int yy = y0; yy <= y1; ++yy) {
-        const int js = njs, je = nje;
-        A.range(min(yy + 1, y1), x0, x1, njs, nje);
-        if (js >= je) continue;
-        float2 qq[KNN_BATCH];
-#pragma unroll
-        for (int u = 0; u < KNN_BATCH; ++u) qq[u] = A.pos(js + u);
-        for (int j0 = js; j0 < je; j0 += KNN_BATCH) {
-            float2 cur[KNN_BATCH];
-#pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) { cur[u] = qq[u]; qq[u] = A.pos(j0 + KNN_BATCH + u); }
-#pragma unroll
-            for (int u = 0; u < KNN_BATCH; ++u) {
-                const int j = j0 + u;
-                const float2 pj = cur[u];
-                const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                if (j >= je || !(d < upper)) continue;      // (a predicated form of this scan measured slower: 751 vs 673 us)
-                const float ds = d * scale;                 // bin = min(floor(ds), KNN_BINS - 1)
-                if (ds < fb) {
-                    if (fuse) {
-                        const float2 f = A.flow_ref(j, 0, pj);
-                        if (p.iwd) { const float w = 1.f / (d + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
-                        else { sy += f.x; sx += f.y; }
-                        if (do_next0) { const float2 g = A.flow_next(j, pj); ny += g.x; nx += g.y; }
-                    }
-                } else if (ds < fb1) {
-                    if (m < KNN_LIST) s_hist[m][tid] = ((unsigned)j << 16) | (unsigned)A.idx(j);
-                    ++m;
-                }
-            }
-        }
-    }
-    float dK = 0.f; int iK = -1;
-    bool listed = (m <= KNN_LIST);
-    if (m <= 4) {
-        // the usual case: rank up to four keys by (distance, index) in registers, straight-line
-        float dd[4]; int ii[4], jj[4]; float2 pp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned w = s_hist[u][tid];
-            const bool valid = u < m;
-            jj[u] = valid ? (int)(w >> 16) : 0;
-            ii[u] = valid ? (int)(w & 0xffffu) : 0x7fffffff;
-            pp[u] = A.pos(jj[u]);
-            dd[u] = valid ? pair_dist(qy, qx, pp[u].x, pp[u].y, L1) : INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int rank = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (e != u) rank += ((dd[e] < dd[u]) | ((dd[e] == dd[u]) & (ii[e] < ii[u]))) ? 1 : 0;
-            if (u < m && rank < need) {
-                if (fuse) {
-                    const float2 f = A.flow_ref(jj[u], 0, pp[u]);
-                    if (p.iwd) { const float w = 1.f / (dd[u] + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
-                    else { sy += f.x; sx += f.y; }
-                    if (do_next0) { const float2 g = A.flow_next(jj[u], pp[u]); ny += g.x; nx += g.y; }
-                }
-                if (rank == need - 1) { dK = dd[u]; iK = ii[u]; }
-            }
-        }
-    } else if (listed) {
-        // rank the listed keys by (distance, index); the first `need` of them are neighbours
-        for (int a = 0; a < m; ++a) {
-            const unsigned wa = s_hist[a][tid];
-            const int ja = (int)(wa >> 16), ia = (int)(wa & 0xffffu);
-            const float2 pj = A.pos(ja);
-            const float da = pair_dist(qy, qx, pj.x, pj.y, L1);
-            int rank = 0;
-            for (int e = 0; e < m; ++e) {
-                const unsigned we = s_hist[e][tid];
-                const float2 pe = A.pos((int)(we >> 16));
-                const float de = pair_dist(qy, qx, pe.x, pe.y, L1);
-                rank += (de < da || (de == da && (int)(we & 0xffffu) < ia)) ? 1 : 0;
-            }
-            if (rank < need) {
-                if (fuse) {
-                    const float2 f = A.flow_ref(ja, 0, pj);
-                    if (p.iwd) { const float w = 1.f / (da + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
-                    else { sy += f.x; sx += f.y; }
-                    if (do_next0) { const float2 g = A.flow_next(ja, pj); ny += g.x; nx += g.y; }
-                }
-                if (rank == need - 1) { dK = da; iK = ia; }
-            }
-        }
-    } else if (m <= 2 * KNN_LIST) {
-        // The bin holds more keys than the packed list (a tight cluster; one workgroup in a thousand at C3, but
-        // it used to cost `need` + 1 further scans and was the tail of small launches): collect the slots once
-        // more as 16-bit entries in the same column, then rank them by (distance, index) as above.
-        int mm = 0;
-        for (int yy = y0; yy <= y1; ++yy) {
-            int js, je;
-            A.range(yy, x0, x1, js, je);
-            for (int j = js; j < je; ++j) {
-                const float2 pj = A.pos(j);
-                const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                if (!(d < upper)) continue;
-                const float ds = d * scale;
-                if (ds < fb || !(ds < fb1)) continue;
-                reinterpret_cast<unsigned short *>(&s_hist[mm >> 1][tid])[mm & 1] = (unsigned short)j;
-                ++mm;
-            }
-        }
-        for (int a = 0; a < mm; ++a) {
-            const int ja = (int)reinterpret_cast<const unsigned short *>(&s_hist[a >> 1][tid])[a & 1];
-            const int ia = A.idx(ja);
-            const float2 pj = A.pos(ja);
-            const float da = pair_dist(qy, qx, pj.x, pj.y, L1);
-            int rank = 0;
-            for (int e = 0; e < mm; ++e) {
-                const int je = (int)reinterpret_cast<const unsigned short *>(&s_hist[e >> 1][tid])[e & 1];
-                const float2 pe = A.pos(je);
-                const float de = pair_dist(qy, qx, pe.x, pe.y, L1);
-                rank += (de < da || (de == da && A.idx(je) < ia)) ? 1 : 0;
-            }
-            if (rank < need) {
-                if (fuse) {
-                    const float2 f = A.flow_ref(ja, 0, pj);
-                    if (p.iwd) { const float w = 1.f / (da + 1e-9f); sy += w * f.x; sx += w * f.y; sw += w; }
-                    else { sy += f.x; sx += f.y; }
-                    if (do_next0) { const float2 g = A.flow_next(ja, pj); ny += g.x; nx += g.y; }
-                }
-                if (rank == need - 1) { dK = da; iK = ia; }
-            }
-        }
-        listed = true;
-    } else {
-        // far more keys in the bin than any list holds (heavy ties): select by repeated minimum
-        float ld = -1.f; int li = -1;
-        for (int it = 0; it < need; ++it) {
-            float bd = INFINITY; int bi = 0x7fffffff;
-            for (int yy = y0; yy <= y1; ++yy) {
-                int js, je;
-                A.range(yy, x0, x1, js, je);
-                for (int j = js; j < je; ++j) {
-                    const float2 pj = A.pos(j);
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                    if (!(d < upper)) continue;
-                    if (min((int)(d * scale), KNN_BINS - 1) != bstar) continue;
-                    if (d < ld || d > bd) continue;
-                    const int id = A.idx(j);
-                    const bool gt_last = (d > ld) || (id > li);
-                    const bool lt_best = (d < bd) || (id < bi);
-                    if (gt_last && lt_best) { bd = d; bi = id; }
-                }
-            }
-            ld = bd; li = bi;
-        }
-        dK = ld; iK = li;
-    }
-    // ---- 4. outputs; a full membership scan per reference time where the sums were not fused ----
-    float norm = 0.f;
-    if (fuse && listed) {
-        float2 ov;
-        if (p.iwd) { ov.x = sy / sw; ov.y = sx / sw; norm = sw; }
-        else { ov.x = sy / (float)p.K; ov.y = sx / (float)p.K; }
-        reinterpret_cast<float2 *>(flow_lut)[q] = ov;
-        if (do_next0) {
-            float2 on; on.x = ny / (float)p.K; on.y = nx / (float)p.K;
-            reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
-        }
-    } else {
-        for (int tr = 0; tr < p.T; ++tr) {
-            sy = sx = sw = ny = nx = 0.f;
-            const bool do_next = (tr == 0) && do_next0;
-            for (int yy = y0; yy <= y1; ++yy) {
-                int js, je;
-                A.range(yy, x0, x1, js, je);
-                for (int j = js; j < je; ++j) {
-                    const float2 pj = A.pos(j);
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                    if (d > dK) continue;
-                    if (d == dK && A.idx(j) > iK) continue;
-                    const float2 f = A.flow_ref(j, tr, pj);
-                    if (p.iwd) {
-                        const float w = 1.f / (d + 1e-9f);
-                        sy += w * f.x; sx += w * f.y; sw += w;
-                    } else {
-                        sy += f.x; sx += f.y;
-                    }
-                    if (do_next) {
-                        const float2 g = A.flow_next(j, pj);
-                        ny += g.x; nx += g.y;
-                    }
-                }
-            }
-            float2 ov;
-            if (p.iwd) { ov.x = sy / sw; ov.y = sx / sw; norm = sw; }
-            else { ov.x = sy / (float)p.K; ov.y = sx / (float)p.K; }
-            reinterpret_cast<float2 *>(flow_lut)[q * p.T + tr] = ov;
-            if (do_next) {
-                float2 on; on.x = ny / (float)p.K; on.y = nx / (float)p.K;
-                reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
-            }
-        }
-    }
-    knn_state[q] = dK;
-    reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
-    knn_state[2 * BQ + q] = norm;
-    // ---- 5. optional: the K indices in ascending (distance, index) order ---------------------
-    if (idx_out != nullptr) {
-        float pd = -1.f; int pi = -1;
-        for (int k = 0; k < p.K; ++k) {
-            float bd = INFINITY; int bi = 0x7fffffff;
-            for (int yy = y0; yy <= y1; ++yy) {
-                int js, je;
-                A.range(yy, x0, x1, js, je);
-                for (int j = js; j < je; ++j) {
-                    const float2 pj = A.pos(j);
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                    const int id = A.idx(j);
-                    const bool gt_last = (d > pd) || (d == pd && id > pi);
-                    const bool lt_best = (d < bd) || (d == bd && id < bi);
-                    if (gt_last && lt_best) { bd = d; bi = id; }
-                }
-            }
-            pd = bd; pi = bi;
-            idx_out[q * p.K + k] = bi;
-        }
-    }
-    dK_out = dK;
-    return true;
-}
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float *__restrict__ traj,
@@ -1049,12 +619,13 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_R0=<d>          offset of the initial search radius                               [0]
 //   MPC_KNN_BWD_TS=16|32    tile side of the backward gather                                  [16]
 //   MPC_KNN_HALO=<h>        rings staged beyond the initial radius by the query kernel        [1]
+//   MPC_KNN_STRIP=0         tile query kernel (k_knn_query) also where the strip kernel applies  [1]
 struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo;
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -1063,6 +634,7 @@ static const KnnTuning &knn_tuning() {
         if ((e = getenv("MPC_KNN_R0"))) v.r0 = atoi(e);
         if ((e = getenv("MPC_KNN_BWD_TS"))) v.bwd_ts = atoi(e) == 32 ? 32 : 16;
         if ((e = getenv("MPC_KNN_HALO"))) v.halo = atoi(e);
+        if ((e = getenv("MPC_KNN_STRIP"))) v.strip = atoi(e) != 0;
         return v;
     }();
     return t;
@@ -1090,6 +662,8 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     float2 *spos = (float2 *)((char *)ws + L.off_spos);
     int *sidx = (int *)((char *)ws + L.off_sidx);
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
+    int *fail = (int *)((char *)ws + L.off_knn_fail);
+    const int ntiles = mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16);
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
@@ -1112,13 +686,13 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if (e) return e;
         const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
         hipLaunchKernelGGL(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
-        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start);
+        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail);
         hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
     } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S);
+        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail);
     else
-        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S);
+        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
@@ -1126,6 +700,9 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     const KnnTuning &tune = knn_tuning();
     r_init += tune.r0;
     if (r_init < 1) r_init = 1;
+    // fast path (num_tref == 1, the shipped configurations): strip kernel + per-query fallback (knn_strip.hip)
+    if (tune.strip && !tune.global_mode && idx_out == nullptr && mpc_knn_strip_usable(s, r_init))
+        return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, st);
     const int want_blocks = tune.blocks, want_nt = tune.nt;
     int RH = r_init + (tune.halo > 0 ? tune.halo : 1);     // halo of the staged region: one ring of slack by default
     if (RH > 16) RH = 16;

@@ -1,0 +1,690 @@
+// Exact K-nearest-neighbour flow look-up table, strip kernel (num_tref == 1): the fast path of mpc_knn_lut_fwd.
+//   reference: src/losses/focus.py:115-180 (KeOps argKmin/Kmin over all n x Q pairs, gather, mean / iwd, flow_to_next)
+//
+// Same search as the tile kernel of knn.hip (square of cells around the query, ring bound, exact (distance, index)
+// order), restated so that the per-candidate work is a handful of vector instructions with no divergence:
+//   * a workgroup owns a vertical STRIP of WS query columns x TH query rows; the bucketed points of the strip's cell
+//     columns +- r are staged row by row, so the candidates of a query -- the rows [cy - r, cy + r] of the strip --
+//     are ONE contiguous slot range (points outside the query's square are farther than the ring bound and drop out
+//     by the same `d < upper` test that makes the search exact);
+//   * pass 1 walks the range in groups of eight slots with a wave-uniform trip count and keeps a distance LEVEL of
+//     every slot (64 levels over [upper / 2, upper), a monotone map of the exact fp32 distance) as one byte of a
+//     register array (statically indexed: the loop is fully unrolled);
+//   * the level holding the K-th smallest is found by bisection with SWAR byte compares on those registers
+//     (count(level < beta) = popcount(((beta + 127) * 0x01010101 - w) & 0x80808080) per word) -- no LDS histogram,
+//     no atomics, no second distance evaluation;
+//   * pass 2 re-reads the bytes: levels below the K-th level add their flow (a 0/1 fma: fma(1, a, b) == a + b),
+//     slots at the K-th level are noted in a bit mask and ranked afterwards by exact (distance, index).
+// A query the fast path cannot serve (fewer than K candidates below the ring bound, more slots or more keys at
+// the K-th level than the registers hold, a square that covers the whole grid, a strip whose points overflow the
+// staging area) is appended to a list and searched by k_knn_fallback, one wavefront per query: the result is the
+// exact K-nearest set for any input, ties to the lowest index.
+#include "knn_device.h"
+
+#define KS_NT 256
+#define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
+#define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
+#define KS_NLEV 64                  // distance levels over [upper / 2, upper) (clipped squares: [upper / 4, upper)); byte value 64 = not a candidate
+#define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
+#define KS_TAIL (4 * KS_MAXCH + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
+#define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
+#define KS_SB 3                     // staging: items per thread whose global loads are in flight together
+#define KS_FB_SLOTS 4               // fallback: candidates per lane (64 * 4 per query)
+
+// value of lane `l` (wave-uniform l): v_readlane, no LDS round trip
+__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ unsigned lane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// search square of a query (the rule of knn_one_query): next to the image border the clipped square starts with the
+// cell count of an unclipped one
+__device__ __forceinline__ int query_radius(const KnnParams &p, int cy, int cx, int r_init) {
+    const int want = (2 * r_init + 1) * (2 * r_init + 1);
+    int r = r_init;
+    for (;;) {
+        const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
+        const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
+        if (hh * ww >= want || (hh == p.hq && ww == p.wq)) break;
+        ++r;
+    }
+    return r;
+}
+
+// 1-D grid of gx * gy * B * nb workgroups (gx strips, gy row blocks) in XCD-contiguous order, 256 threads,
+// dynamic LDS sized by the launcher
+template <int WS, bool L1, bool NEXT, bool IWD>
+__global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
+                                                     const int *__restrict__ cell_start,
+                                                     const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                     float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                                     float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                                     int *__restrict__ fail, int r_init, int cap, int gx, int gy) {
+    constexpr int TH = KS_NT / WS;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
+    const int tid = threadIdx.x;
+    const int nblk = gx * gy * p.B * p.nb;
+    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (lblk >= nblk) return;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int sy = bxy / gx, sx = bxy - sy * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
+    const int qx0 = sx * WS, qy0 = sy * TH;
+    const int qx1 = min(qx0 + WS, p.wq) - 1, qy1 = min(qy0 + TH, p.hq) - 1;
+    const int R2 = 2 * r_init;                   // no clipped square needs a larger radius (corner: r + 1 >= 2 r_init + 1)
+    const int ry_base = qy0 - R2;                // grid row of region row 0 (may lie outside the grid: an empty row)
+    const int NR = TH + 2 * R2;                  // region rows (launcher: NR <= KS_NT)
+    // ---- LDS carve-up ----------------------------------------------------------------------------
+    int4 *s_row = reinterpret_cast<int4 *>(s_dyn);             // [NR] {xlo, xhi} of the row, then {first slot, first bucketed slot, points, slots}
+    int *s_rowstart = reinterpret_cast<int *>(s_row + NR);     // [NR + 1] first slot of every region row
+    size_t o = ((size_t)NR * 16 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15;
+    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
+    float2 *lflow = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
+    float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL) * 8 : 0;
+    unsigned short *lidx = reinterpret_cast<unsigned short *>(s_dyn + o);
+
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    const float2 *sp_ = spos + (size_t)bt * p.n;
+    const int *si_ = sidx + (size_t)bt * p.n;
+    const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
+
+    // ---- the query of this thread and its search square -------------------------------------------
+    const int cy = qy0 + tid / WS, cx = qx0 + tid % WS;
+    const bool valid = cy <= qy1 && cx <= qx1;
+    int r = r_init, y0 = 0, y1 = -1, x0 = 0, x1 = -1;
+    if (valid) {
+        r = query_radius(p, cy, cx, r_init);
+        y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
+        x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
+    }
+    // ---- column extent of every region row = union of the squares that use the row ---------------------
+    // queries that no border clips all have radius r_init: their rows get the default extent directly; only the
+    // (few) clipped queries widen rows with LDS atomics
+    const int icx0 = max(qx0, r_init), icx1 = min(qx1, p.wq - 1 - r_init);
+    const int icy0 = max(qy0, r_init), icy1 = min(qy1, p.hq - 1 - r_init);
+    const bool has_inner = icx0 <= icx1 && icy0 <= icy1;
+    if (tid < NR) {
+        const int y = ry_base + tid;
+        const bool dflt = has_inner && y >= icy0 - r_init && y <= icy1 + r_init;
+        s_row[tid] = make_int4(dflt ? icx0 - r_init : 0x7fffffff, dflt ? icx1 + r_init : -1, 0, 0);
+    }
+    __syncthreads();
+    const bool inner = valid && cx >= icx0 && cx <= icx1 && cy >= icy0 && cy <= icy1;
+    if (valid && !inner) {
+        for (int y = y0; y <= y1; ++y) {
+            atomicMin(&s_row[y - ry_base].x, x0);
+            atomicMax(&s_row[y - ry_base].y, x1);
+        }
+    }
+    __syncthreads();
+    // ---- slots of the region rows: an exclusive scan of the row lengths; a row of even length gets one dummy
+    //      slot so that the row pitch is odd (consecutive rows then start in different LDS banks: with the 8 points
+    //      per row of a regular lattice an unpadded pitch puts every fourth row on the same banks) ---------------
+    int len = 0, padded = 0, gs = 0;
+    if (tid < NR) {
+        const int y = ry_base + tid;
+        const int xl = s_row[tid].x, xh = s_row[tid].y;
+        if (y >= 0 && y < p.hq && xh >= xl) {
+            gs = cs[y * p.wq + xl];
+            len = cs[y * p.wq + xh + 1] - gs;
+            padded = len + ((len & 1) ? 0 : 1);
+        }
+    }
+    int incl = padded;
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if ((tid & 63) >= o2) incl += v; }
+    const int wmx = wave_max_i(padded);
+    if ((tid & 63) == 63) { s_wsum[tid >> 6] = incl; s_wmax[tid >> 6] = wmx; }
+    __syncthreads();
+    int run = incl - padded;
+    for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
+    if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int4(run, gs, len, padded); }
+    if (tid == NR - 1) s_rowstart[NR] = run + padded;
+    int sh = 3;                                                     // row pitch of the staging loop: 2^sh >= longest row
+    {
+        const int maxlen = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+        while ((1 << sh) < maxlen) ++sh;
+    }
+    __syncthreads();
+    const int total = s_rowstart[NR];
+    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
+    if (total > cap) {
+        // the points of this strip do not fit the staging area (heavily clustered input): every query goes to the list
+        if (valid) fail[1 + atomicAdd(&fail[0], 1)] = (int)((unsigned)q | (3u << 30));
+        return;
+    }
+    // ---- stage positions, flows and indices: item = (region row, k-th slot of the row), KS_SB items per thread
+    //      with their (dependent) global loads in flight together ----------------------------------------------
+    {
+        const float2 *tref0 = traj_b;                                     // T == 1: the reference time
+        const float2 *tnext = traj_b + (size_t)(p.T + t + 1) * p.n;       // next bin (if any)
+        const bool has_next = NEXT && (t < p.nb - 1);
+        const int items = NR << sh, kmask = (1 << sh) - 1;
+        for (int base = 0; base < items; base += KS_NT * KS_SB) {
+            int slot[KS_SB], id[KS_SB];
+            bool in[KS_SB], real[KS_SB];
+            float2 pj[KS_SB], f0[KS_SB], f1[KS_SB];
+#pragma unroll
+            for (int u = 0; u < KS_SB; ++u) {
+                const int it = base + u * KS_NT + tid, rr = min(it >> sh, NR - 1), k = it & kmask;
+                const int4 row = s_row[rr];
+                in[u] = it < items && k < row.w;
+                real[u] = in[u] && k < row.z;
+                slot[u] = row.x + k;
+                pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
+                if (real[u]) { pj[u] = sp_[row.y + k]; id[u] = si_[row.y + k]; }
+            }
+#pragma unroll
+            for (int u = 0; u < KS_SB; ++u) {
+                f0[u] = f1[u] = make_float2(0.f, 0.f);
+                if (real[u]) {
+                    const float2 a = tref0[id[u]];
+                    f0[u] = make_float2(a.x - pj[u].x, a.y - pj[u].y);      // traj(t_ref) - traj(t_mid)  focus.py:140-141
+                    if (has_next) { const float2 c = tnext[id[u]]; f1[u] = make_float2(c.x - pj[u].x, c.y - pj[u].y); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KS_SB; ++u) {
+                if (in[u]) {
+                    lpos[slot[u]] = pj[u];
+                    lflow[slot[u]] = f0[u];
+                    if (NEXT) lnext[slot[u]] = f1[u];
+                    lidx[slot[u]] = (unsigned short)id[u];
+                }
+            }
+        }
+        // the tail behind the staged slots: far-away positions, zero flows (lanes whose range is shorter than the
+        // wavefront's trip count read them, flagged off)
+        for (int i = total + tid; i < total + KS_TAIL; i += KS_NT) {
+            lpos[i] = make_float2(KS_FAR, KS_FAR);
+            lflow[i] = make_float2(0.f, 0.f);
+            if (NEXT) lnext[i] = make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+
+    // ---- search --------------------------------------------------------------------------------------
+    const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+    bool failed = false;
+    unsigned why = 0u;                 // diagnostics: top two bits of a list entry (0 few candidates, 1 too many slots, 2 too many keys at the K-th level, 3 staging overflow)
+    int s = 0, nsl = 0;
+    if (valid) {
+        const bool whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
+        s = s_rowstart[y0 - ry_base];
+        nsl = s_rowstart[y1 - ry_base + 1] - s;
+        if (whole || nsl > 4 * KS_MAXCH) { failed = true; why = 1u; nsl = 0; s = 0; }
+    }
+    // anything outside the square is at least lb away along one axis
+    const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
+    const float upper = L1 ? lb : lb * lb;
+    // level of a distance: (d - lo) * NLEV / (upper - lo) saturated to [0, NLEV]: a monotone map (that is all exactness
+    // needs: a slot at a higher level is farther than every slot at a lower one); level NLEV <=> not below the ring
+    // bound (or a dummy slot).  lo = upper / 2: the K-th distance of an unclipped square sits near 0.83 upper; a
+    // clipped square was enlarged by whole rings, its K-th distance can be as low as upper / 2: lo = upper / 4.
+    const float lo_d = (r == r_init) ? 0.5f * upper : 0.25f * upper;
+    const float scale = (float)KS_NLEV / (upper - lo_d), loff = -lo_d * scale;
+    const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
+    const float2 *pp = lpos + s;
+    // pass 1: level of every slot, one byte each; groups of 8 slots whose loads are issued together
+    unsigned w[KS_MAXCH];
+#pragma unroll
+    for (int g = 0; g < KS_MAXCH / 2; ++g) {
+        w[2 * g] = w[2 * g + 1] = 0x01010101u * KS_NLEV;
+        if (8 * g < nmax) {
+            float2 pj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pj[u] = pp[8 * g + u];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                unsigned acc = 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = pair_dist(qy, qx, pj[4 * h + u].x, pj[4 * h + u].y, L1);
+                    const float lvf = fminf(fmaf(d, scale, loff), (float)KS_NLEV);
+                    acc = __builtin_amdgcn_cvt_pk_u8_f32(lvf, u, acc);       // saturating: negative -> 0
+                }
+                w[2 * g + h] = acc;
+            }
+        }
+    }
+    // number of slots below level beta (1 <= beta <= NLEV): bytes are <= NLEV < 128, so (beta + 127 - byte) keeps
+    // bit 7 exactly when byte < beta, and no borrow crosses a byte (words of groups not visited hold level NLEV)
+    auto count_lt = [&](unsigned beta) {
+        const unsigned C = (beta + 127u) * 0x01010101u;
+        int acc = 0;
+#pragma unroll
+        for (int c = 0; c < KS_BASECH; ++c) acc += __popc((C - w[c]) & 0x80808080u);
+        // (an inner query has 7 rows of 9 slots; only wavefronts next to the image border, whose rows are wider, get
+        // here: real branches on the wave-uniform trip count -- the empty asm keeps them from being if-converted)
+        if (nmax > 4 * KS_BASECH) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = KS_BASECH; c < KS_BASECH + 4; ++c) acc += __popc((C - w[c]) & 0x80808080u);
+            if (nmax > 4 * KS_BASECH + 16) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = KS_BASECH + 4; c < KS_MAXCH; ++c) acc += __popc((C - w[c]) & 0x80808080u);
+            }
+        }
+        return acc;
+    };
+    int bstar = 0, before = 0, inbin = 0;
+    if (valid && !failed) {
+        const int cnt = count_lt(KS_NLEV);
+        if (cnt < p.K) failed = true;              // fewer than K candidates below the ring bound: the square must grow
+        else {
+            int lo = 0, clo = 0, hi = KS_NLEV, chi = cnt;      // count_lt(lo) < K <= count_lt(hi)
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const int cm = count_lt((unsigned)mid);
+                if (cm >= p.K) { hi = mid; chi = cm; } else { lo = mid; clo = cm; }
+            }
+            bstar = lo; before = clo; inbin = chi - clo;     // level of the K-th smallest, slots below it, slots in it
+        }
+    }
+    const bool live = valid && !failed;
+    // pass 2: flows of the levels below bstar (flag = clamp(bstar - level, 0, 1)); slots at level bstar into a bit mask
+    const bool do_next = NEXT && (t < p.nb - 1);
+    float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
+    unsigned E[(KS_MAXCH + 7) / 8];
+#pragma unroll
+    for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) E[e] = 0u;
+    const float ubf = live ? (float)bstar : 0.f;             // dead lanes: nothing is below level 0 ...
+    const unsigned ue = live ? (unsigned)bstar : 0xffu;      // ... and nothing at level 255
+    const float2 *pf = lflow + s, *pn = lnext + s;
+#pragma unroll
+    for (int g = 0; g < KS_MAXCH / 2; ++g) {
+        if (8 * g < nmax) {
+            float2 fj[8], gj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { fj[u] = pf[8 * g + u]; if (NEXT) gj[u] = pn[8 * g + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned lv = (w[2 * g + (u >> 2)] >> (8 * (u & 3))) & 0xffu;
+                if (IWD) {
+                    if (lv < ue) {                               // (ue == bstar on live lanes, 255 never matters: lv <= NLEV)
+                        if (live) {
+                            const float2 pj = pp[8 * g + u];
+                            const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                            const float wgt = 1.f / (d + 1e-9f);                  // focus.py:159-161
+                            sy_ += wgt * fj[u].x; sx_ += wgt * fj[u].y; sw_ += wgt;
+                            if (do_next) { ny_ += gj[u].x; nx_ += gj[u].y; }
+                        }
+                    }
+                } else {
+                    const float flag = fminf(fmaxf(ubf - (float)lv, 0.f), 1.f);
+                    sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_);
+                    if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
+                }
+                E[g / 4] |= (lv == ue) ? (1u << ((8 * g + u) & 31)) : 0u;
+            }
+        }
+    }
+    // ---- the K-th level: rank its keys by exact (distance, index); the first `need` are neighbours -----------------
+    // Lanes with at most KS_LMAX keys there (nearly all) rank them in registers.  The others -- a lattice with little
+    // flow has shells of up to eight points at practically one distance -- are HEAVY: rare per lane but present in
+    // most wavefronts, so the whole wavefront serves them one at a time, a lane per slot (any number of keys).
+    const int need = p.K - before;
+    float dK = 0.f; int iK = -1;
+    const bool heavy = live && inbin > KS_LMAX;
+    {
+        float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX];
+        const bool light = live && !heavy;
+        const int mmax = __builtin_amdgcn_readfirstlane(wave_max_i(light ? inbin : 0));
+        unsigned long long em = ((unsigned long long)E[1] << 32) | E[0];
+        unsigned e2 = E[2];
+#pragma unroll
+        for (int a = 0; a < KS_LMAX; ++a) {
+            dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0;
+            if (a < mmax) {
+                int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // lowest slot still in the mask
+                if (em) em &= em - 1ull; else e2 &= e2 - 1u;
+                if (light && k >= 0) {
+                    const float2 pj = pp[k];
+                    jj[a] = k;
+                    dd[a] = pair_dist(qy, qx, pj.x, pj.y, L1);
+                    ii[a] = (int)lidx[s + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < KS_LMAX; ++a) {
+            if (a < mmax) {
+                int rank = 0;
+#pragma unroll
+                for (int e = 0; e < KS_LMAX; ++e)
+                    if (e != a) rank += ((dd[e] < dd[a]) | ((dd[e] == dd[a]) & (ii[e] < ii[a]))) ? 1 : 0;
+                if (light && a < inbin && rank < need) {
+                    const float2 f = pf[jj[a]];
+                    if (IWD) { const float wgt = 1.f / (dd[a] + 1e-9f); sy_ += wgt * f.x; sx_ += wgt * f.y; sw_ += wgt; }
+                    else { sy_ += f.x; sx_ += f.y; }
+                    if (do_next) { const float2 g2 = pn[jj[a]]; ny_ += g2.x; nx_ += g2.y; }
+                    if (rank == need - 1) { dK = dd[a]; iK = ii[a]; }
+                }
+            }
+        }
+    }
+    {
+        unsigned long long hm = __ballot(heavy);
+        const int lane = tid & 63;
+        while (hm != 0ull) {                                       // wave-uniform loop over the heavy lanes
+            const int h = __ffsll((long long)hm) - 1;
+            hm &= hm - 1ull;
+            const int hs = lane_i(s, h), hneed = lane_i(need, h);
+            const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h);
+            const float hqy = lane_f(qy, h), hqx = lane_f(qx, h);
+            // this lane's two slots of the heavy query: lane and lane + 64
+            const bool b0 = (((lane < 32 ? h0 : h1) >> (lane & 31)) & 1u) != 0u, b1 = lane < 32 && ((h2 >> lane) & 1u) != 0u;
+            float d0 = INFINITY, d1 = INFINITY;
+            int i0 = 0x7fffffff, i1 = 0x7fffffff, r0_ = 0, r1_ = 0;
+            if (b0) { const float2 pj = lpos[hs + lane]; d0 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i0 = (int)lidx[hs + lane]; }
+            if (b1) { const float2 pj = lpos[hs + 64 + lane]; d1 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i1 = (int)lidx[hs + 64 + lane]; }
+            unsigned long long km = ((unsigned long long)h1 << 32) | h0;
+            while (km != 0ull) {
+                const int k = __ffsll((long long)km) - 1;
+                km &= km - 1ull;
+                const float kd = lane_f(d0, k); const int ki = lane_i(i0, k);
+                r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
+                r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
+            }
+            unsigned k2 = h2;
+            while (k2 != 0u) {
+                const int k = __ffs(k2) - 1;
+                k2 &= k2 - 1u;
+                const float kd = lane_f(d1, k); const int ki = lane_i(i1, k);
+                r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
+                r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
+            }
+            float cy_ = 0.f, cx_ = 0.f, cw_ = 0.f, cny = 0.f, cnx = 0.f, cdk = 0.f;
+            int cik = -1;
+            const bool hnext = NEXT && (t < p.nb - 1);
+            if (b0 && r0_ < hneed) {
+                const float2 f = lflow[hs + lane];
+                if (IWD) { const float wgt = 1.f / (d0 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
+                if (hnext) { const float2 g2 = lnext[hs + lane]; cny += g2.x; cnx += g2.y; }
+                if (r0_ == hneed - 1) { cdk = d0; cik = i0; }
+            }
+            if (b1 && r1_ < hneed) {
+                const float2 f = lflow[hs + 64 + lane];
+                if (IWD) { const float wgt = 1.f / (d1 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
+                if (hnext) { const float2 g2 = lnext[hs + 64 + lane]; cny += g2.x; cnx += g2.y; }
+                if (r1_ == hneed - 1) { cdk = d1; cik = i1; }
+            }
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                cy_ += __shfl_xor(cy_, o2, 64); cx_ += __shfl_xor(cx_, o2, 64);
+                if (IWD) cw_ += __shfl_xor(cw_, o2, 64);
+                if (NEXT) { cny += __shfl_xor(cny, o2, 64); cnx += __shfl_xor(cnx, o2, 64); }
+                cdk = fmaxf(cdk, __shfl_xor(cdk, o2, 64)); cik = max(cik, __shfl_xor(cik, o2, 64));
+            }
+            if (lane == h) { sy_ += cy_; sx_ += cx_; sw_ += cw_; ny_ += cny; nx_ += cnx; dK = cdk; iK = cik; }
+        }
+    }
+    // ---- outputs ---------------------------------------------------------------------------------------
+    if (live) {
+        const size_t BQ = (size_t)p.B * p.nb * p.G;
+        float2 ov; float norm = 0.f;
+        if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
+        else { ov.x = sy_ / (float)p.K; ov.y = sx_ / (float)p.K; }
+        reinterpret_cast<float2 *>(flow_lut)[q] = ov;
+        if (do_next) {
+            float2 on; on.x = ny_ / (float)p.K; on.y = nx_ / (float)p.K;
+            reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
+        }
+        knn_state[q] = dK;
+        reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
+#ifdef KS_DEBUG_INBIN
+        norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
+#endif
+        knn_state[2 * BQ + q] = norm;
+    }
+    {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
+        const bool push = valid && !live;
+        const unsigned long long pm = __ballot(push);
+        if (pm != 0ull) {
+            const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
+            int base = 0;
+            if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
+            base = __shfl(base, first, 64);
+            if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | (why << 30));
+        }
+    }
+    // largest K-th distance per 16x16 cell tile (bounds the search windows of the backward): a wavefront covers
+    // 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
+    {
+        float m = live ? dK : 0.f;
+#pragma unroll
+        for (int o2 = 8 * WS; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+        if ((tid & (16 * WS - 1)) == 0 && cy <= qy1) {
+            const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+            atomicMax(reinterpret_cast<int *>(tile_dkmax) + ((size_t)bt * gy16 + (cy >> 4)) * gx16 + (qx0 >> 4), __float_as_int(m));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The queries the strip kernel could not serve: ONE WAVEFRONT per query (a thread per query would spend ~100 us
+// in dependent global loads).  The square grows as in knn_one_query; the lanes take its candidates in parallel
+// (up to 64 * KS_FB_SLOTS of them), every candidate is broadcast in turn and each lane counts how many keys
+// (distance, index) are smaller than its own: rank < K <=> neighbour.  A square with more candidates than that is
+// searched by lane 0 with the generic routine.
+// grid: a fixed number of workgroups (the list length is only known on the device), 256 threads = 4 queries at a time
+// ------------------------------------------------------------------------------------------
+template <bool L1>
+__device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const int *__restrict__ cell_start,
+                                   const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                   float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, int q, int r_init,
+                                   unsigned (*s_hist)[256]) {
+    const int lane = threadIdx.x & 63;
+    const int bt = q / p.G, cell = q - bt * p.G;
+    const int cy = cell / p.wq, cx = cell - cy * p.wq;
+    const int b = bt / p.nb, t = bt - b * p.nb;
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    const float2 *sp_ = spos + (size_t)bt * p.n;
+    const int *si_ = sidx + (size_t)bt * p.n;
+    const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
+    const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+    int r = query_radius(p, cy, cx, r_init);
+    float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS], gg[KS_FB_SLOTS];
+    bool serial = false;
+    for (;;) {
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, p.hq - 1), x0 = max(cx - r, 0), x1 = min(cx + r, p.wq - 1);
+        const bool whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
+        const int nrows = y1 - y0 + 1;
+        if (nrows > 64) { serial = true; break; }
+        const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
+        const float upper = whole ? INFINITY : (L1 ? lb : lb * lb);
+        // lane l < nrows: the bucketed range of row y0 + l; exclusive scan over the lanes -> flat candidate numbering
+        int js = 0, ln = 0;
+        if (lane < nrows) { js = cs[(y0 + lane) * p.wq + x0]; ln = cs[(y0 + lane) * p.wq + x1 + 1] - js; }
+        int incl = ln;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if (lane >= o2) incl += v; }
+        const int N = __shfl(incl, 63, 64);
+        if (N > 64 * KS_FB_SLOTS) { serial = true; break; }
+        const int excl = incl - ln;
+        int cnt = 0;
+#pragma unroll
+        for (int m = 0; m < KS_FB_SLOTS; ++m) {
+            const int k = lane + 64 * m;                    // flat candidate number of this lane's m-th slot
+            dd[m] = INFINITY; ii[m] = 0x7fffffff; gg[m] = 0;
+            // row of candidate k: the last lane whose exclusive offset is <= k (offsets are non-decreasing)
+            int lo = 0, hi = 64;
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const int mid = (lo + hi) >> 1;
+                const int ev = __shfl(excl, mid, 64);
+                if (ev <= k) lo = mid; else hi = mid;
+            }
+            const int rjs = __shfl(js, lo, 64), rex = __shfl(excl, lo, 64);
+            if (k < N) {
+                const int g = rjs + (k - rex);
+                const float2 pj = sp_[g];
+                const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                if (d < upper) { dd[m] = d; ii[m] = si_[g]; gg[m] = g; ++cnt; }
+            }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
+        if (cnt >= p.K || whole) break;
+        r += 1 + (r >> 2);
+    }
+    if (serial) {
+        // more candidates than the lanes hold (a very dense place): the generic thread-serial search
+        if (lane == 0) {
+            QueryCtx c;
+            c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
+            c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
+            c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
+            float dK = 0.f;
+            knn_one_query<false, L1, 256>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, nullptr, dK);
+            const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+            atomicMax(reinterpret_cast<int *>(tile_dkmax) + ((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4), __float_as_int(dK));
+        }
+        return;
+    }
+    // rank of every candidate among all of them
+    int rank[KS_FB_SLOTS];
+#pragma unroll
+    for (int m = 0; m < KS_FB_SLOTS; ++m) rank[m] = 0;
+#pragma unroll
+    for (int mo = 0; mo < KS_FB_SLOTS; ++mo) {
+        unsigned long long vm = __ballot(dd[mo] < INFINITY);       // lanes holding a candidate in this slot
+        while (vm != 0ull) {
+            const int l = __ffsll((long long)vm) - 1;
+            vm &= vm - 1ull;
+            const float od = lane_f(dd[mo], l);
+            const int oi = lane_i(ii[mo], l);
+#pragma unroll
+            for (int m = 0; m < KS_FB_SLOTS; ++m) rank[m] += ((od < dd[m]) | ((od == dd[m]) & (oi < ii[m]))) ? 1 : 0;
+        }
+    }
+    // neighbours: rank < K (indices are distinct, so ranks are); sums in lane order
+    const bool do_next = p.want_next && (t < p.nb - 1);
+    float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f, dK = 0.f;
+    int iK = -1;
+#pragma unroll
+    for (int m = 0; m < KS_FB_SLOTS; ++m) {
+        if (dd[m] < INFINITY && rank[m] < p.K) {
+            const float2 pj = sp_[gg[m]];
+            const float2 a = traj_b[ii[m]];                                   // T == 1
+            const float fy = a.x - pj.x, fx = a.y - pj.y;
+            if (p.iwd) { const float wgt = 1.f / (dd[m] + 1e-9f); sy_ += wgt * fy; sx_ += wgt * fx; sw_ += wgt; }
+            else { sy_ += fy; sx_ += fx; }
+            if (do_next) { const float2 c = traj_b[(size_t)(p.T + t + 1) * p.n + ii[m]]; ny_ += c.x - pj.x; nx_ += c.y - pj.y; }
+            if (rank[m] == p.K - 1) { dK = dd[m]; iK = ii[m]; }
+        }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        sy_ += __shfl_xor(sy_, o2, 64); sx_ += __shfl_xor(sx_, o2, 64); sw_ += __shfl_xor(sw_, o2, 64);
+        ny_ += __shfl_xor(ny_, o2, 64); nx_ += __shfl_xor(nx_, o2, 64);
+        dK = fmaxf(dK, __shfl_xor(dK, o2, 64)); iK = max(iK, __shfl_xor(iK, o2, 64));
+    }
+    if (lane == 0) {
+        const size_t BQ = (size_t)p.B * p.nb * p.G;
+        float2 ov; float norm = 0.f;
+        if (p.iwd) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
+        else { ov.x = sy_ / (float)p.K; ov.y = sx_ / (float)p.K; }
+        reinterpret_cast<float2 *>(flow_lut)[q] = ov;
+        if (do_next) {
+            float2 on; on.x = ny_ / (float)p.K; on.y = nx_ / (float)p.K;
+            reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
+        }
+        knn_state[q] = dK;
+        reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
+        knn_state[2 * BQ + q] = norm;
+        const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+        atomicMax(reinterpret_cast<int *>(tile_dkmax) + ((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4), __float_as_int(dK));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const float *__restrict__ traj,
+                                                      const int *__restrict__ cell_start,
+                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                                      const int *__restrict__ fail, int r_init) {
+    __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
+    const int nfail = fail[0];
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int i = wv; i < nfail; i += nw) {
+        const int q = fail[1 + i] & 0x3fffffff;
+        if (p.l1) fallback_one_query<true>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, s_hist);
+        else fallback_one_query<false>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, s_hist);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launcher (called by mpc_knn_lut_fwd once the points are bucketed; `fail[0]` and tile_dkmax zeroed by the bucket kernel)
+// ------------------------------------------------------------------------------------------
+static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out, size_t *lds_out) {
+    const int TH = KS_NT / WS, R2 = 2 * r_init, NR = TH + 2 * R2;
+    if (NR > KS_NT) return false;
+    const double dens = (double)s->n / ((double)s->hq * s->wq);
+    const double row_pts = dens * (WS + 2 * r_init);                       // points per region row of an inner strip
+    // slots of an inner query: its rows, one dummy slot per even row; must leave room for denser places
+    if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * KS_MAXCH) return false;
+    const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
+    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 64;
+    cap = (cap + 63) / 64 * 64;
+    const bool next = (s->flags & MPC_F_WANT_NEXT) != 0;
+    const size_t lds = (((size_t)NR * 16 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + KS_TAIL) * 8 * (next ? 3 : 2) +
+                       (size_t)cap * 2 + 16;
+    if (lds > 64 * 1024) return false;
+    *cap_out = cap; *lds_out = lds;
+    return true;
+}
+
+bool mpc_knn_strip_usable(const mpc_shape *s, int r_init) {
+    int cap; size_t lds;
+    if (s->T != 1 || s->n >= 65536 || s->K < 1 || s->K > 4 * KS_MAXCH) return false;
+    if (s->hq < 2 * r_init + 2 || s->wq < 2 * r_init + 2) return false;       // tiny grids: the square is the whole grid
+    return strip_geometry(s, r_init, 2, &cap, &lds);
+}
+
+template <int WS>
+static void launch_strip(const KnnParams &p, const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos,
+                         const int *sidx, float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail,
+                         int r_init, int cap, size_t lds, hipStream_t st) {
+    const int TH = KS_NT / WS;
+    const int gx = mpc_cdiv(s->wq, WS), gy = mpc_cdiv(s->hq, TH);
+    const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
+#define KS_LAUNCH(L1_, NEXT_, IWD_)                                                                                       \
+    hipLaunchKernelGGL((k_knn_strip<WS, L1_, NEXT_, IWD_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx,  \
+                       flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy)
+    const int sel = (p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0);
+    switch (sel) {
+    case 0: KS_LAUNCH(false, false, false); break;
+    case 1: KS_LAUNCH(false, false, true); break;
+    case 2: KS_LAUNCH(false, true, false); break;
+    case 3: KS_LAUNCH(false, true, true); break;
+    case 4: KS_LAUNCH(true, false, false); break;
+    case 5: KS_LAUNCH(true, false, true); break;
+    case 6: KS_LAUNCH(true, true, false); break;
+    default: KS_LAUNCH(true, true, true); break;
+    }
+#undef KS_LAUNCH
+}
+
+int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
+                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
+                         hipStream_t st) {
+    const KnnParams p = knn_params(s);
+    int cap = 0; size_t lds = 0;
+    if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
+    launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, st);
+    MPC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
+                       knn_state, tile_dkmax, fail, r_init);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}

@@ -14,6 +14,17 @@ __global__ void k(float *out, int iters) {
         } else if (MODE == 1) {  // 4 fma + 4 int ops
             a0 = fmaf(a0, b, c); a1 = fmaf(a1, b, c); a2 = fmaf(a2, b, c); a3 = fmaf(a3, b, c);
             i0 = (i0 * 3) ^ it; i1 = (i1 + i0) & 0xffff; i2 = max(i2, i1) + 1; i3 = (i3 << 1) | (i2 & 1);
+        } else if (MODE == 3) {  // 8 independent packed fp32 multiplies (2 x fp32 per lane per instruction)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, bb = {b, b};
+            asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                         "v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(bb));
+            a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+        } else if (MODE == 4) {  // 8 independent plain fp32 multiplies, same asm form (reference for MODE 3)
+            asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                         "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
         } else {                 // compare + select chains
             a0 = a0 > a1 ? a0 * b : a1 + c; a1 = a1 > a2 ? a1 * b : a2 + c; a2 = a2 > a3 ? a2 * b : a3 + c; a3 = a3 > a0 ? a3 * b : a0 + c;
             a4 = a4 > a5 ? a4 * b : a5 + c; a5 = a5 > a6 ? a5 * b : a6 + c; a6 = a6 > a7 ? a6 * b : a7 + c; a7 = a7 > a4 ? a7 * b : a4 + c;
@@ -44,5 +55,7 @@ int main() {
     for (int w : {1, 2, 4, 8}) run<0>(d, w, 8);
     for (int w : {1, 2, 4, 8}) run<1>(d, w, 12);
     for (int w : {1, 2, 4, 8}) run<2>(d, w, 24);
+    for (int w : {1, 2, 4, 8}) run<3>(d, w, 8);
+    for (int w : {1, 2, 4, 8}) run<4>(d, w, 8);
     return 0;
 }
