@@ -20,6 +20,7 @@
 // staging area) is appended to a list and searched by k_knn_fallback, one wavefront per query: the result is the
 // exact K-nearest set for any input, ties to the lowest index.
 #include "knn_device.h"
+#include <stdlib.h>
 
 #define KS_NT 256
 #define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
@@ -146,11 +147,8 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
     if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int4(run, gs, len, padded); }
     if (tid == NR - 1) s_rowstart[NR] = run + padded;
-    int sh = 3;                                                     // row pitch of the staging loop: 2^sh >= longest row
-    {
-        const int maxlen = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
-        while ((1 << sh) < maxlen) ++sh;
-    }
+    // row pitch of the staging loop = the longest row of the region
+    const int pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
     __syncthreads();
     const int total = s_rowstart[NR];
     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
@@ -165,14 +163,17 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         const float2 *tref0 = traj_b;                                     // T == 1: the reference time
         const float2 *tnext = traj_b + (size_t)(p.T + t + 1) * p.n;       // next bin (if any)
         const bool has_next = NEXT && (t < p.nb - 1);
-        const int items = NR << sh, kmask = (1 << sh) - 1;
+        // item -> (row, slot of the row) with a reciprocal multiply: (it + 0.5) / pitch is at least 0.5 / pitch away from
+        // an integer, far more than the rounding of the product (it < 2^14)
+        const int items = NR * pitch;
+        const float inv_pitch = 1.f / (float)pitch;
         for (int base = 0; base < items; base += KS_NT * KS_SB) {
             int slot[KS_SB], id[KS_SB];
             bool in[KS_SB], real[KS_SB];
             float2 pj[KS_SB], f0[KS_SB], f1[KS_SB];
 #pragma unroll
             for (int u = 0; u < KS_SB; ++u) {
-                const int it = base + u * KS_NT + tid, rr = min(it >> sh, NR - 1), k = it & kmask;
+                const int it = base + u * KS_NT + tid, rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1), k = it - rr * pitch;
                 const int4 row = s_row[rr];
                 in[u] = it < items && k < row.w;
                 real[u] = in[u] && k < row.z;
@@ -276,18 +277,19 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     };
     int bstar = 0, before = 0, inbin = 0;
     if (valid && !failed) {
-        const int cnt = count_lt(KS_NLEV);
-        if (cnt < p.K) failed = true;              // fewer than K candidates below the ring bound: the square must grow
-        else {
-            int lo = 0, clo = 0, hi = KS_NLEV, chi = cnt;      // count_lt(lo) < K <= count_lt(hi)
+        int lo = 0, clo = 0, hi = KS_NLEV, chi = -1;      // count_lt(lo) < K <= count_lt(hi) -- assumed for hi = NLEV, checked below
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo + hi) >> 1;
-                const int cm = count_lt((unsigned)mid);
-                if (cm >= p.K) { hi = mid; chi = cm; } else { lo = mid; clo = cm; }
-            }
-            bstar = lo; before = clo; inbin = chi - clo;     // level of the K-th smallest, slots below it, slots in it
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const int cm = count_lt((unsigned)mid);
+            if (cm >= p.K) { hi = mid; chi = cm; } else { lo = mid; clo = cm; }
         }
+        // the number of candidates below the ring bound is only needed when the search ends at the top level (rare)
+        if (chi < 0) {
+            chi = count_lt(KS_NLEV);
+            if (chi < p.K) failed = true;          // fewer than K candidates below the ring bound: the square must grow
+        }
+        bstar = lo; before = clo; inbin = chi - clo;     // level of the K-th smallest, slots below it, slots in it
     }
     const bool live = valid && !failed;
     // pass 2: flows of the levels below bstar (flag = clamp(bstar - level, 0, 1)); slots at level bstar into a bit mask
@@ -482,7 +484,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
                                    const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                    float *__restrict__ knn_state, float *__restrict__ tile_dkmax, int q, int r_init,
-                                   unsigned (*s_hist)[256]) {
+                                   bool grow_first, unsigned (*s_hist)[256]) {
     const int lane = threadIdx.x & 63;
     const int bt = q / p.G, cell = q - bt * p.G;
     const int cy = cell / p.wq, cx = cell - cy * p.wq;
@@ -493,6 +495,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
     int r = query_radius(p, cy, cx, r_init);
+    if (grow_first) r += 1 + (r >> 2);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS], gg[KS_FB_SLOTS];
     bool serial = false;
     for (;;) {
@@ -618,8 +621,9 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     for (int i = wv; i < nfail; i += nw) {
         const int q = fail[1 + i] & 0x3fffffff;
-        if (p.l1) fallback_one_query<true>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, s_hist);
-        else fallback_one_query<false>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, s_hist);
+        const bool grow = ((unsigned)fail[1 + i] >> 30) == 0u;       // too few candidates at the first radius: skip it
+        if (p.l1) fallback_one_query<true>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, grow, s_hist);
+        else fallback_one_query<false>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, grow, s_hist);
     }
 }
 
@@ -634,13 +638,15 @@ static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out,
     // slots of an inner query: its rows, one dummy slot per even row; must leave room for denser places
     if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * KS_MAXCH) return false;
     const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
-    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 64;
+    static const double slack = getenv("MPC_KS_SLACK") ? atof(getenv("MPC_KS_SLACK")) : 1.15;      // (tuning)
+    int cap = (int)(slack * rows * (row_pts + 0.5)) + 64;
     cap = (cap + 63) / 64 * 64;
     const bool next = (s->flags & MPC_F_WANT_NEXT) != 0;
     const size_t lds = (((size_t)NR * 16 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + KS_TAIL) * 8 * (next ? 3 : 2) +
                        (size_t)cap * 2 + 16;
     if (lds > 64 * 1024) return false;
-    *cap_out = cap; *lds_out = lds;
+    static const int pad_lds = getenv("MPC_KS_PADLDS") ? atoi(getenv("MPC_KS_PADLDS")) : 0;             // (tuning: occupancy experiments)
+    *cap_out = cap; *lds_out = lds + (size_t)pad_lds;
     return true;
 }
 
@@ -683,7 +689,7 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_
     if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
     launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, st);
     MPC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_knn_fallback, dim3(1024), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
+    hipLaunchKernelGGL(k_knn_fallback, dim3(256), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
                        knn_state, tile_dkmax, fail, r_init);
     MPC_CHECK_LAUNCH();
     return 0;

@@ -25,6 +25,19 @@ __global__ void k(float *out, int iters) {
             asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
                          "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        } else if (MODE == 5) {  // SWAR count step with 32-bit literals: sub, and, bcnt-accumulate (x4 independent)
+            asm volatile("v_sub_u32 %0, 0xbfbfbfbf, %4\n v_and_b32 %0, 0x80808080, %0\n v_bcnt_u32_b32 %4, %0, %4\n"
+                         "v_sub_u32 %1, 0xbfbfbfbf, %5\n v_and_b32 %1, 0x80808080, %1\n v_bcnt_u32_b32 %5, %1, %5\n"
+                         "v_sub_u32 %2, 0xbfbfbfbf, %6\n v_and_b32 %2, 0x80808080, %2\n v_bcnt_u32_b32 %6, %2, %6\n"
+                         "v_sub_u32 %3, 0xbfbfbfbf, %7\n v_and_b32 %3, 0x80808080, %3\n v_bcnt_u32_b32 %7, %3, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));
+        } else if (MODE == 6) {  // the same with the constants in scalar registers
+            int c1 = 0xbfbfbfbf, c2 = 0x80808080;
+            asm volatile("v_sub_u32 %0, %8, %4\n v_and_b32 %0, %9, %0\n v_bcnt_u32_b32 %4, %0, %4\n"
+                         "v_sub_u32 %1, %8, %5\n v_and_b32 %1, %9, %1\n v_bcnt_u32_b32 %5, %1, %5\n"
+                         "v_sub_u32 %2, %8, %6\n v_and_b32 %2, %9, %2\n v_bcnt_u32_b32 %6, %2, %6\n"
+                         "v_sub_u32 %3, %8, %7\n v_and_b32 %3, %9, %3\n v_bcnt_u32_b32 %7, %3, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "s"(c1), "s"(c2));
         } else {                 // compare + select chains
             a0 = a0 > a1 ? a0 * b : a1 + c; a1 = a1 > a2 ? a1 * b : a2 + c; a2 = a2 > a3 ? a2 * b : a3 + c; a3 = a3 > a0 ? a3 * b : a0 + c;
             a4 = a4 > a5 ? a4 * b : a5 + c; a5 = a5 > a6 ? a5 * b : a6 + c; a6 = a6 > a7 ? a6 * b : a7 + c; a7 = a7 > a4 ? a7 * b : a4 + c;
@@ -57,5 +70,7 @@ int main() {
     for (int w : {1, 2, 4, 8}) run<2>(d, w, 24);
     for (int w : {1, 2, 4, 8}) run<3>(d, w, 8);
     for (int w : {1, 2, 4, 8}) run<4>(d, w, 8);
+    for (int w : {2, 4, 8}) run<5>(d, w, 12);
+    for (int w : {2, 4, 8}) run<6>(d, w, 12);
     return 0;
 }
