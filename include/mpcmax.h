@@ -90,12 +90,16 @@ int64_t mpc_workspace_bytes(const mpc_shape *s);
  * traj      [B][T+nb][n][2]  (y,x); rows [0,T) are the reference times, [T,T+nb) the bin mids
  * flow_lut  [B][nb][hq][wq][T][2]                                   (out)
  * flow_next [B][nb-1][hq][wq][1][2]  or NULL unless MPC_F_WANT_NEXT (out)
- * knn_state [3][B][nb][hq*wq] + [B][nb][ceil(hq/16)*ceil(wq/16)] : K-th distance (f32), K-th
- *           index (i32 bits), iwd normaliser, then the largest K-th distance of every 16x16
- *           cell tile (out; consumed by _bwd)
+ * knn_state mpc_knn_state_floats(s) floats = [3][B][nb][hq*wq] + [B][nb][ceil(hq/16)*ceil(wq/16)][5] : K-th distance
+ *           (f32), K-th index (i32 bits; bit 30 set if a point at exactly the K-th distance was excluded by the index
+ *           tie rule), iwd normaliser, then the largest K-th distance of every 16x16 cell tile per class of query
+ *           (inner / within r+1 cells of the top, bottom, left, right border) (out; consumed by _bwd)
  * idx_out   [B][nb][hq*wq][K] int32, ascending by (distance, index), or NULL (debug/tests)  */
 int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                     float *knn_state, int32_t *idx_out, void *ws, void *stream);
+
+/* Number of floats of the knn_state buffer of mpc_knn_lut_fwd / _bwd for this shape. */
+int64_t mpc_knn_state_floats(const mpc_shape *s);
 
 /* Diagnostics: byte offset, inside the workspace, of the list of queries that mpc_knn_lut_fwd's strip kernel handed to
  * its per-query fallback: int32 count, then count entries (query id = ((b*nb + bin)*hq + cy)*wq + cx in the low 30 bits,

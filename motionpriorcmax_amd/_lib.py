@@ -27,7 +27,7 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
-           'mpc_knn_fail_list_offset']
+           'mpc_knn_fail_list_offset', 'mpc_knn_state_floats']
 
 
 class Shape(ctypes.Structure):
@@ -73,6 +73,7 @@ def lib():
     L.mpc_workspace_bytes.restype = i64
     L.mpc_workspace_bytes.argtypes = [sp]
     L.mpc_knn_fail_list_offset.argtypes = [sp]
+    L.mpc_knn_state_floats.argtypes = [sp]
     L.mpc_knn_lut_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_knn_lut_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_event_splat_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp]
@@ -88,6 +89,7 @@ def lib():
         getattr(L, name).restype = ctypes.c_int
     L.mpc_voxel_workspace_bytes.restype = i64
     L.mpc_knn_fail_list_offset.restype = i64
+    L.mpc_knn_state_floats.restype = i64
     isp = ctypes.POINTER(IngestShape)
     L.mpc_ingest_workspace_bytes.argtypes = [isp]
     L.mpc_ingest_workspace_bytes.restype = i64

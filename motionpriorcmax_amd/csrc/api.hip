@@ -117,6 +117,14 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     return L;
 }
 
+extern "C" int64_t mpc_knn_state_floats(const mpc_shape *s) {
+    if (!s) { mpc_set_error("mpc_knn_state_floats: null shape"); return MPC_E_NULL; }
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const int64_t bt = (int64_t)s->B * s->nb;
+    return 3 * bt * s->hq * s->wq + bt * mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16) * 5;
+}
+
 extern "C" int64_t mpc_knn_fail_list_offset(const mpc_shape *s) {
     if (!s) { mpc_set_error("mpc_knn_fail_list_offset: null shape"); return MPC_E_NULL; }
     int rc = mpc_validate_shape(s);

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     const int bt = blockIdx.x / S, part = blockIdx.x - bt * S, b = bt / p.nb, t = bt - b * p.nb;
     // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
     // atomicMax and its fallback list is appended to (knn_strip.hip)
-    if (part == 0) for (int i = tid; i < ntiles; i += 1024) tile_dkmax[(size_t)bt * ntiles + i] = 0.f;
+    if (part == 0) for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;
     if (blockIdx.x == 0 && tid == 0) fail[0] = 0;
     const int rows_per = (p.hq + S - 1) / S;
     const int g_lo = min(part * rows_per, p.hq) * p.wq, g_hi = min((part + 1) * rows_per, p.hq) * p.wq, Gp = g_hi - g_lo;
@@ -132,10 +132,19 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     }
     __syncthreads();
     const int own = Gp > 0 ? s_cnt[Gp - 1] : 0;
-    for (int sl = tid; sl < own; sl += 1024) {
-        const int i = l_idx[sl];
-        si_[sl] = i;
-        sp_[sl] = pts[i];
+    // (eight gathers of a thread in flight together: one after the other they were ~19 dependent L2 round trips)
+    for (int sl0 = tid; sl0 < own; sl0 += 8 * 1024) {
+        int i[8];
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) i[u] = (sl0 + u * 1024 < own) ? (int)l_idx[sl0 + u * 1024] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pts[i[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = sl0 + u * 1024;
+            if (sl < own) { si_[sl] = i[u]; sp_[sl] = v[u]; }
+        }
     }
 }
 
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
                                                           float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, bt = blockIdx.x;
-    for (int i = tid; i < ntiles; i += 1024) tile_dkmax[(size_t)bt * ntiles + i] = 0.f;       // (see k_knn_bucket)
+    for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;       // (see k_knn_bucket)
     if (bt == 0 && tid == 0) fail[0] = 0;
     int *cur = cursor + (size_t)bt * p.G;
     int *cs = cell_start + (size_t)bt * (p.G + 1);
@@ -337,10 +346,19 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
         const int ty16 = by_ * (TY / 16) + (tid >> 8);
         if (ty16 < gy16) {
             const int w0 = tid >> 6;
-            tile_dkmax[((size_t)bt * gy16 + ty16) * gx + bx_] =
-                fmaxf(fmaxf(s_maxf[w0], s_maxf[w0 + 1]), fmaxf(s_maxf[w0 + 2], s_maxf[w0 + 3]));
+            // (this kernel does not classify its queries: everything in class 0, whose region is the whole tile)
+            float *dst = tile_dkmax + (((size_t)bt * gy16 + ty16) * gx + bx_) * KNN_NCLS;
+            dst[0] = fmaxf(fmaxf(s_maxf[w0], s_maxf[w0 + 1]), fmaxf(s_maxf[w0 + 2], s_maxf[w0 + 3]));
+#pragma unroll
+            for (int c = 1; c < KNN_NCLS; ++c) dst[c] = 0.f;
         }
     }
+}
+
+__device__ __forceinline__ int wave_max_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 // Gather over the query window of one trajectory point (num_tref == 1, 'mean'): one 16-byte LDS read
@@ -385,7 +403,9 @@ __global__ __launch_bounds__(256) void k_knn_reach(const KnnParams p, const floa
     const int ntx = (p.wq + 15) >> 4, nty = (p.hq + 15) >> 4, nt = ntx * nty;
     const int bt = blockIdx.x;
     for (int tb = threadIdx.x; tb < nt; tb += 256) {
-        const float dk = tile_dkmax[(size_t)bt * nt + tb];
+        float dk = 0.f;
+#pragma unroll
+        for (int c = 0; c < KNN_NCLS; ++c) dk = fmaxf(dk, tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c]);
         s_lin[tb] = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
     }
     __syncthreads();
@@ -492,7 +512,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
             if (yy >= 0 && yy < p.hq && xx >= 0 && xx < p.wq) {
                 const size_t q = (size_t)bt * p.G + (size_t)yy * p.wq + xx;
                 dk = knn_state[q];
-                ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & ~KNN_TIE_FLAG;
                 g = gl2[(size_t)yy * p.wq + xx];
                 if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
             }
@@ -547,7 +567,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
                     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
                     const float dk = knn_state[q];
                     if (d > dk) continue;
-                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & ~KNN_TIE_FLAG;
                     if (d == dk && i > ik) continue;
                     const float nm = p.iwd ? knn_state[2 * BQ + q] : 1.f;
                     const float2 gq = gl2[((size_t)cy * p.wq + cx) * p.T + tr];
@@ -560,6 +580,239 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
             tmp_g[((size_t)bt * p.n + i) * p.T + tr] = make_float2(ay, ax);
         }
         tmp_a[(size_t)bt * p.n + i] = an;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward for num_tref == 1, 'mean' (the shipped configurations): k_knn_reach and the gather in ONE launch, with a
+// cheaper window loop.
+//   * the workgroup derives the reach of its 16x16 tile from the tile maxima itself (one coalesced read);
+//   * the squared column offsets of a point's window are computed once (registers, statically indexed: the window
+//     is at most KNN_BW_WMAX cells wide in this variant), so a visited cell costs: one 16-byte LDS read, one add,
+//     one compare, one select and two FMAs (0/1 weight: fma(1, a, b) == a + b);
+//   * the membership test is `d <= K-th distance` unless a staged query has a point EXCLUDED at exactly its K-th
+//     distance (tie resolved by index; the forward flags such queries in bit 30 of the K-th index): those
+//     workgroups, and windows wider than KNN_BW_WMAX, take the exact (distance, index) loop of bwd_window.
+// grid: 1-D, XCD-contiguous, 256 threads, dynamic LDS (RWmax^2 float4 + KNN_BW_WMAX of slack [+ float2 per cell])
+// ------------------------------------------------------------------------------------------
+#define KNN_BW_WMAX 10
+template <bool L1, bool NEXT>
+__global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
+                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
+                                                      const float *__restrict__ knn_state,
+                                                      const float *__restrict__ tile_dkmax,
+                                                      float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
+                                                      int gx, int gy, int bd) {
+    constexpr int TS = 16;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ int s_rowbase[TS + 1];
+    __shared__ int s_rowg[TS];
+    __shared__ float s_wr[4];
+    __shared__ int s_tiew[4];
+    const int tid = threadIdx.x;
+    const int nblk = gx * gy * p.B * p.nb;
+    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (lblk >= nblk) return;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
+    const size_t BQ = (size_t)p.B * p.nb * p.G;
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    // ---- phase 1: reach of this tile = the largest linear K-th distance among the tiles whose queries can touch it
+    //      (Chebyshev gap between this tile's cell area and their query centres); bucketed ranges of the tile rows --
+    {
+        const int ntx = gx, nty = gy, nt = ntx * nty;
+        const float ay0 = (float)(by_ * 16 * p.sp) - 0.5f, ay1 = (float)(min(by_ * 16 + 16, p.hq) * p.sp) - 0.5f;
+        const float ax0 = (float)(bx_ * 16 * p.sp) - 0.5f, ax1 = (float)(min(bx_ * 16 + 16, p.wq) * p.sp) - 0.5f;
+        float r = 0.f;
+        for (int tb = tid; tb < nt; tb += 256) {
+            const int sy = tb / ntx, sx = tb - sy * ntx;
+            const int ty0 = sy * 16, ty1 = min(ty0 + 16, p.hq) - 1, tx0 = sx * 16, tx1 = min(tx0 + 16, p.wq) - 1;
+#pragma unroll
+            for (int c = 0; c < KNN_NCLS; ++c) {
+                // cells of the source tile that can hold queries of class c (knn_device.h)
+                int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
+                if (c == 1) cy1 = min(cy1, bd - 1);
+                if (c == 2) cy0 = max(cy0, p.hq - bd);
+                if (c == 3) cx1 = min(cx1, bd - 1);
+                if (c == 4) cx0 = max(cx0, p.wq - bd);
+                if (cy0 > cy1 || cx0 > cx1) continue;
+                const float dk = tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c];
+                const float lin = (L1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
+                const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
+                const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
+                const float gyv = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1)), gxv = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
+                if (dk > 0.f && lin >= fmaxf(gyv, gxv)) r = fmaxf(r, lin);
+            }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) r = fmaxf(r, __shfl_xor(r, o2, 64));
+        if ((tid & 63) == 0) s_wr[tid >> 6] = r;
+    }
+    if (tid < 64) {
+        int gs = 0, ge = 0;
+        const int yy = by_ * TS + tid;
+        if (tid < TS && yy < p.hq) {
+            const int xa = bx_ * TS, xb = min(xa + TS, p.wq);
+            gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
+        }
+        int run = ge - gs;
+#pragma unroll
+        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
+        if (tid < TS) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
+        if (tid == 0) s_rowbase[0] = 0;
+    }
+    // ---- phase 2 (after the reach is known; staging a guessed halo before it, so that the loads of the two phases
+    //      travel together, measured slower: too many tiles stage twice): the K-th distance, K-th index | tie flag and
+    //      dL/dLUT of the tile's query cells and the halo the reach asks for ------------------------------------------
+    float *ldk; int *lik; float2 *lg, *lgn;
+    int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS, rx0 = bx_ * TS;
+    const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
+    const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
+    const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
+    auto stage = [&]() {
+        RW = TS + 2 * RQ;
+        // row pitch of the staged arrays: 32 entries where the region fits (consecutive rows then start on the same
+        // banks and the points of a cell row read consecutive words)
+        RP = RW <= 32 ? 32 : RW;
+        ry0 = by_ * TS - RQ; rx0 = bx_ * TS - RQ;
+        // separate arrays (the hot loop reads the K-th distance and the gradient only; neighbouring lanes then read
+        // neighbouring 4- and 8-byte words): K-th distance, K-th index, dL/dLUT, dL/dflow_next
+        const size_t ncell = (size_t)RW * RP + KNN_BW_WMAX;
+        ldk = reinterpret_cast<float *>(s_dyn);
+        lik = reinterpret_cast<int *>(s_dyn + ncell * 4);
+        lg = reinterpret_cast<float2 *>(s_dyn + ncell * 8);
+        lgn = reinterpret_cast<float2 *>(s_dyn + ncell * 16);
+        int tie = 0;
+        for (int rr = tid >> 5; rr < RW; rr += 8) {
+            const int yy = ry0 + rr;
+            for (int cc = tid & 31; cc < RP; cc += 32) {          // (columns RW..RP-1: padding, never a member)
+                const int xx = rx0 + cc;
+                float dk = -1.f; int ik = -1;
+                float2 g = make_float2(0.f, 0.f), gn = make_float2(0.f, 0.f);
+                if (cc < RW && yy >= 0 && yy < p.hq && xx >= 0 && xx < p.wq) {
+                    const size_t q = (size_t)bt * p.G + (size_t)yy * p.wq + xx;
+                    dk = knn_state[q];
+                    ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                    g = gl2[(size_t)yy * p.wq + xx];
+                    if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
+                    tie |= ik & KNN_TIE_FLAG;
+                    ik &= ~KNN_TIE_FLAG;
+                }
+                ldk[rr * RP + cc] = dk; lik[rr * RP + cc] = ik; lg[rr * RP + cc] = g;
+                if (NEXT) lgn[rr * RP + cc] = gn;
+            }
+        }
+        if (tid < KNN_BW_WMAX) {                    // slack behind the last row: never a member
+            ldk[RW * RP + tid] = -1.f; lik[RW * RP + tid] = -1; lg[RW * RP + tid] = make_float2(0.f, 0.f);
+            if (NEXT) lgn[RW * RP + tid] = make_float2(0.f, 0.f);
+        }
+        const bool wt = __ballot(tie != 0) != 0ull;
+        if ((tid & 63) == 0) s_tiew[tid >> 6] = wt ? 1 : 0;
+    };
+    if ((tid & 63) == 0) s_tiew[tid >> 6] = 0;
+    __syncthreads();
+    const float R = fmaxf(fmaxf(s_wr[0], s_wr[1]), fmaxf(s_wr[2], s_wr[3]));
+    const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo the reach asks for, in cells
+    const bool use_lds = RQ_need <= KNN_RQ_MAX;
+    if (use_lds) {
+        RQ = RQ_need;
+        stage();
+    }
+    __syncthreads();
+    const bool anytie = (s_tiew[0] | s_tiew[1] | s_tiew[2] | s_tiew[3]) != 0;
+    const int total = s_rowbase[TS];
+    const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
+    const float2 *sp_ = spos + (size_t)bt * p.n;
+    const int *si_ = sidx + (size_t)bt * p.n;
+    for (int base = 0; base < total; base += 256) {
+        const int pi = base + tid;
+        const bool act = pi < total;
+        if (__ballot(act) == 0ull) continue;          // (a tile holds ~256 points: a second round is mostly one wavefront)
+        int lo = 0, hi = TS;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
+        const int g = act ? s_rowg[lo] + (pi - s_rowbase[lo]) : 0;
+        const float2 pt = sp_[g];
+        const int i = si_[g];
+        // query cells within reach: |q - p| <= R per axis (R carries a 0.01 px + 1e-4 relative margin, which dominates
+        // the rounding of these expressions)
+        int y0 = (int)ceilf((pt.x - R - p.off) * inv_sp), y1 = (int)floorf((pt.x + R - p.off) * inv_sp);
+        int x0 = (int)ceilf((pt.y - R - p.off) * inv_sp), x1 = (int)floorf((pt.y + R - p.off) * inv_sp);
+        y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, p.hq - 1); x1 = min(x1, p.wq - 1);
+        float ay = 0.f, ax = 0.f;
+        float2 an = make_float2(0.f, 0.f);
+        if (use_lds) {
+            y0 = max(y0, ry0); x0 = max(x0, rx0); y1 = min(y1, ry0 + RW - 1); x1 = min(x1, rx0 + RW - 1);
+            if (!act) { y1 = y0 - 1; x1 = x0 - 1; }
+            const int nxw = x1 - x0 + 1, nyw = y1 - y0 + 1;
+            const bool narrow = __ballot(nxw > KNN_BW_WMAX) == 0ull;
+            if (narrow && !anytie) {
+                float dx2[KNN_BW_WMAX];
+#pragma unroll
+                for (int c = 0; c < KNN_BW_WMAX; ++c) {
+                    const float dx = ((float)((x0 + c) * p.sp) + p.off) - pt.y;
+                    dx2[c] = (c < nxw) ? (L1 ? fabsf(dx) : dx * dx) : INFINITY;
+                }
+                const int nymax = __builtin_amdgcn_readfirstlane(wave_max_int(nyw));
+                for (int r = 0; r < nymax; ++r) {
+                    const int cyr = min(max(y0 + r, ry0), ry0 + RW - 1);
+                    const float dy = ((float)(cyr * p.sp) + p.off) - pt.x;
+                    const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
+                    // (a point far outside the image sits in a border cell with an EMPTY window whose x0 lies beyond the
+                    // staged region: the unconditional reads below must stay inside it)
+                    const int xb = min(x0, rx0 + RW - 1) - rx0;
+                    const float *rdk = ldk + (cyr - ry0) * RP + xb;
+                    const float2 *rg = lg + (cyr - ry0) * RP + xb, *rown = lgn + (cyr - ry0) * RP + xb;
+#pragma unroll
+                    for (int c = 0; c < KNN_BW_WMAX; ++c) {
+                        const float d = dy2 + dx2[c];
+                        const float w = (d <= rdk[c]) ? 1.f : 0.f;
+                        const float2 e = rg[c];
+                        ay = fmaf(w, e.x, ay); ax = fmaf(w, e.y, ax);
+                        if (NEXT) { const float2 gq = rown[c]; an.x = fmaf(w, gq.x, an.x); an.y = fmaf(w, gq.y, an.y); }
+                    }
+                }
+            } else if (act) {
+                // exact (distance, index) membership: queries with an excluded tie, or a window wider than KNN_BW_WMAX
+                for (int cy = y0; cy <= y1; ++cy) {
+                    const float dy = ((float)(cy * p.sp) + p.off) - pt.x;
+                    const float dy2 = L1 ? fabsf(dy) : dy * dy;
+                    const int ro = (cy - ry0) * RP - rx0;
+                    for (int cx = x0; cx <= x1; ++cx) {
+                        const float dx = ((float)(cx * p.sp) + p.off) - pt.y;
+                        const float d = dy2 + (L1 ? fabsf(dx) : dx * dx);
+                        const float dk = ldk[ro + cx];
+                        const bool in = (d < dk) || (d == dk && i <= lik[ro + cx]);
+                        if (in) {
+                            const float2 e = lg[ro + cx];
+                            ay += e.x; ax += e.y;
+                            if (NEXT) { const float2 gq = lgn[ro + cx]; an.x += gq.x; an.y += gq.y; }
+                        }
+                    }
+                }
+            }
+        } else if (act) {
+            for (int cy = y0; cy <= y1; ++cy) {
+                const float qy = (float)(cy * p.sp) + p.off;
+                for (int cx = x0; cx <= x1; ++cx) {
+                    const float qx = (float)(cx * p.sp) + p.off;
+                    const float d = pair_dist(qy, qx, pt.x, pt.y, L1);
+                    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
+                    const float dk = knn_state[q];
+                    if (d > dk) continue;
+                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & ~KNN_TIE_FLAG;
+                    if (d == dk && i > ik) continue;
+                    const float2 gq = gl2[(size_t)cy * p.wq + cx];
+                    ay += gq.x; ax += gq.y;
+                    if (has_next) { const float2 gnq = gn2[(size_t)cy * p.wq + cx]; an.x += gnq.x; an.y += gnq.y; }
+                }
+            }
+        }
+        if (act) {
+            tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
+            if (gnext != nullptr) tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
+        }
     }
 }
 
@@ -620,12 +873,13 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_BWD_TS=16|32    tile side of the backward gather                                  [16]
 //   MPC_KNN_HALO=<h>        rings staged beyond the initial radius by the query kernel        [1]
 //   MPC_KNN_STRIP=0         tile query kernel (k_knn_query) also where the strip kernel applies  [1]
+//   MPC_KNN_BWD_FUSED=0     backward as k_knn_reach + k_knn_bwd_points also where k_knn_bwd_tile applies [1]
 struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip;
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -635,9 +889,18 @@ static const KnnTuning &knn_tuning() {
         if ((e = getenv("MPC_KNN_BWD_TS"))) v.bwd_ts = atoi(e) == 32 ? 32 : 16;
         if ((e = getenv("MPC_KNN_HALO"))) v.halo = atoi(e);
         if ((e = getenv("MPC_KNN_STRIP"))) v.strip = atoi(e) != 0;
+        if ((e = getenv("MPC_KNN_BWD_FUSED"))) v.bwd_fused = atoi(e) != 0;
         return v;
     }();
     return t;
+}
+
+// smallest square that can hold K points at the mean point density and pass the ring bound
+int mpc_knn_r_init(const mpc_shape *s) {
+    const double dens = (double)s->n / ((double)s->hq * s->wq);
+    int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
+    r_init += knn_tuning().r0;
+    return r_init < 1 ? 1 : r_init;
 }
 
 static int set_max_lds(const void *fn, const char *who) {
@@ -696,10 +959,8 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
-    int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
     const KnnTuning &tune = knn_tuning();
-    r_init += tune.r0;
-    if (r_init < 1) r_init = 1;
+    const int r_init = mpc_knn_r_init(s);
     // fast path (num_tref == 1, the shipped configurations): strip kernel + per-query fallback (knn_strip.hip)
     if (tune.strip && !tune.global_mode && idx_out == nullptr && mpc_knn_strip_usable(s, r_init))
         return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, st);
@@ -773,9 +1034,31 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<16>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<32>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, true>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, true>, __func__))) return rc;
         attr_once.mark();
     }
     const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
+    if (s->T == 1 && !p.iwd && knn_tuning().bwd_ts == 16 && knn_tuning().bwd_fused) {
+        const int RWm = 16 + 2 * KNN_RQ_MAX;
+        const size_t ldsb = ((size_t)RWm * RWm + KNN_BW_WMAX) * (16 + (grad_flow_next ? 8 : 0));      // RWm >= 32: covers pitch 32 too
+        const int gxb = mpc_cdiv(s->wq, 16), gyb = mpc_cdiv(s->hq, 16);
+        const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
+#define KB_LAUNCH(L1_, NEXT_)                                                                                            \
+        hipLaunchKernelGGL((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)))
+        if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
+        else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
+#undef KB_LAUNCH
+        MPC_CHECK_LAUNCH();
+        const int64_t totalb = (int64_t)s->B * s->n;
+        hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
+                           grad_flow_next ? tmp_a : nullptr, grad_traj);
+        MPC_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);
     MPC_CHECK_LAUNCH();
     // (32x32-cell tiles with 1024 threads measured slower at C3: 296 vs 229 us)

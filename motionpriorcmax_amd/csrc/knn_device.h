@@ -12,6 +12,16 @@
 #endif
 #define KNN_HW (KNN_BINS / 4)   // histogram words per query: four 8-bit bins per word
 #define KNN_LIST KNN_HW          // {candidate slot, trajectory index} pairs kept in a (dead) histogram column
+// bit 30 of the saved K-th index: some point lies at exactly the K-th distance but was excluded (tie resolved by
+// index); without it the backward's membership test is simply `d <= K-th distance`
+#define KNN_TIE_FLAG 0x40000000
+// Largest K-th distance per 16x16 cell tile, kept per CLASS of query so that the backward's search reach stays tight:
+// queries next to the image border have clipped neighbourhoods and therefore K-th distances up to 2-4x larger than
+// inner ones, but they sit in a thin band; a per-tile maximum over all of them would inflate the reach of every tile
+// adjacent to a border tile.  Class 0: every query of the tile that lies at least `bd` cells from all borders;
+// 1 / 2 / 3 / 4: queries within `bd` cells of the top / bottom / left / right border (a corner query counts for both).
+// Layout: tile_dkmax[((b*nb + bin) * ntiles + tile) * KNN_NCLS + class].
+#define KNN_NCLS 5
 #define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
 
 struct KnnParams {
@@ -417,7 +427,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
         }
     }
     knn_state[q] = dK;
-    reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
+    reinterpret_cast<int *>(knn_state)[BQ + q] = iK | KNN_TIE_FLAG;      // (this routine does not look for excluded ties: flagged conservatively)
     knn_state[2 * BQ + q] = norm;
     // ---- 5. optional: the K indices in ascending (distance, index) order ---------------------
     if (idx_out != nullptr) {
@@ -443,6 +453,28 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     dK_out = dK;
     return true;
 }
+
+// band depth (cells) of the border classes of the tile maxima
+__host__ __device__ static inline int knn_band_depth(int r_init) { return r_init + 1; }
+// first search radius of a query (cells), from the point density; shared by the forward and the backward
+int mpc_knn_r_init(const mpc_shape *s);
+
+#ifdef __HIPCC__
+// classes of the query (cy, cx): bit c set <=> it counts for class c
+__device__ __forceinline__ unsigned knn_query_classes(const KnnParams &p, int cy, int cx, int bd) {
+    const unsigned m = (cy < bd ? 2u : 0u) | (cy >= p.hq - bd ? 4u : 0u) | (cx < bd ? 8u : 0u) | (cx >= p.wq - bd ? 16u : 0u);
+    return m ? m : 1u;
+}
+// one query's K-th distance into the tile maxima (atomicMax on the bits of a non-negative float)
+__device__ __forceinline__ void knn_tile_max_add(float *__restrict__ tile_dkmax, const KnnParams &p, int bt, int cy, int cx,
+                                                 int bd, float dK) {
+    const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+    int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4)) * KNN_NCLS;
+    const unsigned m = knn_query_classes(p, cy, cx, bd);
+#pragma unroll
+    for (int c = 0; c < KNN_NCLS; ++c) if ((m >> c) & 1u) atomicMax(dst + c, __float_as_int(dK));
+}
+#endif
 
 // ---- strip kernel (knn_strip.hip): the fast path of the forward for num_tref == 1 ---------------------------
 // `fail` = int [1 + B*nb*G]: fail[0] counts the queries handed to the fallback kernel (zeroed, like tile_dkmax, by the

@@ -335,6 +335,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     // most wavefronts, so the whole wavefront serves them one at a time, a lane per slot (any number of keys).
     const int need = p.K - before;
     float dK = 0.f; int iK = -1;
+    bool tie = false;                 // a point at exactly the K-th distance that is NOT a neighbour (higher index): KNN_TIE_FLAG
     const bool heavy = live && inbin > KS_LMAX;
     {
         float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX];
@@ -372,6 +373,8 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                 }
             }
         }
+#pragma unroll
+        for (int a = 0; a < KS_LMAX; ++a) tie = tie || (light && a < inbin && dd[a] == dK && ii[a] > iK);
     }
     {
         unsigned long long hm = __ballot(heavy);
@@ -426,7 +429,8 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                 if (NEXT) { cny += __shfl_xor(cny, o2, 64); cnx += __shfl_xor(cnx, o2, 64); }
                 cdk = fmaxf(cdk, __shfl_xor(cdk, o2, 64)); cik = max(cik, __shfl_xor(cik, o2, 64));
             }
-            if (lane == h) { sy_ += cy_; sx_ += cx_; sw_ += cw_; ny_ += cny; nx_ += cnx; dK = cdk; iK = cik; }
+            const bool htie = __ballot((b0 && d0 == cdk && i0 > cik) || (b1 && d1 == cdk && i1 > cik)) != 0ull;
+            if (lane == h) { sy_ += cy_; sx_ += cx_; sw_ += cw_; ny_ += cny; nx_ += cnx; dK = cdk; iK = cik; tie = htie; }
         }
     }
     // ---- outputs ---------------------------------------------------------------------------------------
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
         knn_state[q] = dK;
-        reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
+        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
 #ifdef KS_DEBUG_INBIN
         norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
 #endif
@@ -461,12 +465,20 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     // largest K-th distance per 16x16 cell tile (bounds the search windows of the backward): a wavefront covers
     // 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
     {
-        float m = live ? dK : 0.f;
+        // per class of query (knn_device.h): only wavefronts next to the image border hold anything but class 0
+        const int bd = knn_band_depth(r_init);
+        const unsigned cls = live ? knn_query_classes(p, cy, cx, bd) : 0u;
+        const bool plain = __ballot(cls > 1u) == 0ull;
+        const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+        int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (min(cy, p.hq - 1) >> 4)) * gx16 + (qx0 >> 4)) * KNN_NCLS;
+        const bool writer = (tid & (16 * WS - 1)) == 0 && cy <= qy1;
 #pragma unroll
-        for (int o2 = 8 * WS; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
-        if ((tid & (16 * WS - 1)) == 0 && cy <= qy1) {
-            const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
-            atomicMax(reinterpret_cast<int *>(tile_dkmax) + ((size_t)bt * gy16 + (cy >> 4)) * gx16 + (qx0 >> 4), __float_as_int(m));
+        for (int c = 0; c < KNN_NCLS; ++c) {
+            if (c > 0 && plain) break;
+            float m = ((cls >> c) & 1u) ? dK : 0.f;
+#pragma unroll
+            for (int o2 = 8 * WS; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+            if (writer && m > 0.f) atomicMax(dst + c, __float_as_int(m));
         }
     }
 }
@@ -549,8 +561,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
             float dK = 0.f;
             knn_one_query<false, L1, 256>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, nullptr, dK);
-            const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
-            atomicMax(reinterpret_cast<int *>(tile_dkmax) + ((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4), __float_as_int(dK));
+            knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
         }
         return;
     }
@@ -592,6 +603,10 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         ny_ += __shfl_xor(ny_, o2, 64); nx_ += __shfl_xor(nx_, o2, 64);
         dK = fmaxf(dK, __shfl_xor(dK, o2, 64)); iK = max(iK, __shfl_xor(iK, o2, 64));
     }
+    bool tie = false;
+#pragma unroll
+    for (int m = 0; m < KS_FB_SLOTS; ++m) tie = tie || (dd[m] == dK && dd[m] < INFINITY && ii[m] > iK);
+    tie = __ballot(tie) != 0ull;
     if (lane == 0) {
         const size_t BQ = (size_t)p.B * p.nb * p.G;
         float2 ov; float norm = 0.f;
@@ -603,10 +618,9 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
         knn_state[q] = dK;
-        reinterpret_cast<int *>(knn_state)[BQ + q] = iK;
+        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
         knn_state[2 * BQ + q] = norm;
-        const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
-        atomicMax(reinterpret_cast<int *>(tile_dkmax) + ((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4), __float_as_int(dK));
+        knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
     }
 }
 

@@ -138,8 +138,7 @@ def knn_lut_fwd(cfg, shape, traj, ws, want_idx=False):
     flow_next = None
     if shape.flags & C.F_WANT_NEXT:
         flow_next = torch.empty((B, max(nb - 1, 0), hq, wq, 1, 2), dtype=torch.float32, device=dev)
-    ntiles = ((hq + 15) // 16) * ((wq + 15) // 16)
-    state = torch.empty(3 * B * nb * Q + B * nb * ntiles, dtype=torch.float32, device=dev)
+    state = torch.empty(int(C.lib().mpc_knn_state_floats(ctypes.byref(shape))), dtype=torch.float32, device=dev)
     idx = torch.empty((B, nb, Q, K), dtype=torch.int32, device=dev) if want_idx else None
     with _stage('mpc_knn_lut_fwd', dev):
         C.check(C.lib().mpc_knn_lut_fwd(ctypes.byref(shape), _ptr(traj), _ptr(flow_lut), _ptr(flow_next),
