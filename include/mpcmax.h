@@ -151,6 +151,33 @@ int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *fl
                         const float *grad_out, float *grad_flow_lut, const float *add_term,
                         void *ws, void *stream);
 
+/* ---- A4: the whole of FocusLoss.calc (focus.py:66-113) and of its backward as ONE call each: the same launch
+ * sequence the stage entry points above issue (KNN LUT -> smoothness -> warp + vote -> blur + objective -> scalars;
+ * event backward -> [scale] -> KNN backward), from C, so that a step costs two host calls instead of sixteen.
+ * All buffers are caller-owned device memory (shapes as documented at the stage entry points):
+ *   flow_next / smooth_grad : NULL unless used (MPC_F_WANT_NEXT; smooth_weight > 0 and the backward is wanted)
+ *   grad_iwe                : NULL for a forward-only call (then also set MPC_F_NO_BWD_RECORDS)
+ * smooth_weight > 0 applies the smoothness term to flow_next when MPC_F_WANT_NEXT is set, else to flow_lut
+ * (focus.py:232-246).  mpc_focus_bwd must follow mpc_focus_fwd on the same buffers and workspace;
+ * grad_lut_scratch [like flow_lut] and grad_next_scratch [like flow_next, or NULL] are scratch. */
+typedef struct mpc_focus_buffers {
+    const float *traj;        /* [B][T+nb][n][2]                      in  */
+    const float *events;      /* [B][M][6]                            in  */
+    const float *t_ref;       /* [T]                                  in  */
+    float *flow_lut;          /* [B][nb][hq][wq][T][2]                out */
+    float *flow_next;         /* [B][nb-1][hq][wq][1][2] or NULL      out */
+    float *knn_state;         /* mpc_knn_state_floats(s)              out */
+    float *smooth_grad;       /* like the smoothed field, or NULL     out */
+    float *iwe_raw;           /* [B*T][P][H][W]                       out */
+    float *iwe_blur;          /* [B*T][P][H][W]                       out */
+    float *grad_iwe;          /* [B*T][P][H][W] or NULL               out */
+    float *scal;              /* [MPC_SCAL_COUNT]                     out */
+    float smooth_weight;
+} mpc_focus_buffers;
+int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream);
+int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, const float *grad_out,
+                  float *grad_lut_scratch, float *grad_next_scratch, float *grad_traj, void *ws, void *stream);
+
 /* y[i] = a[0] * x[i] (device scalar a; used to scale the smoothness gradient by grad_out). */
 int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *stream);
 

@@ -27,13 +27,20 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
-           'mpc_knn_fail_list_offset', 'mpc_knn_state_floats']
+           'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd']
 
 
 class Shape(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in
                 ('B', 'M', 'Mp', 'nb', 'T', 'H', 'W', 'sp', 'hq', 'wq', 'n', 'K')] + \
                [('flags', ctypes.c_uint32)]
+
+
+class FocusBuffers(ctypes.Structure):
+    """include/mpcmax.h: struct mpc_focus_buffers."""
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ('traj', 'events', 't_ref', 'flow_lut', 'flow_next', 'knn_state', 'smooth_grad', 'iwe_raw', 'iwe_blur',
+                 'grad_iwe', 'scal')] + [('smooth_weight', ctypes.c_float)]
 
 
 class VoxShape(ctypes.Structure):
@@ -82,6 +89,9 @@ def lib():
     L.mpc_finalize.argtypes = [sp, i32, i32, f32, vp, vp, vp]
     L.mpc_event_splat_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_scale.argtypes = [vp, vp, vp, i64, vp]
+    fb = ctypes.POINTER(FocusBuffers)
+    L.mpc_focus_fwd.argtypes = [sp, fb, vp, vp]
+    L.mpc_focus_bwd.argtypes = [sp, fb, vp, vp, vp, vp, vp, vp]
     vsp = ctypes.POINTER(VoxShape)
     L.mpc_voxel_workspace_bytes.argtypes = [vsp]
     L.mpc_voxel_grid.argtypes = [vsp, vp, vp, vp, vp, vp]

@@ -138,3 +138,45 @@ extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {
     if (rc) return rc;
     return mpc_layout(s).total;
 }
+
+// ---- A4: FocusLoss.calc and its backward as one call each (reference src/losses/focus.py:66-113) -----------------
+extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && io && ws, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(io->traj && io->flow_lut && io->knn_state && io->iwe_raw && io->iwe_blur && io->scal, MPC_E_NULL, "null buffer");
+    int rc = mpc_knn_lut_fwd(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream);
+    if (rc) return rc;
+    int s_nimg = 0, s_C = 0;
+    if (io->smooth_weight > 0.f) {
+        const bool on_next = (s->flags & MPC_F_WANT_NEXT) != 0;
+        const float *field = on_next ? io->flow_next : io->flow_lut;
+        s_nimg = on_next ? s->B * (s->nb - 1) : s->B * s->nb;
+        s_C = on_next ? 2 : 2 * s->T;
+        if (s_nimg > 0) {
+            if ((rc = mpc_lut_smooth(s, field, s_nimg, s_C, io->smooth_weight, io->smooth_grad, ws, stream))) return rc;
+        } else s_C = 0;
+    }
+    if ((rc = mpc_event_splat_fwd(s, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream))) return rc;
+    if ((rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream))) return rc;
+    return mpc_finalize(s, s_nimg, s_C, io->smooth_weight, io->scal, ws, stream);
+}
+
+extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, const float *grad_out,
+                             float *grad_lut_scratch, float *grad_next_scratch, float *grad_traj, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && io && ws && grad_lut_scratch && grad_traj, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(io->grad_iwe, MPC_E_NULL, "mpc_focus_fwd was called without grad_iwe (forward only)");
+    const bool on_next = (s->flags & MPC_F_WANT_NEXT) != 0;
+    const bool smooth = io->smooth_weight > 0.f && io->smooth_grad != nullptr;
+    // the smoothness gradient on flow_to_tref is folded into the event backward; on flow_to_next it is a separate
+    // gradient of the KNN backward, scaled by grad_out
+    int rc = mpc_event_splat_bwd(s, io->events, io->flow_lut, io->t_ref, io->grad_iwe, io->scal, grad_out, grad_lut_scratch,
+                                 (smooth && !on_next) ? io->smooth_grad : nullptr, ws, stream);
+    if (rc) return rc;
+    const float *g_next = nullptr;
+    if (smooth && on_next && s->nb > 1) {
+        MPC_CHECK_ARG(grad_next_scratch, MPC_E_NULL, "grad_next_scratch is null");
+        const int64_t cnt = (int64_t)s->B * (s->nb - 1) * s->hq * s->wq * 2;
+        if (grad_out) { if ((rc = mpc_scale(io->smooth_grad, grad_out, grad_next_scratch, cnt, stream))) return rc; g_next = grad_next_scratch; }
+        else g_next = io->smooth_grad;
+    }
+    return mpc_knn_lut_bwd(s, io->traj, grad_lut_scratch, g_next, io->knn_state, grad_traj, ws, stream);
+}

@@ -206,6 +206,58 @@ def scale(x, a):
     return y
 
 
+FUSED_CALLS = True    # FocusCalcFn: mpc_focus_fwd / mpc_focus_bwd (two C-ABI calls per step) instead of one call per stage
+
+
+def _vp(t):
+    return None if t is None else t.data_ptr()
+
+
+def _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal):
+    return C.FocusBuffers(traj=_vp(traj), events=_vp(ev), t_ref=_vp(tr), flow_lut=_vp(flow_lut), flow_next=_vp(flow_next),
+                          knn_state=_vp(state), smooth_grad=_vp(g_field), iwe_raw=_vp(raw), iwe_blur=_vp(blur),
+                          grad_iwe=_vp(gimg), scal=_vp(scal), smooth_weight=float(cfg.smooth_weight))
+
+
+def focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad):
+    """FocusLoss.calc forward as ONE C-ABI call (mpc_focus_fwd)."""
+    dev = traj.device
+    B, nb, T = shape.B, shape.nb, shape.T
+    hq, wq = shape.hq, shape.wq
+    flow_lut = torch.empty((B, nb, hq, wq, T, 2), dtype=torch.float32, device=dev)
+    flow_next = None
+    if shape.flags & C.F_WANT_NEXT:
+        flow_next = torch.empty((B, max(nb - 1, 0), hq, wq, 1, 2), dtype=torch.float32, device=dev)
+    state = torch.empty(int(C.lib().mpc_knn_state_floats(ctypes.byref(shape))), dtype=torch.float32, device=dev)
+    g_field = None
+    if cfg.smooth_weight > 0 and need_grad:
+        field = flow_next if cfg.smooth_on_next else flow_lut
+        if field is not None and field.numel() > 0:
+            g_field = torch.empty_like(field)
+    P = 2 if shape.flags & C.F_POLARITY_SPLIT else 1
+    raw = torch.empty((B * T, P, shape.H, shape.W), dtype=torch.float32, device=dev)
+    blur = torch.empty_like(raw)
+    gimg = torch.empty_like(raw) if need_grad else None
+    scal = torch.empty(C.SCAL_COUNT, dtype=torch.float32, device=dev)
+    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal)
+    with _stage('mpc_focus_fwd', dev):
+        C.check(C.lib().mpc_focus_fwd(ctypes.byref(shape), ctypes.byref(io), _ptr(ws), _stream(dev)), 'mpc_focus_fwd')
+    return flow_lut, flow_next, state, g_field, blur, gimg, scal
+
+
+def focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, grad_out, ws):
+    """Backward of the above to the trajectories as ONE C-ABI call (mpc_focus_bwd)."""
+    dev = traj.device
+    g_lut = torch.empty_like(flow_lut)
+    g_next = torch.empty_like(g_field) if (g_field is not None and cfg.smooth_on_next) else None
+    g_traj = torch.empty_like(traj)
+    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, None, state, g_field, None, None, gimg, scal)
+    with _stage('mpc_focus_bwd', dev):
+        C.check(C.lib().mpc_focus_bwd(ctypes.byref(shape), ctypes.byref(io), _ptr(grad_out), _ptr(g_lut), _ptr(g_next),
+                                      _ptr(g_traj), _ptr(ws), _stream(dev)), 'mpc_focus_bwd')
+    return g_traj
+
+
 def _check_events(events, cfg, num_pos):
     _require_gpu(events, "batch['events']")
     if events.dim() != 3 or events.shape[-1] != 6:
@@ -244,19 +296,23 @@ class FocusCalcFn(torch.autograd.Function):
         shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
         ws = alloc_workspace(shape, dev)
 
-        flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
-        g_field = None
-        s_nimg = s_C = 0
-        if cfg.smooth_weight > 0:
-            if cfg.smooth_on_next:
-                field, s_nimg, s_C = flow_next, B * (nb - 1), 2
-            else:
-                field, s_nimg, s_C = flow_lut, B * nb, 2 * T
-            if s_nimg > 0:
-                g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
-        raw = event_splat_fwd(shape, ev, flow_lut, tr, ws)
-        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
-        scal = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
+        if STAGE_TIMER is None and FUSED_CALLS:
+            # one C-ABI call for the whole forward (mpc_focus_fwd issues the same launches)
+            flow_lut, flow_next, state, g_field, blur, gimg, scal = focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad)
+        else:
+            flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
+            g_field = None
+            s_nimg = s_C = 0
+            if cfg.smooth_weight > 0:
+                if cfg.smooth_on_next:
+                    field, s_nimg, s_C = flow_next, B * (nb - 1), 2
+                else:
+                    field, s_nimg, s_C = flow_lut, B * nb, 2 * T
+                if s_nimg > 0:
+                    g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
+            raw = event_splat_fwd(shape, ev, flow_lut, tr, ws)
+            blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+            scal = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
 
         ctx.cfg, ctx.shape = cfg, shape
         ctx.ws = ws
@@ -274,6 +330,9 @@ class FocusCalcFn(torch.autograd.Function):
         if g_loss is None:
             return None, None, None, None, None
         g = _f32c(g_loss.reshape(1))
+        if STAGE_TIMER is None and FUSED_CALLS:
+            g_traj = focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, g, ws)
+            return g_traj, None, None, None, None
         g_next = None
         g_lut = torch.empty_like(flow_lut)
         if g_field is not None and not cfg.smooth_on_next:
