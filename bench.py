@@ -96,12 +96,12 @@ def stage_bytes(B, M, nb, n, T=1, P=2):
 
 # kernels behind each C-ABI stage (for the PMC traffic figure)
 # the kernel that carries (almost all of) a stage's time, per the committed rocprofv3 summaries
-DOMINANT_KERNEL = {'mpc_knn_lut_fwd': 'k_knn_query', 'mpc_knn_lut_bwd': 'k_knn_bwd_points', 'mpc_event_splat_fwd': 'k_ev_bin',
+DOMINANT_KERNEL = {'mpc_knn_lut_fwd': 'k_knn_strip', 'mpc_knn_lut_bwd': 'k_knn_bwd_tile', 'mpc_event_splat_fwd': 'k_ev_bin',
                    'mpc_event_splat_bwd': 'k_lut_accum', 'mpc_contrast_fwd': 'k_contrast_fused', 'mpc_lut_smooth': 'k_lut_smooth',
                    'mpc_finalize': 'k_finalize'}
 STAGE_KERNELS = {
-    'mpc_knn_lut_fwd': ['k_knn_bucket', 'k_knn_query'],
-    'mpc_knn_lut_bwd': ['k_knn_reach', 'k_knn_bwd_points', 'k_knn_bwd_combine'],
+    'mpc_knn_lut_fwd': ['k_knn_bucket', 'k_knn_strip', 'k_knn_fallback', 'k_knn_query'],
+    'mpc_knn_lut_bwd': ['k_knn_bwd_tile', 'k_knn_reach', 'k_knn_bwd_points', 'k_knn_bwd_combine'],
     'mpc_event_splat_fwd': ['k_ev_bin', 'k_iwe_accum', 'k_iwe_overflow', 'k_splat_fwd_atomic'],
     'mpc_event_splat_bwd': ['k_lut_accum', 'k_lut_overflow', 'k_splat_bwd_atomic'],
     'mpc_contrast_fwd': ['k_contrast_fused', 'k_contrast_fwd', 'k_contrast_bwd_var', 'k_image_means'],
@@ -119,6 +119,32 @@ def pmc_traffic(workload, stage):
     d = json.load(open(f))
     tot = sum(d[k]['hbm_bytes_per_launch'] for k in STAGE_KERNELS.get(stage, []) if k in d)
     return round(tot) if tot > 0 else None
+
+
+def knn_ceiling(workload, stages, B, nb):
+    """The KNN stage against the ceiling that applies to it (it is VALU-issue bound, not HBM bound): queries per second
+    from the live stage times, and the share of the chip's vector-instruction issue slots its dominant kernels used, from
+    the committed SQ-counter summary of this workload (profiles/r02_sq_<workload>.csv: SQ_INSTS_VALU per launch and the
+    kernel's duration in the same profile; one VALU instruction occupies its SIMD for 4 cycles, 1024 SIMDs, 2.4 GHz)."""
+    Q = (H // SP) * (W // SP)
+    out = {}
+    fwd = stages.get('mpc_knn_lut_fwd'); bwd = stages.get('mpc_knn_lut_bwd')
+    if fwd and fwd['us_per_step'] > 0:
+        out['queries_per_s'] = round(B * nb * Q / (fwd['us_per_step'] * 1e-6), 1)
+        out['fwd_us'] = round(fwd['us_per_step'], 1)
+    if bwd and bwd['us_per_step'] > 0:
+        out['bwd_us'] = round(bwd['us_per_step'], 1)
+    f = os.path.join(ROOT, 'profiles', f'r02_sq_{workload}.json')
+    if os.path.exists(f):
+        d = json.load(open(f))
+        for key in ('k_knn_strip', 'k_knn_bwd_tile'):
+            if key in d:
+                k = d[key]
+                out[key] = {'valu_wave_instr_per_launch': k['valu_insts'], 'kernel_us_in_profile': k['kernel_us'],
+                            'valu_issue_frac': round(k['valu_insts'] * 4.0 / (k['kernel_us'] * 1e-6 * 2.4e9 * 1024), 3),
+                            'wait_any_frac': k.get('wait_any_frac')}
+        out['source'] = f'profiles/r02_sq_{workload}.json (rocprofv3 --pmc SQ passes, tools/sq_profile.sh)'
+    return out
 
 
 def cpu_baseline(wl, budget_s=20.0):
@@ -163,24 +189,25 @@ def cpu_baseline(wl, budget_s=20.0):
         event_step()
         reps += 1
     t_event = (time.perf_counter() - t0) / reps
-    # KNN: a slice of the queries of one (sample, bin)
+    # KNN: ONE WHOLE (sample, bin) -- every query cell against every trajectory point -- selected with a K-min scan
+    # (torch.topk; what KeOps' argKmin does), then x num_bins for the sample.  The KNN cost does not depend on the
+    # event count.
     grid, _, _ = O.lut_grid_points((H, W), SP)
-    q_slice = 1024
     pts = traj[0, 1]
-    O.knn_indices(pts, grid[:256], KNN, 'l2')
+    O.knn_indices(pts, grid[:512], KNN, 'l2', kmin=True)
     t0 = time.perf_counter()
-    O.knn_indices(pts, grid[:q_slice], KNN, 'l2', q_chunk=512)
-    t_knn_slice = time.perf_counter() - t0
-    t_knn_sample = t_knn_slice * (hq * wq / q_slice) * nb
+    O.knn_indices(pts, grid, KNN, 'l2', q_chunk=1024, kmin=True)
+    t_knn_bin = time.perf_counter() - t0
+    t_knn_sample = t_knn_bin * nb
     valid = float(ev[..., 5].sum())
-    t_sample = t_event + t_knn_sample
     return {
-        'value': valid / t_sample / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'kind': 'port',
-        'sample': (f'1 sample of the batch ({int(valid)} valid events): event path fwd+bwd timed '
-                   f'{reps}x = {t_event * 1e3:.1f} ms; brute-force KNN timed on {q_slice} of {hq * wq} '
-                   f'query cells of one bin = {t_knn_slice:.2f} s, extrapolated x{hq * wq // q_slice}x{nb} bins '
-                   f'= {t_knn_sample:.1f} s/sample'),
-        'event_path_only_value': valid / t_event / 1e6,
+        # headline: the event path (warp -> IWE -> objective -> backward), measured in full on one sample
+        'value': valid / t_event / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'kind': 'port',
+        'sample': (f'1 sample of the batch ({int(valid)} valid events): event path fwd+bwd (LUT given) timed {reps}x = '
+                   f'{t_event * 1e3:.1f} ms per step'),
+        'with_knn_value': valid / (t_event + t_knn_sample) / 1e6,
+        'with_knn_sample': (f'brute-force K-min KNN (torch.topk) timed on one whole (sample, bin) = {t_knn_bin:.2f} s, '
+                            f'x{nb} bins = {t_knn_sample:.1f} s per sample, added to the event path'),
     }
 
 
@@ -396,8 +423,21 @@ def main():
                 del gr, lg, tg
             except Exception as e:      # informational
                 graph_ms = repr(e)[:120]
+        # one cross-check of the number the timed steps computed, outside the timed region: the same step through the
+        # in-library global-atomic event kernels (a second implementation of warp + vote + backward)
+        check = None
+        if instrument:
+            La = LossFactory.get_loss_calculator('FOCUS', dict(loss_config(wl), debug_atomic_path=True))
+            ta = trajd.detach().clone().requires_grad_(True)
+            la, _, _ = La.calc(ta, times_d, batch)
+            la.backward()
+            tb = trajd.detach().clone().requires_grad_(True)
+            lb, _, _ = L.calc(tb, times_d, batch)
+            lb.backward()
+            check = {'loss_rel_diff_vs_atomic_path': abs(la.item() - lb.item()) / abs(lb.item()),
+                     'grad_rel_l2_vs_atomic_path': float((ta.grad - tb.grad).norm() / tb.grad.norm())}
         return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, graph_ms=graph_ms,
-                    loss=float(last.item()), n=traj.shape[2])
+                    loss=float(last.item()), n=traj.shape[2], check=check)
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
     r_comm = None
@@ -433,13 +473,14 @@ def main():
         return {
             'bound': 'hbm', 'kernel': DOMINANT_KERNEL.get(dom, dom), 'stage': dom,
             'note': 'HIP events bracket the C-ABI stage (all kernels_in_stage); the rocprofv3 summary in profiles/ splits it'
-                    + ('; this kernel is VALU-issue bound (exact K-nearest selection, ~3.2k VALU per 64 queries, VALU busy ~77 %: '
-                       'DESIGN.md section 4), the HBM fraction is reported as measured' if dom.startswith('mpc_knn') else ''),
+                    + ('; this stage is VALU-issue bound (exact K-nearest selection: `knn` below has its queries/s and issue-slot '
+                       'share), the HBM fraction is reported as measured' if dom.startswith('mpc_knn') else ''),
             'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(wname, dom) if wname else None,
             'algorithmic_bytes': int(d['algorithmic_MB'] * 1e6),
             'kernel_us': round(d['us_per_step'], 1), 'kernels_in_stage': STAGE_KERNELS.get(dom, []),
             'event_path': event_path_roofline(per_step, wl_),
+            'knn': knn_ceiling(wname, per_step, wl_['B'], wl_['nb']) if wname else {},
             'path': {'algorithmic_MB': round(path_b / 1e6, 2), 'gpu_us_per_step': round(gpu_us, 1),
                      'achieved': round(path_b / (gpu_us * 1e-6) / 1e9, 1) if gpu_us > 0 else 0.0,
                      'frac': round(path_b / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if gpu_us > 0 else 0.0},
@@ -457,7 +498,7 @@ def main():
                    'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
         'rccl_ranks': rccl_ranks,
-        'loss': r['loss'],
+        'loss': r['loss'], 'loss_check': r.get('check'),
         'roofline': roofline_of(r, args.workload),
     }
     if isinstance(r.get('graph_ms'), float):

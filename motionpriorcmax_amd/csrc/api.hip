@@ -96,20 +96,14 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
         L.cstrip_rows = mpc_cdiv(s->hq, L.n_cstrips);
         L.nfb = s->B * L.P * L.n_strips;
         L.nbb = s->B * s->nb * L.n_cstrips;
+        // a bucket holds whatever can reach it: every event of a polarity block may vote into one image strip, every
+        // event of a sample may lie in one (bin, LUT strip).  Address space only: untouched slots cost nothing.
         const int64_t mpol = (L.P == 2) ? (s->Mp > s->M - s->Mp ? s->Mp : s->M - s->Mp) : s->M;
-        int64_t fc = 4 * ((mpol + L.n_strips - 1) / L.n_strips);
-        if (fc < 8192) fc = 8192;
-        if (fc > mpol) fc = mpol;
-        int64_t bc = 4 * (((int64_t)s->M + (int64_t)s->nb * L.n_cstrips - 1) / ((int64_t)s->nb * L.n_cstrips));
-        if (bc < 8192) bc = 8192;
-        if (bc > s->M) bc = s->M;
-        L.fcap = (int)(fc > 0 ? fc : 1);
-        L.bcap = (int)(bc > 0 ? bc : 1);
+        L.fcap = (int)(mpol > 0 ? mpol : 1);
+        L.bcap = (int)(s->M > 0 ? s->M : 1);
         L.off_fcount = off; off += mpc_align((int64_t)(L.nfb + L.nbb + 8) * sizeof(int32_t));
         L.off_frec = off;   off += mpc_align((int64_t)L.nfb * L.fcap * 16);
         L.off_brec = off;   off += mpc_align((int64_t)L.nbb * L.bcap * 16);
-        L.off_fovf = off;   off += mpc_align((int64_t)2 * s->B * s->M * 16 + 16);
-        L.off_bovf = off;   off += mpc_align((int64_t)s->B * s->M * 16 + 16);
     } else {
         L.strip_rows = L.cstrip_rows = 0;
     }
@@ -143,7 +137,7 @@ extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {
 extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream) {
     MPC_CHECK_ARG(s && io && ws, MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(io->traj && io->flow_lut && io->knn_state && io->iwe_raw && io->iwe_blur && io->scal, MPC_E_NULL, "null buffer");
-    int rc = mpc_knn_lut_fwd(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream);
+    int rc = mpc_knn_lut_fwd_ex(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream, 1);
     if (rc) return rc;
     int s_nimg = 0, s_C = 0;
     if (io->smooth_weight > 0.f) {
@@ -155,7 +149,8 @@ extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, vo
             if ((rc = mpc_lut_smooth(s, field, s_nimg, s_C, io->smooth_weight, io->smooth_grad, ws, stream))) return rc;
         } else s_C = 0;
     }
-    if ((rc = mpc_event_splat_fwd(s, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream))) return rc;
+    // (the bucket counters were zeroed by the first kernel of the KNN forward, unless the event path is not the tiled one)
+    if ((rc = mpc_event_splat_fwd_ex(s, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, 1))) return rc;
     if ((rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream))) return rc;
     return mpc_finalize(s, s_nimg, s_C, io->smooth_weight, io->scal, ws, stream);
 }

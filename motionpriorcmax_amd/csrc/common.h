@@ -61,11 +61,9 @@ struct mpc_ws_layout {
     int64_t off_knn_reach;   // float  [B*nb][ceil(hq/16)][ceil(wq/16)]  backward search reach per 16x16 tile
     int64_t off_knn_fail;    // int32  [1 + B*nb*G]  queries handed from the strip kernel to the fallback kernel
     // event partition (LDS-tiled path)
-    int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, spill counters, marker
+    int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, marker
     int64_t off_frec;        // float4 [nfb][fcap]
     int64_t off_brec;        // float4 [nbb][bcap]
-    int64_t off_fovf;        // float4 [2*B*M]  forward spill list
-    int64_t off_bovf;        // float4 [B*M]    backward spill list
     int32_t P, nimg, G;
     int32_t strip_rows, n_strips;   // destination strips of the IWE (forward buckets)
     int32_t cstrip_rows, n_cstrips; // source strips of LUT cell rows (backward buckets)
@@ -82,6 +80,12 @@ struct mpc_ws_layout {
 #define MPC_SM_W 60   // + 2*2 halo cells = 64 = one wavefront row
 
 mpc_ws_layout mpc_layout(const mpc_shape *s);
+// internal variants of two entry points used by mpc_focus_fwd (api.hip): the KNN forward's first kernel zeroes the event
+// bucket counters, so that the event forward can skip its own zeroing launch
+int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
+                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters);
+int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
+                           float *iwe_raw, void *ws, void *stream, int counters_zeroed);
 int mpc_validate_shape(const mpc_shape *s);
 
 // ---- device helpers ---------------------------------------------------------------------

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(256) void k_splat_bwd_atomic(const mpc_shape s,
 //                          with plain coalesced stores (no zero-fill, no global atomics)
 //   backward  k_lut_accum  one workgroup per (sample, bin, LUT strip): gathers the 4 taps of the
 //                          adjoint image per record and accumulates d/dLUT in LDS (Q33.30)
-//   overflow  records beyond a bucket's capacity go to a spill list and are applied afterwards
-//             with global atomics (exact for any event distribution; empty in the common case)
+//   capacity  a bucket holds every record that can reach it (all events of a polarity block can vote into one
+//             strip; all events of a sample can sit in one (bin, LUT strip)): address space, not traffic -- only the
+//             filled part is ever touched -- so no spill path exists and the sums are bitwise reproducible for any
+//             event distribution; a concentrated distribution costs a long tail of the busiest workgroup instead
 //
 // Why fixed point: on gfx950 ds_add_f32 serialises the wave (~193 cycles per instruction) while
 // ds_add_u64 takes ~8-12 (profiles/r01_ubench_lds_atomics.txt).  Q33.30 resolves 9.3e-10, finer
@@ -183,7 +185,6 @@ struct BinLayout {
     int SR, NS, CSR, NCS, NF, NBk, fcap, bcap, P;
     int *gcount;            // [NF + NBk + 8]
     float4 *frec, *brec;    // bucket storage
-    float4 *fovf, *bovf;    // spill lists
 };
 
 __device__ __forceinline__ long long ev_to_fixed_small(float v) {   // |v| < 2
@@ -210,31 +211,15 @@ __device__ __forceinline__ int xcd_swizzle(int p, int n) {
 #define EV_STAGE 1152      // records of one workgroup laid out in LDS before they are written (>= 2.25 per event)
 #endif
 
-// one record into slot `slot` of local bucket `lb` (forward buckets first, then backward ones), or into the
-// spill list of its kind when the bucket is full
+// one record into slot `slot` of local bucket `lb` (forward buckets first, then backward ones)
 __device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, int b, int nf_loc, int lb, int slot,
                                         float4 rec) {
     if (lb < nf_loc) {
         const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
-        if (slot < L.fcap) L.frec[(size_t)g * L.fcap + slot] = rec;
-        else {
-            // spill: the strip id rides in the sign-free high bits of the image id
-            const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 0], 1);
-            rec.w = __int_as_float(((lb % L.NS) << 20) | __float_as_int(rec.w));
-            L.fovf[ov] = rec;
-        }
+        L.frec[(size_t)g * L.fcap + slot] = rec;
     } else {
         const int gb = b * p.nb * L.NCS + (lb - nf_loc);
-        if (slot < L.bcap) L.brec[(size_t)gb * L.bcap + slot] = rec;
-        else {
-            // spill: the record carries the cell offset inside its LUT strip; the list wants the LUT index
-            const int ov = atomicAdd(&L.gcount[L.NF + L.NBk + 1], 1);
-            const unsigned aux = __float_as_uint(rec.w);
-            const int it = (lb - nf_loc) / L.NCS, cst = (lb - nf_loc) - it * L.NCS;
-            const unsigned lutidx = (unsigned)((b * p.nb + it) * (p.hq * p.wq) + cst * L.CSR * p.wq) + (aux & 0x7fffffffu);
-            rec.w = __uint_as_float((aux & 0x80000000u) | lutidx);
-            L.bovf[ov] = rec;
-        }
+        L.brec[(size_t)gb * L.bcap + slot] = rec;
     }
 }
 
@@ -387,7 +372,7 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
     const int npix = (row1 - row0) * W;
     for (int i = tid; i < npix; i += 1024) s_acc[i] = 0ull;
     __syncthreads();
-    const int n = min(L.gcount[g], L.fcap);
+    const int n = L.gcount[g];
     const float4 *rec = L.frec + (size_t)g * L.fcap;
     for (int r0 = tid; r0 < n; r0 += 4 * 1024) {           // four record loads in flight per thread
         float4 e[4];
@@ -411,18 +396,6 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
     __syncthreads();
     float *dst = iwe + ((size_t)img * H + row0) * W;
     for (int i = tid; i < npix; i += 1024) dst[i] = ev_from_fixed((long long)s_acc[i]);
-}
-
-// spill records of the forward pass (rare): global float atomics after the strips were written
-__global__ __launch_bounds__(256) void k_iwe_overflow(const BinLayout L, float *__restrict__ iwe, int H, int W) {
-    const int n = L.gcount[L.NF + L.NBk + 0];
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
-        const float4 e = L.fovf[r];
-        const int code = __float_as_int(e.w), img = code & 0xfffff, strip = code >> 20;
-        const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
-        float *dst = iwe + (size_t)img * H * W;
-        record_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) { atomicAdd(dst + (size_t)yy * W + xx, v); });
-    }
 }
 
 struct __attribute__((packed, aligned(4))) pair4 { float x, y; };
@@ -479,7 +452,7 @@ __global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s,
     for (int i = tid; i < 2 * ncell; i += EV_LUT_THREADS) s_acc[i] = 0ull;
     __syncthreads();
     const bool valid = L.gcount[L.NF + L.NBk + 2] == EV_MARKER;
-    const int n = valid ? min(L.gcount[L.NF + g], L.bcap) : 0;
+    const int n = valid ? L.gcount[L.NF + g] : 0;
     const float4 *rec = L.brec + (size_t)g * L.bcap;
     // four records per thread in flight: their adjoint-image gathers (the latency of this kernel) overlap
     for (int r0 = tid; r0 < n; r0 += EV_LUT_INFLIGHT * EV_LUT_THREADS) {
@@ -513,26 +486,6 @@ __global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s,
     }
 }
 
-__global__ __launch_bounds__(256) void k_lut_overflow(const mpc_shape s, const BinLayout L,
-                                                      const float *__restrict__ gimg,
-                                                      const float *__restrict__ scal,
-                                                      const float *__restrict__ grad_out,
-                                                      float *__restrict__ glut) {
-    const EvParams p = make_params(s);
-    const int n = L.gcount[L.NF + L.NBk + 1];
-    const float coef = scal[MPC_SCAL_GCOEF] * (grad_out ? grad_out[0] : 1.f);
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
-        const float4 e = L.bovf[r];
-        const unsigned a = __float_as_uint(e.w);
-        const int pol = (int)(a >> 31), lutidx = (int)(a & 0x7fffffffu);
-        const int b = lutidx / (p.nb * p.hq * p.wq);
-        float gy, gx;
-        record_grad(e.x, e.y, e.z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy, gx);
-        atomicAdd(glut + 2 * (size_t)lutidx, coef * gy);
-        atomicAdd(glut + 2 * (size_t)lutidx + 1, coef * gx);
-    }
-}
-
 static BinLayout bin_layout(const mpc_shape *s, const mpc_ws_layout &L, void *ws) {
     BinLayout B;
     B.SR = L.strip_rows; B.NS = L.n_strips; B.CSR = L.cstrip_rows; B.NCS = L.n_cstrips;
@@ -540,8 +493,6 @@ static BinLayout bin_layout(const mpc_shape *s, const mpc_ws_layout &L, void *ws
     B.gcount = (int *)((char *)ws + L.off_fcount);
     B.frec = (float4 *)((char *)ws + L.off_frec);
     B.brec = (float4 *)((char *)ws + L.off_brec);
-    B.fovf = (float4 *)((char *)ws + L.off_fovf);
-    B.bovf = (float4 *)((char *)ws + L.off_bovf);
     return B;
 }
 
@@ -558,6 +509,11 @@ static int set_max_lds_ev(const void *fn, const char *who) {
 // ------------------------------------------------------------------------------------------
 extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, const float *flow_lut,
                                    const float *t_ref, float *iwe_raw, void *ws, void *stream) {
+    return mpc_event_splat_fwd_ex(s, events, flow_lut, t_ref, iwe_raw, ws, stream, 0);
+}
+
+int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
+                           float *iwe_raw, void *ws, void *stream, int counters_zeroed) {
     MPC_CHECK_ARG(s && iwe_raw && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) || flow_lut, MPC_E_NULL, "flow_lut is null");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
@@ -574,7 +530,7 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
         }
         const BinLayout BL = bin_layout(s, L, ws);
         const int want_bwd = (s->flags & (MPC_F_NO_WARP | MPC_F_NO_BWD_RECORDS)) ? 0 : 1;
-        if ((rc = mpc_zero_async(BL.gcount, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st))) return rc;
+        if (!counters_zeroed && (rc = mpc_zero_async(BL.gcount, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st))) return rc;
         if (s->B > 0 && s->M > 0) {
             const int nblk = mpc_cdiv(s->M, 256 * EV_PER_THREAD) * s->B;
             const dim3 grid(((nblk + 7) / 8) * 8);
@@ -585,8 +541,6 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
         }
         if (L.nfb > 0) {
             hipLaunchKernelGGL(k_iwe_accum, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
-            MPC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_iwe_overflow, dim3(64), dim3(256), 0, st, BL, iwe_raw, s->H, s->W);
             MPC_CHECK_LAUNCH();
         }
         return 0;
@@ -620,8 +574,6 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
         if (L.nbb > 0) {
             hipLaunchKernelGGL(k_lut_accum, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
                                grad_iwe, scal, grad_out, grad_flow_lut, add_term);
-            MPC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(k_lut_overflow, dim3(64), dim3(256), 0, st, *s, BL, grad_iwe, scal, grad_out, grad_flow_lut);
             MPC_CHECK_LAUNCH();
         }
         return 0;

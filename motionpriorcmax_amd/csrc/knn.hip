@@ -27,7 +27,8 @@ template <bool CACHED>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start,
                                                      float2 *__restrict__ spos, int *__restrict__ sidx, int S,
-                                                     float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail) {
+                                                     float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail,
+                                                     int *__restrict__ zero_ptr, int zero_words) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
     __shared__ int s_low[16];
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     // atomicMax and its fallback list is appended to (knn_strip.hip)
     if (part == 0) for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;
     if (blockIdx.x == 0 && tid == 0) fail[0] = 0;
+    if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
     const int rows_per = (p.hq + S - 1) / S;
     const int g_lo = min(part * rows_per, p.hq) * p.wq, g_hi = min((part + 1) * rows_per, p.hq) * p.wq, Gp = g_hi - g_lo;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
@@ -166,11 +168,13 @@ __global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, con
 // grid B*nb, 1024 threads
 __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
                                                           int *__restrict__ cell_start,
-                                                          float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail) {
+                                                          float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail,
+                                                          int *__restrict__ zero_ptr, int zero_words) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, bt = blockIdx.x;
     for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;       // (see k_knn_bucket)
     if (bt == 0 && tid == 0) fail[0] = 0;
+    if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
     int *cur = cursor + (size_t)bt * p.G;
     int *cs = cell_start + (size_t)bt * (p.G + 1);
     const int chunk = (p.G + 1023) / 1024;
@@ -911,6 +915,12 @@ static int set_max_lds(const void *fn, const char *who) {
 
 extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                                float *knn_state, int32_t *idx_out, void *ws, void *stream) {
+    return mpc_knn_lut_fwd_ex(s, traj, flow_lut, flow_next, knn_state, idx_out, ws, stream, 0);
+}
+
+// zero_event_counters: the first kernel also zeroes the bucket counters of mpc_event_splat_fwd (mpc_focus_fwd: one launch less)
+int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
+                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters) {
     MPC_CHECK_ARG(s && traj && flow_lut && knn_state && ws, MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(!(s->flags & MPC_F_WANT_NEXT) || flow_next, MPC_E_NULL, "flow_next is null");
     int rc = mpc_validate_shape(s);
@@ -927,6 +937,8 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     int *fail = (int *)((char *)ws + L.off_knn_fail);
     const int ntiles = mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16);
+    int *zero_ptr = (int *)((char *)ws + L.off_fcount);
+    const int zero_words = (zero_event_counters && L.strip_rows > 0) ? L.nfb + L.nbb + 8 : 0;
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
@@ -949,13 +961,13 @@ extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flo
         if (e) return e;
         const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
         hipLaunchKernelGGL(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
-        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail);
+        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words);
         hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
     } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail);
+        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words);
     else
-        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail);
+        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;

@@ -131,10 +131,12 @@ def lut_grid_points(image_shape, sp: int) -> Tuple[torch.Tensor, int, int]:
 
 
 def knn_indices(points: torch.Tensor, queries: torch.Tensor, k: int, dist_norm: str,
-                q_chunk: int = 2048):
+                q_chunk: int = 2048, kmin: bool = False):
     """Exact K nearest of `points` [n,2] for each of `queries` [Q,2]; distance formula and
     operand order as focus.py:132-135 ((grid - traj)**2 summed y then x, or abs).  Ties: lowest
-    point index first.  Returns (idx [Q,k] int64, dist [Q,k])."""
+    point index first (stable sort).  `kmin=True` selects with torch.topk instead -- a K-min scan like KeOps'
+    argKmin, the fair thing to TIME (bench.py's cpu_baseline); its tie order is not defined, so the checker
+    never uses it.  Returns (idx [Q,k] int64, dist [Q,k])."""
     pts = points.detach()
     idx_out, d_out = [], []
     for s in range(0, queries.shape[0], q_chunk):
@@ -146,7 +148,10 @@ def knn_indices(points: torch.Tensor, queries: torch.Tensor, k: int, dist_norm: 
             d = diff.abs().sum(-1)
         else:
             raise ValueError(dist_norm)
-        dv, di = torch.sort(d, dim=1, stable=True)
+        if kmin:
+            dv, di = torch.topk(d, k, dim=1, largest=False, sorted=True)
+        else:
+            dv, di = torch.sort(d, dim=1, stable=True)
         idx_out.append(di[:, :k])
         d_out.append(dv[:, :k])
     return torch.cat(idx_out), torch.cat(d_out)

@@ -185,9 +185,9 @@ def test_tiled_and_atomic_paths_agree():
     assert _rel_l2(outs[0][2], outs[1][2]) < 1e-5
 
 
-def test_bucket_overflow_spill_path():
-    """All events inside one image strip and one time bin: the per-bucket capacity of the
-    LDS-tiled path overflows and the spill lists (global atomics) must keep the result exact."""
+def test_all_events_in_one_bucket():
+    """All events inside one image strip and one time bin: one bucket of the LDS-tiled path receives everything (buckets
+    hold whatever can reach them; there is no spill path), the result stays exact and bitwise reproducible."""
     from motionpriorcmax_amd import ops
     from oracle import focus_oracle as O
     dev = _dev()
@@ -212,6 +212,10 @@ def test_bucket_overflow_spill_path():
     assert abs(f.item() - fo.item()) <= 2e-6 * abs(fo.item())
     np.testing.assert_allclose(raw.cpu().numpy(), rawo.detach().numpy(), atol=1e-5 * rawo.max().item())
     assert _rel_l2(lt.grad.cpu().numpy(), lo.grad.numpy()) < 1e-4
+    lt2 = lut.to(dev).requires_grad_(True)
+    f2, _, raw2 = ops.EventFocusFn.apply(lt2, ev.to(dev), torch.tensor([0.41], device=dev), L._cfg, num_pos)
+    f2.backward()
+    assert torch.equal(raw2, raw) and torch.equal(lt2.grad, lt.grad) and f2.item() == f.item()
 
 
 @pytest.mark.parametrize('shape,sp,patch', [((50, 70), 4, 4), ((33, 47), 2, 3), ((64, 96), 8, 4), ((45, 63), 3, 3)])

@@ -1,7 +1,19 @@
+#!/bin/bash
+# Round-2 evidence run on the GPU box: bench line, kernel-trace stats and SQ counters per workload, PMC traffic with the
+# FETCH_SIZE calibration.  Everything lands in gpurun_out/r02_*; the summaries are copied into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_C3.json 2> gpurun_out/bench_err.log; tail -c 600 gpurun_out/bench_C3.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 bench.py --also "" --no-cpu-baseline --steps 40 > /dev/null 2>&1
-cp gpurun_out/ks/*/*kernel_stats.csv gpurun_out/kernel_stats_C3.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pf -- python3 bench.py --also "" --no-cpu-baseline --steps 10 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pw -- python3 bench.py --also "" --no-cpu-baseline --steps 10 > /dev/null 2>&1
-python tools/summarize_pmc.py gpurun_out/pf gpurun_out/pw gpurun_out/traffic_C3.json
+O=gpurun_out
+python bench.py > $O/r02_bench_C3.json 2> $O/r02_bench_err.log; tail -c 400 $O/r02_bench_C3.json
+for wl in C3 C2 C4; do
+  tools/sq_profile.sh r02_$wl bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --steps 10 > /dev/null 2>&1
+  python3 tools/sq_to_json.py $O/r02_${wl}_sq.csv $O/r02_${wl}_kstats.csv $O/r02_sq_$wl.json > /dev/null
+done
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_f -- tools/ubench/fetch_calib.bin > $O/r02_fetch_calib.txt 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_w -- tools/ubench/fetch_calib.bin > /dev/null 2>&1
+for wl in C3 C2 C4; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf_$wl -- python3 bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --steps 10 > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw_$wl -- python3 bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --steps 10 > /dev/null 2>&1
+  python3 tools/summarize_pmc.py $O/pf_$wl $O/pw_$wl $O/traffic_$wl.json $O/cal_f $O/cal_w | tail -12
+  rm -rf $O/pf_$wl $O/pw_$wl
+done
+rm -rf $O/cal_f $O/cal_w

@@ -53,7 +53,7 @@ def main():
         ev, num_pos = O.synth_events(B, M, (H, W), nb, seed=seed, pad_frac=rng.choice([0.0, 0.05]), num_pos=np_choice)
         dist_kind = rng.choice(['uniform', 'uniform', 'band', 'spot'])
         if dist_kind != 'uniform' and M > 0:
-            # concentrated events: one image strip / LUT strip receives (almost) everything -> bucket overflow, spill lists
+            # concentrated events: one image strip / LUT strip receives (almost) everything -> one bucket holds (almost) all records
             y0c, x0c = rng.random() * (H - 2), rng.random() * (W - 2)
             rows = ev[..., 5] > 0
             ev[..., 0] = torch.where(rows, y0c + torch.rand(ev.shape[:2], generator=g) * 1.5, ev[..., 0])

@@ -1,4 +1,4 @@
-"""Event-path time when the events are spatially concentrated (bucket overflow -> spill lists) (diagnostics)."""
+"""Event-path time when the events are spatially concentrated (a few buckets hold most records: the tail of the busiest workgroups) (diagnostics)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""<tag>_sq.csv + <tag>_kstats.csv (tools/sq_profile.sh) -> the per-kernel JSON bench.py reads for `roofline.knn`.
+
+    python tools/sq_to_json.py <sq.csv> <kstats.csv> <out.json>"""
+import csv
+import json
+import sys
+
+
+def main():
+    ks = {}
+    for r in csv.DictReader(open(sys.argv[2])):
+        name = r['Name'].split('(')[0].replace('void ', '').split('<')[0]
+        ks[name] = float(r['AverageNs']) / 1e3
+    out = {}
+    for r in csv.DictReader(open(sys.argv[1])):
+        name = r['kernel'].split('<')[0]
+        if name not in ks or not r.get('SQ_INSTS_VALU'):
+            continue
+        out[name] = {'valu_insts': float(r['SQ_INSTS_VALU']), 'waves': float(r['SQ_WAVES']), 'kernel_us': ks[name],
+                     'valu_per_wave': float(r['valu_per_wave'] or 0), 'wait_any_frac': float(r['wait_any_frac'] or 0),
+                     'wait_inst_frac': float(r['wait_inst_frac'] or 0), 'lds_per_wave': float(r['lds_per_wave'] or 0)}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    print(json.dumps(out, indent=1)[:1500])
+
+
+if __name__ == '__main__':
+    main()
