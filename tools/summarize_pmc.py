@@ -64,7 +64,9 @@ def main():
         if cg:
             payload = GiB / 4                      # 256 MiB of 8-byte words; + 128 MiB of indices, streamed
             calib['gather_8B_counter_bytes_over_payload'] = 1024.0 * cg[-1] / payload
-            factors['g'] = 1.0                     # a gather's counter already counts whole 64-byte requests: keep raw
+            # a gather's counter is requests x 64 B as well; whether its requests are 64 or 128 bytes is not resolved by this
+            # calibration, so the doubled figure is an UPPER bound for gather-dominated kernels (flagged in the output)
+            factors['g'] = 2.0
         ww = cw.get('k_calib_copy', [])
         if len(ww) >= 3:
             calib['write_bytes_over_counter_16B'] = GiB / (1024.0 * ww[len(ww) // 3 * 3 - 1])
@@ -76,6 +78,7 @@ def main():
         fac = factors.get(width)
         corrected = fb * fac if fac else fb
         out[k] = {'fetch_bytes_raw': fb, 'read_width': width, 'fetch_factor': fac if fac else 1.0,
+                  'fetch_factor_is_upper_bound': width == 'g' or width is None,
                   'fetch_bytes_corrected': corrected, 'write_bytes': wb,
                   'hbm_bytes_per_launch': corrected + wb, 'hbm_bytes_per_launch_raw': fb + wb,
                   'launches_seen': len(fetch.get(k, []))}
