@@ -258,9 +258,15 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     // bit 7 exactly when byte < beta, and no borrow crosses a byte (words of groups not visited hold level NLEV)
     auto count_lt = [&](unsigned beta) {
         const unsigned C = (beta + 127u) * 0x01010101u;
-        int acc = 0;
+        // (two v_bcnt_u32_b32 accumulate chains: the compiler's own form is bcnt + a tree of adds, half an instruction
+        // more per word)
+        int acc = 0, acc1 = 0;
 #pragma unroll
-        for (int c = 0; c < KS_BASECH; ++c) acc += __popc((C - w[c]) & 0x80808080u);
+        for (int c = 0; c < KS_BASECH; c += 2) {
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"((C - w[c]) & 0x80808080u));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc1) : "v"((C - w[c + 1]) & 0x80808080u));
+        }
+        acc += acc1;
         // (an inner query has 7 rows of 9 slots; only wavefronts next to the image border, whose rows are wider, get
         // here: real branches on the wave-uniform trip count -- the empty asm keeps them from being if-converted)
         if (nmax > 4 * KS_BASECH) {
@@ -299,7 +305,10 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
 #pragma unroll
     for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) E[e] = 0u;
     const float ubf = live ? (float)bstar : 0.f;             // dead lanes: nothing is below level 0 ...
-    const unsigned ue = live ? (unsigned)bstar : 0xffu;      // ... and nothing at level 255
+    // slots AT level bstar, by a SWAR zero-byte test per word: z = w ^ (bstar in every byte) has bytes <= 127, so
+    // (0x80 - byte) keeps bit 7 exactly for byte == 0 and no borrow crosses a byte.  The four flags of word j (of the
+    // eight words of a mask) go to bits j, 8 + j, 16 + j, 24 + j: slot 32 m + 4 j + u <-> bit j + 8 u of E[m].
+    const unsigned ue4 = (live ? (unsigned)bstar : 0x7fu) * 0x01010101u;      // (dead lanes: no level is 127)
     const float2 *pf = lflow + s, *pn = lnext + s;
 #pragma unroll
     for (int g = 0; g < KS_MAXCH / 2; ++g) {
@@ -308,10 +317,16 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
 #pragma unroll
             for (int u = 0; u < 8; ++u) { fj[u] = pf[8 * g + u]; if (NEXT) gj[u] = pn[8 * g + u]; }
 #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = (2 * g + h) & 7;
+                const unsigned f7 = 0x80808080u - (w[2 * g + h] ^ ue4);
+                E[g / 4] |= (f7 >> (7 - j)) & (0x01010101u << j);
+            }
+#pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const unsigned lv = (w[2 * g + (u >> 2)] >> (8 * (u & 3))) & 0xffu;
                 if (IWD) {
-                    if (lv < ue) {                               // (ue == bstar on live lanes, 255 never matters: lv <= NLEV)
+                    if ((float)lv < ubf) {
                         if (live) {
                             const float2 pj = pp[8 * g + u];
                             const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
@@ -325,7 +340,6 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                     sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_);
                     if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
                 }
-                E[g / 4] |= (lv == ue) ? (1u << ((8 * g + u) & 31)) : 0u;
             }
         }
     }
@@ -347,8 +361,9 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         for (int a = 0; a < KS_LMAX; ++a) {
             dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0;
             if (a < mmax) {
-                int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // lowest slot still in the mask
+                int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // a bit still in the mask ...
                 if (em) em &= em - 1ull; else e2 &= e2 - 1u;
+                k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
                 if (light && k >= 0) {
                     const float2 pj = pp[k];
                     jj[a] = k;
@@ -386,23 +401,26 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h);
             const float hqy = lane_f(qy, h), hqx = lane_f(qx, h);
             // this lane's two slots of the heavy query: lane and lane + 64
-            const bool b0 = (((lane < 32 ? h0 : h1) >> (lane & 31)) & 1u) != 0u, b1 = lane < 32 && ((h2 >> lane) & 1u) != 0u;
+            const int mybit = ((lane >> 2) & 7) + 8 * (lane & 3);            // bit of slot `lane` (and of slot 64 + lane) in its mask word
+            const bool b0 = (((lane < 32 ? h0 : h1) >> mybit) & 1u) != 0u, b1 = lane < 32 && ((h2 >> mybit) & 1u) != 0u;
             float d0 = INFINITY, d1 = INFINITY;
             int i0 = 0x7fffffff, i1 = 0x7fffffff, r0_ = 0, r1_ = 0;
             if (b0) { const float2 pj = lpos[hs + lane]; d0 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i0 = (int)lidx[hs + lane]; }
             if (b1) { const float2 pj = lpos[hs + 64 + lane]; d1 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i1 = (int)lidx[hs + 64 + lane]; }
             unsigned long long km = ((unsigned long long)h1 << 32) | h0;
             while (km != 0ull) {
-                const int k = __ffsll((long long)km) - 1;
+                const int kb = __ffsll((long long)km) - 1;
                 km &= km - 1ull;
+                const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot of the bit
                 const float kd = lane_f(d0, k); const int ki = lane_i(i0, k);
                 r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
                 r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
             }
             unsigned k2 = h2;
             while (k2 != 0u) {
-                const int k = __ffs(k2) - 1;
+                const int kb = __ffs(k2) - 1;
                 k2 &= k2 - 1u;
+                const int k = 4 * (kb & 7) + (kb >> 3);                          // slot - 64 of the bit
                 const float kd = lane_f(d1, k); const int ki = lane_i(i1, k);
                 r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
                 r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
