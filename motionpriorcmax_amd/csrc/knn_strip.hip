@@ -528,6 +528,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     if (grow_first) r += 1 + (r >> 2);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS], gg[KS_FB_SLOTS];
     bool serial = false;
+    int ns = KS_FB_SLOTS;                  // slots per lane actually in use (wave-uniform): ceil(candidates / 64)
     for (;;) {
         const int y0 = max(cy - r, 0), y1 = min(cy + r, p.hq - 1), x0 = max(cx - r, 0), x1 = min(cx + r, p.wq - 1);
         const bool whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
@@ -543,12 +544,14 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if (lane >= o2) incl += v; }
         const int N = __shfl(incl, 63, 64);
         if (N > 64 * KS_FB_SLOTS) { serial = true; break; }
+        ns = (N + 63) >> 6;
         const int excl = incl - ln;
         int cnt = 0;
 #pragma unroll
         for (int m = 0; m < KS_FB_SLOTS; ++m) {
             const int k = lane + 64 * m;                    // flat candidate number of this lane's m-th slot
             dd[m] = INFINITY; ii[m] = 0x7fffffff; gg[m] = 0;
+            if (m >= ns) continue;
             // row of candidate k: the last lane whose exclusive offset is <= k (offsets are non-decreasing)
             int lo = 0, hi = 64;
 #pragma unroll
@@ -589,6 +592,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     for (int m = 0; m < KS_FB_SLOTS; ++m) rank[m] = 0;
 #pragma unroll
     for (int mo = 0; mo < KS_FB_SLOTS; ++mo) {
+        if (mo >= ns) break;
         unsigned long long vm = __ballot(dd[mo] < INFINITY);       // lanes holding a candidate in this slot
         while (vm != 0ull) {
             const int l = __ffsll((long long)vm) - 1;
@@ -596,7 +600,8 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             const float od = lane_f(dd[mo], l);
             const int oi = lane_i(ii[mo], l);
 #pragma unroll
-            for (int m = 0; m < KS_FB_SLOTS; ++m) rank[m] += ((od < dd[m]) | ((od == dd[m]) & (oi < ii[m]))) ? 1 : 0;
+            for (int m = 0; m < KS_FB_SLOTS; ++m)
+                if (m < ns) rank[m] += ((od < dd[m]) | ((od == dd[m]) & (oi < ii[m]))) ? 1 : 0;
         }
     }
     // neighbours: rank < K (indices are distinct, so ranks are); sums in lane order
