@@ -5,6 +5,7 @@
 // HBM-bound stencils: every image is read once and written once per kernel, tiles are staged
 // in LDS with their halo, reductions use wavefront shuffles and fp64 block partials.
 #include "common.h"
+#include <stdlib.h>
 
 // torchvision gaussian_blur(kernel_size=3, sigma=1): [a, c, a] = exp(-x^2/2)/sum, fp32
 __device__ __forceinline__ void blur_taps(float &a, float &c) {
@@ -103,6 +104,128 @@ __device__ __forceinline__ float blurT_w(int q, int y, int n, float ka, float kc
     if (q == 0 && y == 1) w += ka;
     if (q == n - 1 && y == n - 2) w += ka;
     return w;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused forward + adjoint image (gradient magnitude), MARCHING form: raw -> blurred, partial sums, Blur^T Sobel^T u
+// with no LDS and no barrier.  One wavefront owns 56 columns (+ 4 halo columns each side: lane = column) and a band of
+// MPC_CT_H rows (+ 4 halo rows each side) and walks down the rows; every stage of the chain keeps the two or three
+// previous rows it needs in registers (the row loop is fully unrolled, so the rolling windows are register renaming,
+// not moves), horizontal neighbours come from the adjacent lanes (DPP wave shifts, no LDS round trip):
+//   row y      : raw a(y)                      -> hb(y)   = ka a[c-1] + kc a[c] + ka a[c+1]           (reflect ring staged)
+//   row y - 1  : B = ka hb(y-2) + kc hb(y-1) + ka hb(y)   (0 outside the image: Sobel pads with zeros)
+//   row y - 2  : dx = hd(y-3) + 2 hd(y-2) + hd(y-1), hd = B[c+1] - B[c-1];  dy = vd[c-1] + 2 vd[c] + vd[c+1], vd = B(y-1) - B(y-3)
+//                u = sign / 2x;  blurred output and objective of the own pixels
+//   row y - 3  : gB = Sobel^T u  (hx = ux[c-1] - ux[c+1] per row, vy = uy(y-4) - uy(y-2) per column)
+//   row y - 4  : adjoint of the blur (border weights fold the reflect ring back) -> grad image of the own pixels
+// Same association of the sums as the tiled kernel below (which stays for reference / the variance objective's twin).
+// The tiled kernel spent 190 vector instructions per pixel on LDS traffic and index arithmetic; this one ~70 per lane-row.
+// grid (ceil(W/56), ceil(H/MPC_CT_H), nimg), 64 threads
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_left(float v) {      // value of lane - 1 (0 for lane 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));     // wave_shr:1
+}
+__device__ __forceinline__ float lane_right(float v) {     // value of lane + 1 (0 for lane 63)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));     // wave_shl:1
+}
+
+template <bool L2N>
+__global__ __launch_bounds__(64) void k_contrast_march(const float *__restrict__ raw, float *__restrict__ blur,
+                                                       float *__restrict__ gimg, double *__restrict__ part, int H, int W) {
+    constexpr int TH = MPC_CT_H, TW = MPC_CF_TW;
+    const int c = threadIdx.x;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const size_t img_off = (size_t)blockIdx.z * H * W;
+    const float *src = raw + img_off;
+    float ka, kc;
+    blur_taps(ka, kc);
+    const int x = tx0 - 4 + c;
+    const bool xin = x >= 0 && x < W;
+    const int xr = (x >= -1 && x <= W) ? reflect1(x, W) : -1;
+    const bool own_col = c >= 4 && c < 4 + TW && x < W;
+    float wx0 = 0.f, wx1 = 0.f, wx2 = 0.f;                   // column weights of the blur adjoint for this lane's pixel
+    if (xin) {
+        wx0 = (x - 1 >= 0) ? blurT_w(x - 1, x, W, ka, kc) : 0.f;
+        wx1 = blurT_w(x, x, W, ka, kc);
+        wx2 = (x + 1 < W) ? blurT_w(x + 1, x, W, ka, kc) : 0.f;
+    }
+    float hb1 = 0.f, hb2 = 0.f;                               // hb(y-1), hb(y-2)
+    float B2 = 0.f, B3 = 0.f, hd2 = 0.f, hd3 = 0.f;           // B and hd at rows y-2, y-3
+    float hx3 = 0.f, hx4 = 0.f, uy3 = 0.f, uy4 = 0.f;         // hx and uy at rows y-3, y-4
+    float hT4 = 0.f, hT5 = 0.f;                               // horizontal part of the blur adjoint at rows y-4, y-5
+    double acc = 0.0;
+    // the raw rows are requested two iterations ahead
+    float a_next[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int y = ty0 - 4 + k;
+        a_next[k] = (xr >= 0 && y >= -1 && y <= H) ? src[(size_t)reflect1(y, H) * W + xr] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < TH + 8; ++it) {
+        const int y = ty0 - 4 + it;
+        const float a = a_next[it & 1];
+        {
+            const int yn = y + 2;
+            a_next[it & 1] = (it + 2 < TH + 8 && xr >= 0 && yn >= -1 && yn <= H) ? src[(size_t)reflect1(yn, H) * W + xr] : 0.f;
+        }
+        // row y: horizontal blur
+        const float hb0 = ka * lane_left(a) + kc * a + ka * lane_right(a);
+        // row y - 1: vertical blur; zero outside the image
+        const int yb = y - 1;
+        const float B1 = (xin && yb >= 0 && yb < H) ? ka * hb2 + kc * hb1 + ka * hb0 : 0.f;
+        const float hd1 = lane_right(B1) - lane_left(B1);
+        // row y - 2: Sobel, u, blurred output, objective
+        const int ys = y - 2;
+        float ux = 0.f, uy2 = 0.f;
+        {
+            const float vd = B1 - B3;
+            const float dxv = hd3 + 2.f * hd2 + hd1;
+            const float dyv = lane_left(vd) + 2.f * vd + lane_right(vd);
+            if (xin && ys >= 0 && ys < H) {
+                if (L2N) { ux = 2.f * dxv; uy2 = 2.f * dyv; }
+                else {
+                    ux = (dxv > 0.f) ? 1.f : ((dxv < 0.f) ? -1.f : 0.f);
+                    uy2 = (dyv > 0.f) ? 1.f : ((dyv < 0.f) ? -1.f : 0.f);
+                }
+                if (own_col && ys >= ty0 && ys < ty0 + TH) {
+                    blur[img_off + (size_t)ys * W + x] = B2;
+                    acc += L2N ? (double)(dxv * dxv + dyv * dyv) : (double)(fabsf(dxv) + fabsf(dyv));
+                }
+            }
+        }
+        const float hx2 = lane_left(ux) - lane_right(ux);
+        // row y - 3: gB = Sobel^T u; zero outside the image
+        const int yg = y - 3;
+        float g = 0.f;
+        {
+            const float vy = uy4 - uy2;
+            const float gx = hx2 + 2.f * hx3 + hx4;
+            const float gy = lane_right(vy) + 2.f * vy + lane_left(vy);
+            if (xin && yg >= 0 && yg < H) g = gx + gy;
+        }
+        const float hT3 = wx0 * lane_left(g) + wx1 * g + wx2 * lane_right(g);
+        // row y - 4: adjoint of the vertical blur (reflect ring folded into the border weights)
+        const int yo = y - 4;
+        if (own_col && yo >= ty0 && yo < ty0 + TH && yo < H) {
+            float o = 0.f;
+            if (yo - 1 >= 0) o += blurT_w(yo - 1, yo, H, ka, kc) * hT5;
+            o += blurT_w(yo, yo, H, ka, kc) * hT4;
+            if (yo + 1 < H) o += blurT_w(yo + 1, yo, H, ka, kc) * hT3;
+            gimg[img_off + (size_t)yo * W + x] = o;
+        }
+        // roll the windows
+        hb2 = hb1; hb1 = hb0;
+        B3 = B2; B2 = B1; hd3 = hd2; hd2 = hd1;
+        hx4 = hx3; hx3 = hx2; uy4 = uy3; uy3 = uy2;
+        hT5 = hT4; hT4 = hT3;
+    }
+    acc = wave_sum_d(acc);
+    if (c == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[2 * bid] = acc;
+        part[2 * bid + 1] = 0.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -475,7 +598,10 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     const int l2 = (s->flags & MPC_F_NORM_L2) ? 1 : 0;
     if (grad_iwe && !variance) {
         const dim3 gridf(mpc_cdiv(s->W, MPC_CF_TW), mpc_cdiv(s->H, MPC_CT_H), L.nimg);
-        hipLaunchKernelGGL(k_contrast_fused, gridf, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
+        static const bool tiled = getenv("MPC_CONTRAST_TILED") && atoi(getenv("MPC_CONTRAST_TILED")) != 0;    // (tuning: the LDS-tiled kernel)
+        if (tiled) hipLaunchKernelGGL(k_contrast_fused, gridf, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
+        else if (l2) hipLaunchKernelGGL(k_contrast_march<true>, gridf, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W);
+        else hipLaunchKernelGGL(k_contrast_march<false>, gridf, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W);
         MPC_CHECK_LAUNCH();
         return 0;
     }
