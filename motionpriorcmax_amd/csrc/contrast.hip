@@ -585,6 +585,87 @@ __global__ void k_scale(const float *__restrict__ x, const float *__restrict__ a
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// smoothness, MARCHING form (as k_contrast_march: lane = column, rows walked with rolling register windows, DPP lane
+// shifts, no LDS, no barrier): one wavefront owns 60 cell columns (+ 2 halo each side) and MPC_SM_H rows (+ 2) of one
+// channel pair.  Same sums, in the same association, as k_lut_smooth above.
+// grid (ceil(wq/60), ceil(hq/MPC_SM_H), nimg*C/2), 64 threads
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lut_smooth_march(const float *__restrict__ field, float *__restrict__ gfield,
+                                                         double *__restrict__ part, int hq, int wq, int C, float gscale) {
+    constexpr int TH = MPC_SM_H, TW = MPC_SM_W;
+    const int c = threadIdx.x;
+    const int C2 = C >> 1;
+    const int img = blockIdx.z / C2, cp = blockIdx.z - img * C2;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const size_t base = (size_t)img * hq * wq * C2 + cp;        // in float2 units
+    const float2 *f2 = reinterpret_cast<const float2 *>(field);
+    float2 *g2 = reinterpret_cast<float2 *>(gfield);
+    const float eps2 = 1e-3f * 1e-3f;   // charbonnier epsilon ** 2 (loss.py:46,55)
+    const int x = x0 - 2 + c;
+    const bool xin = x >= 0 && x < wq;
+    const bool own_col = c >= 2 && c < 2 + TW && x < wq;
+    float2 f1 = make_float2(0.f, 0.f), f2r = f1, hd1 = f1, hd2 = f1;          // f and hd at rows y-1, y-2
+    float2 hx2 = f1, hx3 = f1, vy2 = f1, vy3 = f1;                              // hx and vy at rows y-2, y-3
+    double a0 = 0.0, a1 = 0.0;
+    float2 f_next[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int y = y0 - 2 + k;
+        f_next[k] = (xin && y >= 0 && y < hq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < TH + 4; ++it) {
+        const int y = y0 - 2 + it;
+        const float2 f0 = f_next[it & 1];
+        {
+            const int yn = y + 2;
+            f_next[it & 1] = (it + 2 < TH + 4 && xin && yn >= 0 && yn < hq) ? f2[base + ((size_t)yn * wq + x) * C2] : make_float2(0.f, 0.f);
+        }
+        const float2 hd0 = make_float2(lane_right(f0.x) - lane_left(f0.x), lane_right(f0.y) - lane_left(f0.y));
+        // row y - 1: Sobel -> charbonnier terms and their derivatives
+        const int ys = y - 1;
+        float2 vx = make_float2(0.f, 0.f), vy1 = make_float2(0.f, 0.f);
+        {
+            const float2 vd = make_float2(f0.x - f2r.x, f0.y - f2r.y);
+            const float dxx = hd2.x + 2.f * hd1.x + hd0.x, dxy = hd2.y + 2.f * hd1.y + hd0.y;
+            const float dyx = lane_left(vd.x) + 2.f * vd.x + lane_right(vd.x), dyy = lane_left(vd.y) + 2.f * vd.y + lane_right(vd.y);
+            if (xin && ys >= 0 && ys < hq) {
+                // hardware sqrt and reciprocal (1 ulp each), as in k_lut_smooth
+                const float sxx = __builtin_amdgcn_sqrtf(dxx * dxx + eps2), syx = __builtin_amdgcn_sqrtf(dyx * dyx + eps2);
+                const float sxy = __builtin_amdgcn_sqrtf(dxy * dxy + eps2), syy = __builtin_amdgcn_sqrtf(dyy * dyy + eps2);
+                vx.x = dxx * __builtin_amdgcn_rcpf(sxx); vy1.x = dyx * __builtin_amdgcn_rcpf(syx);
+                vx.y = dxy * __builtin_amdgcn_rcpf(sxy); vy1.y = dyy * __builtin_amdgcn_rcpf(syy);
+                if (own_col && ys >= y0 && ys < y0 + TH) {
+                    a0 += (double)sxx; a1 += (double)syx;
+                    a0 += (double)sxy; a1 += (double)syy;
+                }
+            }
+        }
+        const float2 hx1 = make_float2(lane_left(vx.x) - lane_right(vx.x), lane_left(vx.y) - lane_right(vx.y));
+        // row y - 2: adjoint of the Sobel pair
+        const int yo = y - 2;
+        {
+            const float2 vyd = make_float2(vy3.x - vy1.x, vy3.y - vy1.y);
+            const float gyx = lane_right(vyd.x) + 2.f * vyd.x + lane_left(vyd.x), gyy = lane_right(vyd.y) + 2.f * vyd.y + lane_left(vyd.y);
+            if (gfield != nullptr && own_col && yo >= y0 && yo < y0 + TH && yo < hq) {
+                float2 o;
+                o.x = gscale * ((hx1.x + 2.f * hx2.x + hx3.x) + gyx);
+                o.y = gscale * ((hx1.y + 2.f * hx2.y + hx3.y) + gyy);
+                g2[base + ((size_t)yo * wq + x) * C2] = o;
+            }
+        }
+        f2r = f1; f1 = f0; hd2 = hd1; hd1 = hd0;
+        hx3 = hx2; hx2 = hx1; vy3 = vy2; vy2 = vy1;
+    }
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1);
+    if (c == 0) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        part[2 * bid] = a0;
+        part[2 * bid + 1] = a1;
+    }
+}
+
 extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float *iwe_blur,
                                 float *grad_iwe, void *ws, void *stream) {
     MPC_CHECK_ARG(s && iwe_raw && iwe_blur && ws, MPC_E_NULL, "null argument");
@@ -637,7 +718,9 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
     double *spart = (double *)((char *)ws + L.off_spart);
     const double count = (double)nimg * C * s->hq * s->wq;
     const float gscale = (float)((double)smooth_weight / (2.0 * count));
-    hipLaunchKernelGGL(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    static const bool tiled = getenv("MPC_SMOOTH_TILED") && atoi(getenv("MPC_SMOOTH_TILED")) != 0;      // (tuning: the LDS-tiled kernel)
+    if (tiled) hipLaunchKernelGGL(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    else hipLaunchKernelGGL(k_lut_smooth_march, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
     MPC_CHECK_LAUNCH();
     return 0;
 }
