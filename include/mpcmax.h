@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 100
+#define MPC_VERSION 101
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -185,10 +185,11 @@ int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *str
  * (VoxelGrid.convert) as called from src/loader/dsec/loader.py:133-139.
  * xytp   [B][N][4] : x, y, t, p per raw event (p in {0,1}; t increasing within a sample; rows beyond
  *                    counts[b] are ignored)                        counts [B] int32 (device)
- * grid   [B][C][H][W] (out, overwritten).  norm: 0 none, 1 'mean_std', 2 'max' (quantile clipping of
- * the reference is not provided: quantile must be 0, the value used by config/exe/flow_training/dsec.yaml). */
+ * grid   [B][C][H][W] (out, overwritten).  norm: 0 none, 1 'mean_std', 2 'max'; quantile clipping before the
+ * normalisation as in the reference (config/exe/flow_training/dsec.yaml uses quantile: 0). */
 typedef struct mpc_vox_shape {
     int32_t B, N, C, H, W, norm;
+    float quantile;   /* 0 <= quantile < 0.15: clip at the (1 - quantile) quantile of |grid| per sample (utils.py:57-61); 0 = off */
 } mpc_vox_shape;
 int64_t mpc_voxel_workspace_bytes(const mpc_vox_shape *s);
 int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const int32_t *counts, float *grid,

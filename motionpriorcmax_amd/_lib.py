@@ -44,7 +44,7 @@ class FocusBuffers(ctypes.Structure):
 
 
 class VoxShape(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'C', 'H', 'W', 'norm')]
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'C', 'H', 'W', 'norm')] + [('quantile', ctypes.c_float)]
 
 
 class IngestShape(ctypes.Structure):
@@ -109,8 +109,8 @@ def lib():
     L.mpc_flow_error_workspace_bytes.argtypes = [ctypes.POINTER(ErrShape)]
     L.mpc_flow_error_workspace_bytes.restype = i64
     L.mpc_flow_error.argtypes = [ctypes.POINTER(ErrShape), vp, vp, vp, vp, vp, vp, vp]
-    if L.mpc_version() != 100:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (100)')
+    if L.mpc_version() != 101:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (101)')
     _lib = L
     return L
 

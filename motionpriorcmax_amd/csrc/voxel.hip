@@ -228,15 +228,120 @@ __global__ __launch_bounds__(256) void k_vox_norm(float *__restrict__ grid, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// quantile clipping (utils.py:57-61): threshold = torch.quantile(|grid|.view(-1), 1 - quantile) per sample, entries
+// beyond it are set to sign * threshold.  The order statistics come from a radix select over the bit patterns of
+// |v| (non-negative floats order like their bits): three histogram passes (11 + 11 + 10 bits) find the element of rank
+// k = floor(pos), a fourth pass the next larger value (rank k + 1 unless it repeats), then torch's own interpolation:
+// pos = float(1 - quantile) * float(n - 1) in fp32, weight = pos - floor(pos), lerp(below, above, weight).
+//   qstate[b][8]: 0 prefix of the key found so far, 1 rank still to go inside the prefix, 2 smallest key above the
+//                 selected one (atomicMin), 3 elements <= selected key, 4 threshold (float bits)
+// ------------------------------------------------------------------------------------------
+#define VOX_QBINS 2048
+__device__ __forceinline__ void vox_qpass(int pass, int &shift, int &bits) {
+    shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    bits = pass == 2 ? 10 : 11;
+}
+
+// grid (nblk, B), 256 threads
+__global__ __launch_bounds__(256) void k_vox_qhist(const float *__restrict__ grid, unsigned *__restrict__ hist,
+                                                   const unsigned *__restrict__ qstate, int64_t per_sample, int pass) {
+    __shared__ unsigned s_h[VOX_QBINS];
+    int shift, bits;
+    vox_qpass(pass, shift, bits);
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < VOX_QBINS; i += 256) s_h[i] = 0u;
+    __syncthreads();
+    const unsigned prefix = qstate[b * 8 + 0];
+    const float *g = grid + (size_t)b * per_sample;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const unsigned key = __float_as_uint(fabsf(g[i]));
+        const bool match = pass == 0 || (key >> (shift + bits)) == prefix;
+        if (match) atomicAdd(&s_h[(key >> shift) & ((1u << bits) - 1u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < VOX_QBINS; i += 256)
+        if (s_h[i]) atomicAdd(&hist[(size_t)b * VOX_QBINS + i], s_h[i]);
+}
+
+// grid B, 256 threads: the bin holding the wanted rank; zeroes the histogram for the next pass
+__global__ __launch_bounds__(256) void k_vox_qscan(unsigned *__restrict__ hist, unsigned *__restrict__ qstate, int64_t per_sample,
+                                                   float qf, int pass) {
+    __shared__ unsigned s_c[VOX_QBINS];
+    __shared__ unsigned s_part[256];
+    int shift, bits;
+    vox_qpass(pass, shift, bits);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned *h = hist + (size_t)b * VOX_QBINS;
+    if (pass == 0 && tid == 0) {
+        const float pos = qf * (float)(per_sample - 1);          // torch.quantile: q and the ranks in the input dtype
+        qstate[b * 8 + 0] = 0u;
+        qstate[b * 8 + 1] = (unsigned)floorf(pos);
+        qstate[b * 8 + 2] = 0xffffffffu;
+        qstate[b * 8 + 3] = 0u;
+    }
+    unsigned loc = 0u;
+    for (int i = 0; i < VOX_QBINS / 256; ++i) { s_c[tid * (VOX_QBINS / 256) + i] = h[tid * (VOX_QBINS / 256) + i]; loc += s_c[tid * (VOX_QBINS / 256) + i]; }
+    s_part[tid] = loc;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned k = qstate[b * 8 + 1], below = qstate[b * 8 + 3], run = 0u;
+        int t = 0;
+        while (t < 255 && run + s_part[t] <= k) { run += s_part[t]; ++t; }
+        int bin = t * (VOX_QBINS / 256);
+        while (bin < VOX_QBINS - 1 && run + s_c[bin] <= k) { run += s_c[bin]; ++bin; }
+        qstate[b * 8 + 0] = (qstate[b * 8 + 0] << bits) | (unsigned)bin;
+        qstate[b * 8 + 1] = k - run;
+        // elements <= the selected key once the last pass is done: everything before the bin at every level, + the bin
+        qstate[b * 8 + 3] = below + run + (pass == 2 ? s_c[bin] : 0u);
+    }
+    __syncthreads();
+    for (int i = tid; i < VOX_QBINS; i += 256) h[i] = 0u;
+}
+
+// grid (nblk, B): smallest key above the selected one
+__global__ __launch_bounds__(256) void k_vox_qnext(const float *__restrict__ grid, unsigned *__restrict__ qstate, int64_t per_sample) {
+    const int b = blockIdx.y;
+    const unsigned sel = qstate[b * 8 + 0];
+    const float *g = grid + (size_t)b * per_sample;
+    unsigned m = 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const unsigned key = __float_as_uint(fabsf(g[i]));
+        if (key > sel) m = min(m, key);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_down((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m != 0xffffffffu) atomicMin(&qstate[b * 8 + 2], m);
+}
+
+// grid (nblk, B): threshold (torch's lerp) and the clip itself, in place
+__global__ __launch_bounds__(256) void k_vox_qclip(float *__restrict__ grid, unsigned *__restrict__ qstate, int64_t per_sample, float qf) {
+    const int b = blockIdx.y;
+    const float pos = qf * (float)(per_sample - 1);
+    const float fl = floorf(pos), w = pos - fl;
+    const unsigned k0 = (unsigned)fl, k1 = (unsigned)ceilf(pos);
+    const float below = __uint_as_float(qstate[b * 8 + 0]);
+    // rank k1 == k0, or the selected value repeats beyond rank k0, or the next larger value
+    const float above = (k1 == k0 || qstate[b * 8 + 3] > k1) ? below : __uint_as_float(qstate[b * 8 + 2]);
+    const float d = above - below;
+    const float thr = (w < 0.5f) ? below + w * d : above - d * (1.f - w);       // at::lerp
+    float *g = grid + (size_t)b * per_sample;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        if (fabsf(v) > thr) g[i] = (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) * thr;        // sign(v) * threshold, utils.py:59-61
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 static int vox_validate(const mpc_vox_shape *s) {
     MPC_CHECK_ARG(s->B >= 0 && s->N >= 0 && s->C >= 1 && s->H >= 1 && s->W >= 1, MPC_E_SHAPE, "bad voxel-grid shape");
     MPC_CHECK_ARG(s->norm >= 0 && s->norm <= 2, MPC_E_SHAPE, "norm must be 0 (none), 1 (mean_std) or 2 (max)");
+    MPC_CHECK_ARG(s->quantile >= 0.f && s->quantile < 0.15f, MPC_E_SHAPE, "quantile must lie in [0, 0.15) (utils.py:27)");
     MPC_CHECK_ARG((int64_t)s->W * 8 <= 150 * 1024, MPC_E_UNSUPPORTED, "sensor too wide for one LDS strip row");
     MPC_CHECK_ARG((int64_t)s->B * s->C * s->H * s->W < (1LL << 31), MPC_E_UNSUPPORTED, "voxel grid too large");
     return 0;
 }
 
-struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_part, off_stat, total; };
+struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_part, off_stat, off_qhist, off_qstate, total; unsigned *qhist, *qstate; };
 
 static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     VoxHostLayout h;
@@ -257,6 +362,8 @@ static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     h.off_ovf = off;   off += mpc_align((int64_t)4 * s->B * s->N * 16 + 16);
     h.off_part = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * L.nstat_blocks * 4 * 8);
     h.off_stat = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 4 * 4);
+    h.off_qhist = off; off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * VOX_QBINS * 4);
+    h.off_qstate = off; off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 8 * 4);
     h.total = off;
     char *w = (char *)ws;
     L.gcount = (int *)(w + h.off_count);
@@ -264,6 +371,8 @@ static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     L.ovf = (float4 *)(w + h.off_ovf);
     L.part = (double *)(w + h.off_part);
     L.stat = (float *)(w + h.off_stat);
+    h.qhist = (unsigned *)(w + h.off_qhist);
+    h.qstate = (unsigned *)(w + h.off_qstate);
     return h;
 }
 
@@ -301,6 +410,20 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
     MPC_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_vox_overflow, dim3(64), dim3(256), 0, st, L, grid, s->H, s->W);
     MPC_CHECK_LAUNCH();
+    if (s->quantile > 0.f) {
+        const int64_t per_sample = (int64_t)s->C * s->H * s->W;
+        const float qf = (float)(1.0 - (double)s->quantile);       // the Python side passes 1 - quantile as a double, torch rounds it to fp32
+        const int e1 = mpc_zero_async(h.qhist, (size_t)s->B * VOX_QBINS * 4, st);
+        if (e1) return e1;
+        const dim3 gq(L.nstat_blocks, s->B);
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL(k_vox_qhist, gq, dim3(256), 0, st, grid, h.qhist, h.qstate, per_sample, pass);
+            hipLaunchKernelGGL(k_vox_qscan, dim3(s->B), dim3(256), 0, st, h.qhist, h.qstate, per_sample, qf, pass);
+        }
+        hipLaunchKernelGGL(k_vox_qnext, gq, dim3(256), 0, st, grid, h.qstate, per_sample);
+        hipLaunchKernelGGL(k_vox_qclip, gq, dim3(256), 0, st, grid, h.qstate, per_sample, qf);
+        MPC_CHECK_LAUNCH();
+    }
     if (s->norm != 0) {
         const int64_t per_sample = (int64_t)s->C * s->H * s->W;
         hipLaunchKernelGGL(k_vox_stats, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.part, per_sample);

@@ -10,7 +10,7 @@ from .. import _lib as C
 from ..ops import _ptr, _require_gpu, _stream, _stage
 
 
-def voxel_grids(xytp: torch.Tensor, counts: torch.Tensor, input_size, norm_type='mean_std') -> torch.Tensor:
+def voxel_grids(xytp: torch.Tensor, counts: torch.Tensor, input_size, norm_type='mean_std', quantile=0.0) -> torch.Tensor:
     """xytp [B, N, 4] (x, y, t, p), counts [B] int32 (valid rows per sample) -> [B, C, H, W]."""
     _require_gpu(xytp, 'events')
     if norm_type not in ('mean_std', 'max', None):
@@ -19,7 +19,7 @@ def voxel_grids(xytp: torch.Tensor, counts: torch.Tensor, input_size, norm_type=
     ev = xytp.float().contiguous()
     B, N, _ = ev.shape
     cnt = counts.to(device=ev.device, dtype=torch.int32).contiguous()
-    shape = C.VoxShape(B=B, N=N, C=Cn, H=H, W=W, norm={None: 0, 'mean_std': 1, 'max': 2}[norm_type])
+    shape = C.VoxShape(B=B, N=N, C=Cn, H=H, W=W, norm={None: 0, 'mean_std': 1, 'max': 2}[norm_type], quantile=float(quantile))
     nbytes = C.lib().mpc_voxel_workspace_bytes(ctypes.byref(shape))
     if nbytes < 0:
         C.check(int(nbytes), 'mpc_voxel_workspace_bytes')
@@ -42,8 +42,6 @@ class VoxelGrid:
         assert self.norm_type in ['mean_std', 'max', None]
         self.quantile = quantile
         assert 0 <= self.quantile < 0.15
-        if self.quantile > 0:
-            raise NotImplementedError('quantile clipping is not part of the MI355X path (dsec.yaml uses quantile: 0)')
 
     def convert(self, events):
         """events: dict of [N] tensors 'p', 't', 'x', 'y' on the GPU -> [C, H, W]."""
@@ -51,4 +49,4 @@ class VoxelGrid:
         ev = torch.stack((x.float(), events['y'].float(), events['t'].float(), events['p'].float()), dim=-1)[None]
         cnt = torch.tensor([ev.shape[1]], dtype=torch.int32, device=ev.device)
         with torch.no_grad():
-            return voxel_grids(ev, cnt, self.input_size, self.norm_type)[0]
+            return voxel_grids(ev, cnt, self.input_size, self.norm_type, self.quantile)[0]

@@ -23,14 +23,17 @@ def main():
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
     from oracle.voxel_oracle import synth_raw_events
-    for name, shape, n, norm, seed in (('g8_voxel_meanstd', (5, 24, 32), 4000, 'mean_std', 1),
-                                        ('g8_voxel_max', (3, 20, 28), 1500, 'max', 2),
-                                        ('g8_voxel_raw', (15, 30, 40), 6000, None, 3)):
+    for name, shape, n, norm, seed, quant in (('g8_voxel_meanstd', (5, 24, 32), 4000, 'mean_std', 1, 0),
+                                               ('g8_voxel_max', (3, 20, 28), 1500, 'max', 2, 0),
+                                               ('g8_voxel_raw', (15, 30, 40), 6000, None, 3, 0),
+                                               ('g8_voxel_q05_meanstd', (5, 24, 32), 9000, 'mean_std', 4, 0.05),
+                                               ('g8_voxel_q10_raw', (3, 20, 28), 5000, None, 5, 0.1),
+                                               ('g8_voxel_q02_max', (4, 22, 30), 12000, 'max', 6, 0.02)):
         x, y, t, p = synth_raw_events(n, shape, seed)
-        vg = mod.VoxelGrid(shape, norm_type=norm, quantile=0)
+        vg = mod.VoxelGrid(shape, norm_type=norm, quantile=quant)
         out = vg.convert({'p': p, 't': t, 'x': x, 'y': y})
         np.savez_compressed(os.path.join(args.out, name + '.npz'), x=x.numpy(), y=y.numpy(), t=t.numpy(),
-                            p=p.numpy(), shape=np.array(shape), norm=str(norm), grid=out.numpy())
+                            p=p.numpy(), shape=np.array(shape), norm=str(norm), quantile=np.float64(quant), grid=out.numpy())
         print(name, tuple(out.shape), float(out.abs().sum()))
 
 

@@ -7,7 +7,7 @@ entries).  Pinned by tests/golden/g8_voxel_*.npz, produced by the unmodified ref
 import torch
 
 
-def voxel_grid(x, y, t, p, shape, norm_type='mean_std'):
+def voxel_grid(x, y, t, p, shape, norm_type='mean_std', quantile=0.0):
     """x, y, t, p: [N] float tensors (t increasing; normalised with its first and last element as in
     utils.py:35-36), shape (C, H, W).  Returns [C, H, W]."""
     C, H, W = shape
@@ -23,6 +23,9 @@ def voxel_grid(x, y, t, p, shape, norm_type='mean_std'):
                 idx = H * W * tl.long() + W * yl.long() + xl.long()
                 grid.put_(idx[m], w[m], accumulate=True)
     grid = grid.reshape(C, H, W)
+    if quantile > 0:                                     # utils.py:57-61: clip at the (1 - quantile) quantile of |grid|
+        thr = torch.quantile(grid.abs().view(-1), 1 - quantile)
+        grid = torch.where(grid.abs() > thr, grid.sign() * thr, grid)
     if norm_type == 'mean_std':
         nz = torch.nonzero(grid, as_tuple=True)
         if nz[0].numel() > 0:

@@ -13,7 +13,7 @@ def test_voxel_golden(name):
     from motionpriorcmax_amd.utils import VoxelGrid
     g, norm = load_vox(name)
     dev = torch.device('cuda:0')
-    vg = VoxelGrid(tuple(int(v) for v in g['shape']), norm_type=norm, quantile=0)
+    vg = VoxelGrid(tuple(int(v) for v in g['shape']), norm_type=norm, quantile=float(g.get('quantile', 0.0)))
     out = vg.convert({k: torch.from_numpy(g[k]).to(dev) for k in ('p', 't', 'x', 'y')})
     assert out.shape == g['grid'].shape
     np.testing.assert_allclose(out.cpu().numpy(), g['grid'], rtol=0, atol=2e-6 * max(1.0, np.abs(g['grid']).max()))
@@ -59,3 +59,25 @@ def test_voxel_bucket_overflow():
     ev = torch.stack((x, y, t, p), -1)[None].cuda()
     out = voxel_grids(ev, torch.tensor([n], dtype=torch.int32), shape, None).cpu()[0]
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize('quantile,norm', [(0.02, 'mean_std'), (0.1, None)])
+def test_voxel_quantile_clipping_full_size_vs_oracle(quantile, norm):
+    """utils.py:57-61 at DSEC size: the clipping threshold is an order statistic of 4.6 M values per sample (radix select on
+    the device against torch.quantile in the oracle), two samples of different length in one batch."""
+    from motionpriorcmax_amd.utils import voxel_grids
+    from oracle import voxel_oracle as V
+    shape = (15, 480, 640)
+    ns = [200000, 120000]
+    ev = torch.zeros(len(ns), max(ns), 4)
+    refs = []
+    for b, n in enumerate(ns):
+        x, y, t, p = V.synth_raw_events(n, shape, seed=70 + b)
+        ev[b, :n] = torch.stack((x, y, t, p), -1)
+        refs.append((x, y, t, p))
+    out = voxel_grids(ev.cuda(), torch.tensor(ns, dtype=torch.int32), shape, norm, quantile).cpu()
+    for b in range(len(ns)):
+        ref = V.voxel_grid(*refs[b], shape, norm, quantile)
+        scale = max(1.0, float(ref.abs().max()))
+        diff = (out[b] - ref).abs()
+        assert (diff > 5e-6 * scale).sum().item() <= 2, float(diff.max())
