@@ -423,6 +423,36 @@ def main():
                 del gr, lg, tg
             except Exception as e:      # informational
                 graph_ms = repr(e)[:120]
+        # SURVEY.md 8f-1, layout half: the same steps on a batch whose rows ingest ordered by (bin, LUT strip)
+        # (FocusLoss.order_events, once per batch, outside the step) -- reported beside the headline, which stays on the
+        # reference's time-ordered tensor
+        ordered = None
+        if instrument and world == 1:
+            ob = L.order_events(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                L.order_events(batch)
+            torch.cuda.synchronize()
+            order_ms = 1e3 * (time.perf_counter() - t0) / 10
+
+            def ostep():
+                lo_, _, _ = L.calc(trajd, times_d, ob)
+                lo_.backward()
+                trajd.grad = None
+                return lo_
+            for _ in range(3):
+                ostep()
+            ots = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    lo_ = ostep()
+                torch.cuda.synchronize()
+                ots.append(time.perf_counter() - t0)
+            ordered = {'ms_per_step': round(1e3 * sorted(ots)[1] / steps, 4), 'order_events_ms': round(order_ms, 4),
+                       'loss_equal': bool(lo_.item() == last.item())}
         # one cross-check of the number the timed steps computed, outside the timed region: the same step through the
         # in-library global-atomic event kernels (a second implementation of warp + vote + backward)
         check = None
@@ -437,7 +467,7 @@ def main():
             check = {'loss_rel_diff_vs_atomic_path': abs(la.item() - lb.item()) / abs(lb.item()),
                      'grad_rel_l2_vs_atomic_path': float((ta.grad - tb.grad).norm() / tb.grad.norm())}
         return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, graph_ms=graph_ms,
-                    loss=float(last.item()), n=traj.shape[2], check=check)
+                    loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered)
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
     r_comm = None
@@ -499,6 +529,7 @@ def main():
                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
         'rccl_ranks': rccl_ranks,
         'loss': r['loss'], 'loss_check': r.get('check'),
+        'bucket_ordered_events': r.get('ordered'),
         'roofline': roofline_of(r, args.workload),
     }
     if isinstance(r.get('graph_ms'), float):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 101
+#define MPC_VERSION 102
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -173,10 +173,28 @@ typedef struct mpc_focus_buffers {
     float *grad_iwe;          /* [B*T][P][H][W] or NULL               out */
     float *scal;              /* [MPC_SCAL_COUNT]                     out */
     float smooth_weight;
+    const int32_t *event_offsets;  /* offsets table of mpc_event_bucket_order if `events` is ordered, else NULL   in  */
 } mpc_focus_buffers;
 int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream);
 int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, const float *grad_out,
                   float *grad_lut_scratch, float *grad_next_scratch, float *grad_traj, void *ws, void *stream);
+
+/* ---- next row, layout half: a bucketed event layout handed from ingest to the loss.
+ * mpc_event_bucket_order orders the rows of every polarity block of events [B][M][6] by (time bin, LUT strip), the key
+ * of the backward buckets (it does not depend on the flow); padding rows stay at the end of their block.  Row order
+ * inside a polarity block does not change the loss -- bit for bit -- so events_out is a valid `events` tensor anywhere.
+ *   offsets [B][2][nb * S + 1] int32 (out), S = mpc_event_lut_strips(s): first row of bucket bin * S + strip of the
+ *   block (strip = LUT row / ceil(hq / S), LUT row = clamp(int(y // sp), 0, hq - 1)), last entry = first padding row;   ws: mpc_event_order_workspace_bytes(s) bytes.
+ * With the offsets, mpc_event_splat_fwd may be called with MPC_F_NO_BWD_RECORDS (it then writes no record per event
+ * for the backward) and mpc_event_splat_bwd_ordered reads the event rows themselves (mpc_focus_buffers.event_offsets
+ * does both). */
+int32_t mpc_event_lut_strips(const mpc_shape *s);
+int64_t mpc_event_order_workspace_bytes(const mpc_shape *s);
+int mpc_event_bucket_order(const mpc_shape *s, const float *events_in, float *events_out, int32_t *offsets,
+                           void *ws, void *stream);
+int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *events, const int32_t *offsets, const float *flow_lut,
+                                const float *t_ref, const float *grad_iwe, const float *scal, const float *grad_out,
+                                float *grad_flow_lut, const float *add_term, void *ws, void *stream);
 
 /* y[i] = a[0] * x[i] (device scalar a; used to scale the smoothness gradient by grad_out). */
 int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *stream);

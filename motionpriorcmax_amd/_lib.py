@@ -27,7 +27,8 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
-           'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd']
+           'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
+           'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered']
 
 
 class Shape(ctypes.Structure):
@@ -40,7 +41,7 @@ class FocusBuffers(ctypes.Structure):
     """include/mpcmax.h: struct mpc_focus_buffers."""
     _fields_ = [(k, ctypes.c_void_p) for k in
                 ('traj', 'events', 't_ref', 'flow_lut', 'flow_next', 'knn_state', 'smooth_grad', 'iwe_raw', 'iwe_blur',
-                 'grad_iwe', 'scal')] + [('smooth_weight', ctypes.c_float)]
+                 'grad_iwe', 'scal')] + [('smooth_weight', ctypes.c_float), ('event_offsets', ctypes.c_void_p)]
 
 
 class VoxShape(ctypes.Structure):
@@ -100,6 +101,11 @@ def lib():
     L.mpc_voxel_workspace_bytes.restype = i64
     L.mpc_knn_fail_list_offset.restype = i64
     L.mpc_knn_state_floats.restype = i64
+    L.mpc_event_lut_strips.argtypes = [sp]
+    L.mpc_event_order_workspace_bytes.argtypes = [sp]
+    L.mpc_event_order_workspace_bytes.restype = i64
+    L.mpc_event_bucket_order.argtypes = [sp, vp, vp, vp, vp, vp]
+    L.mpc_event_splat_bwd_ordered.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     isp = ctypes.POINTER(IngestShape)
     L.mpc_ingest_workspace_bytes.argtypes = [isp]
     L.mpc_ingest_workspace_bytes.restype = i64
@@ -109,8 +115,8 @@ def lib():
     L.mpc_flow_error_workspace_bytes.argtypes = [ctypes.POINTER(ErrShape)]
     L.mpc_flow_error_workspace_bytes.restype = i64
     L.mpc_flow_error.argtypes = [ctypes.POINTER(ErrShape), vp, vp, vp, vp, vp, vp, vp]
-    if L.mpc_version() != 101:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (101)')
+    if L.mpc_version() != 102:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (102)')
     _lib = L
     return L
 

@@ -23,7 +23,8 @@ def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    # MPC_EXTRA_HIPCC_FLAGS: tuning sweeps (-DEV_LUT_INFLIGHT=4 ...); never set for a product build
+    cmd = [hipcc] + FLAGS + os.environ.get('MPC_EXTRA_HIPCC_FLAGS', '').split() + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -150,7 +150,12 @@ extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, vo
         } else s_C = 0;
     }
     // (the bucket counters were zeroed by the first kernel of the KNN forward, unless the event path is not the tiled one)
-    if ((rc = mpc_event_splat_fwd_ex(s, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, 1))) return rc;
+    {
+        // ordered events: no record per event for the backward (it reads the rows themselves)
+        mpc_shape sf = *s;
+        if (io->event_offsets) sf.flags |= MPC_F_NO_BWD_RECORDS;
+        if ((rc = mpc_event_splat_fwd_ex(&sf, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, 1))) return rc;
+    }
     if ((rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream))) return rc;
     return mpc_finalize(s, s_nimg, s_C, io->smooth_weight, io->scal, ws, stream);
 }
@@ -163,8 +168,8 @@ extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, co
     const bool smooth = io->smooth_weight > 0.f && io->smooth_grad != nullptr;
     // the smoothness gradient on flow_to_tref is folded into the event backward; on flow_to_next it is a separate
     // gradient of the KNN backward, scaled by grad_out
-    int rc = mpc_event_splat_bwd(s, io->events, io->flow_lut, io->t_ref, io->grad_iwe, io->scal, grad_out, grad_lut_scratch,
-                                 (smooth && !on_next) ? io->smooth_grad : nullptr, ws, stream);
+    int rc = mpc_event_splat_bwd_ordered(s, io->events, io->event_offsets, io->flow_lut, io->t_ref, io->grad_iwe, io->scal, grad_out,
+                                         grad_lut_scratch, (smooth && !on_next) ? io->smooth_grad : nullptr, ws, stream);
     if (rc) return rc;
     const float *g_next = nullptr;
     if (smooth && on_next && s->nb > 1) {

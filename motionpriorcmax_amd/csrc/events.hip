@@ -30,23 +30,25 @@ __device__ __forceinline__ EvParams make_params(const mpc_shape s) {
 
 // Warp one event for reference time `tr`.  `e` = the 6 columns of the event row.
 // Returns false if the event contributes nothing (weight exactly 0).
-__device__ __forceinline__ bool warp_event(const EvParams &p, const float e[6], int b, int tr,
-                                           const float *__restrict__ lut, float t_ref, Warped &o) {
+// LUT cell of an event (focus.py:184-191): it = int(bin), iy = int(y // sp), ix = int(x // sp)
+__device__ __forceinline__ void warp_cell(const EvParams &p, const float e[6], int b, int tr, Warped &o) {
+    int it = (int)e[4];
+    int iy = (int)floorf(e[0] / (float)p.sp);
+    int ix = (int)floorf(e[1] / (float)p.sp);
+    // torch indexing would raise on out-of-range indices; clamp instead of faulting
+    it = min(max(it, 0), p.nb - 1);
+    iy = min(max(iy, 0), p.hq - 1);
+    ix = min(max(ix, 0), p.wq - 1);
+    o.it = it; o.iy = iy; o.ix = ix;
+    o.lut = (((b * p.nb + it) * p.hq + iy) * p.wq + ix) * p.T + tr;
+}
+
+// Warp with the flow `f` of the event's LUT cell already at hand (warp_cell + a read of the table).
+__device__ __forceinline__ bool warp_event_with(const EvParams &p, const float e[6], const float2 f, float t_ref, Warped &o) {
     float w = (p.flags & MPC_F_UNIT_WEIGHT) ? 1.0f : e[5];
     float y = e[0], x = e[1];
-    o.lut = -1;
     if (!(p.flags & MPC_F_NO_WARP)) {
-        // focus.py:184-191: it = int(bin), iy = int(y // sp), ix = int(x // sp); pos = lut + event
-        int it = (int)e[4];
-        int iy = (int)floorf(e[0] / (float)p.sp);
-        int ix = (int)floorf(e[1] / (float)p.sp);
-        // torch indexing would raise on out-of-range indices; clamp instead of faulting
-        it = min(max(it, 0), p.nb - 1);
-        iy = min(max(iy, 0), p.hq - 1);
-        ix = min(max(ix, 0), p.wq - 1);
-        o.it = it; o.iy = iy; o.ix = ix;
-        o.lut = (((b * p.nb + it) * p.hq + iy) * p.wq + ix) * p.T + tr;
-        const float2 f = reinterpret_cast<const float2 *>(lut)[o.lut];
+        // focus.py:191: pos = lut + event
         y = f.x + e[0];
         x = f.y + e[1];
     }
@@ -68,6 +70,17 @@ __device__ __forceinline__ bool warp_event(const EvParams &p, const float e[6], 
     o.y0 = (int)fminf(fmaxf(y0f, -4.f), (float)p.H + 4.f);
     o.x0 = (int)fminf(fmaxf(x0f, -4.f), (float)p.W + 4.f);
     return w != 0.f;
+}
+
+__device__ __forceinline__ bool warp_event(const EvParams &p, const float e[6], int b, int tr,
+                                           const float *__restrict__ lut, float t_ref, Warped &o) {
+    o.lut = -1;
+    float2 f = make_float2(0.f, 0.f);
+    if (!(p.flags & MPC_F_NO_WARP)) {
+        warp_cell(p, e, b, tr, o);
+        f = reinterpret_cast<const float2 *>(lut)[o.lut];
+    }
+    return warp_event_with(p, e, f, t_ref, o);
 }
 
 __device__ __forceinline__ void load_event(const float *__restrict__ events, size_t row, float e[6]) {
@@ -427,17 +440,32 @@ __device__ __forceinline__ void record_grad(float y, float x, float w, const flo
 
 // grid NBk, 512 threads, dynamic LDS = CSR * wq * 2 * 8 bytes.
 // glut = grad_out * (GCOEF * sum + add_term): the smoothness gradient is folded in here.
+#ifndef EV_LUT_THREADS
 #define EV_LUT_THREADS 512
+#endif
+#ifndef EV_LUT_THREADS_ORD
+#define EV_LUT_THREADS_ORD 1024      // ordered variant: 72 KB of LDS per workgroup -> two per CU; 1024 threads keep the CU's waves
+#endif
+#ifndef EV_LUT_INFLIGHT_ORD
+#define EV_LUT_INFLIGHT_ORD 2
+#endif
 #ifndef EV_LUT_INFLIGHT
 #define EV_LUT_INFLIGHT 5   // 5 x 512 covers the largest bucket of C3 in one batch (4: 43.8 us, 5: 42.4, 6: 43.6, 8: 52.3)
 #endif
-__global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s, const BinLayout L,
+// ORDERED: the events were ordered by mpc_event_bucket_order -- the rows of bucket (bin, LUT strip) of each polarity
+// block are contiguous (offsets table) -- so the kernel reads the event rows themselves and redoes the warp instead of
+// reading records that the forward would have had to write (section 7 of DESIGN.md).
+template <bool ORDERED>
+__global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void k_lut_accum(const mpc_shape s, const BinLayout L,
                                                     const float *__restrict__ gimg,
                                                     const float *__restrict__ scal,
                                                     const float *__restrict__ grad_out,
                                                     float *__restrict__ glut,
-                                                    const float *__restrict__ add_term) {
+                                                    const float *__restrict__ add_term,
+                                                    const float *__restrict__ events, const float *__restrict__ lut,
+                                                    const float *__restrict__ t_ref, const int *__restrict__ offsets) {
     extern __shared__ unsigned long long s_acc[];
+    constexpr int NT = ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS, NIF = ORDERED ? EV_LUT_INFLIGHT_ORD : EV_LUT_INFLIGHT;
     const EvParams p = make_params(s);
     const int tid = threadIdx.x;
     // logical order (sample, LUT strip, bin): the bins of one strip read the same adjoint-image rows
@@ -449,25 +477,58 @@ __global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s,
     const int g = bt * L.NCS + cst;                   // bucket id: (b*nb + it)*NCS + cstrip
     const int crow0 = cst * L.CSR, crow1 = min(crow0 + L.CSR, p.hq);
     const int ncell = (crow1 - crow0) * p.wq;
-    for (int i = tid; i < 2 * ncell; i += EV_LUT_THREADS) s_acc[i] = 0ull;
+    for (int i = tid; i < 2 * ncell; i += NT) s_acc[i] = 0ull;
+    // ORDERED: the bucket's strip of the table goes to LDS (coalesced, while the event rows are on their way), so the
+    // warp costs no dependent round trip of its own
+    float2 *s_lut = reinterpret_cast<float2 *>(s_acc + 2 * ncell);
+    if (ORDERED) {
+        const float2 *src = reinterpret_cast<const float2 *>(lut) + ((size_t)(b * p.nb + it) * p.hq + crow0) * p.wq;
+        for (int i = tid; i < ncell; i += NT) s_lut[i] = src[i];
+    }
     __syncthreads();
-    const bool valid = L.gcount[L.NF + L.NBk + 2] == EV_MARKER;
-    const int n = valid ? L.gcount[L.NF + g] : 0;
+    const bool valid = ORDERED || L.gcount[L.NF + L.NBk + 2] == EV_MARKER;
+    const int NK = p.nb * L.NCS, key = it * L.NCS + cst;
+    int n, n_pos = 0, o_pos = 0, o_neg = 0;
+    if (ORDERED) {
+        const int *ob = offsets + (size_t)b * 2 * (NK + 1);
+        // (clamped: a table that does not belong to this tensor must not make the kernel read outside it)
+        o_pos = min(max(ob[key], 0), p.M); n_pos = min(max(ob[key + 1] - o_pos, 0), p.M - o_pos);
+        o_neg = min(max(ob[NK + 1 + key], 0), p.M);
+        n = n_pos + min(max(ob[NK + 1 + key + 1] - o_neg, 0), p.M - o_neg);
+    } else n = valid ? L.gcount[L.NF + g] : 0;
     const float4 *rec = L.brec + (size_t)g * L.bcap;
+    const float tref = (ORDERED && (p.flags & MPC_F_SCALE_BY_DT)) ? t_ref[0] : 0.f;
+    // record r of this bucket: from the forward's list, or rebuilt from event row r of the ordered tensor
+    auto fetch = [&](int r) -> float4 {
+        if (!ORDERED) return rec[r];
+        const int pol = r >= n_pos ? 1 : 0;
+        const int row = pol ? o_neg + (r - n_pos) : o_pos + r;
+        float e[6];
+        load_event(events, (size_t)b * p.M + row, e);
+        Warped o;
+        warp_cell(p, e, b, 0, o);
+        // (an ordered tensor puts every row into the bucket of its own cell; a row that does not belong here -- a
+        // foreign tensor passed with offsets -- contributes nothing)
+        const bool here = o.it == it && o.iy >= crow0 && o.iy < crow1;
+        const int cell = here ? (o.iy - crow0) * p.wq + o.ix : 0;
+        const bool mine = warp_event_with(p, e, s_lut[cell], tref, o) && here;
+        const unsigned aux = ((unsigned)((p.P == 2) ? pol : 0) << 31) | (unsigned)cell;
+        return make_float4(o.y, o.x, mine ? o.w : 0.f, __uint_as_float(aux));
+    };
     // four records per thread in flight: their adjoint-image gathers (the latency of this kernel) overlap
-    for (int r0 = tid; r0 < n; r0 += EV_LUT_INFLIGHT * EV_LUT_THREADS) {
-        float4 e[EV_LUT_INFLIGHT];
+    for (int r0 = tid; r0 < n; r0 += NIF * NT) {
+        float4 e[NIF];
 #pragma unroll
-        for (int u = 0; u < EV_LUT_INFLIGHT; ++u) e[u] = rec[min(r0 + u * EV_LUT_THREADS, n - 1)];
-        float gy[EV_LUT_INFLIGHT], gx[EV_LUT_INFLIGHT];
+        for (int u = 0; u < NIF; ++u) e[u] = fetch(min(r0 + u * NT, n - 1));
+        float gy[NIF], gx[NIF];
 #pragma unroll
-        for (int u = 0; u < EV_LUT_INFLIGHT; ++u) {
+        for (int u = 0; u < NIF; ++u) {
             const int pol = (int)(__float_as_uint(e[u].w) >> 31);
             record_grad(e[u].x, e[u].y, e[u].z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy[u], gx[u]);
         }
 #pragma unroll
-        for (int u = 0; u < EV_LUT_INFLIGHT; ++u) {
-            if (r0 + u * EV_LUT_THREADS < n) {
+        for (int u = 0; u < NIF; ++u) {
+            if (r0 + u * NT < n && (!ORDERED || e[u].z != 0.f)) {
                 const int cell = (int)(__float_as_uint(e[u].w) & 0x7fffffffu);
                 atomicAdd(&s_acc[2 * cell], (unsigned long long)ev_to_fixed(gy[u]));
                 atomicAdd(&s_acc[2 * cell + 1], (unsigned long long)ev_to_fixed(gx[u]));
@@ -479,7 +540,7 @@ __global__ __launch_bounds__(EV_LUT_THREADS) void k_lut_accum(const mpc_shape s,
     const float coef = valid ? scal[MPC_SCAL_GCOEF] * gout : __int_as_float(0x7fc00000);
     float2 *dst = reinterpret_cast<float2 *>(glut) + ((size_t)bt * p.hq + crow0) * p.wq;
     const float2 *add = add_term ? reinterpret_cast<const float2 *>(add_term) + ((size_t)bt * p.hq + crow0) * p.wq : nullptr;
-    for (int i = tid; i < ncell; i += EV_LUT_THREADS) {
+    for (int i = tid; i < ncell; i += NT) {
         float2 v = make_float2(coef * ev_from_fixed((long long)s_acc[2 * i]), coef * ev_from_fixed((long long)s_acc[2 * i + 1]));
         if (add) { const float2 o = add[i]; v.x += gout * o.x; v.y += gout * o.y; }
         dst[i] = v;
@@ -525,7 +586,8 @@ int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float 
         static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
         if (attr_once.need()) {
             if ((rc = set_max_lds_ev((const void *)k_iwe_accum, __func__))) return rc;
-            if ((rc = set_max_lds_ev((const void *)k_lut_accum, __func__))) return rc;
+            if ((rc = set_max_lds_ev((const void *)k_lut_accum<false>, __func__))) return rc;
+            if ((rc = set_max_lds_ev((const void *)k_lut_accum<true>, __func__))) return rc;
             attr_once.mark();
         }
         const BinLayout BL = bin_layout(s, L, ws);
@@ -560,6 +622,13 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
                                    const float *t_ref, const float *grad_iwe, const float *scal,
                                    const float *grad_out, float *grad_flow_lut, const float *add_term,
                                    void *ws, void *stream) {
+    return mpc_event_splat_bwd_ordered(s, events, nullptr, flow_lut, t_ref, grad_iwe, scal, grad_out, grad_flow_lut, add_term, ws, stream);
+}
+
+extern "C" int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *events, const int32_t *offsets, const float *flow_lut,
+                                           const float *t_ref, const float *grad_iwe, const float *scal,
+                                           const float *grad_out, float *grad_flow_lut, const float *add_term,
+                                           void *ws, void *stream) {
     MPC_CHECK_ARG(s && flow_lut && grad_iwe && scal && grad_flow_lut && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(!(s->flags & MPC_F_NO_WARP), MPC_E_UNSUPPORTED, "no LUT to differentiate with MPC_F_NO_WARP");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
@@ -572,8 +641,14 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
         // the records must come from mpc_event_splat_fwd on this same workspace: the kernel checks
         // the marker that call left behind and poisons the output with NaN if it is missing
         if (L.nbb > 0) {
-            hipLaunchKernelGGL(k_lut_accum, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
-                               grad_iwe, scal, grad_out, grad_flow_lut, add_term);
+            MPC_CHECK_ARG(!offsets || (size_t)L.cstrip_rows * s->wq * 24 <= 160 * 1024 - 512, MPC_E_UNSUPPORTED,
+                          "LUT too wide for the ordered backward (use mpc_event_splat_bwd)");
+            if (offsets)
+                hipLaunchKernelGGL(k_lut_accum<true>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS_ORD), (size_t)L.cstrip_rows * s->wq * 24, st, *s, BL,
+                                   grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets);
+            else
+                hipLaunchKernelGGL(k_lut_accum<false>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
+                                   grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets);
             MPC_CHECK_LAUNCH();
         }
         return 0;
@@ -593,6 +668,125 @@ extern "C" int mpc_event_splat_bwd(const mpc_shape *s, const float *events, cons
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_splat_bwd_atomic, dim3(grid), dim3(256), 0, st, *s, events, flow_lut, t_ref,
                        grad_iwe, scal, grad_out, grad_flow_lut);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ==========================================================================================
+// f-1, layout half (reference loader.py:360-415 builds the padded tensor in time order): order the rows of
+// every polarity block by (time bin, LUT strip) -- the key of the BACKWARD buckets, which does not depend on the flow.
+// Permuting rows inside a polarity block does not change the loss (bit for bit: the accumulators are integers), so the
+// ordered tensor is a valid `events` for the reference too; with its offsets table the forward need not write, and the
+// backward not read back, a 16-byte record per event.  Padding rows (valid == 0) keep their place at the end of their block.
+//   offsets [B][2][nb*NCS + 1]: first row of every (bin, LUT strip) inside the block; [nb*NCS] = first padding row
+// Counting sort: per-chunk counts -> per-sample scan -> scatter (order inside a bucket is not defined and need not be).
+// ==========================================================================================
+#define EVO_ROWS 2048          // rows of one chunk (256 threads x 8)
+
+struct EvoKey { int NCS, CSR, NK; };
+
+__device__ __forceinline__ int evo_key(const EvParams &p, const EvoKey &k, const float e[6]) {
+    if (e[5] == 0.f && !(p.flags & MPC_F_UNIT_WEIGHT)) return k.NK;   // padding row (weight 0: it votes for nothing)
+    const int it = min(max((int)e[4], 0), p.nb - 1);
+    const int iy = min(max((int)floorf(e[0] / (float)p.sp), 0), p.hq - 1);      // as warp_event
+    return it * k.NCS + iy / k.CSR;
+}
+
+// grid (chunks, 2 * B): counts[b][pol][chunk][NK + 1]
+__global__ __launch_bounds__(256) void k_evo_count(const mpc_shape s, const EvoKey k, const float *__restrict__ events,
+                                                   int *__restrict__ counts, int chunks) {
+    extern __shared__ int s_c[];
+    const EvParams p = make_params(s);
+    const int b = blockIdx.y >> 1, pol = blockIdx.y & 1, chunk = blockIdx.x;
+    const int r0 = pol ? p.Mp : 0, r1 = pol ? p.M : p.Mp;
+    for (int i = threadIdx.x; i <= k.NK; i += 256) s_c[i] = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < EVO_ROWS; j += 256) {
+        const int row = r0 + chunk * EVO_ROWS + j;
+        if (row >= r1) break;
+        float e[6];
+        load_event(events, (size_t)b * p.M + row, e);
+        atomicAdd(&s_c[evo_key(p, k, e)], 1);
+    }
+    __syncthreads();
+    int *dst = counts + ((size_t)(b * 2 + pol) * chunks + chunk) * (k.NK + 1);
+    for (int i = threadIdx.x; i <= k.NK; i += 256) dst[i] = s_c[i];
+}
+
+// grid 2 * B, 256 threads: per key the running offset over the chunks (in place), then the key bases -> offsets
+__global__ __launch_bounds__(256) void k_evo_scan(const mpc_shape s, const EvoKey k, int *__restrict__ counts,
+                                                  int *__restrict__ offsets, int chunks) {
+    extern __shared__ int s_tot[];
+    const EvParams p = make_params(s);
+    const int b = blockIdx.x >> 1, pol = blockIdx.x & 1;
+    int *c = counts + (size_t)(b * 2 + pol) * chunks * (k.NK + 1);
+    for (int i = threadIdx.x; i <= k.NK; i += 256) {
+        int run = 0;
+        for (int ch = 0; ch < chunks; ++ch) { const int v = c[(size_t)ch * (k.NK + 1) + i]; c[(size_t)ch * (k.NK + 1) + i] = run; run += v; }
+        s_tot[i] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = pol ? p.Mp : 0;
+        int *o = offsets + (size_t)(b * 2 + pol) * (k.NK + 1);
+        for (int i = 0; i <= k.NK; ++i) { o[i] = run; run += s_tot[i]; }
+    }
+}
+
+// grid (chunks, 2 * B)
+__global__ __launch_bounds__(256) void k_evo_scatter(const mpc_shape s, const EvoKey k, const float *__restrict__ events,
+                                                     const int *__restrict__ counts, const int *__restrict__ offsets,
+                                                     float *__restrict__ out, int chunks) {
+    extern __shared__ int s_c[];
+    const EvParams p = make_params(s);
+    const int b = blockIdx.y >> 1, pol = blockIdx.y & 1, chunk = blockIdx.x;
+    const int r0 = pol ? p.Mp : 0, r1 = pol ? p.M : p.Mp;
+    const int *cb = counts + ((size_t)(b * 2 + pol) * chunks + chunk) * (k.NK + 1);
+    const int *ob = offsets + (size_t)(b * 2 + pol) * (k.NK + 1);
+    for (int i = threadIdx.x; i <= k.NK; i += 256) s_c[i] = ob[i] + cb[i];      // first destination row of the chunk's share
+    __syncthreads();
+    for (int j = threadIdx.x; j < EVO_ROWS; j += 256) {
+        const int row = r0 + chunk * EVO_ROWS + j;
+        if (row >= r1) break;
+        float e[6];
+        load_event(events, (size_t)b * p.M + row, e);
+        const int dst = atomicAdd(&s_c[evo_key(p, k, e)], 1);
+        float2 *d = reinterpret_cast<float2 *>(out + ((size_t)b * p.M + dst) * 6);
+        d[0] = make_float2(e[0], e[1]); d[1] = make_float2(e[2], e[3]); d[2] = make_float2(e[4], e[5]);
+    }
+}
+
+extern "C" int32_t mpc_event_lut_strips(const mpc_shape *s) {
+    if (!s || mpc_validate_shape(s)) return MPC_E_SHAPE;
+    return mpc_layout(s).n_cstrips;
+}
+
+extern "C" int64_t mpc_event_order_workspace_bytes(const mpc_shape *s) {
+    if (!s || mpc_validate_shape(s)) return MPC_E_SHAPE;
+    const mpc_ws_layout L = mpc_layout(s);
+    const int64_t chunks = mpc_cdiv(s->M > 0 ? s->M : 1, EVO_ROWS);
+    return mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 2 * chunks * ((int64_t)s->nb * L.n_cstrips + 1) * 4);
+}
+
+extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in, float *events_out, int32_t *offsets,
+                                      void *ws, void *stream) {
+    MPC_CHECK_ARG(s && events_out && offsets && ws && (events_in || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const mpc_ws_layout L = mpc_layout(s);
+    MPC_CHECK_ARG(L.n_cstrips > 0, MPC_E_UNSUPPORTED, "no LDS-tiled event path for this shape (num_tref > 1 or the atomic debugging path)");
+    MPC_CHECK_ARG(events_in != events_out, MPC_E_SHAPE, "in-place ordering is not supported");
+    if (s->B == 0 || s->M == 0) return 0;
+    const EvoKey k{L.n_cstrips, L.cstrip_rows, s->nb * L.n_cstrips};
+    const int chunks = mpc_cdiv(s->M, EVO_ROWS);       // of the longer block at most; chunks beyond a block's rows are empty
+    hipStream_t st = (hipStream_t)stream;
+    int *counts = (int *)ws;
+    const size_t lds = (size_t)(k.NK + 1) * 4;
+    hipLaunchKernelGGL(k_evo_count, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, chunks);
+    hipLaunchKernelGGL(k_evo_scan, dim3(2 * s->B), dim3(256), lds, st, *s, k, counts, (int *)offsets, chunks);
+    hipLaunchKernelGGL(k_evo_scatter, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, (const int *)offsets,
+                       events_out, chunks);
     MPC_CHECK_LAUNCH();
     return 0;
 }

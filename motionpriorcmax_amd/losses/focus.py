@@ -86,6 +86,17 @@ class FocusLoss(base.TrajectoryLossBase):
         t_mid = (t_bins[:-1] + t_bins[1:]) / 2
         return torch.concat((t_ref, t_mid), dim=0)
 
+    def order_events(self, batch):
+        """Not in the reference (layout half): `batch` with its event rows ordered by (time bin, LUT
+        strip) inside each polarity block and the table `event_offsets` added.  `calc` returns the same loss and
+        gradient for the ordered batch bit for bit, and with the table skips one record per event in each direction.
+        Meant for the data pipeline: once per batch, next to `utils.ingest_events`."""
+        num_pos = batch['num_pos_events'] if 'num_pos_events' in batch else -1
+        ev, offs = ops.event_bucket_order(self._cfg, batch['events'], int(num_pos))
+        out = dict(batch)
+        out['events'], out['event_offsets'] = ev, offs
+        return out
+
     def calc(self, trajectories, times, batch):
         """Reference focus.py:66-113.
 
@@ -98,11 +109,12 @@ class FocusLoss(base.TrajectoryLossBase):
         assert not self.polarity_aware_batching or num_pos_events > -1
 
         t_ref = times[:self.num_tref]
+        offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events (optional)
         if self.profiler is not None:
             with torch.profiler.record_function('mpcmax::FocusLoss.calc'):
-                out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events))
+                out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets)
         else:
-            out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events))
+            out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets)
         loss, focus_loss, smooth_loss, iwes = out
 
         h, w = self._cfg.image_shape

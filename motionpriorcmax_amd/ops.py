@@ -190,9 +190,9 @@ def finalize(shape, smooth_nimg, smooth_C, weight, ws, device):
     return scal
 
 
-def event_splat_bwd(shape, events, flow_lut, t_ref, gimg, scal, grad_out, g_lut, add_term, ws):
+def event_splat_bwd(shape, events, flow_lut, t_ref, gimg, scal, grad_out, g_lut, add_term, ws, offs=None):
     with _stage('mpc_event_splat_bwd', events.device):
-        C.check(C.lib().mpc_event_splat_bwd(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
+        C.check(C.lib().mpc_event_splat_bwd_ordered(ctypes.byref(shape), _ptr(events), _ptr(offs), _ptr(flow_lut), _ptr(t_ref),
                                             _ptr(gimg), _ptr(scal), _ptr(grad_out), _ptr(g_lut),
                                             _ptr(add_term), _ptr(ws), _stream(events.device)),
                 'mpc_event_splat_bwd')
@@ -213,13 +213,13 @@ def _vp(t):
     return None if t is None else t.data_ptr()
 
 
-def _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal):
+def _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal, offs=None):
     return C.FocusBuffers(traj=_vp(traj), events=_vp(ev), t_ref=_vp(tr), flow_lut=_vp(flow_lut), flow_next=_vp(flow_next),
                           knn_state=_vp(state), smooth_grad=_vp(g_field), iwe_raw=_vp(raw), iwe_blur=_vp(blur),
-                          grad_iwe=_vp(gimg), scal=_vp(scal), smooth_weight=float(cfg.smooth_weight))
+                          grad_iwe=_vp(gimg), scal=_vp(scal), smooth_weight=float(cfg.smooth_weight), event_offsets=_vp(offs))
 
 
-def focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad):
+def focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad, offs=None):
     """FocusLoss.calc forward as ONE C-ABI call (mpc_focus_fwd)."""
     dev = traj.device
     B, nb, T = shape.B, shape.nb, shape.T
@@ -239,23 +239,57 @@ def focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad):
     blur = torch.empty_like(raw)
     gimg = torch.empty_like(raw) if need_grad else None
     scal = torch.empty(C.SCAL_COUNT, dtype=torch.float32, device=dev)
-    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal)
+    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal, offs)
     with _stage('mpc_focus_fwd', dev):
         C.check(C.lib().mpc_focus_fwd(ctypes.byref(shape), ctypes.byref(io), _ptr(ws), _stream(dev)), 'mpc_focus_fwd')
     return flow_lut, flow_next, state, g_field, blur, gimg, scal
 
 
-def focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, grad_out, ws):
+def focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, grad_out, ws, offs=None):
     """Backward of the above to the trajectories as ONE C-ABI call (mpc_focus_bwd)."""
     dev = traj.device
     g_lut = torch.empty_like(flow_lut)
     g_next = torch.empty_like(g_field) if (g_field is not None and cfg.smooth_on_next) else None
     g_traj = torch.empty_like(traj)
-    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, None, state, g_field, None, None, gimg, scal)
+    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, None, state, g_field, None, None, gimg, scal, offs)
     with _stage('mpc_focus_bwd', dev):
         C.check(C.lib().mpc_focus_bwd(ctypes.byref(shape), ctypes.byref(io), _ptr(grad_out), _ptr(g_lut), _ptr(g_next),
                                       _ptr(g_traj), _ptr(ws), _stream(dev)), 'mpc_focus_bwd')
     return g_traj
+
+
+def event_bucket_order(cfg: PathConfig, events, num_pos):
+    """SURVEY.md 8f-1, layout half (mpc_event_bucket_order): the rows of each polarity block of `events` [B, M, 6]
+    ordered by (time bin, LUT strip), and the offsets table [B, 2, nb * strips + 1] int32.  The ordered tensor gives
+    the same loss and gradient bit for bit; handed to FocusCalcFn together with the table, the step skips one 16-byte
+    record per event in each direction.  Done once per batch, outside the training step (it belongs to ingest)."""
+    B, M, Mp = _check_events(events, cfg, num_pos)
+    dev = events.device
+    ev = _f32c(events.detach())
+    shape = make_shape(cfg, B, M, Mp, 1)
+    ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+    if ncs <= 0:
+        raise ValueError('no bucketed event layout for this configuration (num_tref > 1 or the atomic debugging path)')
+    out = torch.empty_like(ev)
+    offs = torch.empty((B, 2, cfg.num_bins * ncs + 1), dtype=torch.int32, device=dev)
+    nbytes = int(C.lib().mpc_event_order_workspace_bytes(ctypes.byref(shape)))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    with _stage('mpc_event_bucket_order', dev):
+        C.check(C.lib().mpc_event_bucket_order(ctypes.byref(shape), _ptr(ev), _ptr(out), _ptr(offs), _ptr(ws), _stream(dev)),
+                'mpc_event_bucket_order')
+    return out, offs
+
+
+def _check_offsets(offs, cfg, shape, device):
+    if offs is None:
+        return None
+    _require_gpu(offs, "batch['event_offsets']")
+    ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+    want = (shape.B, 2, cfg.num_bins * ncs + 1)
+    if ncs <= 0 or offs.dtype != torch.int32 or tuple(offs.shape) != want or offs.device != device:
+        raise ValueError(f"event_offsets must be int32 {want} on {device} (from event_bucket_order with this configuration), "
+                         f"got {offs.dtype} {tuple(offs.shape)} on {offs.device}")
+    return offs.contiguous()
 
 
 def _check_events(events, cfg, num_pos):
@@ -280,7 +314,7 @@ class FocusCalcFn(torch.autograd.Function):
     -> warp + vote -> blur + objective in forward, hand-derived backward to `trajectories`."""
 
     @staticmethod
-    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int):
+    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, event_offsets=None):
         _require_gpu(trajectories, 'trajectories')
         B, M, Mp = _check_events(events, cfg, num_pos)
         T, nb = cfg.num_tref, cfg.num_bins
@@ -295,10 +329,11 @@ class FocusCalcFn(torch.autograd.Function):
         need_grad = trajectories.requires_grad
         shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
         ws = alloc_workspace(shape, dev)
+        offs = _check_offsets(event_offsets, cfg, shape, dev)
 
         if STAGE_TIMER is None and FUSED_CALLS:
             # one C-ABI call for the whole forward (mpc_focus_fwd issues the same launches)
-            flow_lut, flow_next, state, g_field, blur, gimg, scal = focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad)
+            flow_lut, flow_next, state, g_field, blur, gimg, scal = focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad, offs)
         else:
             flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
             g_field = None
@@ -310,11 +345,13 @@ class FocusCalcFn(torch.autograd.Function):
                     field, s_nimg, s_C = flow_lut, B * nb, 2 * T
                 if s_nimg > 0:
                     g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
-            raw = event_splat_fwd(shape, ev, flow_lut, tr, ws)
+            fshape = shape if offs is None else make_shape(cfg, B, M, Mp, n, extra_flags=C.F_NO_BWD_RECORDS)
+            raw = event_splat_fwd(fshape, ev, flow_lut, tr, ws)
             blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
             scal = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
 
         ctx.cfg, ctx.shape = cfg, shape
+        ctx.offs = offs
         ctx.ws = ws
         ctx.set_materialize_grads(False)      # no zero-filled [B,P,H,W] gradient for the detached outputs
         ctx.save_for_backward(traj, ev, tr, flow_lut, state, gimg, scal, g_field)
@@ -328,21 +365,22 @@ class FocusCalcFn(torch.autograd.Function):
         cfg, shape, ws = ctx.cfg, ctx.shape, ctx.ws
         traj, ev, tr, flow_lut, state, gimg, scal, g_field = ctx.saved_tensors
         if g_loss is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         g = _f32c(g_loss.reshape(1))
+        offs = ctx.offs
         if STAGE_TIMER is None and FUSED_CALLS:
-            g_traj = focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, g, ws)
-            return g_traj, None, None, None, None
+            g_traj = focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, g, ws, offs)
+            return g_traj, None, None, None, None, None
         g_next = None
         g_lut = torch.empty_like(flow_lut)
         if g_field is not None and not cfg.smooth_on_next:
-            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, g_field, ws)   # smoothness folded in
+            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, g_field, ws, offs)   # smoothness folded in
         else:
-            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, None, ws)
+            event_splat_bwd(shape, ev, flow_lut, tr, gimg, scal, g, g_lut, None, ws, offs)
             if g_field is not None:
                 g_next = scale(g_field, g)
         g_traj = knn_lut_bwd(shape, traj, g_lut, g_next, state, ws)
-        return g_traj, None, None, None, None
+        return g_traj, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------

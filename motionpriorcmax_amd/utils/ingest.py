@@ -10,10 +10,12 @@ from .. import _lib as C
 from ..ops import _ptr, _require_gpu, _stream, _stage
 
 
-def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input=False):
+def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input=False, order_for=None):
     """x, y, p: [B, N] float32; t_us: [B, N] int64 (increasing per sample); counts: [B] valid lengths.
     Returns {'events': [B, M, 6], 'num_pos_events': int, 'xytp': [B, N, 4] or None}.
-    One host round trip (two integers) sizes the output, as the reference's CPU collate does."""
+    One host round trip (two integers) sizes the output, as the reference's CPU collate does.
+    order_for: a FocusLoss -- the rows of each polarity block are then ordered by (time bin, LUT strip) for that loss
+    (FocusLoss.order_events) and the dict carries 'event_offsets'; `calc` gives the same loss and gradient bit for bit."""
     _require_gpu(x, 'x')
     dev = x.device
     B, N = x.shape
@@ -36,4 +38,5 @@ def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input
     with _stage('mpc_ingest_scatter', dev):
         C.check(C.lib().mpc_ingest_scatter(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
                                            max_pos, max_neg, _ptr(events), _ptr(xytp), _ptr(ws), st), 'mpc_ingest_scatter')
-    return {'events': events, 'num_pos_events': max_pos, 'xytp': xytp}
+    out = {'events': events, 'num_pos_events': max_pos, 'xytp': xytp}
+    return out if order_for is None else order_for.order_events(out)

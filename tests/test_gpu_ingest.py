@@ -52,6 +52,19 @@ def test_ingest_full_size_ragged_vs_oracle_and_feeds_the_loss():
     loss, _, misc = LossFactory.get_loss_calculator('FOCUS', cfg).calc(
         traj.cuda(), times.cuda(), {'events': out['events'], 'num_pos_events': out['num_pos_events']})
     assert torch.isfinite(loss).item() and misc['iwes'].shape == (len(ns), 1, 2, H, W)
+    # the bucketed layout straight from ingest (layout half): same loss and gradient bit for bit
+    from motionpriorcmax_amd.utils import ingest_events
+    L = LossFactory.get_loss_calculator('FOCUS', cfg)
+    dev = torch.device('cuda:0')
+    ordered = ingest_events(*(torch.from_numpy(a).to(dev) for a in (x, y, t, p)), torch.tensor(ns, dtype=torch.int32), (H, W), nb, order_for=L)
+    assert ordered['num_pos_events'] == num_pos and 'event_offsets' in ordered
+    res = []
+    for batch in ({'events': out['events'], 'num_pos_events': num_pos}, ordered):
+        tg = traj.cuda().requires_grad_(True)
+        l, _, m = L.calc(tg, times.cuda(), batch)
+        l.backward()
+        res.append((l.detach(), tg.grad, m['iwes']))
+    assert all(torch.equal(a, b) for a, b in zip(*res))
     vox = voxel_grids(out['xytp'][:2], torch.tensor(ns[:2], dtype=torch.int32), (nb, H, W), 'mean_std')
     assert torch.isfinite(vox).all()
 
