@@ -693,7 +693,7 @@ __device__ __forceinline__ int evo_key(const EvParams &p, const EvoKey &k, const
     return it * k.NCS + iy / k.CSR;
 }
 
-// grid (chunks, 2 * B): counts[b][pol][chunk][NK + 1]
+// grid (chunks, 2 * B): counts[b][pol][key][chunk]
 __global__ __launch_bounds__(256) void k_evo_count(const mpc_shape s, const EvoKey k, const float *__restrict__ events,
                                                    int *__restrict__ counts, int chunks) {
     extern __shared__ int s_c[];
@@ -710,28 +710,57 @@ __global__ __launch_bounds__(256) void k_evo_count(const mpc_shape s, const EvoK
         atomicAdd(&s_c[evo_key(p, k, e)], 1);
     }
     __syncthreads();
-    int *dst = counts + ((size_t)(b * 2 + pol) * chunks + chunk) * (k.NK + 1);
-    for (int i = threadIdx.x; i <= k.NK; i += 256) dst[i] = s_c[i];
+    int *dst = counts + (size_t)(b * 2 + pol) * (k.NK + 1) * chunks + chunk;
+    for (int i = threadIdx.x; i <= k.NK; i += 256) dst[(size_t)i * chunks] = s_c[i];
 }
 
-// grid 2 * B, 256 threads: per key the running offset over the chunks (in place), then the key bases -> offsets
+// grid 2 * B, 256 threads.  counts is [b][pol][key][chunk]: one wavefront per key scans the chunks (lanes = chunks,
+// in place -> the chunk's first row inside the key), then the keys are scanned across the workgroup -> offsets
 __global__ __launch_bounds__(256) void k_evo_scan(const mpc_shape s, const EvoKey k, int *__restrict__ counts,
                                                   int *__restrict__ offsets, int chunks) {
-    extern __shared__ int s_tot[];
+    extern __shared__ int s_tot[];          // [NK + 1] key totals, then [256] segment sums
     const EvParams p = make_params(s);
     const int b = blockIdx.x >> 1, pol = blockIdx.x & 1;
-    int *c = counts + (size_t)(b * 2 + pol) * chunks * (k.NK + 1);
-    for (int i = threadIdx.x; i <= k.NK; i += 256) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *c = counts + (size_t)(b * 2 + pol) * (k.NK + 1) * chunks;
+    for (int i = wave; i <= k.NK; i += 4) {
+        int *ci = c + (size_t)i * chunks;
         int run = 0;
-        for (int ch = 0; ch < chunks; ++ch) { const int v = c[(size_t)ch * (k.NK + 1) + i]; c[(size_t)ch * (k.NK + 1) + i] = run; run += v; }
-        s_tot[i] = run;
+        for (int c0 = 0; c0 < chunks; c0 += 64) {
+            const int ch = c0 + lane;
+            const int v = ch < chunks ? ci[ch] : 0;
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            if (ch < chunks) ci[ch] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) s_tot[i] = run;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = pol ? p.Mp : 0;
-        int *o = offsets + (size_t)(b * 2 + pol) * (k.NK + 1);
-        for (int i = 0; i <= k.NK; ++i) { o[i] = run; run += s_tot[i]; }
+    // exclusive scan of the NK + 1 totals: a contiguous segment per thread, segment sums scanned by thread 0's wave
+    int *s_seg = s_tot + (k.NK + 1);
+    const int per = (k.NK + 1 + 255) / 256;
+    const int k0 = min((int)threadIdx.x * per, k.NK + 1), k1 = min(k0 + per, k.NK + 1);
+    int sum = 0;
+    for (int i = k0; i < k1; ++i) sum += s_tot[i];
+    s_seg[threadIdx.x] = sum;
+    __syncthreads();
+    if (wave == 0) {
+        int carry = 0;
+        for (int c0 = 0; c0 < 256; c0 += 64) {
+            const int v = s_seg[c0 + lane];
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            s_seg[c0 + lane] = carry + incl - v;
+            carry += __shfl(incl, 63);
+        }
     }
+    __syncthreads();
+    int run = (pol ? p.Mp : 0) + s_seg[threadIdx.x];
+    int *o = offsets + (size_t)(b * 2 + pol) * (k.NK + 1);
+    for (int i = k0; i < k1; ++i) { o[i] = run; run += s_tot[i]; }
 }
 
 // grid (chunks, 2 * B)
@@ -742,9 +771,9 @@ __global__ __launch_bounds__(256) void k_evo_scatter(const mpc_shape s, const Ev
     const EvParams p = make_params(s);
     const int b = blockIdx.y >> 1, pol = blockIdx.y & 1, chunk = blockIdx.x;
     const int r0 = pol ? p.Mp : 0, r1 = pol ? p.M : p.Mp;
-    const int *cb = counts + ((size_t)(b * 2 + pol) * chunks + chunk) * (k.NK + 1);
+    const int *cb = counts + (size_t)(b * 2 + pol) * (k.NK + 1) * chunks + chunk;
     const int *ob = offsets + (size_t)(b * 2 + pol) * (k.NK + 1);
-    for (int i = threadIdx.x; i <= k.NK; i += 256) s_c[i] = ob[i] + cb[i];      // first destination row of the chunk's share
+    for (int i = threadIdx.x; i <= k.NK; i += 256) s_c[i] = ob[i] + cb[(size_t)i * chunks];   // first destination row of the chunk's share
     __syncthreads();
     for (int j = threadIdx.x; j < EVO_ROWS; j += 256) {
         const int row = r0 + chunk * EVO_ROWS + j;
@@ -784,7 +813,7 @@ extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in
     int *counts = (int *)ws;
     const size_t lds = (size_t)(k.NK + 1) * 4;
     hipLaunchKernelGGL(k_evo_count, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, chunks);
-    hipLaunchKernelGGL(k_evo_scan, dim3(2 * s->B), dim3(256), lds, st, *s, k, counts, (int *)offsets, chunks);
+    hipLaunchKernelGGL(k_evo_scan, dim3(2 * s->B), dim3(256), lds + 256 * 4, st, *s, k, counts, (int *)offsets, chunks);
     hipLaunchKernelGGL(k_evo_scatter, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, (const int *)offsets,
                        events_out, chunks);
     MPC_CHECK_LAUNCH();

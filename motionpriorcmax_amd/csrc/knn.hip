@@ -587,6 +587,35 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     }
 }
 
+// window loop of k_knn_bwd_tile, CW columns wide (fully unrolled: the squared column offsets live in registers).
+// Membership is `d <= K-th distance` (callers: no excluded tie among the staged queries).
+template <int CW, bool L1, bool NEXT>
+__device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2 pt, int x0, int y0, int nxw, int nyw, int nymax,
+                                                int ry0, int RW, int RP, int xb, const float *ldk, const float2 *lg,
+                                                const float2 *lgn, float &ay, float &ax, float2 &an) {
+    float dx2[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const float dx = ((float)((x0 + c) * p.sp) + p.off) - pt.y;
+        dx2[c] = (c < nxw) ? (L1 ? fabsf(dx) : dx * dx) : INFINITY;
+    }
+    for (int r = 0; r < nymax; ++r) {
+        const int cyr = min(max(y0 + r, ry0), ry0 + RW - 1);
+        const float dy = ((float)(cyr * p.sp) + p.off) - pt.x;
+        const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
+        const float *rdk = ldk + (cyr - ry0) * RP + xb;
+        const float2 *rg = lg + (cyr - ry0) * RP + xb, *rown = lgn + (cyr - ry0) * RP + xb;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float d = dy2 + dx2[c];
+            const float w = (d <= rdk[c]) ? 1.f : 0.f;
+            const float2 e = rg[c];
+            ay = fmaf(w, e.x, ay); ax = fmaf(w, e.y, ax);
+            if (NEXT) { const float2 gq = rown[c]; an.x = fmaf(w, gq.x, an.x); an.y = fmaf(w, gq.y, an.y); }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward for num_tref == 1, 'mean' (the shipped configurations): k_knn_reach and the gather in ONE launch, with a
 // cheaper window loop.
@@ -599,7 +628,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
 //     workgroups, and windows wider than KNN_BW_WMAX, take the exact (distance, index) loop of bwd_window.
 // grid: 1-D, XCD-contiguous, 256 threads, dynamic LDS (RWmax^2 float4 + KNN_BW_WMAX of slack [+ float2 per cell])
 // ------------------------------------------------------------------------------------------
-#define KNN_BW_WMAX 10
+#define KNN_BW_WMAX 16
 template <bool L1, bool NEXT>
 __global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
                                                       const float2 *__restrict__ spos, const int *__restrict__ sidx,
@@ -752,31 +781,19 @@ __global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, cons
             const int nxw = x1 - x0 + 1, nyw = y1 - y0 + 1;
             const bool narrow = __ballot(nxw > KNN_BW_WMAX) == 0ull;
             if (narrow && !anytie) {
-                float dx2[KNN_BW_WMAX];
-#pragma unroll
-                for (int c = 0; c < KNN_BW_WMAX; ++c) {
-                    const float dx = ((float)((x0 + c) * p.sp) + p.off) - pt.y;
-                    dx2[c] = (c < nxw) ? (L1 ? fabsf(dx) : dx * dx) : INFINITY;
-                }
+                // (the unrolled column loop comes in three widths, picked by the widest window of the wavefront: an inner
+                // tile's reach of ~3.3 cells gives windows of 7-8 columns, and a column beyond the window costs as much
+                // as one inside it)
+                const int nxmax = __builtin_amdgcn_readfirstlane(wave_max_int(nxw));
                 const int nymax = __builtin_amdgcn_readfirstlane(wave_max_int(nyw));
-                for (int r = 0; r < nymax; ++r) {
-                    const int cyr = min(max(y0 + r, ry0), ry0 + RW - 1);
-                    const float dy = ((float)(cyr * p.sp) + p.off) - pt.x;
-                    const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
-                    // (a point far outside the image sits in a border cell with an EMPTY window whose x0 lies beyond the
-                    // staged region: the unconditional reads below must stay inside it)
-                    const int xb = min(x0, rx0 + RW - 1) - rx0;
-                    const float *rdk = ldk + (cyr - ry0) * RP + xb;
-                    const float2 *rg = lg + (cyr - ry0) * RP + xb, *rown = lgn + (cyr - ry0) * RP + xb;
-#pragma unroll
-                    for (int c = 0; c < KNN_BW_WMAX; ++c) {
-                        const float d = dy2 + dx2[c];
-                        const float w = (d <= rdk[c]) ? 1.f : 0.f;
-                        const float2 e = rg[c];
-                        ay = fmaf(w, e.x, ay); ax = fmaf(w, e.y, ax);
-                        if (NEXT) { const float2 gq = rown[c]; an.x = fmaf(w, gq.x, an.x); an.y = fmaf(w, gq.y, an.y); }
-                    }
-                }
+                const int xb = min(x0, rx0 + RW - 1) - rx0;
+                // (a point far outside the image sits in a border cell with an EMPTY window whose x0 lies beyond the
+                // staged region: the unconditional reads must stay inside it -- xb, cyr)
+                if (nxmax <= 7) bwd_window_fast<7, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                else if (nxmax <= 8) bwd_window_fast<8, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                else if (nxmax <= 10) bwd_window_fast<10, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                else if (nxmax <= 13) bwd_window_fast<13, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                else bwd_window_fast<KNN_BW_WMAX, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
             } else if (act) {
                 // exact (distance, index) membership: queries with an excluded tie, or a window wider than KNN_BW_WMAX
                 for (int cy = y0; cy <= y1; ++cy) {

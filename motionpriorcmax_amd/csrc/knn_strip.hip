@@ -526,7 +526,8 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
     int r = query_radius(p, cy, cx, r_init);
     if (grow_first) r += 1 + (r >> 2);
-    float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS], gg[KS_FB_SLOTS];
+    float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS];
+    float2 pq[KS_FB_SLOTS];
     bool serial = false;
     int ns = KS_FB_SLOTS;                  // slots per lane actually in use (wave-uniform): ceil(candidates / 64)
     for (;;) {
@@ -550,7 +551,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
 #pragma unroll
         for (int m = 0; m < KS_FB_SLOTS; ++m) {
             const int k = lane + 64 * m;                    // flat candidate number of this lane's m-th slot
-            dd[m] = INFINITY; ii[m] = 0x7fffffff; gg[m] = 0;
+            dd[m] = INFINITY; ii[m] = 0x7fffffff; pq[m] = make_float2(0.f, 0.f);
             if (m >= ns) continue;
             // row of candidate k: the last lane whose exclusive offset is <= k (offsets are non-decreasing)
             int lo = 0, hi = 64;
@@ -564,8 +565,9 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             if (k < N) {
                 const int g = rjs + (k - rex);
                 const float2 pj = sp_[g];
+                const int id = si_[g];                          // (with the position: one round trip, not two)
                 const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                if (d < upper) { dd[m] = d; ii[m] = si_[g]; gg[m] = g; ++cnt; }
+                if (d < upper) { dd[m] = d; ii[m] = id; pq[m] = pj; ++cnt; }
             }
         }
 #pragma unroll
@@ -586,45 +588,43 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         }
         return;
     }
-    // rank of every candidate among all of them
-    int rank[KS_FB_SLOTS];
+    // the K-th smallest key (distance bits, index) by a bitwise search from the top: distances are non-negative floats
+    // (their bit patterns order like unsigned integers), indices are distinct and < 2^16, a slot without a candidate holds
+    // (inf, 0x7fffffff).  Bit by bit: the smallest V with count(key <= V) >= K.  47 wave-uniform steps of one 64-bit
+    // compare per slot -- the broadcast-every-candidate rank loop this replaces cost ~16 instructions per candidate.
+    unsigned long long key[KS_FB_SLOTS];
 #pragma unroll
-    for (int m = 0; m < KS_FB_SLOTS; ++m) rank[m] = 0;
+    for (int m = 0; m < KS_FB_SLOTS; ++m) key[m] = ((unsigned long long)__float_as_uint(dd[m]) << 32) | (unsigned)ii[m];
+    unsigned long long V = 0ull;
+    for (int bit = 62; bit >= 0; --bit) {
+        if (bit == 31) bit = 15;                                // index bits 16..31 are zero for every candidate
+        const unsigned long long cand = V | ((1ull << bit) - 1ull);
+        int c = 0;
 #pragma unroll
-    for (int mo = 0; mo < KS_FB_SLOTS; ++mo) {
-        if (mo >= ns) break;
-        unsigned long long vm = __ballot(dd[mo] < INFINITY);       // lanes holding a candidate in this slot
-        while (vm != 0ull) {
-            const int l = __ffsll((long long)vm) - 1;
-            vm &= vm - 1ull;
-            const float od = lane_f(dd[mo], l);
-            const int oi = lane_i(ii[mo], l);
-#pragma unroll
-            for (int m = 0; m < KS_FB_SLOTS; ++m)
-                if (m < ns) rank[m] += ((od < dd[m]) | ((od == dd[m]) & (oi < ii[m]))) ? 1 : 0;
-        }
+        for (int m = 0; m < KS_FB_SLOTS; ++m)
+            if (m < ns) c += __popcll(__ballot(key[m] <= cand));
+        if (c < p.K) V |= 1ull << bit;
     }
     // neighbours: rank < K (indices are distinct, so ranks are); sums in lane order
     const bool do_next = p.want_next && (t < p.nb - 1);
-    float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f, dK = 0.f;
-    int iK = -1;
+    float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
+    const float dK = __uint_as_float((unsigned)(V >> 32));
+    const int iK = (int)(unsigned)(V & 0xffffffffull);
 #pragma unroll
     for (int m = 0; m < KS_FB_SLOTS; ++m) {
-        if (dd[m] < INFINITY && rank[m] < p.K) {
-            const float2 pj = sp_[gg[m]];
+        if (dd[m] < INFINITY && key[m] <= V) {
+            const float2 pj = pq[m];
             const float2 a = traj_b[ii[m]];                                   // T == 1
             const float fy = a.x - pj.x, fx = a.y - pj.y;
             if (p.iwd) { const float wgt = 1.f / (dd[m] + 1e-9f); sy_ += wgt * fy; sx_ += wgt * fx; sw_ += wgt; }
             else { sy_ += fy; sx_ += fx; }
             if (do_next) { const float2 c = traj_b[(size_t)(p.T + t + 1) * p.n + ii[m]]; ny_ += c.x - pj.x; nx_ += c.y - pj.y; }
-            if (rank[m] == p.K - 1) { dK = dd[m]; iK = ii[m]; }
         }
     }
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) {
         sy_ += __shfl_xor(sy_, o2, 64); sx_ += __shfl_xor(sx_, o2, 64); sw_ += __shfl_xor(sw_, o2, 64);
         ny_ += __shfl_xor(ny_, o2, 64); nx_ += __shfl_xor(nx_, o2, 64);
-        dK = fmaxf(dK, __shfl_xor(dK, o2, 64)); iK = max(iK, __shfl_xor(iK, o2, 64));
     }
     bool tie = false;
 #pragma unroll
@@ -654,11 +654,15 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
                                                       float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                       const int *__restrict__ fail, int r_init) {
     __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
-    const int nfail = fail[0];
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    // (the first entry is read together with the length, not after it: the list has room for every query, so the
+    // address is valid whatever the length turns out to be)
+    int ent = fail[1 + min(wv, p.B * p.nb * p.G - 1)];
+    const int nfail = fail[0];
     for (int i = wv; i < nfail; i += nw) {
-        const int q = fail[1 + i] & 0x3fffffff;
-        const bool grow = ((unsigned)fail[1 + i] >> 30) == 0u;       // too few candidates at the first radius: skip it
+        if (i != wv) ent = fail[1 + i];
+        const int q = ent & 0x3fffffff;
+        const bool grow = ((unsigned)ent >> 30) == 0u;       // too few candidates at the first radius: skip it
         if (p.l1) fallback_one_query<true>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, grow, s_hist);
         else fallback_one_query<false>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, grow, s_hist);
     }
