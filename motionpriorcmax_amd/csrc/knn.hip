@@ -636,8 +636,16 @@ __global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, cons
                                                       const float *__restrict__ knn_state,
                                                       const float *__restrict__ tile_dkmax,
                                                       float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
-                                                      int gx, int gy, int bd) {
+                                                      int gx, int gy, int bd
+#ifdef KNN_BW_STAMP
+                                                      , int *__restrict__ stamp
+#endif
+                                                      ) {
     constexpr int TS = 16;
+#ifdef KNN_BW_STAMP
+    const unsigned long long st0 = wall_clock64();
+    int st_slow = 0;
+#endif
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_rowbase[TS + 1];
     __shared__ int s_rowg[TS];
@@ -755,6 +763,9 @@ __global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, cons
     }
     __syncthreads();
     const bool anytie = (s_tiew[0] | s_tiew[1] | s_tiew[2] | s_tiew[3]) != 0;
+#ifdef KNN_BW_STAMP
+    const unsigned long long st1 = wall_clock64();
+#endif
     const int total = s_rowbase[TS];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
@@ -795,6 +806,9 @@ __global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, cons
                 else if (nxmax <= 13) bwd_window_fast<13, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
                 else bwd_window_fast<KNN_BW_WMAX, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
             } else if (act) {
+#ifdef KNN_BW_STAMP
+                st_slow = 1;
+#endif
                 // exact (distance, index) membership: queries with an excluded tie, or a window wider than KNN_BW_WMAX
                 for (int cy = y0; cy <= y1; ++cy) {
                     const float dy = ((float)(cy * p.sp) + p.off) - pt.x;
@@ -835,6 +849,15 @@ __global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, cons
             if (gnext != nullptr) tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
         }
     }
+#ifdef KNN_BW_STAMP
+    __syncthreads();
+    const bool anyslow = __syncthreads_or(st_slow) != 0;
+    if (tid == 0) {
+        const unsigned long long st2 = wall_clock64();
+        stamp[4 * lblk + 0] = (int)(st2 - st0); stamp[4 * lblk + 1] = (int)(st1 - st0);
+        stamp[4 * lblk + 2] = RQ | (use_lds ? 0 : 256) | (anytie ? 512 : 0) | (anyslow ? 1024 : 0); stamp[4 * lblk + 3] = total;
+    }
+#endif
 }
 
 // backward, step 2: one thread per (sample, trajectory point): combine the per-bin partials.
@@ -1075,9 +1098,14 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         const size_t ldsb = ((size_t)RWm * RWm + KNN_BW_WMAX) * (16 + (grad_flow_next ? 8 : 0));      // RWm >= 32: covers pitch 32 too
         const int gxb = mpc_cdiv(s->wq, 16), gyb = mpc_cdiv(s->hq, 16);
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
+#ifdef KNN_BW_STAMP
+#define KB_STAMP_ARG , (int *)((char *)ws + L.off_knn_fail)
+#else
+#define KB_STAMP_ARG
+#endif
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
         hipLaunchKernelGGL((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)))
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH

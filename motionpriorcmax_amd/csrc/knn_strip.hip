@@ -96,7 +96,16 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
 
     // ---- the query of this thread and its search square -------------------------------------------
-    const int cy = qy0 + tid / WS, cx = qx0 + tid % WS;
+    // Thread -> query: 16-row groups of the strip (a wavefront = two groups = two LUT tiles of the reach bookkeeping
+    // below).  The queries next to the top and bottom border of the image are the expensive ones (enlarged squares, wider
+    // staged rows: up to 96 slots against 63) and a wavefront pays for its most expensive lane, so the group holding the
+    // bottom border trades places with group 1: ONE wavefront of a full-height strip carries both borders, not two.
+    int grp = tid / (16 * WS);
+    if (qy0 == 0 && p.hq <= TH) {
+        const int gb = (p.hq - 1) >> 4;
+        if (gb >= 2) grp = (grp == 1) ? gb : ((grp == gb) ? 1 : grp);
+    }
+    const int cy = qy0 + grp * 16 + (tid % (16 * WS)) / WS, cx = qx0 + tid % WS;
     const bool valid = cy <= qy1 && cx <= qx1;
     int r = r_init, y0 = 0, y1 = -1, x0 = 0, x1 = -1;
     if (valid) {
