@@ -680,7 +680,8 @@ extern "C" int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *even
 // ordered tensor is a valid `events` for the reference too; with its offsets table the forward need not write, and the
 // backward not read back, a 16-byte record per event.  Padding rows (valid == 0) keep their place at the end of their block.
 //   offsets [B][2][nb*NCS + 1]: first row of every (bin, LUT strip) inside the block; [nb*NCS] = first padding row
-// Counting sort: per-chunk counts -> per-sample scan -> scatter (order inside a bucket is not defined and need not be).
+// Counting sort: per-chunk counts -> scan over the chunks of every key -> scan over the keys -> scatter (the order inside a
+// bucket is not defined and need not be).
 // ==========================================================================================
 #define EVO_ROWS 2048          // rows of one chunk (256 threads x 8)
 
@@ -714,39 +715,40 @@ __global__ __launch_bounds__(256) void k_evo_count(const mpc_shape s, const EvoK
     for (int i = threadIdx.x; i <= k.NK; i += 256) dst[(size_t)i * chunks] = s_c[i];
 }
 
-// grid 2 * B, 256 threads.  counts is [b][pol][key][chunk]: one wavefront per key scans the chunks (lanes = chunks,
-// in place -> the chunk's first row inside the key), then the keys are scanned across the workgroup -> offsets
-__global__ __launch_bounds__(256) void k_evo_scan(const mpc_shape s, const EvoKey k, int *__restrict__ counts,
-                                                  int *__restrict__ offsets, int chunks) {
-    extern __shared__ int s_tot[];          // [NK + 1] key totals, then [256] segment sums
-    const EvParams p = make_params(s);
-    const int b = blockIdx.x >> 1, pol = blockIdx.x & 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *c = counts + (size_t)(b * 2 + pol) * (k.NK + 1) * chunks;
-    for (int i = wave; i <= k.NK; i += 4) {
-        int *ci = c + (size_t)i * chunks;
-        int run = 0;
-        for (int c0 = 0; c0 < chunks; c0 += 64) {
-            const int ch = c0 + lane;
-            const int v = ch < chunks ? ci[ch] : 0;
-            int incl = v;
+// counts is [b][pol][key][chunk].  Step 1, grid (ceil((NK + 1) / 4), 2 * B), 256 threads: one wavefront per key scans
+// its chunks (lanes = chunks; in place -> the chunk's first row inside the key) and leaves the key's total.
+__global__ __launch_bounds__(256) void k_evo_scan_chunks(const EvoKey k, int *__restrict__ counts, int *__restrict__ totals, int chunks) {
+    const int lane = threadIdx.x & 63, key = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (key > k.NK) return;
+    int *ci = counts + ((size_t)blockIdx.y * (k.NK + 1) + key) * chunks;
+    int run = 0;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+        const int ch = c0 + lane;
+        const int v = ch < chunks ? ci[ch] : 0;
+        int incl = v;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-            if (ch < chunks) ci[ch] = run + incl - v;
-            run += __shfl(incl, 63);
-        }
-        if (lane == 0) s_tot[i] = run;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (ch < chunks) ci[ch] = run + incl - v;
+        run += __shfl(incl, 63);
     }
-    __syncthreads();
-    // exclusive scan of the NK + 1 totals: a contiguous segment per thread, segment sums scanned by thread 0's wave
-    int *s_seg = s_tot + (k.NK + 1);
+    if (lane == 0) totals[(size_t)blockIdx.y * (k.NK + 1) + key] = run;
+}
+
+// Step 2, grid 2 * B, 256 threads: exclusive scan of the NK + 1 key totals of a polarity block -> offsets (a contiguous
+// segment of keys per thread, the 256 segment sums scanned by the first wavefront)
+__global__ __launch_bounds__(256) void k_evo_scan_keys(const mpc_shape s, const EvoKey k, const int *__restrict__ totals,
+                                                       int *__restrict__ offsets) {
+    __shared__ int s_seg[256];
+    const EvParams p = make_params(s);
+    const int pol = blockIdx.x & 1, lane = threadIdx.x & 63;
+    const int *tot = totals + (size_t)blockIdx.x * (k.NK + 1);
     const int per = (k.NK + 1 + 255) / 256;
     const int k0 = min((int)threadIdx.x * per, k.NK + 1), k1 = min(k0 + per, k.NK + 1);
     int sum = 0;
-    for (int i = k0; i < k1; ++i) sum += s_tot[i];
+    for (int i = k0; i < k1; ++i) sum += tot[i];
     s_seg[threadIdx.x] = sum;
     __syncthreads();
-    if (wave == 0) {
+    if (threadIdx.x < 64) {
         int carry = 0;
         for (int c0 = 0; c0 < 256; c0 += 64) {
             const int v = s_seg[c0 + lane];
@@ -759,8 +761,8 @@ __global__ __launch_bounds__(256) void k_evo_scan(const mpc_shape s, const EvoKe
     }
     __syncthreads();
     int run = (pol ? p.Mp : 0) + s_seg[threadIdx.x];
-    int *o = offsets + (size_t)(b * 2 + pol) * (k.NK + 1);
-    for (int i = k0; i < k1; ++i) { o[i] = run; run += s_tot[i]; }
+    int *o = offsets + (size_t)blockIdx.x * (k.NK + 1);
+    for (int i = k0; i < k1; ++i) { o[i] = run; run += tot[i]; }
 }
 
 // grid (chunks, 2 * B)
@@ -795,7 +797,7 @@ extern "C" int64_t mpc_event_order_workspace_bytes(const mpc_shape *s) {
     if (!s || mpc_validate_shape(s)) return MPC_E_SHAPE;
     const mpc_ws_layout L = mpc_layout(s);
     const int64_t chunks = mpc_cdiv(s->M > 0 ? s->M : 1, EVO_ROWS);
-    return mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 2 * chunks * ((int64_t)s->nb * L.n_cstrips + 1) * 4);
+    return mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 2 * (chunks + 1) * ((int64_t)s->nb * L.n_cstrips + 1) * 4);      // counts + key totals
 }
 
 extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in, float *events_out, int32_t *offsets,
@@ -813,7 +815,9 @@ extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in
     int *counts = (int *)ws;
     const size_t lds = (size_t)(k.NK + 1) * 4;
     hipLaunchKernelGGL(k_evo_count, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, chunks);
-    hipLaunchKernelGGL(k_evo_scan, dim3(2 * s->B), dim3(256), lds + 256 * 4, st, *s, k, counts, (int *)offsets, chunks);
+    int *totals = counts + (size_t)2 * s->B * (k.NK + 1) * chunks;
+    hipLaunchKernelGGL(k_evo_scan_chunks, dim3(mpc_cdiv(k.NK + 1, 4), 2 * s->B), dim3(256), 0, st, k, counts, totals, chunks);
+    hipLaunchKernelGGL(k_evo_scan_keys, dim3(2 * s->B), dim3(256), 0, st, *s, k, totals, (int *)offsets);
     hipLaunchKernelGGL(k_evo_scatter, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, (const int *)offsets,
                        events_out, chunks);
     MPC_CHECK_LAUNCH();
