@@ -70,6 +70,9 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
     const int tid = threadIdx.x;
+#ifdef KS_STAMP
+    const unsigned long long st0 = wall_clock64();      // diagnostics build: per-workgroup durations (tools/strip_stamp_probe.py)
+#endif
     const int nblk = gx * gy * p.B * p.nb;
     const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
     if (lblk >= nblk) return;
@@ -218,6 +221,9 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         }
     }
     __syncthreads();
+#ifdef KS_STAMP
+    const unsigned long long st1 = wall_clock64();
+#endif
 
     // ---- search --------------------------------------------------------------------------------------
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
@@ -508,6 +514,17 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             if (writer && m > 0.f) atomicMax(dst + c, __float_as_int(m));
         }
     }
+#ifdef KS_STAMP
+    {
+        const unsigned long long st2 = wall_clock64();      // this wavefront's end
+        __syncthreads();
+        const size_t BQ = (size_t)p.B * p.nb * p.G;
+        const size_t q0 = (size_t)bt * p.G + (size_t)qy0 * p.wq + qx0;
+        // plane 2 of the state (unused by the 'mean' backward): rows qy0 .. qy0 + 4 of the strip's first column
+        if ((tid & 63) == 0) knn_state[2 * BQ + q0 + (size_t)(1 + (tid >> 6)) * p.wq] = (float)(st2 - st0);
+        if (tid == 0) { knn_state[2 * BQ + q0] = (float)(wall_clock64() - st0); knn_state[2 * BQ + q0 + 1] = (float)(st1 - st0); }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
