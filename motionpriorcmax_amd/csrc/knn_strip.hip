@@ -85,9 +85,9 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     const int ry_base = qy0 - R2;                // grid row of region row 0 (may lie outside the grid: an empty row)
     const int NR = TH + 2 * R2;                  // region rows (launcher: NR <= KS_NT)
     // ---- LDS carve-up ----------------------------------------------------------------------------
-    int4 *s_row = reinterpret_cast<int4 *>(s_dyn);             // [NR] {xlo, xhi} of the row, then {first slot, first bucketed slot, points, slots}
+    int2 *s_row = reinterpret_cast<int2 *>(s_dyn);             // [NR] {xlo, xhi} of the row, then {first bucketed slot, points (-1: no such row)}
     int *s_rowstart = reinterpret_cast<int *>(s_row + NR);     // [NR + 1] first slot of every region row
-    size_t o = ((size_t)NR * 16 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15;
+    size_t o = ((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15;
     float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
     float2 *lflow = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
     float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL) * 8 : 0;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     if (tid < NR) {
         const int y = ry_base + tid;
         const bool dflt = has_inner && y >= icy0 - r_init && y <= icy1 + r_init;
-        s_row[tid] = make_int4(dflt ? icx0 - r_init : 0x7fffffff, dflt ? icx1 + r_init : -1, 0, 0);
+        s_row[tid] = make_int2(dflt ? icx0 - r_init : 0x7fffffff, dflt ? icx1 + r_init : -1);
     }
     __syncthreads();
     const bool inner = valid && cx >= icx0 && cx <= icx1 && cy >= icy0 && cy <= icy1;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     // ---- slots of the region rows: an exclusive scan of the row lengths; a row of even length gets one dummy
     //      slot so that the row pitch is odd (consecutive rows then start in different LDS banks: with the 8 points
     //      per row of a regular lattice an unpadded pitch puts every fourth row on the same banks) ---------------
-    int len = 0, padded = 0, gs = 0;
+    int len = -1, padded = 0, gs = 0;
     if (tid < NR) {
         const int y = ry_base + tid;
         const int xl = s_row[tid].x, xh = s_row[tid].y;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     __syncthreads();
     int run = incl - padded;
     for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
-    if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int4(run, gs, len, padded); }
+    if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int2(gs, len); }
     if (tid == NR - 1) s_rowstart[NR] = run + padded;
     // row pitch of the staging loop = the longest row of the region
     const int pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
@@ -186,12 +186,12 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
 #pragma unroll
             for (int u = 0; u < KS_SB; ++u) {
                 const int it = base + u * KS_NT + tid, rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1), k = it - rr * pitch;
-                const int4 row = s_row[rr];
-                in[u] = it < items && k < row.w;
-                real[u] = in[u] && k < row.z;
-                slot[u] = row.x + k;
+                const int2 row = s_row[rr];                                     // {first bucketed slot, points}
+                in[u] = it < items && row.y >= 0 && k < (row.y | 1);            // (an even row has one dummy slot: odd pitch)
+                real[u] = in[u] && k < row.y;
+                slot[u] = s_rowstart[rr] + k;
                 pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
-                if (real[u]) { pj[u] = sp_[row.y + k]; id[u] = si_[row.y + k]; }
+                if (real[u]) { pj[u] = sp_[row.x + k]; id[u] = si_[row.x + k]; }
             }
 #pragma unroll
             for (int u = 0; u < KS_SB; ++u) {
@@ -707,9 +707,9 @@ static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out,
     const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
     static const double slack = getenv("MPC_KS_SLACK") ? atof(getenv("MPC_KS_SLACK")) : 1.15;      // (tuning)
     int cap = (int)(slack * rows * (row_pts + 0.5)) + 64;
-    cap = (cap + 63) / 64 * 64;
+    cap = (cap + 15) / 16 * 16;
     const bool next = (s->flags & MPC_F_WANT_NEXT) != 0;
-    const size_t lds = (((size_t)NR * 16 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + KS_TAIL) * 8 * (next ? 3 : 2) +
+    const size_t lds = (((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + KS_TAIL) * 8 * (next ? 3 : 2) +
                        (size_t)cap * 2 + 16;
     if (lds > 64 * 1024) return false;
     static const int pad_lds = getenv("MPC_KS_PADLDS") ? atoi(getenv("MPC_KS_PADLDS")) : 0;             // (tuning: occupancy experiments)
