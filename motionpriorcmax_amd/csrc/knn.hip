@@ -629,8 +629,11 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 // grid: 1-D, XCD-contiguous, 256 threads, dynamic LDS (RWmax^2 float4 + KNN_BW_WMAX of slack [+ float2 per cell])
 // ------------------------------------------------------------------------------------------
 #define KNN_BW_WMAX 16
+#ifndef KNN_BW_OCC
+#define KNN_BW_OCC 8      // workgroups per CU the register budget is set for (8 -> 64 VGPRs)
+#endif
 template <bool L1, bool NEXT>
-__global__ __launch_bounds__(256, 8) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
                                                       const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                       const float *__restrict__ glut, const float *__restrict__ gnext,
                                                       const float *__restrict__ knn_state,
