@@ -922,11 +922,11 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_STRIP=0         tile query kernel (k_knn_query) also where the strip kernel applies  [1]
 //   MPC_KNN_BWD_FUSED=0     backward as k_knn_reach + k_knn_bwd_points also where k_knn_bwd_tile applies [1]
 struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused;
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -937,6 +937,7 @@ static const KnnTuning &knn_tuning() {
         if ((e = getenv("MPC_KNN_HALO"))) v.halo = atoi(e);
         if ((e = getenv("MPC_KNN_STRIP"))) v.strip = atoi(e) != 0;
         if ((e = getenv("MPC_KNN_BWD_FUSED"))) v.bwd_fused = atoi(e) != 0;
+        if ((e = getenv("MPC_KNN_BUCKET_S"))) v.bucket_s = atoi(e);
         return v;
     }();
     return t;
@@ -995,6 +996,7 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     // eight ways 19 us)
     int S = 256 / (s->B * s->nb);
     if (S > 8) S = 8;
+    if (knn_tuning().bucket_s > 0) S = knn_tuning().bucket_s;
     if (S > s->hq) S = s->hq;
     if (S < 1) S = 1;
     const size_t sort_lds = (size_t)((s->hq + S - 1) / S) * s->wq * 4 + (size_t)((s->n + 1) / 2 * 2) * 2;
