@@ -66,8 +66,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.nimg = s->B * s->T * L.P;
     L.G = s->hq * s->wq;
     int64_t off = 0;
-    // sized for the finer of the two contrast tilings (fused kernel: 56-wide tiles, unfused: 64-wide)
-    L.n_cblocks = mpc_cdiv(s->W, MPC_CF_TW) * mpc_cdiv(s->H, MPC_CT_H) * (L.nimg > 0 ? L.nimg : 1);
+    // sized for the finest of the contrast tilings (marching kernel: 56-wide bands of MPC_CT_H / 2 rows)
+    L.n_cblocks = mpc_cdiv(s->W, MPC_CF_TW) * mpc_cdiv(s->H, MPC_CT_H / 2) * (L.nimg > 0 ? L.nimg : 1);
     L.off_cpart = off; off += mpc_align((int64_t)L.n_cblocks * 2 * sizeof(double));
     L.n_sblocks_max = mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H) * (s->B > 0 ? s->B : 1) * s->nb * s->T;
     L.off_spart = off; off += mpc_align((int64_t)L.n_sblocks_max * 2 * sizeof(double));

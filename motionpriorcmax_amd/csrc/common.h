@@ -72,7 +72,9 @@ struct mpc_ws_layout {
 };
 
 // contrast tiles
+#ifndef MPC_CT_H
 #define MPC_CT_H 32
+#endif
 #define MPC_CT_W 64
 #define MPC_CF_TW 56   // fused kernel: tile + 2*4 halo columns = 64 = one wavefront row
 // smoothness tiles (LUT cells)
