@@ -69,7 +69,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     // sized for the finest of the contrast tilings (marching kernel: 56-wide bands of MPC_CT_H / 2 rows)
     L.n_cblocks = mpc_cdiv(s->W, MPC_CF_TW) * mpc_cdiv(s->H, MPC_CT_H / 2) * (L.nimg > 0 ? L.nimg : 1);
     L.off_cpart = off; off += mpc_align((int64_t)L.n_cblocks * 2 * sizeof(double));
-    L.n_sblocks_max = mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H) * (s->B > 0 ? s->B : 1) * s->nb * s->T;
+    L.n_sblocks_max = mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H / 2) * (s->B > 0 ? s->B : 1) * s->nb * s->T;    // (bands of MPC_SM_H / 2 rows at most)
     L.off_spart = off; off += mpc_align((int64_t)L.n_sblocks_max * 2 * sizeof(double));
     L.off_counts = off; off += mpc_align(64 + (int64_t)(L.nimg > 0 ? L.nimg : 1) * sizeof(float));
     const int64_t bt = (int64_t)(s->B > 0 ? s->B : 1) * s->nb;

@@ -597,9 +597,11 @@ __global__ void k_scale(const float *__restrict__ x, const float *__restrict__ a
 // channel pair.  Same sums, in the same association, as k_lut_smooth above.
 // grid (ceil(wq/60), ceil(hq/MPC_SM_H), nimg*C/2), 64 threads
 // ------------------------------------------------------------------------------------------
+// TH rows per band: MPC_SM_H (16), or half of it for small fields (smooth_band_rows below)
+template <int TH>
 __global__ __launch_bounds__(64) void k_lut_smooth_march(const float *__restrict__ field, float *__restrict__ gfield,
                                                          double *__restrict__ part, int hq, int wq, int C, float gscale) {
-    constexpr int TH = MPC_SM_H, TW = MPC_SM_W;
+    constexpr int TW = MPC_SM_W;
     const int c = threadIdx.x;
     const int C2 = C >> 1;
     const int img = blockIdx.z / C2, cp = blockIdx.z - img * C2;
@@ -718,6 +720,13 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     return 0;
 }
 
+// rows per band of the marching smoothness kernel -- mpc_lut_smooth and mpc_finalize (which adds the partial sums of
+// the bands) must agree on it: bands of 8 rows when 16 would leave the chip short of wavefronts (B = 1: 360 bands)
+static int smooth_band_rows(const mpc_shape *s, int nimg, int C) {
+    const int64_t bands = (int64_t)mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H) * nimg * (C / 2);
+    return bands < 1536 ? MPC_SM_H / 2 : MPC_SM_H;
+}
+
 extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t nimg, int32_t C,
                               float smooth_weight, float *grad_field, void *ws, void *stream) {
     MPC_CHECK_ARG(s && field && ws, MPC_E_NULL, "null argument");
@@ -725,16 +734,18 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
     if (rc) return rc;
     const mpc_ws_layout L = mpc_layout(s);
     MPC_CHECK_ARG(nimg > 0 && C > 0 && (C % 2) == 0, MPC_E_SHAPE, "field must have an even number of channels");
-    const dim3 grid(mpc_cdiv(s->wq, MPC_SM_W), mpc_cdiv(s->hq, MPC_SM_H), nimg * (C / 2));
+    static const bool tiled = getenv("MPC_SMOOTH_TILED") && atoi(getenv("MPC_SMOOTH_TILED")) != 0;      // (tuning: the LDS-tiled kernel)
+    const int band = tiled ? MPC_SM_H : smooth_band_rows(s, nimg, C);
+    const dim3 grid(mpc_cdiv(s->wq, MPC_SM_W), mpc_cdiv(s->hq, band), nimg * (C / 2));
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
     MPC_CHECK_ARG(nblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
     hipStream_t st = (hipStream_t)stream;
     double *spart = (double *)((char *)ws + L.off_spart);
     const double count = (double)nimg * C * s->hq * s->wq;
     const float gscale = (float)((double)smooth_weight / (2.0 * count));
-    static const bool tiled = getenv("MPC_SMOOTH_TILED") && atoi(getenv("MPC_SMOOTH_TILED")) != 0;      // (tuning: the LDS-tiled kernel)
     if (tiled) hipLaunchKernelGGL(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
-    else hipLaunchKernelGGL(k_lut_smooth_march, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    else if (band == MPC_SM_H) hipLaunchKernelGGL(k_lut_smooth_march<MPC_SM_H>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    else hipLaunchKernelGGL(k_lut_smooth_march<MPC_SM_H / 2>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
     MPC_CHECK_LAUNCH();
     return 0;
 }
@@ -749,7 +760,9 @@ extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smo
     int64_t nsblk = 0;
     double count = 1.0;
     if (smooth_nimg > 0) {
-        nsblk = (int64_t)mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, MPC_SM_H) * smooth_nimg * (smooth_C / 2);
+        static const bool tiled = getenv("MPC_SMOOTH_TILED") && atoi(getenv("MPC_SMOOTH_TILED")) != 0;
+        const int band = tiled ? MPC_SM_H : smooth_band_rows(s, smooth_nimg, smooth_C);
+        nsblk = (int64_t)mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, band) * smooth_nimg * (smooth_C / 2);
         MPC_CHECK_ARG(nsblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
         count = (double)smooth_nimg * smooth_C * s->hq * s->wq;
     }
