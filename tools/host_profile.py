@@ -37,4 +37,11 @@ for _ in range(200):
     step()
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+# forward and backward separately
+t0 = time.perf_counter(); fw = 0.0
+for _ in range(200):
+    a = time.perf_counter(); l, _, _ = L.calc(t, times, batch); fw += time.perf_counter() - a
+    l.backward(); t.grad = None
+tot = time.perf_counter() - t0
+print(f'calc {1e6 * fw / 200:.1f} us, backward {1e6 * (tot - fw) / 200:.1f} us (host issue, per step)')
