@@ -132,6 +132,9 @@ __device__ __forceinline__ float lane_right(float v) {     // value of lane + 1 
 // TH rows per band: MPC_CT_H (32) for batches, 16 when that leaves the chip short of wavefronts (B = 1: 360 bands of 32
 // rows on 256 CUs; measured at C2 18.2 -> 12.0 us, neutral at C3); `nslots` entries of the partial-sum array exist and
 // the finalize kernel adds them all, so the bands of the coarser tiling clear the entries they do not use
+#ifndef CM_PF
+#define CM_PF 4      // rows of the raw image in flight ahead of the row being processed (2: 35.5 us at C3, 4: 34.7, 8: 34.3)
+#endif
 template <bool L2N, int TH>
 __global__ __launch_bounds__(64) void k_contrast_march(const float *__restrict__ raw, float *__restrict__ blur,
                                                        float *__restrict__ gimg, double *__restrict__ part, int H, int W,
@@ -158,20 +161,20 @@ __global__ __launch_bounds__(64) void k_contrast_march(const float *__restrict__
     float hx3 = 0.f, hx4 = 0.f, uy3 = 0.f, uy4 = 0.f;         // hx and uy at rows y-3, y-4
     float hT4 = 0.f, hT5 = 0.f;                               // horizontal part of the blur adjoint at rows y-4, y-5
     double acc = 0.0;
-    // the raw rows are requested two iterations ahead
-    float a_next[2];
+    // the raw rows are requested CM_PF iterations ahead
+    float a_next[CM_PF];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < CM_PF; ++k) {
         const int y = ty0 - 4 + k;
         a_next[k] = (xr >= 0 && y >= -1 && y <= H) ? src[(size_t)reflect1(y, H) * W + xr] : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < TH + 8; ++it) {
         const int y = ty0 - 4 + it;
-        const float a = a_next[it & 1];
+        const float a = a_next[it % CM_PF];
         {
-            const int yn = y + 2;
-            a_next[it & 1] = (it + 2 < TH + 8 && xr >= 0 && yn >= -1 && yn <= H) ? src[(size_t)reflect1(yn, H) * W + xr] : 0.f;
+            const int yn = y + CM_PF;
+            a_next[it % CM_PF] = (it + CM_PF < TH + 8 && xr >= 0 && yn >= -1 && yn <= H) ? src[(size_t)reflect1(yn, H) * W + xr] : 0.f;
         }
         // row y: horizontal blur
         const float hb0 = ka * lane_left(a) + kc * a + ka * lane_right(a);
