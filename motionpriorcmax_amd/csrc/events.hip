@@ -802,13 +802,15 @@ extern "C" int64_t mpc_event_order_workspace_bytes(const mpc_shape *s) {
 
 extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in, float *events_out, int32_t *offsets,
                                       void *ws, void *stream) {
-    MPC_CHECK_ARG(s && events_out && offsets && ws && (events_in || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(s && ws && ((events_in && events_out) || s->M == 0 || s->B == 0) && (offsets || s->B == 0), MPC_E_NULL, "null argument");
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     const mpc_ws_layout L = mpc_layout(s);
     MPC_CHECK_ARG(L.n_cstrips > 0, MPC_E_UNSUPPORTED, "no LDS-tiled event path for this shape (num_tref > 1 or the atomic debugging path)");
+    if (s->B == 0) return 0;
+    // no rows: every bucket is empty and starts at row 0
+    if (s->M == 0) return mpc_zero_async(offsets, (size_t)s->B * 2 * ((size_t)s->nb * L.n_cstrips + 1) * sizeof(int32_t), (hipStream_t)stream);
     MPC_CHECK_ARG(events_in != events_out, MPC_E_SHAPE, "in-place ordering is not supported");
-    if (s->B == 0 || s->M == 0) return 0;
     const EvoKey k{L.n_cstrips, L.cstrip_rows, s->nb * L.n_cstrips};
     const int chunks = mpc_cdiv(s->M, EVO_ROWS);       // of the longer block at most; chunks beyond a block's rows are empty
     hipStream_t st = (hipStream_t)stream;

@@ -128,6 +128,21 @@ def test_unit_weight_rows_and_empty_blocks():
         assert torch.equal(l0, l1) and torch.equal(g0, g1)
 
 
+def test_no_events_at_all():
+    """M = 0: the table is all zeros and the step runs (found by tools/fuzz_parity.py)."""
+    from motionpriorcmax_amd import LossFactory
+    shape, B, nb = (96, 128), 2, 5
+    _, _, traj, times = _case(shape, B, 100, nb, 3)
+    dev = torch.device('cuda:0')
+    L = LossFactory.get_loss_calculator('FOCUS', _cfg(shape, nb))
+    batch = {'events': torch.zeros(B, 0, 6, device=dev), 'num_pos_events': 0}
+    ob = L.order_events(batch)
+    assert ob['events'].shape == (B, 0, 6) and int(ob['event_offsets'].abs().sum()) == 0
+    l0, g0, _ = _step(L, traj.to(dev), times.to(dev), batch)
+    l1, g1, _ = _step(L, traj.to(dev), times.to(dev), ob)
+    assert (torch.equal(l0, l1) or (torch.isnan(l0) and torch.isnan(l1))) and torch.equal(torch.nan_to_num(g0), torch.nan_to_num(g1))
+
+
 def test_offsets_are_checked():
     from motionpriorcmax_amd import LossFactory
     shape, B, M, nb = (96, 128), 2, 4000, 5

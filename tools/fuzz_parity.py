@@ -96,6 +96,19 @@ def main():
                     ok &= rel_l2(tr_g.grad.cpu().numpy(), tr_o.grad.numpy()) < (3e-2 if cfg['focus_loss_norm'] == 'l1' else 1e-3)
             else:
                 ok &= not np.isfinite(lg_v)
+            # bucket-ordered events (mpc_event_bucket_order): the same loss, IWE and gradient bit for bit, with and
+            # without the offsets table (num_tref == 1 and the LDS-tiled event path only)
+            if T == 1:
+                ob = L.order_events({'events': ev.to(dev), 'num_pos_events': num_pos})
+                for bt_ in (ob, {'events': ob['events'], 'num_pos_events': num_pos}):
+                    tr_2 = traj.to(dev).requires_grad_(True)
+                    l2_, _, m2_ = L.calc(tr_2, times.to(dev), bt_)
+                    l2_.backward()
+                    same = torch.equal(l2_.detach(), lg.detach()) or (not np.isfinite(lg_v) and not np.isfinite(float(l2_.detach())))
+                    same &= torch.equal(m2_['iwes'], miscg['iwes']) and (torch.equal(tr_2.grad, tr_g.grad) or not np.isfinite(lg_v))
+                    if not same:
+                        ok = False
+                        print('ORDERED-EVENTS MISMATCH', tag, float(l2_.detach()), lg_v)
             if not ok:
                 bad += 1
                 print('MISMATCH', tag, 'loss', lo_v, lg_v, 'iwe', float(np.abs(ig - io).max()),
