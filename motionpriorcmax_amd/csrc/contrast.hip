@@ -536,6 +536,13 @@ __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ cp
     __shared__ double s_var;
     const int tid = threadIdx.x;
     double val = 0.0, gcoef = 0.0;
+    // (the thread's share of the smoothness partials is read here, with the contrast partials, not after their reduction:
+    // one memory round trip of this single-workgroup kernel instead of two)
+    double sm_a = 0.0, sm_b = 0.0;
+    for (int i = tid; i < n_sblocks; i += 1024) {
+        sm_a += spart[2 * (size_t)i];
+        sm_b += spart[2 * (size_t)i + 1];
+    }
     if (!variance) {
         double a = 0.0;
         for (int i = tid; i < n_cblocks; i += 1024) a += cpart[2 * (size_t)i];
@@ -563,13 +570,8 @@ __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ cp
     }
     double smooth = 0.0;
     if (n_sblocks > 0) {
-        double a = 0.0, b = 0.0;
-        for (int i = tid; i < n_sblocks; i += 1024) {
-            a += spart[2 * (size_t)i];
-            b += spart[2 * (size_t)i + 1];
-        }
-        const double sx = block_sum_d<1024>(a, s_red[0]);
-        const double sy = block_sum_d<1024>(b, s_red[1]);
+        const double sx = block_sum_d<1024>(sm_a, s_red[0]);
+        const double sy = block_sum_d<1024>(sm_b, s_red[1]);
         smooth = (double)smooth_weight * ((sx / smooth_count + sy / smooth_count) / 2.0);
     }
     if (tid == 0) {
