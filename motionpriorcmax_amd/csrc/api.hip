@@ -82,6 +82,15 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_knn_cursor = off; off += big_sort ? mpc_align(bt * (int64_t)L.G * sizeof(int32_t)) : 0;
     L.off_knn_reach = off;  off += mpc_align(bt * (int64_t)mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16) * sizeof(float));
     L.off_knn_fail = off;   off += mpc_align((1 + bt * (int64_t)L.G) * sizeof(int32_t));
+    L.knn_lean = (s->B > 0 && mpc_knn_lean(s)) ? 1 : 0;
+    if (L.knn_lean) {
+        int64_t mb, rb, fb, gb;
+        mpc_knn_lean_sizes(s, &mb, &rb, &fb, &gb);
+        L.off_knn_mask = off;   off += mpc_align(mb);
+        L.off_knn_rowtab = off; off += mpc_align(rb);
+        L.off_knn_fbits = off;  off += mpc_align(fb);
+        L.off_knn_gacc = off;   off += mpc_align(gb);
+    }
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;
     L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));

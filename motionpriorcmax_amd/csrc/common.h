@@ -60,6 +60,12 @@ struct mpc_ws_layout {
     int64_t off_knn_cursor;  // int32  [B*nb][G]  fill cursors of the global-memory bucket sort (only when G*4 B exceeds the LDS sort)
     int64_t off_knn_reach;   // float  [B*nb][ceil(hq/16)][ceil(wq/16)]  backward search reach per 16x16 tile
     int64_t off_knn_fail;    // int32  [1 + B*nb*G]  queries handed from the strip kernel to the fallback kernel
+    // scatter backward of the KNN LUT (knn_lean != 0; knn_device.h: KnnLeanBufs), kept from the forward to the backward
+    int32_t knn_lean;
+    int64_t off_knn_mask;    // uint32 [B*nb][strips][3][256]
+    int64_t off_knn_rowtab;  // int2   [B*nb][strips][NR + 1]
+    int64_t off_knn_fbits;   // uint32 [B*nb][hq][ceil(wq/32)]
+    int64_t off_knn_gacc;    // uint64 [1 or 2][B*nb][n]  accumulators of workgroups whose points do not fit their LDS
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, marker
     int64_t off_frec;        // float4 [nfb][fcap]
@@ -89,6 +95,9 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed);
 int mpc_validate_shape(const mpc_shape *s);
+// KNN: does the scatter backward serve this shape, and the sizes of what the forward leaves for it (knn.hip, knn_strip.hip)
+bool mpc_knn_lean(const mpc_shape *s);
+void mpc_knn_lean_sizes(const mpc_shape *s, int64_t *mask_bytes, int64_t *rowtab_bytes, int64_t *fbits_bytes, int64_t *gacc_bytes);
 
 // ---- device helpers ---------------------------------------------------------------------
 #ifdef __HIPCC__

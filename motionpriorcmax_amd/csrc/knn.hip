@@ -28,7 +28,8 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
                                                      int *__restrict__ cell_start,
                                                      float2 *__restrict__ spos, int *__restrict__ sidx, int S,
                                                      float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail,
-                                                     int *__restrict__ zero_ptr, int zero_words) {
+                                                     int *__restrict__ zero_ptr, int zero_words,
+                                                     unsigned *__restrict__ fbits, int fwords) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
     __shared__ int s_low[16];
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
     // atomicMax and its fallback list is appended to (knn_strip.hip)
     if (part == 0) for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;
+    if (part == 0) for (int i = tid; i < fwords; i += 1024) fbits[(size_t)bt * fwords + i] = 0u;      // (scatter backward: map of the fallback's queries)
     if (blockIdx.x == 0 && tid == 0) fail[0] = 0;
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
     const int rows_per = (p.hq + S - 1) / S;
@@ -169,10 +171,12 @@ __global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, con
 __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
                                                           int *__restrict__ cell_start,
                                                           float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail,
-                                                          int *__restrict__ zero_ptr, int zero_words) {
+                                                          int *__restrict__ zero_ptr, int zero_words,
+                                                          unsigned *__restrict__ fbits, int fwords) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, bt = blockIdx.x;
     for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;       // (see k_knn_bucket)
+    for (int i = tid; i < fwords; i += 1024) fbits[(size_t)bt * fwords + i] = 0u;
     if (bt == 0 && tid == 0) fail[0] = 0;
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
     int *cur = cursor + (size_t)bt * p.G;
@@ -921,12 +925,14 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_HALO=<h>        rings staged beyond the initial radius by the query kernel        [1]
 //   MPC_KNN_STRIP=0         tile query kernel (k_knn_query) also where the strip kernel applies  [1]
 //   MPC_KNN_BWD_FUSED=0     backward as k_knn_reach + k_knn_bwd_points also where k_knn_bwd_tile applies [1]
+//   MPC_KNN_BWD_SCATTER=0   gather backward (k_knn_bwd_tile) also where the scatter backward applies    [1]
+//   MPC_KNN_BWD_G=<g>       strips per workgroup of the scatter backward                               [by grid size]
 struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s;
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s, bwd_scatter;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0, 1};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -938,6 +944,7 @@ static const KnnTuning &knn_tuning() {
         if ((e = getenv("MPC_KNN_STRIP"))) v.strip = atoi(e) != 0;
         if ((e = getenv("MPC_KNN_BWD_FUSED"))) v.bwd_fused = atoi(e) != 0;
         if ((e = getenv("MPC_KNN_BUCKET_S"))) v.bucket_s = atoi(e);
+        if ((e = getenv("MPC_KNN_BWD_SCATTER"))) v.bwd_scatter = atoi(e) != 0;
         return v;
     }();
     return t;
@@ -949,6 +956,27 @@ int mpc_knn_r_init(const mpc_shape *s) {
     int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
     r_init += knn_tuning().r0;
     return r_init < 1 ? 1 : r_init;
+}
+
+// The backward of this shape is the query-centric scatter (knn_bwd_scatter.hip): the strip kernel serves the forward
+// (whatever idx_out), one reference time, 'mean' interpolation.
+bool mpc_knn_lean(const mpc_shape *s) {
+    const KnnTuning &t = knn_tuning();
+    if (!t.bwd_scatter || !t.strip || t.global_mode) return false;
+    if (s->T != 1 || ((s->flags & MPC_F_SCHEME_IWD) && s->K > 1)) return false;
+    if (s->n < s->K || s->K < 1) return false;
+    return mpc_knn_strip_usable(s, mpc_knn_r_init(s)) && mpc_knn_bwd_scatter_usable(s);
+}
+
+void mpc_knn_lean_sizes(const mpc_shape *s, int64_t *mask_bytes, int64_t *rowtab_bytes, int64_t *fbits_bytes, int64_t *gacc_bytes) {
+    KnnStripGeom g;
+    *mask_bytes = *rowtab_bytes = *fbits_bytes = *gacc_bytes = 0;
+    if (!mpc_knn_strip_geom(s, mpc_knn_r_init(s), &g)) return;
+    const int64_t bt = (int64_t)s->B * s->nb, strips = (int64_t)g.gx * g.gy;
+    *mask_bytes = bt * strips * 3 * 256 * 4;
+    *rowtab_bytes = bt * strips * (g.NR + 1) * 8;
+    *fbits_bytes = bt * s->hq * ((s->wq + 31) / 32) * 4;
+    *gacc_bytes = bt * (int64_t)s->n * 8 * ((s->flags & MPC_F_WANT_NEXT) ? 2 : 1);
 }
 
 static int set_max_lds(const void *fn, const char *who) {
@@ -983,6 +1011,14 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     const int ntiles = mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16);
     int *zero_ptr = (int *)((char *)ws + L.off_fcount);
     const int zero_words = (zero_event_counters && L.strip_rows > 0) ? L.nfb + L.nbb + 8 : 0;
+    KnnLeanBufs lean{nullptr, nullptr, nullptr};
+    if (L.knn_lean) {
+        lean.masks = (unsigned *)((char *)ws + L.off_knn_mask);
+        lean.rowtab = (int2 *)((char *)ws + L.off_knn_rowtab);
+        lean.fbits = (unsigned *)((char *)ws + L.off_knn_fbits);
+    }
+    unsigned *lean_fbits = lean.fbits;
+    const int lean_fwords = L.knn_lean ? s->hq * ((s->wq + 31) / 32) : 0;
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
@@ -1006,13 +1042,13 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         if (e) return e;
         const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
         hipLaunchKernelGGL(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
-        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words);
+        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
         hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
     } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words);
+        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
     else
-        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words);
+        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
@@ -1020,7 +1056,11 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     const int r_init = mpc_knn_r_init(s);
     // fast path (num_tref == 1, the shipped configurations): strip kernel + per-query fallback (knn_strip.hip)
     if (tune.strip && !tune.global_mode && idx_out == nullptr && mpc_knn_strip_usable(s, r_init))
-        return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, st);
+        return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init,
+                                    L.knn_lean ? &lean : nullptr, st);
+    // (idx_out wanted where the scatter backward applies: the tile kernel below writes the indices, then the strip
+    // kernels run as well so that the state the backward expects exists -- a diagnostics path)
+    const bool also_strip = L.knn_lean && idx_out != nullptr;
     const int want_blocks = tune.blocks, want_nt = tune.nt;
     int RH = r_init + (tune.halo > 0 ? tune.halo : 1);     // halo of the staged region: one ring of slack by default
     if (RH > 16) RH = 16;
@@ -1067,6 +1107,8 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         hipLaunchKernelGGL(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
                            flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
     MPC_CHECK_LAUNCH();
+    if (also_strip)
+        return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, &lean, st);
     return 0;
 }
 
@@ -1096,6 +1138,18 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, false>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, true>, __func__))) return rc;
         attr_once.mark();
+    }
+    if (L.knn_lean) {
+        // scatter backward: every query adds dLUT / K to its neighbours, read from the bit masks the strip kernel left
+        KnnLeanBufs lean{(unsigned *)((char *)ws + L.off_knn_mask), (int2 *)((char *)ws + L.off_knn_rowtab),
+                         (unsigned *)((char *)ws + L.off_knn_fbits)};
+        if ((rc = mpc_knn_bwd_scatter_launch(s, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, knn_state, &lean,
+                                             (unsigned long long *)((char *)ws + L.off_knn_gacc), tmp_g, tmp_a, st))) return rc;
+        const int64_t totalb = (int64_t)s->B * s->n;
+        hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
+                           grad_flow_next ? tmp_a : nullptr, grad_traj);
+        MPC_CHECK_LAUNCH();
+        return 0;
     }
     const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
     if (s->T == 1 && !p.iwd && knn_tuning().bwd_ts == 16 && knn_tuning().bwd_fused) {

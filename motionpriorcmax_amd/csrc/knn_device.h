@@ -468,6 +468,7 @@ __device__ __forceinline__ unsigned knn_query_classes(const KnnParams &p, int cy
 // one query's K-th distance into the tile maxima (atomicMax on the bits of a non-negative float)
 __device__ __forceinline__ void knn_tile_max_add(float *__restrict__ tile_dkmax, const KnnParams &p, int bt, int cy, int cx,
                                                  int bd, float dK) {
+    if (tile_dkmax == nullptr) return;          // scatter backward: no tile maxima
     const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
     int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4)) * KNN_NCLS;
     const unsigned m = knn_query_classes(p, cy, cx, bd);
@@ -476,10 +477,41 @@ __device__ __forceinline__ void knn_tile_max_add(float *__restrict__ tile_dkmax,
 }
 #endif
 
+#ifdef __HIPCC__
+// search square of a query (the rule of knn_one_query): next to the image border the clipped square starts with the
+// cell count of an unclipped one
+__device__ __forceinline__ int query_radius(const KnnParams &p, int cy, int cx, int r_init) {
+    const int want = (2 * r_init + 1) * (2 * r_init + 1);
+    int r = r_init;
+    for (;;) {
+        const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
+        const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
+        if (hh * ww >= want || (hh == p.hq && ww == p.wq)) break;
+        ++r;
+    }
+    return r;
+}
+#endif
+
 // ---- strip kernel (knn_strip.hip): the fast path of the forward for num_tref == 1 ---------------------------
 // `fail` = int [1 + B*nb*G]: fail[0] counts the queries handed to the fallback kernel (zeroed, like tile_dkmax, by the
 // bucket kernels), fail[1..] lists them.
 bool mpc_knn_strip_usable(const mpc_shape *s, int r_init);
+// geometry of the strip kernel's launch: strips of WS query columns x TH rows, gx x gy of them per (sample, bin), NR region
+// rows and `cap` staged slots per strip
+struct KnnStripGeom { int WS, TH, gx, gy, NR, cap; size_t lds; };
+bool mpc_knn_strip_geom(const mpc_shape *s, int r_init, KnnStripGeom *g);
+// what the strip kernel leaves for the scatter backward (knn_bwd_scatter.hip), all in the workspace:
+//   masks  uint32 [B*nb][gy*gx][3][256]   neighbours of every query as bits over its slot range (query = row-major in the strip)
+//   rowtab int2   [B*nb][gy*gx][NR + 1]   {first bucketed point, first slot | points << 16} of every region row; then {slots, 0}
+//   fbits  uint32 [B*nb][hq][ceil(wq/32)] queries served by the fallback kernel (zeroed by the bucket kernels)
+struct KnnLeanBufs { unsigned *masks; int2 *rowtab; unsigned *fbits; };
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
-                         hipStream_t st);
+                         const KnnLeanBufs *lean, hipStream_t st);
+// true where the backward of this shape is the scatter kernel (strip forward, num_tref == 1, 'mean'; MPC_KNN_BWD_SCATTER=0: off)
+bool mpc_knn_lean(const mpc_shape *s);
+bool mpc_knn_bwd_scatter_usable(const mpc_shape *s);
+int mpc_knn_bwd_scatter_launch(const mpc_shape *s, const int *cell_start, const float2 *spos, const int *sidx,
+                               const float *grad_flow_lut, const float *grad_flow_next, const float *knn_state,
+                               const KnnLeanBufs *lean, unsigned long long *gacc, float2 *tmp_g, float2 *tmp_a, hipStream_t st);

@@ -43,29 +43,21 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-// search square of a query (the rule of knn_one_query): next to the image border the clipped square starts with the
-// cell count of an unclipped one
-__device__ __forceinline__ int query_radius(const KnnParams &p, int cy, int cx, int r_init) {
-    const int want = (2 * r_init + 1) * (2 * r_init + 1);
-    int r = r_init;
-    for (;;) {
-        const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
-        const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
-        if (hh * ww >= want || (hh == p.hq && ww == p.wq)) break;
-        ++r;
-    }
-    return r;
-}
-
 // 1-D grid of gx * gy * B * nb workgroups (gx strips, gy row blocks) in XCD-contiguous order, 256 threads,
 // dynamic LDS sized by the launcher
-template <int WS, bool L1, bool NEXT, bool IWD>
+// LEAN: the backward is the query-centric scatter of knn_bwd_scatter.hip, which reads each query's neighbours from a
+// bit mask over its slot range (`mask_out`: three words per query, bit 8 u + j of word m <-> slot 32 m + 4 j + u) and
+// the strip's row table (`rowtab_out`) instead of re-deriving them from the K-th key: no K-th key, tie flag or tile
+// maxima are written for the queries served here; the queries handed to the fallback kernel are flagged in `fbits`.
+template <int WS, bool L1, bool NEXT, bool IWD, bool LEAN>
 __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
                                                      const int *__restrict__ cell_start,
                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                     int *__restrict__ fail, int r_init, int cap, int gx, int gy) {
+                                                     int *__restrict__ fail, int r_init, int cap, int gx, int gy,
+                                                     unsigned *__restrict__ mask_out, int2 *__restrict__ rowtab_out,
+                                                     unsigned *__restrict__ fbits) {
     constexpr int TH = KS_NT / WS;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
@@ -159,14 +151,29 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
     if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int2(gs, len); }
     if (tid == NR - 1) s_rowstart[NR] = run + padded;
+    if (LEAN) {      // row table of the strip for the backward: {first bucketed slot, first slot | points << 16}, then the slot total
+        int2 *rt = rowtab_out + (size_t)lblk * (NR + 1);
+        if (tid < NR) rt[tid] = make_int2(gs, (run & 0xffff) | (max(len, 0) << 16));
+        if (tid == NR - 1) rt[NR] = make_int2(run + padded, 0);
+    }
     // row pitch of the staging loop = the longest row of the region
     const int pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
     __syncthreads();
     const int total = s_rowstart[NR];
     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
+    // LEAN: this query's place in the strip's block of the mask planes, and its bit in the map of failed queries
+    const int qi = (cy - qy0) * WS + (cx - qx0);
+    unsigned *mq = LEAN ? mask_out + (size_t)lblk * (3 * KS_NT) + qi : nullptr;
+    const int fwpr = (p.wq + 31) >> 5;
     if (total > cap) {
         // the points of this strip do not fit the staging area (heavily clustered input): every query goes to the list
-        if (valid) fail[1 + atomicAdd(&fail[0], 1)] = (int)((unsigned)q | (3u << 30));
+        if (valid) {
+            fail[1 + atomicAdd(&fail[0], 1)] = (int)((unsigned)q | (3u << 30));
+            if (LEAN) {
+                mq[0] = 0u; mq[KS_NT] = 0u; mq[2 * KS_NT] = 0u;
+                atomicOr(&fbits[((size_t)bt * p.hq + cy) * fwpr + (cx >> 5)], 1u << (cx & 31));
+            }
+        }
         return;
     }
     // ---- stage positions, flows and indices: item = (region row, k-th slot of the row), KS_SB items per thread
@@ -317,8 +324,10 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     const bool do_next = NEXT && (t < p.nb - 1);
     float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
     unsigned E[(KS_MAXCH + 7) / 8];
+    unsigned Mm[(KS_MAXCH + 7) / 8];     // LEAN: the neighbours of the query, same bit <-> slot map as E
 #pragma unroll
-    for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) E[e] = 0u;
+    for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) { E[e] = 0u; Mm[e] = 0u; }
+    const unsigned cl4 = ((live ? (unsigned)bstar : 0u) + 127u) * 0x01010101u;      // bit 7 of (cl4 - byte) <=> level < bstar
     const float ubf = live ? (float)bstar : 0.f;             // dead lanes: nothing is below level 0 ...
     // slots AT level bstar, by a SWAR zero-byte test per word: z = w ^ (bstar in every byte) has bytes <= 127, so
     // (0x80 - byte) keeps bit 7 exactly for byte == 0 and no borrow crosses a byte.  The four flags of word j (of the
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                 const int j = (2 * g + h) & 7;
                 const unsigned f7 = 0x80808080u - (w[2 * g + h] ^ ue4);
                 E[g / 4] |= (f7 >> (7 - j)) & (0x01010101u << j);
+                if (LEAN) Mm[g / 4] |= ((cl4 - w[2 * g + h]) >> (7 - j)) & (0x01010101u << j);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -367,17 +377,18 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     bool tie = false;                 // a point at exactly the K-th distance that is NOT a neighbour (higher index): KNN_TIE_FLAG
     const bool heavy = live && inbin > KS_LMAX;
     {
-        float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX];
+        float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX], kraw[KS_LMAX];
         const bool light = live && !heavy;
         const int mmax = __builtin_amdgcn_readfirstlane(wave_max_i(light ? inbin : 0));
         unsigned long long em = ((unsigned long long)E[1] << 32) | E[0];
         unsigned e2 = E[2];
 #pragma unroll
         for (int a = 0; a < KS_LMAX; ++a) {
-            dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0;
+            dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0; kraw[a] = 0;
             if (a < mmax) {
                 int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // a bit still in the mask ...
                 if (em) em &= em - 1ull; else e2 &= e2 - 1u;
+                kraw[a] = k;
                 k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
                 if (light && k >= 0) {
                     const float2 pj = pp[k];
@@ -400,6 +411,10 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                     else { sy_ += f.x; sx_ += f.y; }
                     if (do_next) { const float2 g2 = pn[jj[a]]; ny_ += g2.x; nx_ += g2.y; }
                     if (rank == need - 1) { dK = dd[a]; iK = ii[a]; }
+                    if (LEAN) {
+                        const unsigned bit = 1u << (kraw[a] & 31);
+                        Mm[0] |= kraw[a] < 32 ? bit : 0u; Mm[1] |= (kraw[a] >= 32 && kraw[a] < 64) ? bit : 0u; Mm[2] |= kraw[a] >= 64 ? bit : 0u;
+                    }
                 }
             }
         }
@@ -464,6 +479,15 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             }
             const bool htie = __ballot((b0 && d0 == cdk && i0 > cik) || (b1 && d1 == cdk && i1 > cik)) != 0ull;
             if (lane == h) { sy_ += cy_; sx_ += cx_; sw_ += cw_; ny_ += cny; nx_ += cnx; dK = cdk; iK = cik; tie = htie; }
+            if (LEAN) {
+                // the selected slots as mask bits: bit `l` of a word belongs to slot 4 (l & 7) + (l >> 3) of its 32 slots,
+                // i.e. to the lane of that number: fetch that lane's flag, then a ballot is the word
+                const int src = (lane & 32) + 4 * (lane & 7) + ((lane & 31) >> 3);
+                const int sel0 = (b0 && r0_ < hneed) ? 1 : 0, sel1 = (b1 && r1_ < hneed) ? 1 : 0;
+                const unsigned long long w01 = __ballot(__shfl(sel0, src, 64) != 0);
+                const unsigned long long w2 = __ballot(lane < 32 && __shfl(sel1, src, 64) != 0);
+                if (lane == h) { Mm[0] |= (unsigned)w01; Mm[1] |= (unsigned)(w01 >> 32); Mm[2] |= (unsigned)w2; }
+            }
         }
     }
     // ---- outputs ---------------------------------------------------------------------------------------
@@ -477,12 +501,19 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             float2 on; on.x = ny_ / (float)p.K; on.y = nx_ / (float)p.K;
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
-        knn_state[q] = dK;
-        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
+        if (!LEAN) {
+            knn_state[q] = dK;
+            reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
+        }
 #ifdef KS_DEBUG_INBIN
         norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
-#endif
         knn_state[2 * BQ + q] = norm;
+#else
+        if (IWD) knn_state[2 * BQ + q] = norm;         // (the 'mean' backward never reads the normaliser)
+#endif
+    }
+    if (LEAN && valid) {
+        mq[0] = live ? Mm[0] : 0u; mq[KS_NT] = live ? Mm[1] : 0u; mq[2 * KS_NT] = live ? Mm[2] : 0u;
     }
     {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
         const bool push = valid && !live;
@@ -493,11 +524,12 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
             base = __shfl(base, first, 64);
             if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | (why << 30));
+            if (LEAN && push) atomicOr(&fbits[((size_t)bt * p.hq + cy) * fwpr + (cx >> 5)], 1u << (cx & 31));
         }
     }
-    // largest K-th distance per 16x16 cell tile (bounds the search windows of the backward): a wavefront covers
+    // largest K-th distance per 16x16 cell tile (bounds the search windows of the gather backward): a wavefront covers
     // 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
-    {
+    if (!LEAN) {
         // per class of query (knn_device.h): only wavefronts next to the image border hold anything but class 0
         const int bd = knn_band_depth(r_init);
         const unsigned cls = live ? knn_query_classes(p, cy, cx, bd) : 0u;
@@ -724,40 +756,61 @@ bool mpc_knn_strip_usable(const mpc_shape *s, int r_init) {
     return strip_geometry(s, r_init, 2, &cap, &lds);
 }
 
+bool mpc_knn_strip_geom(const mpc_shape *s, int r_init, KnnStripGeom *g) {
+    int cap; size_t lds;
+    if (!strip_geometry(s, r_init, 2, &cap, &lds)) return false;
+    g->WS = 2; g->TH = KS_NT / 2; g->gx = mpc_cdiv(s->wq, 2); g->gy = mpc_cdiv(s->hq, KS_NT / 2);
+    g->NR = g->TH + 4 * r_init; g->cap = cap; g->lds = lds;
+    return true;
+}
+
 template <int WS>
 static void launch_strip(const KnnParams &p, const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos,
                          const int *sidx, float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail,
-                         int r_init, int cap, size_t lds, hipStream_t st) {
+                         int r_init, int cap, size_t lds, const KnnLeanBufs *lean, hipStream_t st) {
     const int TH = KS_NT / WS;
     const int gx = mpc_cdiv(s->wq, WS), gy = mpc_cdiv(s->hq, TH);
     const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
-#define KS_LAUNCH(L1_, NEXT_, IWD_)                                                                                       \
-    hipLaunchKernelGGL((k_knn_strip<WS, L1_, NEXT_, IWD_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx,  \
-                       flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy)
+    unsigned *mk = lean ? lean->masks : nullptr, *fb = lean ? lean->fbits : nullptr;
+    int2 *rt = lean ? lean->rowtab : nullptr;
+#define KS_LAUNCH(L1_, NEXT_, IWD_, LEAN_)                                                                                    \
+    hipLaunchKernelGGL((k_knn_strip<WS, L1_, NEXT_, IWD_, LEAN_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx, \
+                       flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy, mk, rt, fb)
     const int sel = (p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0);
+    if (lean) {                  // (never with 'iwd': its backward is the gather)
+        switch (sel) {
+        case 0: KS_LAUNCH(false, false, false, true); break;
+        case 2: KS_LAUNCH(false, true, false, true); break;
+        case 4: KS_LAUNCH(true, false, false, true); break;
+        default: KS_LAUNCH(true, true, false, true); break;
+        }
+        return;
+    }
     switch (sel) {
-    case 0: KS_LAUNCH(false, false, false); break;
-    case 1: KS_LAUNCH(false, false, true); break;
-    case 2: KS_LAUNCH(false, true, false); break;
-    case 3: KS_LAUNCH(false, true, true); break;
-    case 4: KS_LAUNCH(true, false, false); break;
-    case 5: KS_LAUNCH(true, false, true); break;
-    case 6: KS_LAUNCH(true, true, false); break;
-    default: KS_LAUNCH(true, true, true); break;
+    case 0: KS_LAUNCH(false, false, false, false); break;
+    case 1: KS_LAUNCH(false, false, true, false); break;
+    case 2: KS_LAUNCH(false, true, false, false); break;
+    case 3: KS_LAUNCH(false, true, true, false); break;
+    case 4: KS_LAUNCH(true, false, false, false); break;
+    case 5: KS_LAUNCH(true, false, true, false); break;
+    case 6: KS_LAUNCH(true, true, false, false); break;
+    default: KS_LAUNCH(true, true, true, false); break;
     }
 #undef KS_LAUNCH
 }
 
+// `lean`: buffers of the scatter backward (knn_bwd_scatter.hip), or null for the gather backward (K-th keys + tile maxima)
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
-                         hipStream_t st) {
+                         const KnnLeanBufs *lean, hipStream_t st) {
     const KnnParams p = knn_params(s);
     int cap = 0; size_t lds = 0;
     if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
-    launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, st);
+    if (lean && p.iwd) { mpc_set_error("mpc_knn_strip_launch: the scatter backward does not serve 'iwd'"); return MPC_E_UNSUPPORTED; }
+    launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, lean, st);
     MPC_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_knn_fallback, dim3(256), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
-                       knn_state, tile_dkmax, fail, r_init);
+                       knn_state, lean ? nullptr : tile_dkmax, fail, r_init);
     MPC_CHECK_LAUNCH();
     return 0;
 }
