@@ -94,38 +94,80 @@ def stage_bytes(B, M, nb, n, T=1, P=2):
     }
 
 
-# kernels behind each C-ABI stage (for the PMC traffic figure)
-# the kernel that carries (almost all of) a stage's time, per the committed rocprofv3 summaries
-DOMINANT_KERNEL = {'mpc_knn_lut_fwd': 'k_knn_strip', 'mpc_knn_lut_bwd': 'k_knn_bwd_tile', 'mpc_event_splat_fwd': 'k_ev_bin',
-                   'mpc_event_splat_bwd': 'k_lut_accum', 'mpc_contrast_fwd': 'k_contrast_fused', 'mpc_lut_smooth': 'k_lut_smooth',
-                   'mpc_finalize': 'k_finalize'}
-STAGE_KERNELS = {
-    'mpc_knn_lut_fwd': ['k_knn_bucket', 'k_knn_strip', 'k_knn_fallback', 'k_knn_query'],
-    'mpc_knn_lut_bwd': ['k_knn_bwd_tile', 'k_knn_reach', 'k_knn_bwd_points', 'k_knn_bwd_combine'],
-    'mpc_event_splat_fwd': ['k_ev_bin', 'k_iwe_accum', 'k_iwe_overflow', 'k_splat_fwd_atomic'],
-    'mpc_event_splat_bwd': ['k_lut_accum', 'k_lut_overflow', 'k_splat_bwd_atomic'],
-    'mpc_contrast_fwd': ['k_contrast_fused', 'k_contrast_fwd', 'k_contrast_bwd_var', 'k_image_means'],
-    'mpc_lut_smooth': ['k_lut_smooth'], 'mpc_finalize': ['k_finalize'], 'mpc_scale': ['k_scale'],
-}
+# Kernels behind each C-ABI stage.  Not a hand-kept table: the kernels are the ones the committed rocprofv3 kernel-trace
+# summary of the workload lists (profiles/r<NN>_rocprofv3_kernel_stats_<workload>.csv, newest round present), attributed to
+# a stage by the naming rule of csrc/ (one prefix per stage), and the dominant kernel of a stage is the one with the
+# largest total time in that summary.
+STAGE_PREFIXES = (          # first match wins
+    ('mpc_knn_lut_bwd', ('k_knn_bwd', 'k_knn_reach')),
+    ('mpc_knn_lut_fwd', ('k_knn_',)),
+    ('mpc_event_splat_bwd', ('k_lut_accum', 'k_splat_bwd', 'k_lut_overflow')),
+    ('mpc_event_splat_fwd', ('k_ev_bin', 'k_iwe_', 'k_splat_fwd')),
+    ('mpc_lut_smooth', ('k_lut_smooth',)),
+    ('mpc_contrast_fwd', ('k_contrast', 'k_image_means')),
+    ('mpc_finalize', ('k_finalize',)),
+    ('mpc_scale', ('k_scale',)),
+)
+
+
+def stage_of_kernel(name):
+    for stage, prefixes in STAGE_PREFIXES:
+        if any(name.startswith(p) for p in prefixes):
+            return stage
+    return None
+
+
+def _short_kernel_name(full):
+    return full.split('(')[0].replace('void ', '').split('<')[0].strip()
+
+
+def profile_kernels(workload):
+    """{stage: [(kernel, total_ns, avg_ns, calls), ...] sorted by total time} from the newest committed kernel-trace summary of
+    `workload`, and the file it came from; ({}, None) if there is none."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_rocprofv3_kernel_stats_{workload}.csv')))
+    if not files:
+        return {}, None
+    agg = {}
+    for r in csv.DictReader(open(files[-1])):
+        k = _short_kernel_name(r['Name'])
+        st = stage_of_kernel(k)
+        if st is None:
+            continue
+        t = agg.setdefault(st, {}).setdefault(k, [0.0, 0])
+        t[0] += float(r['TotalDurationNs']); t[1] += int(r['Calls'])
+    out = {st: sorted(((k, v[0], v[0] / max(v[1], 1), v[1]) for k, v in ks.items()), key=lambda x: -x[1]) for st, ks in agg.items()}
+    return out, os.path.relpath(files[-1], ROOT)
 
 
 def pmc_traffic(workload, stage):
-    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC summary of this workload
-    (profiles/traffic_<workload>.json, made by tools/summarize_pmc.py from separate FETCH_SIZE and
-    WRITE_SIZE passes; gfx950 x2 correction on the read side).  None if no summary is present."""
+    """HBM-side bytes per step of `stage` from the committed rocprofv3 PMC summary of this workload
+    (profiles/traffic_<workload>.json, tools/summarize_pmc.py: separate FETCH_SIZE and WRITE_SIZE passes), summed over
+    the kernels the kernel-trace summary attributes to the stage.  Returns (upper, lower): the read counter doubled as the
+    calibration in the same file prescribes for reads served from HBM (gfx950 tallies 128-byte requests at 64), and the raw
+    counters -- a kernel whose reads hit the Infinity Cache lies between the two.  (None, None) without a summary."""
     f = os.path.join(ROOT, 'profiles', f'traffic_{workload}.json')
-    if not os.path.exists(f):
-        return None
+    ks, _ = profile_kernels(workload)
+    if not os.path.exists(f) or stage not in ks:
+        return None, None
     d = json.load(open(f))
-    tot = sum(d[k]['hbm_bytes_per_launch'] for k in STAGE_KERNELS.get(stage, []) if k in d)
-    return round(tot) if tot > 0 else None
+    up = lo = 0.0
+    for k, _, _, calls in ks[stage]:
+        if k in d:
+            per_step = d[k].get('launches_per_step', 1)
+            up += per_step * (d[k]['hbm_bytes_upper'] if 'hbm_bytes_upper' in d[k] else d[k]['hbm_bytes_per_launch'])
+            lo += per_step * (d[k]['hbm_bytes_lower'] if 'hbm_bytes_lower' in d[k] else d[k]['hbm_bytes_per_launch_raw'])
+    return (round(up), round(lo)) if up > 0 else (None, None)
 
 
 def knn_ceiling(workload, stages, B, nb):
-    """The KNN stage against the ceiling that applies to it (it is VALU-issue bound, not HBM bound): queries per second
-    from the live stage times, and the share of the chip's vector-instruction issue slots its dominant kernels used, from
-    the committed SQ-counter summary of this workload (profiles/r02_sq_<workload>.csv: SQ_INSTS_VALU per launch and the
-    kernel's duration in the same profile; one VALU instruction occupies its SIMD for 4 cycles, 1024 SIMDs, 2.4 GHz)."""
+    """The KNN stages against the ceiling that applies to them (VALU issue, not HBM): queries per second from the LIVE stage
+    times; and, clearly marked as FROM THE COMMITTED PROFILE (not re-measured by this run, and only valid for the library
+    that profile was taken with), the share of the chip's vector-instruction issue slots their dominant kernels used
+    (profiles/r<NN>_sq_<workload>.json: SQ_INSTS_VALU per launch x 4 cycles / (duration x SIMDs x clock); SIMD count and
+    clock from the device properties when a GPU is present)."""
+    import glob
     Q = (H // SP) * (W // SP)
     out = {}
     fwd = stages.get('mpc_knn_lut_fwd'); bwd = stages.get('mpc_knn_lut_bwd')
@@ -134,16 +176,25 @@ def knn_ceiling(workload, stages, B, nb):
         out['fwd_us'] = round(fwd['us_per_step'], 1)
     if bwd and bwd['us_per_step'] > 0:
         out['bwd_us'] = round(bwd['us_per_step'], 1)
-    f = os.path.join(ROOT, 'profiles', f'r02_sq_{workload}.json')
-    if os.path.exists(f):
-        d = json.load(open(f))
-        for key in ('k_knn_strip', 'k_knn_bwd_tile'):
-            if key in d:
-                k = d[key]
-                out[key] = {'valu_wave_instr_per_launch': k['valu_insts'], 'kernel_us_in_profile': k['kernel_us'],
-                            'valu_issue_frac': round(k['valu_insts'] * 4.0 / (k['kernel_us'] * 1e-6 * 2.4e9 * 1024), 3),
-                            'wait_any_frac': k.get('wait_any_frac')}
-        out['source'] = f'profiles/r02_sq_{workload}.json (rocprofv3 --pmc SQ passes, tools/sq_profile.sh)'
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_sq_{workload}.json')))
+    if files:
+        d = json.load(open(files[-1]))
+        simds, ghz = 1024, 2.4
+        try:
+            pr = torch.cuda.get_device_properties(0)
+            simds = pr.multi_processor_count * 4
+            ghz = getattr(pr, 'clock_rate', 2400000) / 1e6
+        except Exception:
+            pass
+        prof = {}
+        for key, k in d.items():
+            if isinstance(k, dict) and stage_of_kernel(key) in ('mpc_knn_lut_fwd', 'mpc_knn_lut_bwd') and k.get('kernel_us', 0) > 20:
+                prof[key] = {'valu_wave_instr_per_launch': k['valu_insts'], 'kernel_us_in_profile': k['kernel_us'],
+                             'valu_issue_frac': round(k['valu_insts'] * 4.0 / (k['kernel_us'] * 1e-6 * ghz * 1e9 * simds), 3),
+                             'wait_any_frac': k.get('wait_any_frac')}
+        out['from_committed_profile'] = {'file': os.path.relpath(files[-1], ROOT), 'library': d.get('_library'),
+                                         'assumes': f'{simds} SIMDs at {ghz:.2f} GHz, 4 cycles per vector instruction',
+                                         'kernels': prof}
     return out
 
 
@@ -229,9 +280,10 @@ def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no rank environment: this process becomes the PARENT of the run,
     as `scripts/flow_training.py:125-128` fans out from one command (`devices=args.gpus`).  It starts N fresh ranks
     (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one per GPU, rendezvous on 127.0.0.1),
-    relays rank 0's JSON line and exits non-zero if any rank fails.  The parent never touches the GPU (no
-    torch.cuda call other than device_count(), which does not initialise HIP), so nothing is re-exec'ed from a
-    process that holds the device."""
+    relays rank 0's JSON line (the line that carries the "metric" key) and exits non-zero if any rank fails.  The parent
+    only COUNTS the devices (torch.cuda.device_count(); on a ROCm build without amdsmi that call may initialise the HIP
+    runtime in the parent -- harmless, because the ranks are fresh child processes started with subprocess, never an exec of
+    this one) and launches nothing on a GPU itself."""
     import subprocess
     dry = os.environ.get('MPC_BENCH_DRYRUN') == '1'
     shared_gpu = os.environ.get('MPC_BENCH_BACKEND', 'nccl') != 'nccl'
@@ -245,7 +297,7 @@ def launch_ranks(args, argv):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
     if r.returncode != 0 or len(lines) != 1:
         sys.stderr.write(r.stdout[-4000:])
         raise SystemExit(r.returncode if r.returncode != 0 else 1)
@@ -378,6 +430,7 @@ def main():
 
         # instrumented pass: HIP events around every C-ABI call, on the stream they launch on
         stages = {}
+        kernels = {}
         if instrument:
             ops.STAGE_TIMER = ops.StageTimer()
             for _ in range(steps):
@@ -386,6 +439,14 @@ def main():
                 trajd.grad = None
             stages = ops.STAGE_TIMER.summary()
             ops.STAGE_TIMER = None
+            # ... and HIP events around every KERNEL (recorded by the library on its launch stream), over the same steps issued
+            # exactly as the timed loop issues them (mpc_focus_fwd / mpc_focus_bwd)
+            with ops.KernelTimer() as kt:
+                for _ in range(steps):
+                    loss, _, _ = L.calc(trajd, times_d, batch)
+                    loss.backward()
+                    trajd.grad = None
+            kernels = kt.summary()
         # the same step captured once into a HIP graph and replayed (static shapes; N = 1 only): what the host-side
         # launch overhead of the eager path costs -- reported beside the eager number, never as `value`
         graph_ms = None
@@ -466,7 +527,7 @@ def main():
             lb.backward()
             check = {'loss_rel_diff_vs_atomic_path': abs(la.item() - lb.item()) / abs(lb.item()),
                      'grad_rel_l2_vs_atomic_path': float((ta.grad - tb.grad).norm() / tb.grad.norm())}
-        return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, graph_ms=graph_ms,
+        return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, kernels=kernels, graph_ms=graph_ms,
                     loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered)
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
@@ -500,16 +561,43 @@ def main():
         ach = d['algorithmic_MB'] * 1e6 / (d['us_per_step'] * 1e-6) / 1e9 if d['us_per_step'] > 0 else 0.0
         gpu_us = sum(v['us_per_step'] for v in per_step.values())
         path_b = algorithmic_bytes(wl_['B'], wl_['M'], wl_['nb'])
+        pk, pfile = profile_kernels(wname) if wname else ({}, None)
+        in_stage = [k for k, _, _, _ in pk.get(dom, [])]
+        # live per-kernel durations (HIP events recorded by the library around every launch of these steps)
+        live = {k: {'us_per_launch': round(v['avg_us'], 2), 'launches_per_step': round(v['launches'] / res['steps'], 2),
+                    'stage': stage_of_kernel(k)} for k, v in sorted(res.get('kernels', {}).items(), key=lambda kv: -kv[1]['total_us'])}
+        dom_k = next(iter(live), None)
+        if dom_k is not None and live[dom_k]['stage'] in per_step:
+            # the dominant KERNEL of the step and its own duration: algorithmic bytes of its stage per launch / that duration
+            dom = live[dom_k]['stage']
+            d = dict(per_step[dom])
+            d['us_per_step'] = live[dom_k]['us_per_launch'] * live[dom_k]['launches_per_step']
+            ach = d['algorithmic_MB'] * 1e6 / (d['us_per_step'] * 1e-6) / 1e9 if d['us_per_step'] > 0 else 0.0
+            in_stage = [k for k in live if live[k]['stage'] == dom]
+        t_up, t_lo = pmc_traffic(wname, dom) if wname else (None, None)
+        ev_path = event_path_roofline(per_step, wl_)
+        if live:
+            # the per-kernel times supersede the stage brackets for the sums (a stage bracket also holds the gaps between its
+            # kernels and, for the staged entry points, launches the fused calls do not make)
+            gpu_us = sum(v['us_per_launch'] * v['launches_per_step'] for v in live.values())
+            ev_us = sum(v['us_per_launch'] * v['launches_per_step'] for v in live.values()
+                        if v['stage'] in ('mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_event_splat_bwd', 'mpc_finalize'))
+            if ev_us > 0:
+                ev_path = {'us_per_step': round(ev_us, 1), 'achieved': round(path_b / (ev_us * 1e-6) / 1e9, 1),
+                           'frac': round(path_b / (ev_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'from': 'per-kernel HIP events'}
         return {
-            'bound': 'hbm', 'kernel': DOMINANT_KERNEL.get(dom, dom), 'stage': dom,
-            'note': 'HIP events bracket the C-ABI stage (all kernels_in_stage); the rocprofv3 summary in profiles/ splits it'
+            'bound': 'hbm', 'kernel': dom_k if dom_k is not None else (in_stage[0] if in_stage else dom), 'stage': dom,
+            'note': 'kernel_us = the average launch of `kernel`, HIP events recorded by the library around that launch on its stream, '
+                    'over the timed steps (kernels_us has every kernel); achieved = algorithmic bytes of its stage / kernel_us'
                     + ('; this stage is VALU-issue bound (exact K-nearest selection: `knn` below has its queries/s and issue-slot '
                        'share), the HBM fraction is reported as measured' if dom.startswith('mpc_knn') else ''),
             'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(wname, dom) if wname else None,
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': t_up, 'traffic_lower_bound': t_lo,
+            'traffic_note': 'PMC FETCH_SIZE x 2 + WRITE_SIZE per step of this stage (reads counted at half on gfx950); the raw counters are the lower bound',
             'algorithmic_bytes': int(d['algorithmic_MB'] * 1e6),
-            'kernel_us': round(d['us_per_step'], 1), 'kernels_in_stage': STAGE_KERNELS.get(dom, []),
-            'event_path': event_path_roofline(per_step, wl_),
+            'kernel_us': round(d['us_per_step'], 1), 'kernels_in_stage': in_stage, 'profile_summary': pfile,
+            'kernels_us': live,
+            'event_path': ev_path,
             'knn': knn_ceiling(wname, per_step, wl_['B'], wl_['nb']) if wname else {},
             'path': {'algorithmic_MB': round(path_b / 1e6, 2), 'gpu_us_per_step': round(gpu_us, 1),
                      'achieved': round(path_b / (gpu_us * 1e-6) / 1e9, 1) if gpu_us > 0 else 0.0,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 102
+#define MPC_VERSION 103
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -82,6 +82,14 @@ typedef struct mpc_shape {
 
 int mpc_version(void);
 const char *mpc_last_error_string(void);
+
+/* Diagnostics (bench.py's instrumented pass; no reference counterpart): between mpc_profile_start() and mpc_profile_stop()
+ * every kernel the library launches is bracketed by two HIP events on its launch stream.  mpc_profile_stop synchronises
+ * on them and returns the number of launches recorded: their kernel names, newline separated, in `names` (names_cap
+ * bytes) and their durations in milliseconds in `ms` (cap entries), in launch order.  Process-wide; not for use inside
+ * a graph capture. */
+int mpc_profile_start(void);
+int mpc_profile_stop(char *names, int32_t names_cap, float *ms, int32_t cap);
 
 /* Bytes of scratch needed by any call with this shape. */
 int64_t mpc_workspace_bytes(const mpc_shape *s);
@@ -208,6 +216,9 @@ int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *str
 typedef struct mpc_vox_shape {
     int32_t B, N, C, H, W, norm;
     float quantile;   /* 0 <= quantile < 0.15: clip at the (1 - quantile) quantile of |grid| per sample (utils.py:57-61); 0 = off */
+    float keep;       /* fp32(1 - quantile) with the subtraction done in DOUBLE by the caller, as `torch.quantile(x, 1 - q)` receives
+                         it in the reference (utils.py:58): fp32(1 - fp64(q)) and 1 - fp32(q) differ by an ulp for ~6 % of the q.
+                         0 = derive it from `quantile` */
 } mpc_vox_shape;
 int64_t mpc_voxel_workspace_bytes(const mpc_vox_shape *s);
 int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const int32_t *counts, float *grid,

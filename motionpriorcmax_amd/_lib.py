@@ -28,7 +28,8 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
            'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
-           'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered']
+           'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
+           'mpc_profile_start', 'mpc_profile_stop']
 
 
 class Shape(ctypes.Structure):
@@ -45,7 +46,7 @@ class FocusBuffers(ctypes.Structure):
 
 
 class VoxShape(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'C', 'H', 'W', 'norm')] + [('quantile', ctypes.c_float)]
+    _fields_ = [(k, ctypes.c_int32) for k in ('B', 'N', 'C', 'H', 'W', 'norm')] + [('quantile', ctypes.c_float), ('keep', ctypes.c_float)]
 
 
 class IngestShape(ctypes.Structure):
@@ -115,8 +116,10 @@ def lib():
     L.mpc_flow_error_workspace_bytes.argtypes = [ctypes.POINTER(ErrShape)]
     L.mpc_flow_error_workspace_bytes.restype = i64
     L.mpc_flow_error.argtypes = [ctypes.POINTER(ErrShape), vp, vp, vp, vp, vp, vp, vp]
-    if L.mpc_version() != 102:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (102)')
+    L.mpc_profile_start.argtypes = []
+    L.mpc_profile_stop.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(f32), i32]
+    if L.mpc_version() != 103:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (103)')
     _lib = L
     return L
 

@@ -13,6 +13,59 @@ void mpc_set_error(const char *fmt, ...) {
 }
 
 extern "C" int mpc_version(void) { return MPC_VERSION; }
+
+// ---- diagnostics: per-kernel HIP-event timer (common.h: MPC_LAUNCH) -----------------------------------------------
+// Process-wide on purpose (the backward of a torch.autograd.Function runs on another thread than its forward); guarded by
+// a mutex; off unless mpc_profile_start() was called, and then every launch costs two hipEventRecord calls.
+#include <mutex>
+#include <vector>
+struct mpc_prof_rec { const char *name; hipEvent_t a, b; };
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;
+static std::vector<mpc_prof_rec> g_prof;
+static thread_local hipEvent_t g_prof_pending = nullptr;
+bool mpc_prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
+void mpc_prof_pre(hipStream_t st) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { g_prof_pending = nullptr; return; }
+    (void)hipEventRecord(e, st);
+    g_prof_pending = e;
+}
+void mpc_prof_post(const char *name, hipStream_t st) {
+    hipEvent_t a = g_prof_pending, e = nullptr;
+    g_prof_pending = nullptr;
+    if (a == nullptr) return;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(a); return; }
+    (void)hipEventRecord(e, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({name, a, e});
+}
+extern "C" int mpc_profile_start(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on.store(true);
+    return 0;
+}
+extern "C" int mpc_profile_stop(char *names, int32_t names_cap, float *ms, int32_t cap) {
+    g_prof_on.store(false);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0, pos = 0;
+    for (auto &r : g_prof) {
+        float t = 0.f;
+        (void)hipEventSynchronize(r.b);
+        const bool ok = hipEventElapsedTime(&t, r.a, r.b) == hipSuccess;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        const int len = (int)strlen(r.name);
+        if (ok && names && ms && n < cap && pos + len + 1 < names_cap) {
+            memcpy(names + pos, r.name, len); names[pos + len] = '\n'; pos += len + 1;
+            ms[n++] = t;
+        }
+    }
+    if (names && names_cap > 0) names[pos < names_cap ? pos : names_cap - 1] = 0;
+    g_prof.clear();
+    return n;
+}
 extern "C" const char *mpc_last_error_string(void) { return g_err; }
 
 __global__ __launch_bounds__(256) void k_zero_words(unsigned *__restrict__ p, size_t n) {
@@ -36,7 +89,7 @@ int mpc_zero_async(void *ptr, size_t bytes, hipStream_t stream) {
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned *)ptr, n);
+    MPC_LAUNCH(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned *)ptr, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mpc_set_error("mpc_zero_async: %s", hipGetErrorString(e)); return (int)e; }
     return 0;

@@ -31,6 +31,20 @@ int mpc_zero_async(void *ptr, size_t bytes, hipStream_t stream);
         }                                                                \
     } while (0)
 
+// Every kernel launch of the library goes through MPC_LAUNCH: the launch itself, and -- only while the diagnostics timer of
+// mpc_profile_start() / mpc_profile_stop() is on (bench.py's instrumented pass; never inside a graph capture) -- a HIP event
+// before and after it ON THE LAUNCH STREAM, so that the duration of every kernel is measured live, per launch.
+bool mpc_prof_on();
+void mpc_prof_pre(hipStream_t st);
+void mpc_prof_post(const char *name, hipStream_t st);
+#define MPC_LAUNCH(kern, grid, block, lds, st, ...)                                  \
+    do {                                                                             \
+        const bool pr__ = mpc_prof_on();                                             \
+        if (pr__) mpc_prof_pre(st);                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                 \
+        if (pr__) mpc_prof_post(#kern, st);                                          \
+    } while (0)
+
 // One-time, idempotent set-up that is PER DEVICE (raising the dynamic-LDS cap of a kernel): one bit per HIP device.
 // need() is true until mark() ran for the current device; two threads (forward and autograd thread) may both run the
 // set-up, which is harmless because it is idempotent -- the flag itself is atomic.

@@ -696,14 +696,14 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
         if (tiled) {
             const int e = mpc_zero_async(cpart, (size_t)L.n_cblocks * 2 * sizeof(double), st);
             if (e) return e;
-            hipLaunchKernelGGL(k_contrast_fused, gridf, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
+            MPC_LAUNCH(k_contrast_fused, gridf, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
         } else if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {
             // few images: bands of 16 rows, twice the wavefronts (the partial-sum array is sized for them)
             const dim3 gridh(gridf.x, mpc_cdiv(s->H, MPC_CT_H / 2), L.nimg);
-            if (l2) hipLaunchKernelGGL((k_contrast_march<true, MPC_CT_H / 2>), gridh, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
-            else hipLaunchKernelGGL((k_contrast_march<false, MPC_CT_H / 2>), gridh, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
-        } else if (l2) hipLaunchKernelGGL((k_contrast_march<true, MPC_CT_H>), gridf, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
-        else hipLaunchKernelGGL((k_contrast_march<false, MPC_CT_H>), gridf, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
+            if (l2) MPC_LAUNCH((k_contrast_march<true, MPC_CT_H / 2>), gridh, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
+            else MPC_LAUNCH((k_contrast_march<false, MPC_CT_H / 2>), gridh, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
+        } else if (l2) MPC_LAUNCH((k_contrast_march<true, MPC_CT_H>), gridf, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
+        else MPC_LAUNCH((k_contrast_march<false, MPC_CT_H>), gridf, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
         MPC_CHECK_LAUNCH();
         return 0;
     }
@@ -711,14 +711,14 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
         const int e = mpc_zero_async(cpart, (size_t)L.n_cblocks * 2 * sizeof(double), st);
         if (e) return e;
     }
-    hipLaunchKernelGGL(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
+    MPC_LAUNCH(k_contrast_fwd, grid, dim3(256), 0, st, iwe_raw, iwe_blur, cpart, s->H, s->W, l2, variance);
     MPC_CHECK_LAUNCH();
     if (grad_iwe) {      // variance objective: the adjoint needs the image means first
         {
             float *means = (float *)((char *)ws + L.off_counts) + 8;   // nimg floats after the counters
-            hipLaunchKernelGGL(k_image_means, dim3(L.nimg), dim3(256), 0, st, cpart, means,
+            MPC_LAUNCH(k_image_means, dim3(L.nimg), dim3(256), 0, st, cpart, means,
                                (int)(grid.x * grid.y), s->H * s->W);
-            hipLaunchKernelGGL(k_contrast_bwd_var, grid, dim3(256), 0, st, iwe_blur, means, grad_iwe, s->H, s->W);
+            MPC_LAUNCH(k_contrast_bwd_var, grid, dim3(256), 0, st, iwe_blur, means, grad_iwe, s->H, s->W);
         }
         MPC_CHECK_LAUNCH();
     }
@@ -748,9 +748,9 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
     double *spart = (double *)((char *)ws + L.off_spart);
     const double count = (double)nimg * C * s->hq * s->wq;
     const float gscale = (float)((double)smooth_weight / (2.0 * count));
-    if (tiled) hipLaunchKernelGGL(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
-    else if (band == MPC_SM_H) hipLaunchKernelGGL(k_lut_smooth_march<MPC_SM_H>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
-    else hipLaunchKernelGGL(k_lut_smooth_march<MPC_SM_H / 2>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    if (tiled) MPC_LAUNCH(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    else if (band == MPC_SM_H) MPC_LAUNCH(k_lut_smooth_march<MPC_SM_H>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    else MPC_LAUNCH(k_lut_smooth_march<MPC_SM_H / 2>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
     MPC_CHECK_LAUNCH();
     return 0;
 }
@@ -771,7 +771,7 @@ extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smo
         MPC_CHECK_ARG(nsblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
         count = (double)smooth_nimg * smooth_C * s->hq * s->wq;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+    MPC_LAUNCH(k_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream,
                        (const double *)((char *)ws + L.off_cpart), L.n_cblocks, tiles, L.nimg,
                        s->H * s->W, (const double *)((char *)ws + L.off_spart), (int)nsblk, count,
                        smooth_weight, (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0, scal);
@@ -783,7 +783,7 @@ extern "C" int mpc_scale(const float *x, const float *a, float *y, int64_t count
     MPC_CHECK_ARG(x && a && y, MPC_E_NULL, "null argument");
     if (count <= 0) return 0;
     const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_scale, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, y, count);
+    MPC_LAUNCH(k_scale, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, y, count);
     MPC_CHECK_LAUNCH();
     return 0;
 }

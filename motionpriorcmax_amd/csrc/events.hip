@@ -598,11 +598,11 @@ int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float 
             const dim3 grid(((nblk + 7) / 8) * 8);
             const int nloc = L.P * L.n_strips + s->nb * L.n_cstrips;
             const size_t lds = (size_t)(((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3) * sizeof(int) + (size_t)EV_STAGE * 16;
-            hipLaunchKernelGGL(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);
+            MPC_LAUNCH(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);
             MPC_CHECK_LAUNCH();
         }
         if (L.nfb > 0) {
-            hipLaunchKernelGGL(k_iwe_accum, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
+            MPC_LAUNCH(k_iwe_accum, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
             MPC_CHECK_LAUNCH();
         }
         return 0;
@@ -613,7 +613,7 @@ int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float 
     const int64_t total = (int64_t)s->B * s->M;
     if (total == 0) return 0;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_splat_fwd_atomic, dim3(grid), dim3(256), 0, st, *s, events, flow_lut, t_ref, iwe_raw);
+    MPC_LAUNCH(k_splat_fwd_atomic, dim3(grid), dim3(256), 0, st, *s, events, flow_lut, t_ref, iwe_raw);
     MPC_CHECK_LAUNCH();
     return 0;
 }
@@ -644,10 +644,10 @@ extern "C" int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *even
             MPC_CHECK_ARG(!offsets || (size_t)L.cstrip_rows * s->wq * 24 <= 160 * 1024 - 512, MPC_E_UNSUPPORTED,
                           "LUT too wide for the ordered backward (use mpc_event_splat_bwd)");
             if (offsets)
-                hipLaunchKernelGGL(k_lut_accum<true>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS_ORD), (size_t)L.cstrip_rows * s->wq * 24, st, *s, BL,
+                MPC_LAUNCH(k_lut_accum<true>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS_ORD), (size_t)L.cstrip_rows * s->wq * 24, st, *s, BL,
                                    grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets);
             else
-                hipLaunchKernelGGL(k_lut_accum<false>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
+                MPC_LAUNCH(k_lut_accum<false>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
                                    grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets);
             MPC_CHECK_LAUNCH();
         }
@@ -666,7 +666,7 @@ extern "C" int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *even
     const int64_t total = (int64_t)s->B * s->M;
     if (total == 0) return 0;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_splat_bwd_atomic, dim3(grid), dim3(256), 0, st, *s, events, flow_lut, t_ref,
+    MPC_LAUNCH(k_splat_bwd_atomic, dim3(grid), dim3(256), 0, st, *s, events, flow_lut, t_ref,
                        grad_iwe, scal, grad_out, grad_flow_lut);
     MPC_CHECK_LAUNCH();
     return 0;
@@ -816,11 +816,11 @@ extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in
     hipStream_t st = (hipStream_t)stream;
     int *counts = (int *)ws;
     const size_t lds = (size_t)(k.NK + 1) * 4;
-    hipLaunchKernelGGL(k_evo_count, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, chunks);
+    MPC_LAUNCH(k_evo_count, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, chunks);
     int *totals = counts + (size_t)2 * s->B * (k.NK + 1) * chunks;
-    hipLaunchKernelGGL(k_evo_scan_chunks, dim3(mpc_cdiv(k.NK + 1, 4), 2 * s->B), dim3(256), 0, st, k, counts, totals, chunks);
-    hipLaunchKernelGGL(k_evo_scan_keys, dim3(2 * s->B), dim3(256), 0, st, *s, k, totals, (int *)offsets);
-    hipLaunchKernelGGL(k_evo_scatter, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, (const int *)offsets,
+    MPC_LAUNCH(k_evo_scan_chunks, dim3(mpc_cdiv(k.NK + 1, 4), 2 * s->B), dim3(256), 0, st, k, counts, totals, chunks);
+    MPC_LAUNCH(k_evo_scan_keys, dim3(2 * s->B), dim3(256), 0, st, *s, k, totals, (int *)offsets);
+    MPC_LAUNCH(k_evo_scatter, dim3(chunks, 2 * s->B), dim3(256), lds, st, *s, k, events_in, counts, (const int *)offsets,
                        events_out, chunks);
     MPC_CHECK_LAUNCH();
     return 0;

@@ -101,9 +101,9 @@ extern "C" int mpc_dense_flow(const mpc_flow_shape *s, const float *traj_flow, c
     if (e) return e;
     const long long total = (long long)s->B * s->n * s->C;
     if (total > 0)
-        hipLaunchKernelGGL(k_list_to_grid, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, *s, traj_flow,
+        MPC_LAUNCH(k_list_to_grid, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, *s, traj_flow,
                            (const long long *)pixel_positions, patch_flow);
-    hipLaunchKernelGGL(k_resize_aa, dim3(mpc_cdiv(s->W, 64), mpc_cdiv(s->H, 4), s->B * s->C), dim3(64, 4), 0, st, *s,
+    MPC_LAUNCH(k_resize_aa, dim3(mpc_cdiv(s->W, 64), mpc_cdiv(s->H, 4), s->B * s->C), dim3(64, 4), 0, st, *s,
                        patch_flow, dense);
     MPC_CHECK_LAUNCH();
     return 0;
@@ -216,12 +216,12 @@ extern "C" int mpc_flow_error(const mpc_err_shape *s, const float *flow_gt, cons
     const bool vec = (HW & 3) == 0 && (((uintptr_t)flow_gt | (uintptr_t)flow_pred) & 15) == 0 &&
                      ((uintptr_t)event_mask & 3) == 0;
     if (vec)
-        hipLaunchKernelGGL(k_flow_err_partial<true>, dim3(FE_BLOCKS, s->B), dim3(256), 0, st, *s, flow_gt, flow_pred,
+        MPC_LAUNCH(k_flow_err_partial<true>, dim3(FE_BLOCKS, s->B), dim3(256), 0, st, *s, flow_gt, flow_pred,
                            event_mask, time_scale, (double *)ws);
     else
-        hipLaunchKernelGGL(k_flow_err_partial<false>, dim3(FE_BLOCKS, s->B), dim3(256), 0, st, *s, flow_gt, flow_pred,
+        MPC_LAUNCH(k_flow_err_partial<false>, dim3(FE_BLOCKS, s->B), dim3(256), 0, st, *s, flow_gt, flow_pred,
                            event_mask, time_scale, (double *)ws);
-    hipLaunchKernelGGL(k_flow_err_final, dim3(1), dim3(64), 0, st, *s, (const double *)ws, out);
+    MPC_LAUNCH(k_flow_err_final, dim3(1), dim3(64), 0, st, *s, (const double *)ws, out);
     MPC_CHECK_LAUNCH();
     return 0;
 }

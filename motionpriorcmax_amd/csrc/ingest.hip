@@ -226,9 +226,9 @@ extern "C" int mpc_ingest_count(const mpc_ingest_shape *s, const float *x, const
     if (e) return e;
     if (s->B == 0) return 0;
     const IngLayout L = ing_layout(s, ws).L;
-    hipLaunchKernelGGL(k_ingest_count, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
+    MPC_LAUNCH(k_ingest_count, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
                        reinterpret_cast<const long long *>(t_us), p, counts);
-    hipLaunchKernelGGL(k_ingest_scan, dim3(s->B), dim3(256), 0, st, L, out_max);
+    MPC_LAUNCH(k_ingest_scan, dim3(s->B), dim3(256), 0, st, L, out_max);
     MPC_CHECK_LAUNCH();
     return 0;
 }
@@ -249,7 +249,7 @@ extern "C" int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, con
     }
     if (s->N == 0) return 0;
     const IngLayout L = ing_layout(s, ws).L;
-    hipLaunchKernelGGL(k_ingest_scatter, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
+    MPC_LAUNCH(k_ingest_scatter, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
                        reinterpret_cast<const long long *>(t_us), p, counts, max_pos, max_neg, events, xytp);
     MPC_CHECK_LAUNCH();
     return 0;

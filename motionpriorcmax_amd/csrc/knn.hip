@@ -925,14 +925,14 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_HALO=<h>        rings staged beyond the initial radius by the query kernel        [1]
 //   MPC_KNN_STRIP=0         tile query kernel (k_knn_query) also where the strip kernel applies  [1]
 //   MPC_KNN_BWD_FUSED=0     backward as k_knn_reach + k_knn_bwd_points also where k_knn_bwd_tile applies [1]
-//   MPC_KNN_BWD_SCATTER=0   gather backward (k_knn_bwd_tile) also where the scatter backward applies    [1]
+//   MPC_KNN_BWD_SCATTER=1   query-centric scatter backward (knn_bwd_scatter.hip) where it applies; measured slower   [0]
 //   MPC_KNN_BWD_G=<g>       strips per workgroup of the scatter backward                               [by grid size]
 struct KnnTuning {
     int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s, bwd_scatter;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0, 1};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0, 0};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -1041,14 +1041,14 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         const int e = mpc_zero_async(cursor, (size_t)s->B * s->nb * p.G * sizeof(int), st);
         if (e) return e;
         const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
-        hipLaunchKernelGGL(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
-        hipLaunchKernelGGL(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
-        hipLaunchKernelGGL(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
-        hipLaunchKernelGGL(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
+        MPC_LAUNCH(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
+        MPC_LAUNCH(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
+        MPC_LAUNCH(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
+        MPC_LAUNCH(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
     } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        hipLaunchKernelGGL(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
+        MPC_LAUNCH(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
     else
-        hipLaunchKernelGGL(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
+        MPC_LAUNCH(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
@@ -1101,10 +1101,10 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     const int gx = mpc_cdiv(s->wq, 16), gy = mpc_cdiv(s->hq, best_nt / 16);
     const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
     if (best_nt == 512)
-        hipLaunchKernelGGL(k_knn_query<512>, grid, dim3(512), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+        MPC_LAUNCH(k_knn_query<512>, grid, dim3(512), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
                            flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
     else
-        hipLaunchKernelGGL(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
+        MPC_LAUNCH(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
                            flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
     MPC_CHECK_LAUNCH();
     if (also_strip)
@@ -1146,7 +1146,7 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         if ((rc = mpc_knn_bwd_scatter_launch(s, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, knn_state, &lean,
                                              (unsigned long long *)((char *)ws + L.off_knn_gacc), tmp_g, tmp_a, st))) return rc;
         const int64_t totalb = (int64_t)s->B * s->n;
-        hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
+        MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
                            grad_flow_next ? tmp_a : nullptr, grad_traj);
         MPC_CHECK_LAUNCH();
         return 0;
@@ -1163,19 +1163,19 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
 #define KB_STAMP_ARG
 #endif
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
-        hipLaunchKernelGGL((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
+        MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
                            grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH
         MPC_CHECK_LAUNCH();
         const int64_t totalb = (int64_t)s->B * s->n;
-        hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
+        MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
                            grad_flow_next ? tmp_a : nullptr, grad_traj);
         MPC_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);
+    MPC_LAUNCH(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);
     MPC_CHECK_LAUNCH();
     // (32x32-cell tiles with 1024 threads measured slower at C3: 296 vs 229 us)
     const int ts = knn_tuning().bwd_ts;
@@ -1184,14 +1184,14 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     const int gx = mpc_cdiv(s->wq, ts), gy = mpc_cdiv(s->hq, ts);
     const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
     if (ts == 32)
-        hipLaunchKernelGGL(k_knn_bwd_points<32>, grid, dim3(1024), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
+        MPC_LAUNCH(k_knn_bwd_points<32>, grid, dim3(1024), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
                            grad_flow_next, knn_state, reach, tmp_g, tmp_a, gx, gy);
     else
-        hipLaunchKernelGGL(k_knn_bwd_points<16>, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
+        MPC_LAUNCH(k_knn_bwd_points<16>, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
                            grad_flow_next, knn_state, reach, tmp_g, tmp_a, gx, gy);
     MPC_CHECK_LAUNCH();
     const int64_t total = (int64_t)s->B * s->n;
-    hipLaunchKernelGGL(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g,
+    MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g,
                        (grad_flow_next || s->T != 1 || p.iwd) ? tmp_a : nullptr, grad_traj);
     MPC_CHECK_LAUNCH();
     return 0;

@@ -63,22 +63,24 @@ __device__ __forceinline__ float2 kb_unpack(unsigned long long v, float inv, flo
     return make_float2(invK * ((float)hi * inv), invK * ((float)lo * inv));
 }
 
-// one word of a query's mask: slot 32 wd + k <-> bit 8 (k & 3) + (k >> 2); Tq = the address table at the query's first slot.
-// The 32 table entries are read first, unconditionally and together (one wait instead of one per slot; entries beyond
-// the query's range belong to other rows or are stale: their mask bits are clear), then one predicated atomic per slot.
-template <bool NEXT, bool GLOBAL>
-__device__ __forceinline__ void kb_scatter_word(unsigned mw, const unsigned short *Tq, int wd, unsigned long long *acc_m1,
-                                                unsigned long long *accn_m1, unsigned long long gp, unsigned long long gpn,
-                                                bool has_next) {
-    unsigned tt[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) tt[k] = Tq[32 * wd + k];
+// One word of the masks of a PAIR of queries (the two columns of a strip at one row: same slot range, so bit b of both
+// masks is the same slot): slot 32 wd + k <-> bit 8 (k & 3) + (k >> 2).  A slot that is a neighbour of both queries gets
+// ONE atomic with the sum of their gradients: neighbouring queries share ~85 % of their neighbours, and the kernel is
+// bound by the number of LDS instructions, not by their width.  `sq` = accumulators of the strip at the pair's first slot
+// (strip layout: slot s + j of the strip kernel is word s + j, no translation).
+template <bool NEXT>
+__device__ __forceinline__ void kb_scatter_pair_word(unsigned ma, unsigned mb, unsigned long long *sq, unsigned long long *sqn, int wd,
+                                                     unsigned long long ga, unsigned long long gb, unsigned long long gab,
+                                                     unsigned long long gna, unsigned long long gnb, unsigned long long gnab,
+                                                     bool has_next) {
+    const unsigned mu = ma | mb;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
         const unsigned bit = 1u << (8 * (k & 3) + (k >> 2));
-        if ((mw & bit) != 0u && tt[k] != 0u) {
-            atomicAdd(acc_m1 + tt[k], gp);
-            if (NEXT) { if (has_next) atomicAdd(accn_m1 + tt[k], gpn); }
+        if (mu & bit) {
+            const bool A = (ma & bit) != 0u, Bq = (mb & bit) != 0u;
+            atomicAdd(sq + 32 * wd + k, A ? (Bq ? gab : ga) : gb);
+            if (NEXT) { if (has_next) atomicAdd(sqn + 32 * wd + k, A ? (Bq ? gnab : gna) : gnb); }
         }
     }
 }
@@ -120,10 +122,15 @@ __global__ __launch_bounds__(KB_NT) void k_knn_bwd_scatter(const KnnParams p, co
     size_t o = (size_t)(TH + 1) * 8;
     unsigned long long *acc = reinterpret_cast<unsigned long long *>(s_dyn + o); o += (size_t)kg.cap_grp * 8;
     unsigned long long *accn = reinterpret_cast<unsigned long long *>(s_dyn + o); o += NEXT ? (size_t)kg.cap_grp * 8 : 0;
-    unsigned short *Tall = reinterpret_cast<unsigned short *>(s_dyn + o); o += (size_t)(KB_NT / 64) * kg.capT * 2;     // (>= KB_FLIST * 4 bytes: launcher)
-    unsigned short *rsw_all = reinterpret_cast<unsigned short *>(s_dyn + o);                                          // [4][64] first slot of the rows a wavefront uses
-    unsigned short *Tw = Tall + (size_t)wv * kg.capT, *rsw = rsw_all + wv * 64;
-    unsigned *flist = reinterpret_cast<unsigned *>(Tall);                       // (after the strips) listed fallback queries
+    // two strips are walked at a time (wavefronts 0-1 / 2-3): their accumulators in the strip kernel's slot order (+ the
+    // tail a mask word can reach beyond the last slot), and the first slot of every region row
+    const size_t sacc_n = (size_t)kg.capT + 96;
+    unsigned long long *sacc_all = reinterpret_cast<unsigned long long *>(s_dyn + o); o += 2 * sacc_n * 8 * (NEXT ? 2 : 1);
+    unsigned short *rsl_all = reinterpret_cast<unsigned short *>(s_dyn + o);          // [2][NR]
+    const int half = wv >> 1, hl = tid & 127;
+    unsigned long long *sacc = sacc_all + (size_t)half * sacc_n * (NEXT ? 2 : 1), *saccn = sacc + sacc_n;
+    unsigned short *rsl = rsl_all + (size_t)half * ((NR + 1) & ~1);
+    unsigned *flist = reinterpret_cast<unsigned *>(sacc_all);                         // (after the strips) listed fallback queries
 
     // ---- 1. rows of the owned region: first point and number of points, exclusive scan -> accumulator slots ------
     int ra = 0, rc = 0;
@@ -189,87 +196,112 @@ __global__ __launch_bounds__(KB_NT) void k_knn_bwd_scatter(const KnnParams p, co
     zero_acc();
     __syncthreads();
 
-    // ---- 3. the strips whose queries can reach the region ---------------------------------------------------------
-    // Software pipeline: everything strip `it + 1` reads from global memory (row-table entries, masks, gradients) is
-    // requested before strip `it` is worked on.
-    const int i_lo = max(jx * kg.G - kg.r_init, 0), i_hi = min(jx * kg.G + kg.G + kg.r_init, kg.gx), ni = i_hi - i_lo;
+    // ---- 3. the strips whose queries can reach the region, two at a time ----------------------------------------------
+    // Per pair of strips: [first slots of the rows -> LDS] barrier [scatter: lane = the pair of queries of one row, one
+    // predicated atomic per slot into the strip's accumulators] barrier [fold: lane = region row, every slot of the row is
+    // taken (exchange with 0) and, where it is one of this workgroup's points, added to the point's accumulator].
+    // Everything the NEXT pair reads from global memory is requested before the current one is worked on.
+    for (size_t i = tid; i < 2 * sacc_n * (NEXT ? 2 : 1); i += KB_NT) sacc_all[i] = 0ull;
+    const int i_lo = max(jx * kg.G - kg.r_init, 0), i_hi = min(jx * kg.G + kg.G + kg.r_init, kg.gx);
+    const int npair = (i_hi - i_lo + 1) >> 1;
     const int sy_lo = max(sy - 1, 0), nsy = min(sy + 1, kg.gy - 1) - sy_lo + 1;
-    const int nneed = 32 + 2 * R2;                 // region rows the 32 query rows of a wavefront use (launcher: <= 64)
-    const int qrow = 32 * wv + (lane & 31), qcol = lane >> 5;
-    struct Pre { int2 e; int tot; unsigned m0, m1, m2; float2 g, gn; int r, cy, cx, ry_base; bool act; };
+    struct Pre {
+        int2 e, e2; int tot, ry_base, cy, ra, rb; bool on, acta, actb;
+        unsigned ma0, ma1, ma2, mb0, mb1, mb2; float2 ga, gb, gna, gnb;
+    };
     auto prefetch = [&](int it) {
         Pre v;
-        const int sy2 = sy_lo + it / ni, i = i_lo + (it - (it / ni) * ni);
-        const int qy0 = sy2 * TH, qy1 = min(qy0 + TH, p.hq) - 1, qx0 = i * WS, qx1 = min(qx0 + WS, p.wq) - 1;
-        const int sid = (bt * kg.gy + sy2) * kg.gx + i;
+        const int sy2 = sy_lo + it / npair, i = i_lo + 2 * (it - (it / npair) * npair) + half;
+        v.on = i < i_hi;                                          // (an odd number of strips: the last pair is half empty)
+        const int ic = min(i, i_hi - 1);
+        const int qy0 = sy2 * TH, qy1 = min(qy0 + TH, p.hq) - 1, qx0 = ic * WS, qx1 = min(qx0 + WS, p.wq) - 1;
+        const int sid = (bt * kg.gy + sy2) * kg.gx + ic;
         v.ry_base = qy0 - R2;
-        v.cy = qy0 + qrow; v.cx = qx0 + qcol;
-        const bool valid = v.cy <= qy1 && v.cx <= qx1;
-        v.r = kg.r_init;
-        if (valid) v.r = query_radius(p, v.cy, v.cx, kg.r_init);
-        v.act = valid && v.cx + v.r >= c0 && v.cx - v.r <= c1 && v.cy + v.r >= oy0 && v.cy - v.r <= oy1;
+        v.cy = qy0 + hl;
+        const bool va = v.on && v.cy <= qy1, vb = va && qx0 + 1 <= qx1;
+        v.ra = v.rb = kg.r_init;
+        if (va) v.ra = query_radius(p, v.cy, qx0, kg.r_init);
+        if (vb) v.rb = query_radius(p, v.cy, qx0 + 1, kg.r_init);
+        v.acta = va && qx0 + v.ra >= c0 && qx0 - v.ra <= c1 && v.cy + v.ra >= oy0 && v.cy - v.ra <= oy1;
+        v.actb = vb && qx0 + 1 + v.rb >= c0 && qx0 + 1 - v.rb <= c1 && v.cy + v.rb >= oy0 && v.cy - v.rb <= oy1;
         const int2 *rt = rowtab + (size_t)sid * (NR + 1);
         v.tot = rt[NR].x;
-        v.e = rt[min(32 * wv + lane, NR)];
-        const unsigned *mq = masks + (size_t)sid * (3 * KB_NT) + qrow * WS + qcol;
-        v.m0 = mq[0]; v.m1 = mq[KB_NT]; v.m2 = mq[2 * KB_NT];
-        const int gi = min(v.cy, p.hq - 1) * p.wq + min(v.cx, p.wq - 1);
-        v.g = gl2[gi];
-        v.gn = has_next ? gn2[gi] : make_float2(0.f, 0.f);
+        v.e = rt[min(hl, NR)];
+        v.e2 = rt[min(128 + hl, NR)];
+        const unsigned *mq = masks + (size_t)sid * (3 * KB_NT) + min(hl, TH - 1) * WS;
+        v.ma0 = mq[0]; v.ma1 = mq[KB_NT]; v.ma2 = mq[2 * KB_NT];
+        v.mb0 = mq[1]; v.mb1 = mq[KB_NT + 1]; v.mb2 = mq[2 * KB_NT + 1];
+        const int gi = min(v.cy, p.hq - 1) * p.wq + qx0, gj = min(v.cy, p.hq - 1) * p.wq + min(qx0 + 1, p.wq - 1);
+        v.ga = gl2[gi]; v.gb = gl2[gj];
+        v.gna = v.gnb = make_float2(0.f, 0.f);
+        if (has_next) { v.gna = gn2[gi]; v.gnb = gn2[gj]; }
         return v;
     };
-    const int nit = nsy * ni;
+    const int nit = nsy * npair;
+    __syncthreads();
     Pre cur = prefetch(0);
     for (int it = 0; it < nit; ++it) {
-        const Pre nx = prefetch(min(it + 1, nit - 1));
         const Pre v = cur;
-        cur = nx;
-        if (__ballot(v.act) == 0ull) continue;
-        if (v.tot > kg.capT) continue;                          // the strip overflowed its staging area: all its queries are fallback queries
-        // address table of the slots of the region rows [32 wv, 32 wv + nneed): lane = row
+        // rows of this half's strip: lane = region row (two rows for the first NR - 128 lanes)
+        const bool live = v.on && v.tot <= kg.capT;            // (a strip that overflowed its staging area served no query)
+        const int rs1 = v.e.y & 0xffff, len1 = (live && hl < NR) ? (int)((unsigned)v.e.y >> 16) : 0;
+        const int rs2 = v.e2.y & 0xffff, len2 = (live && 128 + hl < NR) ? (int)((unsigned)v.e2.y >> 16) : 0;
+        if (hl < NR) rsl[hl] = (unsigned short)rs1;
+        if (128 + hl < NR) rsl[128 + hl] = (unsigned short)rs2;
+        __syncthreads();
+        cur = prefetch(min(it + 1, nit - 1));
+        // ---- scatter ----
         {
-            const int rr = 32 * wv + lane;
-            int gs = 0, rs = 0, len = 0, gfirst = 0, gslot = 0, cnt = 0;
-            if (lane < nneed && rr < NR) {
-                gs = v.e.x; rs = v.e.y & 0xffff; len = (int)((unsigned)v.e.y >> 16);
-                const int y = v.ry_base + rr;
-                if (y >= oy0 && y <= oy1) { const int2 gr = grow[y - oy0]; gfirst = gr.x; gslot = gr.y; cnt = grow[y - oy0 + 1].y - gr.y; }
-            }
-            rsw[lane] = (unsigned short)rs;
-            const int lmax = __builtin_amdgcn_readfirstlane(kb_wave_max(len));
-            for (int k = 0; k < lmax; ++k) {
-                if (k < len) {
-                    const int og = gs + k - gfirst;
-                    const bool own = og >= 0 && og < cnt;
-                    Tw[rs + k] = (unsigned short)(own ? (use_global ? gs + k + 1 : gslot + og + 1) : 0);
+            const bool acta = live && v.acta, actb = live && v.actb;
+            unsigned ma0 = acta ? v.ma0 : 0u, ma1 = acta ? v.ma1 : 0u, ma2 = acta ? v.ma2 : 0u;
+            unsigned mb0 = actb ? v.mb0 : 0u, mb1 = actb ? v.mb1 : 0u, mb2 = actb ? v.mb2 : 0u;
+            if (__ballot(acta || actb) != 0ull) {
+                const unsigned long long pa = kb_pack(v.ga, scl.x), pb = kb_pack(v.gb, scl.x);
+                const unsigned long long pna = has_next ? kb_pack(v.gna, scn.x) : 0ull, pnb = has_next ? kb_pack(v.gnb, scn.x) : 0ull;
+                const int rowa = max(v.cy - v.ra, 0) - v.ry_base, rowb = max(v.cy - v.rb, 0) - v.ry_base;
+                const int sa = (acta || actb) ? (int)rsl[min(max(rowa, 0), NR - 1)] : 0, sb = (acta || actb) ? (int)rsl[min(max(rowb, 0), NR - 1)] : 0;
+                // (the two columns of a strip next to the left or right image border can have squares of different size:
+                // their slot ranges then start at different rows, and they are walked one after the other)
+                const bool split = __ballot(acta && actb && sa != sb) != 0ull;
+                for (int pass = 0; pass < (split ? 2 : 1); ++pass) {
+                    unsigned a0 = ma0, a1 = ma1, a2 = ma2, b0 = mb0, b1 = mb1, b2 = mb2;
+                    int s0 = acta ? sa : sb;
+                    if (split) {
+                        if (pass == 0) { b0 = b1 = b2 = 0u; s0 = sa; } else { a0 = a1 = a2 = 0u; s0 = sb; }
+                    }
+                    unsigned long long *sq = sacc + s0, *sqn = saccn + s0;
+                    kb_scatter_pair_word<NEXT>(a0, b0, sq, sqn, 0, pa, pb, pa + pb, pna, pnb, pna + pnb, has_next);
+                    kb_scatter_pair_word<NEXT>(a1, b1, sq, sqn, 1, pa, pb, pa + pb, pna, pnb, pna + pnb, has_next);
+                    if (__ballot((a2 | b2) != 0u) != 0ull)
+                        kb_scatter_pair_word<NEXT>(a2, b2, sq, sqn, 2, pa, pb, pa + pb, pna, pnb, pna + pnb, has_next);
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        unsigned m0 = 0u, m1 = 0u, m2 = 0u;
-        unsigned long long gp = 0ull, gpn = 0ull;
-        int s = 0;
-        if (v.act) {
-            m0 = v.m0; m1 = v.m1; m2 = v.m2;
-            gp = kb_pack(v.g, scl.x);
-            if (has_next) gpn = kb_pack(v.gn, scn.x);
-            s = (int)rsw[max(v.cy - v.r, 0) - v.ry_base - 32 * wv];
+        __syncthreads();
+        // ---- fold ----
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int rr = h2 * 128 + hl, gs = h2 ? v.e2.x : v.e.x, rs = h2 ? rs2 : rs1, len = h2 ? len2 : len1;
+            const int lmax = __builtin_amdgcn_readfirstlane(kb_wave_max(len));
+            if (lmax == 0) continue;
+            int gfirst = 0, gslot = 0, cnt = 0;
+            const int y = v.ry_base + rr;
+            if (len > 0 && y >= oy0 && y <= oy1) { const int2 gr = grow[y - oy0]; gfirst = gr.x; gslot = gr.y; cnt = grow[y - oy0 + 1].y - gr.y; }
+            for (int k = 0; k < lmax; ++k) {
+                if (k < len) {
+                    const unsigned long long val = atomicExch(sacc + rs + k, 0ull);
+                    const int og = gs + k - gfirst;
+                    const bool own = og >= 0 && og < cnt;
+                    if (own && val != 0ull) { if (use_global) atomicAdd(ga + gs + k, val); else atomicAdd(acc + gslot + og, val); }
+                    if (NEXT && has_next) {
+                        const unsigned long long vn = atomicExch(saccn + rs + k, 0ull);
+                        if (own && vn != 0ull) { if (use_global) atomicAdd(gan + gs + k, vn); else atomicAdd(accn + gslot + og, vn); }
+                    }
+                }
+            }
         }
-        const unsigned short *Tq = Tw + s;
-        if (!use_global) {
-            kb_scatter_word<NEXT, false>(m0, Tq, 0, acc - 1, accn - 1, gp, gpn, has_next);
-            kb_scatter_word<NEXT, false>(m1, Tq, 1, acc - 1, accn - 1, gp, gpn, has_next);
-            if (__ballot(m2 != 0u) != 0ull) kb_scatter_word<NEXT, false>(m2, Tq, 2, acc - 1, accn - 1, gp, gpn, has_next);
-        } else {
-            kb_scatter_word<NEXT, true>(m0, Tq, 0, ga - 1, gan - 1, gp, gpn, has_next);
-            kb_scatter_word<NEXT, true>(m1, Tq, 1, ga - 1, gan - 1, gp, gpn, has_next);
-            if (__ballot(m2 != 0u) != 0ull) kb_scatter_word<NEXT, true>(m2, Tq, 2, ga - 1, gan - 1, gp, gpn, has_next);
-        }
-        // (the table is rewritten for the next strip by this same wavefront: LDS operations of a wavefront execute in order)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        // (the next pair's first-slot table is written after this fold by the same threads that read it above; the
+        // accumulators it scatters into are separated from this fold by the barrier at the top of the loop)
     }
     if (use_global) __threadfence();
     __syncthreads();
@@ -413,13 +445,13 @@ static bool kb_geometry(const mpc_shape *s, bool next, KbGeom *kg, size_t *lds_o
     const int r_init = mpc_knn_r_init(s);
     KnnStripGeom g;
     if (!mpc_knn_strip_geom(s, r_init, &g)) return false;
-    if (32 + 4 * r_init > 64) return false;                     // (one lane per region row of a wavefront)
+    if (g.TH != 128 || g.WS != 2) return false;                 // (lane = the pair of queries of one strip row; two strips per workgroup pass)
     const int64_t bt = (int64_t)s->B * s->nb;
     static const int g_env = getenv("MPC_KNN_BWD_G") ? atoi(getenv("MPC_KNN_BWD_G")) : 0;
     const double dens = (double)s->n / ((double)s->hq * s->wq);
     // Strips per workgroup, G: a workgroup walks G + 2 r_init strips (r_init on either side belong to its neighbours), so a
-    // large G repeats fewer queries; a small G gives more, shorter workgroups.  Model: rounds of 256 workgroups x strips
-    // walked, among the G whose accumulators leave room for two workgroups per CU.
+    // large G repeats fewer queries; a small G gives more, shorter workgroups.  Model: rounds of 256 workgroups x pairs of
+    // strips walked, among the G whose accumulators leave room for two workgroups per CU.
     int best = 0, best_cap = 0; size_t best_lds = 0; double best_cost = 0.0;
     for (int G = 1; G <= g.gx && G <= 64; ++G) {
         if (g_env > 0 && G != g_env) continue;
@@ -427,12 +459,12 @@ static bool kb_geometry(const mpc_shape *s, bool next, KbGeom *kg, size_t *lds_o
         int cap_grp = (int)(1.25 * dens * cols * rows) + 192;
         cap_grp = (cap_grp + 63) / 64 * 64;
         if (cap_grp > 65534) break;                               // (16-bit accumulator addresses)
-        size_t tbytes = (size_t)(KB_NT / 64) * g.cap * 2;
-        if (tbytes < (size_t)KB_FLIST * 4) tbytes = (size_t)KB_FLIST * 4;
-        const size_t lds = (size_t)(g.TH + 1) * 8 + (size_t)cap_grp * 8 * (next ? 2 : 1) + tbytes + (KB_NT / 64) * 64 * 2 + 64;
+        size_t sbytes = 2 * ((size_t)g.cap + 96) * 8 * (next ? 2 : 1);          // strip accumulators of the two halves (later: the fallback list)
+        if (sbytes < (size_t)KB_FLIST * 4) sbytes = (size_t)KB_FLIST * 4;
+        const size_t lds = (size_t)(g.TH + 1) * 8 + (size_t)cap_grp * 8 * (next ? 2 : 1) + sbytes + 2 * (size_t)((g.NR + 1) & ~1) * 2 + 64;
         if (lds > (G == 1 || g_env > 0 ? (size_t)150 * 1024 : (size_t)64 * 1024)) break;
         const int64_t nwg = bt * g.gy * mpc_cdiv(g.gx, G);
-        const double cost = (double)((nwg + 255) / 256) * (double)((G < g.gx ? G : g.gx) + 2 * r_init + 2);
+        const double cost = (double)((nwg + 255) / 256) * (double)(((G < g.gx ? G : g.gx) + 2 * r_init + 1) / 2 + 2);
         if (best == 0 || cost < best_cost) { best = G; best_cap = cap_grp; best_lds = lds; best_cost = cost; }
     }
     if (best == 0) return false;
@@ -475,7 +507,7 @@ int mpc_knn_bwd_scatter_launch(const mpc_shape *s, const int *cell_start, const 
     const int64_t nblk = (int64_t)kg.ngx * kg.gy * s->B * s->nb;
     const dim3 grid((nblk + 7) / 8 * 8);
 #define KB_LAUNCH(L1_, NEXT_)                                                                                              \
-    hipLaunchKernelGGL((k_knn_bwd_scatter<L1_, NEXT_>), grid, dim3(KB_NT), lds, st, p, kg, cell_start, spos, sidx,        \
+    MPC_LAUNCH((k_knn_bwd_scatter<L1_, NEXT_>), grid, dim3(KB_NT), lds, st, p, kg, cell_start, spos, sidx,        \
                        grad_flow_lut, grad_flow_next, knn_state, lean->masks, lean->rowtab, lean->fbits, gacc, tmp_g, tmp_a)
     const bool next = grad_flow_next != nullptr;
     if (p.l1) { if (next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }

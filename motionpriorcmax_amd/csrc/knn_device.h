@@ -509,7 +509,7 @@ struct KnnLeanBufs { unsigned *masks; int2 *rowtab; unsigned *fbits; };
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
                          const KnnLeanBufs *lean, hipStream_t st);
-// true where the backward of this shape is the scatter kernel (strip forward, num_tref == 1, 'mean'; MPC_KNN_BWD_SCATTER=0: off)
+// true where the backward of this shape is the scatter kernel (MPC_KNN_BWD_SCATTER=1 and: strip forward, num_tref == 1, 'mean')
 bool mpc_knn_lean(const mpc_shape *s);
 bool mpc_knn_bwd_scatter_usable(const mpc_shape *s);
 int mpc_knn_bwd_scatter_launch(const mpc_shape *s, const int *cell_start, const float2 *spos, const int *sidx,

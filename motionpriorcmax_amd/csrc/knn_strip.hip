@@ -774,7 +774,7 @@ static void launch_strip(const KnnParams &p, const mpc_shape *s, const float *tr
     unsigned *mk = lean ? lean->masks : nullptr, *fb = lean ? lean->fbits : nullptr;
     int2 *rt = lean ? lean->rowtab : nullptr;
 #define KS_LAUNCH(L1_, NEXT_, IWD_, LEAN_)                                                                                    \
-    hipLaunchKernelGGL((k_knn_strip<WS, L1_, NEXT_, IWD_, LEAN_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx, \
+    MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_, LEAN_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx, \
                        flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy, mk, rt, fb)
     const int sel = (p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0);
     if (lean) {                  // (never with 'iwd': its backward is the gather)
@@ -809,7 +809,7 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_
     if (lean && p.iwd) { mpc_set_error("mpc_knn_strip_launch: the scatter backward does not serve 'iwd'"); return MPC_E_UNSUPPORTED; }
     launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, lean, st);
     MPC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_knn_fallback, dim3(256), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
+    MPC_LAUNCH(k_knn_fallback, dim3(256), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
                        knn_state, lean ? nullptr : tile_dkmax, fail, r_init);
     MPC_CHECK_LAUNCH();
     return 0;

@@ -402,33 +402,34 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
     if (e0) return e0;
     if (s->N > 0) {
         const int nblk = mpc_cdiv(s->N, 256 * VOX_PER_THREAD) * s->B;
-        hipLaunchKernelGGL(k_vox_bin, dim3(((nblk + 7) / 8) * 8), dim3(256), (size_t)s->C * L.NS * 2 * sizeof(int), st,
+        MPC_LAUNCH(k_vox_bin, dim3(((nblk + 7) / 8) * 8), dim3(256), (size_t)s->C * L.NS * 2 * sizeof(int), st,
                            *s, L, reinterpret_cast<const float4 *>(xytp), counts);
         MPC_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_vox_accum, dim3(L.NBk), dim3(1024), (size_t)L.SR * s->W * 8, st, L, grid, s->H, s->W);
+    MPC_LAUNCH(k_vox_accum, dim3(L.NBk), dim3(1024), (size_t)L.SR * s->W * 8, st, L, grid, s->H, s->W);
     MPC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_vox_overflow, dim3(64), dim3(256), 0, st, L, grid, s->H, s->W);
+    MPC_LAUNCH(k_vox_overflow, dim3(64), dim3(256), 0, st, L, grid, s->H, s->W);
     MPC_CHECK_LAUNCH();
     if (s->quantile > 0.f) {
         const int64_t per_sample = (int64_t)s->C * s->H * s->W;
-        const float qf = (float)(1.0 - (double)s->quantile);       // the Python side passes 1 - quantile as a double, torch rounds it to fp32
+        // torch.quantile(x, 1 - q) gets 1 - q computed in double and rounds it to fp32: the caller passes that value
+        const float qf = s->keep > 0.f ? s->keep : (float)(1.0 - (double)s->quantile);
         const int e1 = mpc_zero_async(h.qhist, (size_t)s->B * VOX_QBINS * 4, st);
         if (e1) return e1;
         const dim3 gq(L.nstat_blocks, s->B);
         for (int pass = 0; pass < 3; ++pass) {
-            hipLaunchKernelGGL(k_vox_qhist, gq, dim3(256), 0, st, grid, h.qhist, h.qstate, per_sample, pass);
-            hipLaunchKernelGGL(k_vox_qscan, dim3(s->B), dim3(256), 0, st, h.qhist, h.qstate, per_sample, qf, pass);
+            MPC_LAUNCH(k_vox_qhist, gq, dim3(256), 0, st, grid, h.qhist, h.qstate, per_sample, pass);
+            MPC_LAUNCH(k_vox_qscan, dim3(s->B), dim3(256), 0, st, h.qhist, h.qstate, per_sample, qf, pass);
         }
-        hipLaunchKernelGGL(k_vox_qnext, gq, dim3(256), 0, st, grid, h.qstate, per_sample);
-        hipLaunchKernelGGL(k_vox_qclip, gq, dim3(256), 0, st, grid, h.qstate, per_sample, qf);
+        MPC_LAUNCH(k_vox_qnext, gq, dim3(256), 0, st, grid, h.qstate, per_sample);
+        MPC_LAUNCH(k_vox_qclip, gq, dim3(256), 0, st, grid, h.qstate, per_sample, qf);
         MPC_CHECK_LAUNCH();
     }
     if (s->norm != 0) {
         const int64_t per_sample = (int64_t)s->C * s->H * s->W;
-        hipLaunchKernelGGL(k_vox_stats, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.part, per_sample);
-        hipLaunchKernelGGL(k_vox_finalize, dim3(s->B), dim3(256), 0, st, L.part, L.stat, L.nstat_blocks, s->norm);
-        hipLaunchKernelGGL(k_vox_norm, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.stat, per_sample, s->norm);
+        MPC_LAUNCH(k_vox_stats, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.part, per_sample);
+        MPC_LAUNCH(k_vox_finalize, dim3(s->B), dim3(256), 0, st, L.part, L.stat, L.nstat_blocks, s->norm);
+        MPC_LAUNCH(k_vox_norm, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.stat, per_sample, s->norm);
         MPC_CHECK_LAUNCH();
     }
     return 0;

@@ -70,6 +70,37 @@ class StageTimer:
 STAGE_TIMER = None   # set to a StageTimer to time every C-ABI call
 
 
+class KernelTimer:
+    """Per-KERNEL HIP-event timing by the library itself (mpc_profile_start / mpc_profile_stop: two events around every
+    launch, on the launch stream).  `with KernelTimer() as kt: ...steps...` then kt.summary() ->
+    {kernel name: {'launches': n, 'avg_us': mean duration of a launch, 'total_us': sum}}.  Diagnostics (bench.py)."""
+
+    def __enter__(self):
+        C.lib().mpc_profile_start()
+        self.records = None
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        cap = 1 << 16
+        names = ctypes.create_string_buffer(cap * 48)
+        ms = (ctypes.c_float * cap)()
+        n = int(C.lib().mpc_profile_stop(names, len(names), ms, cap))
+        out = {}
+        for nm, t in zip(names.value.decode().split('\n')[:n], ms[:n]):
+            k = nm.strip().lstrip('(').split('<')[0].rstrip(')').strip()
+            r = out.setdefault(k, {'launches': 0, 'total_us': 0.0})
+            r['launches'] += 1
+            r['total_us'] += 1e3 * t
+        for r in out.values():
+            r['avg_us'] = r['total_us'] / r['launches']
+        self.records = out
+        return False
+
+    def summary(self):
+        return self.records or {}
+
+
 class _stage:
     def __init__(self, name, device):
         self.name, self.device = name, device

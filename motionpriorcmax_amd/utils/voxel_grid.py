@@ -19,7 +19,8 @@ def voxel_grids(xytp: torch.Tensor, counts: torch.Tensor, input_size, norm_type=
     ev = xytp.float().contiguous()
     B, N, _ = ev.shape
     cnt = counts.to(device=ev.device, dtype=torch.int32).contiguous()
-    shape = C.VoxShape(B=B, N=N, C=Cn, H=H, W=W, norm={None: 0, 'mean_std': 1, 'max': 2}[norm_type], quantile=float(quantile))
+    shape = C.VoxShape(B=B, N=N, C=Cn, H=H, W=W, norm={None: 0, 'mean_std': 1, 'max': 2}[norm_type], quantile=float(quantile),
+                       keep=float(1.0 - float(quantile)) if quantile > 0 else 0.0)      # 1 - q in double, rounded once (torch.quantile's argument)
     nbytes = C.lib().mpc_voxel_workspace_bytes(ctypes.byref(shape))
     if nbytes < 0:
         C.check(int(nbytes), 'mpc_voxel_workspace_bytes')

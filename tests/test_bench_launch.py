@@ -33,7 +33,7 @@ def test_world_size_must_match_gpus():
 
 
 def test_more_gpus_than_visible_is_refused_by_the_parent():
-    # no dry run: the parent counts devices (torch.cuda.device_count() does not initialise HIP) and refuses
+    # no dry run: the parent counts the devices and refuses (it starts no rank)
     import torch
     if torch.cuda.device_count() >= 64:
         return

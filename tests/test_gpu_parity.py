@@ -31,7 +31,7 @@ def _loss_obj(cfg, **kw):
 
 def test_native_library_is_loaded():
     from motionpriorcmax_amd import _lib
-    assert _lib.lib().mpc_version() == 102
+    assert _lib.lib().mpc_version() == 103
     with open('/proc/self/maps') as f:
         assert 'libmpcmax.so' in f.read()
 
@@ -298,10 +298,12 @@ def test_single_sample_single_event_and_far_out_of_bounds_flow():
 
 
 @pytest.mark.parametrize('env', [{'MPC_KNN_MODE': 'global'}, {'MPC_KNN_STAGE_FLOW': '0'}, {'MPC_KNN_BLOCKS': '8'},
-                                 {'MPC_KNN_NT': '512', 'MPC_KNN_BWD_TS': '32'}])
+                                 {'MPC_KNN_NT': '512', 'MPC_KNN_BWD_TS': '32'},
+                                 {'MPC_KNN_BWD_SCATTER': '1'}, {'MPC_KNN_BWD_SCATTER': '1', 'MPC_KNN_BWD_G': '3'}])
 def test_alternative_knn_kernels_agree_with_goldens(env):
     """The unstaged per-thread search, the variant that gathers the flows from global memory, a tiny LDS
-    staging capacity (tiles that overflow it finish on the global arrays) and the larger workgroup shapes --
+    staging capacity (tiles that overflow it finish on the global arrays), the larger workgroup shapes and the
+    query-centric scatter backward (default and with three strips per workgroup) --
     tuning switches read once per process -- must pass the same parity tests as the default: the golden,
     odd-size and brute-force KNN tests of this file are re-run in a subprocess with the switch set."""
     import os
@@ -311,6 +313,8 @@ def test_alternative_knn_kernels_agree_with_goldens(env):
         pytest.skip('already inside the child run')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = 'golden_full_calc or golden_stages or odd_image_sizes or knn_large_k or knn_degenerate or full_size_knn'
+    if 'MPC_KNN_BWD_SCATTER' in env:      # the scatter backward (knn_bwd_scatter.hip): also every test with a KNN gradient
+        sel += ' or many_keys or hd_sensor or bitwise_reproducible or vs_oracle_seeded or recovers_a_known_flow'
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-x', '-q', '-m', 'gpu', '-k', sel],
                        cwd=root, env=dict(os.environ, MPC_ALT_KNN_CHILD='1', **env), capture_output=True, text=True,
                        timeout=900)

@@ -3,7 +3,9 @@
 
     python tools/sq_to_json.py <sq.csv> <kstats.csv> <out.json>"""
 import csv
+import hashlib
 import json
+import os
 import sys
 
 
@@ -20,6 +22,10 @@ def main():
         out[name] = {'valu_insts': float(r['SQ_INSTS_VALU']), 'waves': float(r['SQ_WAVES']), 'kernel_us': ks[name],
                      'valu_per_wave': float(r['valu_per_wave'] or 0), 'wait_any_frac': float(r['wait_any_frac'] or 0),
                      'wait_inst_frac': float(r['wait_inst_frac'] or 0), 'lds_per_wave': float(r['lds_per_wave'] or 0)}
+    # which library the counters belong to: bench.py prints it beside the figures it takes from this file
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'motionpriorcmax_amd', 'libmpcmax.so')
+    if os.path.exists(lib):
+        out['_library'] = 'libmpcmax.so sha256 ' + hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16]
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(out, indent=1)[:1500])
 

@@ -1,30 +1,24 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM bytes per launch.
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM-side bytes per launch.
 
-    python tools/summarize_pmc.py <fetch_dir> <write_dir> <out.json> [<calib_fetch_dir> <calib_write_dir>]
+    python tools/summarize_pmc.py <fetch_dir> <write_dir> <out.json> [<calib_fetch_dir> <calib_write_dir>] [--steps N]
 
-The counters are in KiB (MI355X_MICROARCH.md, HBM section).  On gfx950 FETCH_SIZE reports half of the bytes of a wide
-coalesced streaming read; other access widths are uncalibrated, so the factor is MEASURED: tools/ubench/fetch_calib.bin
-reads 1 GiB with 4-, 8- and 16-byte accesses per lane and gathers 8-byte words at random; the optional calibration
-passes give bytes / counter per access width.  Every kernel is listed with its RAW counter bytes and with a corrected
-figure that uses the factor of its dominant read width (table KERNEL_WIDTH below, from the kernels' sources); both are
-kept, the corrected one is what bench.py reports as `roofline.traffic`.  FETCH_SIZE and WRITE_SIZE come from separate
-passes (they do not fit one)."""
+The counters are in KiB (MI355X_MICROARCH.md, HBM section).  On gfx950 FETCH_SIZE tallies a 128-byte request at 64 bytes:
+tools/ubench/fetch_calib.bin reads 1 GiB (beyond the 256 MiB Infinity Cache) with 4-, 8- and 16-byte accesses per lane and
+the calibration passes give bytes / counter = 2.00 for all three; it also writes and then reads a 34 MB buffer (the size of
+the path's intermediate images: producer -> consumer through the Infinity Cache), where the counter still tallies the
+requests but at their true size when they are served on-die.  So for EVERY kernel, with the same labels:
+    fetch_bytes_raw          the counter as it stands        -> with write_bytes: hbm_bytes_lower
+    fetch_bytes_x2           the counter x the 1 GiB factor  -> with write_bytes: hbm_bytes_upper
+A kernel that streams from HBM sits at the upper figure, one whose input was just written by its producer nearer the lower
+one; nothing else is claimed per kernel.  WRITE_SIZE reads the bytes exactly.  FETCH_SIZE and WRITE_SIZE come from separate
+passes (they do not fit one).  `launches_per_step` = launches seen / steps of the profiled command (--steps, default 10 + the
+8 set-up and 5 warm-up steps and the instrumented and check passes of bench.py make this approximate: it is rounded)."""
 import collections
 import csv
 import glob
 import json
 import sys
-
-# dominant global READ access of every kernel of the path: 16 = 16 bytes per lane streaming, 8 / 4 = narrower streaming,
-# 'g' = gathers (a cache line per lane access)
-KERNEL_WIDTH = {
-    'k_iwe_accum': 16, 'k_lut_accum': 16,            # float4 records, streamed (k_lut_accum also gathers the adjoint image)
-    'k_ev_bin': 8, 'k_knn_bwd_combine': 8, 'k_lut_smooth': 8, 'k_knn_bucket': 8,
-    'k_contrast_fused': 4, 'k_finalize': 8, 'k_zero_words': 16,
-    'k_knn_strip': 'g', 'k_knn_bwd_tile': 'g', 'k_knn_fallback': 'g', 'k_knn_query': 'g', 'k_knn_bwd_points': 'g',
-}
-
 
 def per_kernel(d, counter):
     agg = collections.defaultdict(list)
@@ -42,50 +36,48 @@ def mean_tail(v):
 
 
 def main():
-    fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
-    write = per_kernel(sys.argv[2], 'WRITE_SIZE')
-    factors = {16: 2.0, 8: None, 4: None, 'g': None}
+    argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+    fetch = per_kernel(argv[0], 'FETCH_SIZE')
+    write = per_kernel(argv[1], 'WRITE_SIZE')
+    factor = 2.0
     calib = None
-    if len(sys.argv) > 5:
-        cf, cw = per_kernel(sys.argv[4], 'FETCH_SIZE'), per_kernel(sys.argv[5], 'WRITE_SIZE')
+    if len(argv) > 4:
+        cf, cw = per_kernel(argv[3], 'FETCH_SIZE'), per_kernel(argv[4], 'WRITE_SIZE')
         GiB = float(1 << 30)
         calib = {}
-        for width, key in ((4, 'k_calib_copy'), ):
-            pass
         # the three copies share one demangled base name; rocprofv3 lists them in launch order: float, float2, float4
         cc = cf.get('k_calib_copy', [])
         if len(cc) >= 3:
             per = len(cc) // 3 * 3
-            w4 = [cc[i] for i in range(0, per, 3)]; w8 = [cc[i] for i in range(1, per, 3)]; w16 = [cc[i] for i in range(2, per, 3)]
-            for width, v in ((4, w4), (8, w8), (16, w16)):
-                calib[f'read_{width}B_per_lane_bytes_over_counter'] = GiB / (1024.0 * v[-1])
-                factors[width] = GiB / (1024.0 * v[-1])
+            for width, off in ((4, 0), (8, 1), (16, 2)):
+                v = [cc[i] for i in range(off, per, 3)]
+                calib[f'read_1GiB_{width}B_per_lane_bytes_over_counter'] = GiB / (1024.0 * v[-1])
+            factor = calib['read_1GiB_16B_per_lane_bytes_over_counter']
         cg = cf.get('k_calib_gather8', [])
         if cg:
-            payload = GiB / 4                      # 256 MiB of 8-byte words; + 128 MiB of indices, streamed
-            calib['gather_8B_counter_bytes_over_payload'] = 1024.0 * cg[-1] / payload
-            # a gather's counter is requests x 64 B as well; whether its requests are 64 or 128 bytes is not resolved by this
-            # calibration, so the doubled figure is an UPPER bound for gather-dominated kernels (flagged in the output)
-            factors['g'] = 2.0
+            calib['gather_8B_counter_bytes_over_payload'] = 1024.0 * cg[-1] / (GiB / 4)
+        cs_ = cf.get('k_calib_small_read', [])
+        if cs_:
+            calib['read_34MB_just_written_bytes_over_counter'] = 34.0e6 / (1024.0 * cs_[-1]) if cs_[-1] > 0 else None
         ww = cw.get('k_calib_copy', [])
         if len(ww) >= 3:
             calib['write_bytes_over_counter_16B'] = GiB / (1024.0 * ww[len(ww) // 3 * 3 - 1])
-    out = {'_calibration': calib, '_factors_used': {str(k): v for k, v in factors.items()}}
+    steps = 10
+    for a in sys.argv[1:]:
+        if a.startswith('--steps='):
+            steps = int(a.split('=')[1])
+    out = {'_calibration': calib, '_fetch_factor_upper': factor}
     for k in sorted(set(fetch) | set(write)):
         fb = mean_tail(fetch.get(k, [0.0]))
         wb = mean_tail(write.get(k, [0.0]))
-        width = KERNEL_WIDTH.get(k)
-        fac = factors.get(width)
-        corrected = fb * fac if fac else fb
-        out[k] = {'fetch_bytes_raw': fb, 'read_width': width, 'fetch_factor': fac if fac else 1.0,
-                  'fetch_factor_is_upper_bound': width == 'g' or width is None,
-                  'fetch_bytes_corrected': corrected, 'write_bytes': wb,
-                  'hbm_bytes_per_launch': corrected + wb, 'hbm_bytes_per_launch_raw': fb + wb,
-                  'launches_seen': len(fetch.get(k, []))}
-    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+        n = len(fetch.get(k, [])) or len(write.get(k, []))
+        out[k] = {'fetch_bytes_raw': fb, 'fetch_bytes_x2': fb * factor, 'write_bytes': wb,
+                  'hbm_bytes_lower': fb + wb, 'hbm_bytes_upper': fb * factor + wb,
+                  'launches_seen': n}
+    json.dump(out, open(argv[2], 'w'), indent=1)
     for k, v in out.items():
-        if not k.startswith('_') and v['hbm_bytes_per_launch'] > 1e5:
-            print(f"{k[:36]:36s} fetch raw {v['fetch_bytes_raw'] / 1e6:8.1f} MB x{v['fetch_factor']:.2f}  write {v['write_bytes'] / 1e6:8.1f} MB")
+        if not k.startswith('_') and v['hbm_bytes_upper'] > 1e5:
+            print(f"{k[:36]:36s} fetch raw {v['fetch_bytes_raw'] / 1e6:8.1f} MB (x{factor:.2f} upper)  write {v['write_bytes'] / 1e6:8.1f} MB")
     print('calibration:', calib)
 
 

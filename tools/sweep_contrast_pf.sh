@@ -1,5 +1,7 @@
 #!/bin/bash
 # tuning sweep on the GPU box: prefetch depth of the marching contrast kernel
+# (every variant overwrites the in-tree libmpcmax.so: the default build is restored when the script ends, however it ends)
+trap "python -m motionpriorcmax_amd.build > /dev/null 2>&1" EXIT
 for v in 4 6 8 2; do
   echo "== CM_PF=$v"
   MPC_EXTRA_HIPCC_FLAGS="-DCM_PF=$v" python -m motionpriorcmax_amd.build > /dev/null 2>&1 || echo BUILD FAILED

@@ -13,6 +13,17 @@ __global__ void k_calib_gather8(const float2 *__restrict__ src, const int *__res
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
 }
 
+// a 34 MB buffer (the size of the path's images at C3) written by one kernel and read by the next: producer -> consumer through
+// the Infinity Cache, the pattern of k_iwe_accum -> k_contrast_march -> k_lut_accum
+__global__ void k_calib_small_write(float *__restrict__ dst, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+__global__ void k_calib_small_read(const float *__restrict__ src, float *__restrict__ out, size_t n) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
+    if (acc == 123.456f) out[0] = acc;
+}
+
 int main() {
     const size_t bytes = 1ull << 30;          // 1 GiB: beyond the 256 MiB Infinity Cache
     void *a, *b; int *idx;
@@ -30,6 +41,10 @@ int main() {
         hipLaunchKernelGGL(k_calib_copy<float2>, dim3(8192), dim3(256), 0, 0, (const float2 *)a, (float2 *)b, bytes / 8);
         hipLaunchKernelGGL(k_calib_copy<float4>, dim3(8192), dim3(256), 0, 0, (const float4 *)a, (float4 *)b, bytes / 16);
         hipLaunchKernelGGL(k_calib_gather8, dim3(8192), dim3(256), 0, 0, (const float2 *)a, idx, (float2 *)b, n8);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(k_calib_small_write, dim3(2048), dim3(256), 0, 0, (float *)b, (size_t)8500000, 1.0f + rep);
+        hipLaunchKernelGGL(k_calib_small_read, dim3(2048), dim3(256), 0, 0, (const float *)b, (float *)a, (size_t)8500000);
     }
     (void)hipDeviceSynchronize();
     printf("{\"copy_bytes_read\": %zu, \"copy_bytes_written\": %zu, \"gather_bytes_read_payload\": %zu, \"gather_index_bytes\": %zu, \"gather_bytes_written\": %zu}\n",
