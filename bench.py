@@ -484,6 +484,32 @@ def main():
                 del gr, lg, tg
             except Exception as e:      # informational
                 graph_ms = repr(e)[:120]
+        # the same steps through FocusLoss(static_shapes=True): the library's own capture-once-and-replay (two HIP graphs per
+        # shape), no capture code on the caller's side
+        static_ms = None
+        if world == 1 and instrument and not args.no_hip_graph:
+            try:
+                Lst = LossFactory.get_loss_calculator('FOCUS', dict(loss_config(wl), static_shapes=True))
+
+                def sstep():
+                    ls_, _, _ = Lst.calc(trajd, times_d, batch)
+                    ls_.backward()
+                    trajd.grad = None
+                    return ls_
+                for _ in range(5):
+                    sstep()
+                sts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        ls_ = sstep()
+                    torch.cuda.synchronize()
+                    sts.append(time.perf_counter() - t0)
+                static_ms = {'ms_per_step': round(1e3 * sorted(sts)[1] / steps, 4), 'loss_equal': bool(ls_.item() == last.item())}
+                del Lst
+            except Exception as e:      # informational
+                static_ms = {'error': repr(e)[:160]}
         # SURVEY.md 8f-1, layout half: the same steps on a batch whose rows ingest ordered by (bin, LUT strip)
         # (FocusLoss.order_events, once per batch, outside the step) -- reported beside the headline, which stays on the
         # reference's time-ordered tensor
@@ -528,7 +554,7 @@ def main():
             check = {'loss_rel_diff_vs_atomic_path': abs(la.item() - lb.item()) / abs(lb.item()),
                      'grad_rel_l2_vs_atomic_path': float((ta.grad - tb.grad).norm() / tb.grad.norm())}
         return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, kernels=kernels, graph_ms=graph_ms,
-                    loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered)
+                    loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered, static=static_ms)
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
     r_comm = None
@@ -618,6 +644,7 @@ def main():
         'rccl_ranks': rccl_ranks,
         'loss': r['loss'], 'loss_check': r.get('check'),
         'bucket_ordered_events': r.get('ordered'),
+        'static_shapes': r.get('static'),
         'roofline': roofline_of(r, args.workload),
     }
     if isinstance(r.get('graph_ms'), float):
@@ -644,6 +671,7 @@ def main():
                 dj = json.loads(r.stdout.strip().splitlines()[-1])
                 also[name] = {'value': dj['value'], 'ms_per_step': dj['ms_per_step'],
                               'hip_graph_ms_per_step': dj.get('hip_graph', {}).get('ms_per_step'),
+                              'static_shapes_ms_per_step': (dj.get('static_shapes') or {}).get('ms_per_step'),
                               'path_frac': dj['roofline']['path']['frac'],
                               'stages_us_per_step': dj['roofline']['stages_us_per_step']}
             except Exception as e:      # informational field: never fail the main line

@@ -26,13 +26,16 @@ class FocusLoss(base.TrajectoryLossBase):
         smooth_type (str): 'on_flow_to_tref' or 'on_flow_to_next'.
         loss_type (str, build-side extension): 'gradient_magnitude' (what the reference hard-codes,
             focus.py:90-91) or 'variance' (reference src/utils/loss.py:14-16).
+        static_shapes (bool, build-side extension, default False): capture `calc` + backward once per input shape into HIP
+            graphs and replay them (ops.StaticFocusPlan): for small batches, whose eager step is bound by the host.
+            `misc_metadata['iwes']` is then only valid until the next `calc`.
     """
 
     def __init__(self, image_shape, num_tref, num_bins, num_knn, smooth_weight,
                  lut_superpixel_size, focus_loss_norm, dist_norm,
                  scale_iwe_by_dt, mask_image_border, polarity_aware_batching,
                  interpolation_scheme, smooth_type, loss_type='gradient_magnitude', profiler=None,
-                 **kwargs):
+                 static_shapes=False, **kwargs):
         super().__init__()
         self.image_shape = image_shape
         self.num_tref = num_tref
@@ -49,6 +52,8 @@ class FocusLoss(base.TrajectoryLossBase):
         self.smooth_type = smooth_type
         self.loss_type = loss_type
         self.profiler = profiler
+        self.static_shapes = bool(static_shapes)
+        self._static_plans = {}
         self.is_needing_offsets = True
         self.imager = EventImageConverter(self.image_shape)
 
@@ -110,7 +115,9 @@ class FocusLoss(base.TrajectoryLossBase):
 
         t_ref = times[:self.num_tref]
         offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events (optional)
-        if self.profiler is not None:
+        if self.static_shapes and ops.STAGE_TIMER is None and not torch.cuda.is_current_stream_capturing():
+            out = ops.StaticFocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets, self._static_plans)
+        elif self.profiler is not None:
             with torch.profiler.record_function('mpcmax::FocusLoss.calc'):
                 out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets)
         else:

@@ -6,6 +6,7 @@ or eager fallback (a CPU tensor raises)."""
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -256,49 +257,90 @@ def _vp(t):
     return None if t is None else t.data_ptr()
 
 
-def _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal, offs=None):
-    return C.FocusBuffers(traj=_vp(traj), events=_vp(ev), t_ref=_vp(tr), flow_lut=_vp(flow_lut), flow_next=_vp(flow_next),
-                          knn_state=_vp(state), smooth_grad=_vp(g_field), iwe_raw=_vp(raw), iwe_blur=_vp(blur),
-                          grad_iwe=_vp(gimg), scal=_vp(scal), smooth_weight=float(cfg.smooth_weight), event_offsets=_vp(offs))
+class _Plan:
+    """What one (configuration, shape) needs on the host and does not change from step to step: the shape struct, the
+    workspace size and the layout of ONE float buffer that holds everything the forward leaves for the backward (LUT,
+    flow_next, KNN state, smoothness gradient, raw IWE, adjoint image, scalars).  A B = 1 step is host bound: building these
+    per step (two ctypes size queries, ~10 torch.empty, two struct fills) cost ~100 us of Python per direction."""
+
+    def __init__(self, cfg, B, M, Mp, n, need_grad, has_offs):
+        self.cfg = cfg
+        self.shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
+        self.shape_ref = ctypes.byref(self.shape)
+        self.need_grad = need_grad
+        nbytes = C.lib().mpc_workspace_bytes(self.shape_ref)
+        if nbytes < 0:
+            C.check(int(nbytes), 'mpc_workspace_bytes')
+        self.ws_bytes = max(int(nbytes), 256)
+        s = self.shape
+        self.P = 2 if s.flags & C.F_POLARITY_SPLIT else 1
+        self.lut_shape = (B, s.nb, s.hq, s.wq, s.T, 2)
+        n_lut = B * s.nb * s.hq * s.wq * s.T * 2
+        n_nxt = B * max(s.nb - 1, 0) * s.hq * s.wq * 2 if s.flags & C.F_WANT_NEXT else 0
+        n_state = int(C.lib().mpc_knn_state_floats(self.shape_ref))
+        n_gf = 0
+        if cfg.smooth_weight > 0 and need_grad:
+            n_gf = n_nxt if cfg.smooth_on_next else n_lut
+        n_img = B * s.T * self.P * s.H * s.W
+        self.img_shape = (B * s.T, self.P, s.H, s.W)
+        off = 0
+        self.o = {}
+        for name, cnt in (('lut', n_lut), ('nxt', n_nxt), ('state', n_state), ('gf', n_gf), ('raw', n_img),
+                          ('gimg', n_img if need_grad else 0), ('scal', C.SCAL_COUNT)):
+            self.o[name] = (off, cnt)
+            off += (cnt + 63) // 64 * 64          # 256-byte aligned pieces
+        self.buf_floats = max(off, 64)
+        # backward scratch: dL/dLUT and (smoothness on flow_to_next) the scaled dL/dflow_next
+        self.n_glut = n_lut
+        self.n_gnext = n_gf if (cfg.smooth_on_next and n_gf) else 0
+        self.smooth_weight = float(cfg.smooth_weight)
+
+    def io(self, base, traj, ev, tr, blur, offs):
+        def at(name):
+            off, cnt = self.o[name]
+            return base + 4 * off if cnt else None
+        return C.FocusBuffers(traj=traj, events=ev, t_ref=tr, flow_lut=at('lut'), flow_next=at('nxt'), knn_state=at('state'),
+                              smooth_grad=at('gf'), iwe_raw=at('raw'), iwe_blur=blur, grad_iwe=at('gimg'), scal=at('scal'),
+                              smooth_weight=self.smooth_weight, event_offsets=offs)
+
+    def view(self, buf, name):
+        off, cnt = self.o[name]
+        return buf[off:off + cnt] if cnt else None
 
 
-def focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad, offs=None):
-    """FocusLoss.calc forward as ONE C-ABI call (mpc_focus_fwd)."""
-    dev = traj.device
-    B, nb, T = shape.B, shape.nb, shape.T
-    hq, wq = shape.hq, shape.wq
-    flow_lut = torch.empty((B, nb, hq, wq, T, 2), dtype=torch.float32, device=dev)
-    flow_next = None
-    if shape.flags & C.F_WANT_NEXT:
-        flow_next = torch.empty((B, max(nb - 1, 0), hq, wq, 1, 2), dtype=torch.float32, device=dev)
-    state = torch.empty(int(C.lib().mpc_knn_state_floats(ctypes.byref(shape))), dtype=torch.float32, device=dev)
-    g_field = None
-    if cfg.smooth_weight > 0 and need_grad:
-        field = flow_next if cfg.smooth_on_next else flow_lut
-        if field is not None and field.numel() > 0:
-            g_field = torch.empty_like(field)
-    P = 2 if shape.flags & C.F_POLARITY_SPLIT else 1
-    raw = torch.empty((B * T, P, shape.H, shape.W), dtype=torch.float32, device=dev)
-    blur = torch.empty_like(raw)
-    gimg = torch.empty_like(raw) if need_grad else None
-    scal = torch.empty(C.SCAL_COUNT, dtype=torch.float32, device=dev)
-    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, flow_next, state, g_field, raw, blur, gimg, scal, offs)
+_PLANS = {}
+
+
+def _plan(cfg, B, M, Mp, n, need_grad, has_offs):
+    key = (cfg, B, M, Mp, n, need_grad, has_offs)
+    p = _PLANS.get(key)
+    if p is None:
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        p = _PLANS[key] = _Plan(cfg, B, M, Mp, n, need_grad, has_offs)
+    return p
+
+
+def _focus_fwd_call(p, dev, traj, ev, tr, buf, blur, ws, offs):
+    io = p.io(buf.data_ptr(), traj.data_ptr(), ev.data_ptr(), tr.data_ptr(), blur.data_ptr(), _vp(offs))
     with _stage('mpc_focus_fwd', dev):
-        C.check(C.lib().mpc_focus_fwd(ctypes.byref(shape), ctypes.byref(io), _ptr(ws), _stream(dev)), 'mpc_focus_fwd')
-    return flow_lut, flow_next, state, g_field, blur, gimg, scal
+        C.check(C.lib().mpc_focus_fwd(p.shape_ref, ctypes.byref(io), ctypes.c_void_p(ws.data_ptr()), _stream(dev)), 'mpc_focus_fwd')
 
 
-def focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, grad_out, ws, offs=None):
-    """Backward of the above to the trajectories as ONE C-ABI call (mpc_focus_bwd)."""
-    dev = traj.device
-    g_lut = torch.empty_like(flow_lut)
-    g_next = torch.empty_like(g_field) if (g_field is not None and cfg.smooth_on_next) else None
-    g_traj = torch.empty_like(traj)
-    io = _focus_io(cfg, shape, traj, ev, tr, flow_lut, None, state, g_field, None, None, gimg, scal, offs)
+def _focus_bwd_call(p, dev, traj, ev, tr, buf, ws, offs, grad_out, scratch, g_traj):
+    io = p.io(buf.data_ptr(), traj.data_ptr(), ev.data_ptr(), tr.data_ptr(), None, _vp(offs))
+    io.flow_next = None
+    io.iwe_raw = None
+    g_lut = scratch.data_ptr()
+    g_next = g_lut + 4 * ((p.n_glut + 63) // 64 * 64) if p.n_gnext else None
     with _stage('mpc_focus_bwd', dev):
-        C.check(C.lib().mpc_focus_bwd(ctypes.byref(shape), ctypes.byref(io), _ptr(grad_out), _ptr(g_lut), _ptr(g_next),
-                                      _ptr(g_traj), _ptr(ws), _stream(dev)), 'mpc_focus_bwd')
-    return g_traj
+        C.check(C.lib().mpc_focus_bwd(p.shape_ref, ctypes.byref(io), ctypes.c_void_p(grad_out.data_ptr()), ctypes.c_void_p(g_lut),
+                                      ctypes.c_void_p(g_next) if g_next else None, ctypes.c_void_p(g_traj.data_ptr()),
+                                      ctypes.c_void_p(ws.data_ptr()), _stream(dev)), 'mpc_focus_bwd')
+
+
+def _bwd_scratch_floats(p):
+    return (p.n_glut + 63) // 64 * 64 + p.n_gnext + 64
 
 
 def event_bucket_order(cfg: PathConfig, events, num_pos):
@@ -352,51 +394,69 @@ def _check_events(events, cfg, num_pos):
 # ------------------------------------------------------------------------------------------
 # autograd: the whole loss  trajectories -> (loss, focus, smooth, iwes)
 # ------------------------------------------------------------------------------------------
+def _calc_inputs(trajectories, events, t_ref, cfg, num_pos):
+    _require_gpu(trajectories, 'trajectories')
+    B, M, Mp = _check_events(events, cfg, num_pos)
+    T, nb = cfg.num_tref, cfg.num_bins
+    if trajectories.dim() != 4 or trajectories.shape[0] != B or trajectories.shape[1] != T + nb \
+            or trajectories.shape[3] != 2:
+        raise ValueError(f'trajectories must be [B={B}, {T + nb}, n, 2], got {tuple(trajectories.shape)}')
+    dev = trajectories.device
+    traj = _f32c(trajectories.detach())
+    ev = _f32c(events.detach())
+    tr = _f32c(t_ref.detach().to(dev))
+    return B, M, Mp, traj.shape[2], dev, traj, ev, tr
+
+
 class FocusCalcFn(torch.autograd.Function):
     """FocusLoss.calc (reference focus.py:66-113) as one differentiable op: KNN LUT -> smoothness
     -> warp + vote -> blur + objective in forward, hand-derived backward to `trajectories`."""
 
     @staticmethod
     def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, event_offsets=None):
-        _require_gpu(trajectories, 'trajectories')
-        B, M, Mp = _check_events(events, cfg, num_pos)
+        B, M, Mp, n, dev, traj, ev, tr = _calc_inputs(trajectories, events, t_ref, cfg, num_pos)
         T, nb = cfg.num_tref, cfg.num_bins
-        if trajectories.dim() != 4 or trajectories.shape[0] != B or trajectories.shape[1] != T + nb \
-                or trajectories.shape[3] != 2:
-            raise ValueError(f'trajectories must be [B={B}, {T + nb}, n, 2], got {tuple(trajectories.shape)}')
-        dev = trajectories.device
-        traj = _f32c(trajectories.detach())
-        ev = _f32c(events.detach())
-        tr = _f32c(t_ref.detach().to(dev))
-        n = traj.shape[2]
         need_grad = trajectories.requires_grad
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)      # no zero-filled [B,P,H,W] gradient for the detached outputs
+
+        if STAGE_TIMER is None and FUSED_CALLS:
+            # one C-ABI call for the whole forward (mpc_focus_fwd issues the same launches); per-shape host state is cached
+            p = _plan(cfg, B, M, Mp, n, need_grad, event_offsets is not None)
+            offs = _check_offsets(event_offsets, cfg, p.shape, dev)
+            ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
+            buf = torch.empty(p.buf_floats, dtype=torch.float32, device=dev)
+            blur = torch.empty(p.img_shape, dtype=torch.float32, device=dev)
+            _focus_fwd_call(p, dev, traj, ev, tr, buf, blur, ws, offs)
+            ctx.plan, ctx.ws, ctx.offs = p, ws, offs
+            ctx.save_for_backward(traj, ev, tr, buf)
+            o = p.o['scal'][0]
+            out = buf[o:o + 3].clone()            # one tiny copy: the outputs must not alias the saved scalars
+            loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
+            ctx.mark_non_differentiable(focus, smooth, blur)
+            return loss, focus, smooth, blur
+
         shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
         ws = alloc_workspace(shape, dev)
         offs = _check_offsets(event_offsets, cfg, shape, dev)
-
-        if STAGE_TIMER is None and FUSED_CALLS:
-            # one C-ABI call for the whole forward (mpc_focus_fwd issues the same launches)
-            flow_lut, flow_next, state, g_field, blur, gimg, scal = focus_fwd(cfg, shape, traj, ev, tr, ws, need_grad, offs)
-        else:
-            flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
-            g_field = None
-            s_nimg = s_C = 0
-            if cfg.smooth_weight > 0:
-                if cfg.smooth_on_next:
-                    field, s_nimg, s_C = flow_next, B * (nb - 1), 2
-                else:
-                    field, s_nimg, s_C = flow_lut, B * nb, 2 * T
-                if s_nimg > 0:
-                    g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
-            fshape = shape if offs is None else make_shape(cfg, B, M, Mp, n, extra_flags=C.F_NO_BWD_RECORDS)
-            raw = event_splat_fwd(fshape, ev, flow_lut, tr, ws)
-            blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
-            scal = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
-
-        ctx.cfg, ctx.shape = cfg, shape
+        flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
+        g_field = None
+        s_nimg = s_C = 0
+        if cfg.smooth_weight > 0:
+            if cfg.smooth_on_next:
+                field, s_nimg, s_C = flow_next, B * (nb - 1), 2
+            else:
+                field, s_nimg, s_C = flow_lut, B * nb, 2 * T
+            if s_nimg > 0:
+                g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
+        fshape = shape if offs is None else make_shape(cfg, B, M, Mp, n, extra_flags=C.F_NO_BWD_RECORDS)
+        raw = event_splat_fwd(fshape, ev, flow_lut, tr, ws)
+        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+        scal = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
+        ctx.plan = None
+        ctx.shape = shape
         ctx.offs = offs
         ctx.ws = ws
-        ctx.set_materialize_grads(False)      # no zero-filled [B,P,H,W] gradient for the detached outputs
         ctx.save_for_backward(traj, ev, tr, flow_lut, state, gimg, scal, g_field)
         out = scal[:3].clone()                # one tiny copy: the outputs must not alias the saved scalars
         loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
@@ -405,15 +465,19 @@ class FocusCalcFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
-        cfg, shape, ws = ctx.cfg, ctx.shape, ctx.ws
-        traj, ev, tr, flow_lut, state, gimg, scal, g_field = ctx.saved_tensors
         if g_loss is None:
             return None, None, None, None, None, None
         g = _f32c(g_loss.reshape(1))
-        offs = ctx.offs
-        if STAGE_TIMER is None and FUSED_CALLS:
-            g_traj = focus_bwd(cfg, shape, traj, ev, tr, flow_lut, state, gimg, scal, g_field, g, ws, offs)
+        cfg, ws, offs = ctx.cfg, ctx.ws, ctx.offs
+        if ctx.plan is not None:
+            p = ctx.plan
+            traj, ev, tr, buf = ctx.saved_tensors
+            scratch = torch.empty(_bwd_scratch_floats(p), dtype=torch.float32, device=traj.device)
+            g_traj = torch.empty_like(traj)
+            _focus_bwd_call(p, traj.device, traj, ev, tr, buf, ws, offs, g, scratch, g_traj)
             return g_traj, None, None, None, None, None
+        shape = ctx.shape
+        traj, ev, tr, flow_lut, state, gimg, scal, g_field = ctx.saved_tensors
         g_next = None
         g_lut = torch.empty_like(flow_lut)
         if g_field is not None and not cfg.smooth_on_next:
@@ -424,6 +488,95 @@ class FocusCalcFn(torch.autograd.Function):
                 g_next = scale(g_field, g)
         g_traj = knn_lut_bwd(shape, traj, g_lut, g_next, state, ws)
         return g_traj, None, None, None, None, None
+
+
+class StaticFocusPlan:
+    """FocusLoss(static_shapes=True): `calc` + backward of ONE shape captured once into two HIP graphs (forward; backward)
+    over buffers that never move, and replayed from then on -- what a B = 1 step costs on the host drops from two eager
+    C-ABI calls with their allocations to two graph launches and three small copies.  The reference has no counterpart
+    (PyTorch eager); the caller is unchanged (src/modules/trajectory_net.py:152-158).  Consequences of buffers that never
+    move, all checked or documented: `misc_metadata['iwes']` is valid until the next `calc` of this shape; a backward must
+    belong to the latest `calc` (checked); inputs are COPIED into the captured buffers every step (events only when the
+    caller hands over a different tensor than last time)."""
+
+    def __init__(self, cfg, B, M, Mp, n, dev, need_grad, traj, ev, tr, offs):
+        p = self.plan = _plan(cfg, B, M, Mp, n, need_grad, offs is not None)
+        self.dev = dev
+        self.offs = _check_offsets(offs, cfg, p.shape, dev)
+        self.traj, self.ev, self.tr = torch.empty_like(traj), torch.empty_like(ev), torch.empty_like(tr)
+        self.ev_src, self.ev_version = None, -1
+        self.ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
+        self.buf = torch.empty(p.buf_floats, dtype=torch.float32, device=dev)
+        self.blur = torch.empty(p.img_shape, dtype=torch.float32, device=dev)
+        self.gout = torch.ones(1, dtype=torch.float32, device=dev)
+        self.scratch = torch.empty(_bwd_scratch_floats(p), dtype=torch.float32, device=dev) if need_grad else None
+        self.g_traj = torch.empty_like(traj) if need_grad else None
+        self.generation = 0
+        self.traj.copy_(traj); self.ev.copy_(ev); self.tr.copy_(tr)
+        # one eager run on a side stream first: the library's one-time set-up must not fall into a capture
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._fwd()
+            if need_grad:
+                self._bwd()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd):
+            self._fwd()
+        self.g_bwd = None
+        if need_grad:
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd):
+                self._bwd()
+
+    def _fwd(self):
+        _focus_fwd_call(self.plan, self.dev, self.traj, self.ev, self.tr, self.buf, self.blur, self.ws, self.offs)
+
+    def _bwd(self):
+        _focus_bwd_call(self.plan, self.dev, self.traj, self.ev, self.tr, self.buf, self.ws, self.offs, self.gout, self.scratch, self.g_traj)
+
+
+class StaticFocusCalcFn(torch.autograd.Function):
+    """FocusCalcFn replayed from the HIP graphs of a StaticFocusPlan."""
+
+    @staticmethod
+    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, event_offsets, plans: dict):
+        B, M, Mp, n, dev, traj, ev, tr = _calc_inputs(trajectories, events, t_ref, cfg, num_pos)
+        need_grad = trajectories.requires_grad
+        key = (B, M, Mp, n, need_grad, dev.index, None if event_offsets is None else event_offsets.data_ptr())
+        sp = plans.get(key)
+        if sp is None:
+            if len(plans) >= 8:              # every shape holds its buffers: keep the set small
+                plans.pop(next(iter(plans)))
+            sp = plans[key] = StaticFocusPlan(cfg, B, M, Mp, n, dev, need_grad, traj, ev, tr, event_offsets)
+        sp.traj.copy_(traj)
+        if sp.ev_src is None or sp.ev_src() is not events or events._version != sp.ev_version:
+            sp.ev.copy_(ev)                 # a new batch (or one modified in place): copied once
+            sp.ev_src, sp.ev_version = weakref.ref(events), events._version
+        sp.tr.copy_(tr)
+        sp.generation += 1
+        ctx.sp, ctx.gen = sp, sp.generation
+        ctx.set_materialize_grads(False)
+        sp.g_fwd.replay()
+        o = sp.plan.o['scal'][0]
+        out = sp.buf[o:o + 3].clone()
+        loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
+        ctx.mark_non_differentiable(focus, smooth)
+        return loss, focus, smooth, sp.blur.detach()
+
+    @staticmethod
+    def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
+        if g_loss is None:
+            return None, None, None, None, None, None, None
+        sp = ctx.sp
+        if ctx.gen != sp.generation:
+            raise RuntimeError('FocusLoss(static_shapes=True): this backward belongs to an earlier calc() of the same shape; the '
+                               'captured buffers hold the latest one (call backward before the next calc, or use static_shapes=False)')
+        sp.gout.copy_(g_loss.reshape(1))
+        sp.g_bwd.replay()
+        return sp.g_traj.clone(), None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------

@@ -37,3 +37,77 @@ def test_calc_and_backward_replay_as_a_hip_graph():
     assert torch.equal(loss_g.detach(), ref_loss)
     assert torch.equal(t.grad, ref_grad)
     assert torch.isfinite(misc_g['iwes']).all()
+
+
+def _c2(seed):
+    import bench
+    wl = dict(bench.WORKLOADS['C2'])
+    ev, num_pos, traj, times = bench.synth_inputs(wl, seed=seed)
+    return wl, ev, num_pos, traj, times
+
+
+def test_static_shapes_replays_calc_and_backward_bit_for_bit():
+    """FocusLoss(static_shapes=True): the caller writes no capture code; loss, IWEs and gradient equal the eager ones bit for
+    bit, step after step, also when the trajectories, the reference time or the event tensor change between steps."""
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(5)
+    Le = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+    Ls = LossFactory.get_loss_calculator('FOCUS', dict(bench.loss_config(wl), static_shapes=True))
+    batch = {'events': ev.to(dev), 'num_pos_events': num_pos}
+    _, ev2, _, _, _ = _c2(6)
+    batch2 = {'events': ev2.to(dev), 'num_pos_events': num_pos}
+    td = times.to(dev)
+    for it in range(6):
+        b = batch if it < 3 else batch2                                   # a new batch from step 3 on
+        tt = (traj + 0.25 * it).to(dev)
+        tdi = td.clone(); tdi[0] = 0.1 + 0.13 * it                          # a new reference time every step
+        te = tt.clone().requires_grad_(True)
+        ts = tt.clone().requires_grad_(True)
+        le, loge, misce = Le.calc(te, tdi, b)
+        (2.5 * le).backward()
+        ls, logs, miscs = Ls.calc(ts, tdi, b)
+        (2.5 * ls).backward()
+        assert torch.equal(ls.detach(), le.detach()), it
+        assert torch.equal(logs['focus_loss'], loge['focus_loss']) and torch.equal(logs['smoothness_loss'], loge['smoothness_loss'])
+        assert torch.equal(miscs['iwes'], misce['iwes'])
+        assert torch.equal(ts.grad, te.grad), it
+    assert len(Ls._static_plans) == 1
+    # an in-place change of the event tensor is noticed as well (version counter)
+    batch2['events'][0, :100, 0] += 1.0
+    te = traj.to(dev).requires_grad_(True); ts = traj.to(dev).requires_grad_(True)
+    le, _, _ = Le.calc(te, td, batch2); le.backward()
+    ls, _, _ = Ls.calc(ts, td, batch2); ls.backward()
+    assert torch.equal(ls.detach(), le.detach()) and torch.equal(ts.grad, te.grad)
+
+
+def test_static_shapes_refuses_a_stale_backward_and_handles_new_shapes_and_no_grad():
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(7)
+    Ls = LossFactory.get_loss_calculator('FOCUS', dict(bench.loss_config(wl), static_shapes=True))
+    Le = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+    batch = {'events': ev.to(dev), 'num_pos_events': num_pos}
+    td = times.to(dev)
+    t1 = traj.to(dev).requires_grad_(True)
+    l1, _, _ = Ls.calc(t1, td, batch)
+    t2 = (traj + 1).to(dev).requires_grad_(True)
+    l2, _, _ = Ls.calc(t2, td, batch)
+    with pytest.raises(RuntimeError, match='earlier calc'):
+        l1.backward()
+    l2.backward()
+    assert torch.isfinite(t2.grad).all()
+    # another shape (fewer events): its own plan; the first keeps working
+    b3 = {'events': ev[:, :30000].contiguous().to(dev), 'num_pos_events': 15000}
+    t3 = traj.to(dev).requires_grad_(True); t3e = traj.to(dev).requires_grad_(True)
+    l3, _, _ = Ls.calc(t3, td, b3); l3.backward()
+    l3e, _, _ = Le.calc(t3e, td, b3); l3e.backward()
+    assert torch.equal(l3.detach(), l3e.detach()) and torch.equal(t3.grad, t3e.grad)
+    assert len(Ls._static_plans) == 2
+    # no gradient wanted (logging callback): forward-only plan
+    with torch.no_grad():
+        l4, _, m4 = Ls.calc(traj.to(dev), td, batch)
+        l4e, _, m4e = Le.calc(traj.to(dev), td, batch)
+    assert torch.equal(l4, l4e) and torch.equal(m4['iwes'], m4e['iwes'])
