@@ -36,6 +36,9 @@ WORKLOADS = {
                     'the per-GPU shard of configs[4] = batch 112 on 8 GPUs)'),
     'C4': dict(B=1, M=500_000, nb=41, k=10, smooth_type='on_flow_to_next', smooth_weight=0.06,
                desc='EVIMO2 480x640, 500k events/window, Bezier degree 10, 41 bins, batch=1 (BASELINE configs[3])'),
+    'C4b6': dict(B=6, M=500_000, nb=41, k=10, smooth_type='on_flow_to_next', smooth_weight=0.06,
+                 desc='EVIMO2 480x640, 500k events/window, Bezier degree 10, 41 bins, batch=6 (configs[3] at the batch size of '
+                      'its yaml: ...Tab2L5.yaml training.batch_size)'),
 }
 H, W, SP, PATCH, KNN = 480, 640, 4, 4, 32
 
@@ -57,7 +60,7 @@ def synth_inputs(wl, seed, B=None):
     g = torch.Generator().manual_seed(seed + 7)
     times = torch.cat((torch.tensor([0.41]), bin_mid_times(nb)))
     mask = utils.get_optical_flow_tile_mask((H, W), PATCH)
-    if wl is WORKLOADS['C4']:
+    if wl['k'] == 10:
         # Bezier control points N(0, 2^2) per tile, (x, y) channel order (bezier.py / polynomial.py:60-61)
         params = torch.randn(B, 2 * k, H // PATCH, W // PATCH, generator=g) * 2.0
         traj, _ = utils.trajectories_from_bezier(params, times, PATCH, (H, W))
@@ -348,7 +351,7 @@ def main():
                          'variant with the all-reduce is timed in a second loop and reported beside it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hip-graph', action='store_true', help='skip the HIP-graph replay timing reported beside the eager one')
-    ap.add_argument('--also', default='C2,C4', help='extra workloads reported in the "also" field (N=1 only)')
+    ap.add_argument('--also', default='C2,C4,C4b6', help='extra workloads reported in the "also" field (N=1 only)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -411,7 +414,7 @@ def main():
         # EXACTLY `steps` steps per timed block, each block bracketed by barrier + synchronize and reduced with
         # MAX over ranks; three consecutive blocks, the MEDIAN one is reported (a fresh box showed one-off host
         # stalls of ~15 ms that land in one block); all block times go into the JSON line
-        blocks = []
+        blocks, own_blocks = [], []
         for _ in range(3):
             if world > 1:
                 dist.barrier()
@@ -424,9 +427,38 @@ def main():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
-            blocks.append(dp.max_over_ranks(time.perf_counter() - t0, comm_dev))
+            own = time.perf_counter() - t0
+            own_blocks.append(own)
+            blocks.append(dp.max_over_ranks(own, comm_dev))
         dt = sorted(blocks)[1]
         total_valid = dp.sum_over_ranks(valid_local, comm_dev)
+        # every rank's own time for the median block and its own event count (the headline uses the MAX over ranks)
+        per_rank = None
+        if world > 1:
+            mine = torch.tensor([sorted(own_blocks)[1], valid_local], dtype=torch.float64, device=comm_dev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = {'ms_per_step': [round(1e3 * float(a[0]) / steps, 4) for a in allr],
+                        'value': [round(float(a[1]) * steps / float(a[0]) / 1e6, 3) for a in allr], 'unit': 'Mevents/s'}
+            per_rank['balance_min_over_max'] = round(min(per_rank['value']) / max(per_rank['value']), 4)
+        # the exchange alone (no loss step beside it): achieved all-reduce rate against the xGMI bounds
+        comm_alone = None
+        if reducer is not None:
+            for _ in range(2):
+                reducer.start(); reducer.wait()
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                reducer.start(); reducer.wait()
+            torch.cuda.synchronize()
+            tc = dp.max_over_ranks((time.perf_counter() - t0) / 5, comm_dev)
+            nbytes = dp.UNET_GRAD_NUMEL * 4
+            link = 153.0                                          # GB/s per xGMI link and direction (7 links per GPU)
+            ring = 2.0 * (world - 1) / world * nbytes / 1e9       # GB every rank sends (and receives) in a ring all-reduce
+            comm_alone = {'ms': round(1e3 * tc, 4), 'algbw_GBps': round(nbytes / tc / 1e9, 1), 'busbw_GBps': round(ring / tc, 1),
+                          'bound_one_link_ms': round(1e3 * ring / link, 4), 'bound_seven_links_ms': round(1e3 * ring / (7 * link), 4),
+                          'note': 'busbw = 2(N-1)/N x bytes / time; a ring is bound by ONE link per neighbour (153 GB/s per direction), '
+                                  'direct reduce-scatter + all-gather by all seven'}
 
         # instrumented pass: HIP events around every C-ABI call, on the stream they launch on
         stages = {}
@@ -554,7 +586,8 @@ def main():
             check = {'loss_rel_diff_vs_atomic_path': abs(la.item() - lb.item()) / abs(lb.item()),
                      'grad_rel_l2_vs_atomic_path': float((ta.grad - tb.grad).norm() / tb.grad.norm())}
         return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, kernels=kernels, graph_ms=graph_ms,
-                    loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered, static=static_ms)
+                    loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered, static=static_ms, per_rank=per_rank,
+                    comm_alone=comm_alone)
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
     r_comm = None
@@ -641,7 +674,7 @@ def main():
                    'global_batch': wl['B'] * world, 'events_per_sample': wl['M'], 'num_bins': wl['nb'],
                    'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
-        'rccl_ranks': rccl_ranks,
+        'rccl_ranks': rccl_ranks, 'per_rank': r.get('per_rank'),
         'loss': r['loss'], 'loss_check': r.get('check'),
         'bucket_ordered_events': r.get('ordered'),
         'static_shapes': r.get('static'),
@@ -656,7 +689,8 @@ def main():
         out['dp_with_grad_allreduce'] = {
             'value': round(r_comm['total_valid'] * r_comm['steps'] / r_comm['dt'] / 1e6, 3), 'unit': 'Mevents/s',
             'ms_per_step': round(1e3 * r_comm['dt'] / r_comm['steps'], 4),
-            'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2),
+            'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2), 'allreduce_alone': r_comm.get('comm_alone'),
+            'per_rank': r_comm.get('per_rank'),
             'note': 'same steps with the 124 MB network-gradient all-reduce (RCCL, 4 buckets, side stream) overlapping the next loss'}
     if rank == 0 and world == 1:
         also = {}

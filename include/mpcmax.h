@@ -128,6 +128,16 @@ int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flo
 int mpc_event_splat_fwd(const mpc_shape *s, const float *events, const float *flow_lut,
                         const float *t_ref, float *iwe_raw, void *ws, void *stream);
 
+/* ---- event-axis sharding ("optional finer split": a batch smaller than the number of ranks; the reference
+ * has batch DDP only, scripts/flow_training.py:125-128).  mpc_event_splat_fwd_fixed = mpc_event_splat_fwd on THIS rank's
+ * rows of `events`, but the output is the image's Q33.30 fixed-point accumulators themselves (int64 [B*T][P][H][W]).
+ * Integer partial images add up exactly and in any order: all-reduce(SUM) them across the ranks, then
+ * mpc_iwe_from_fixed converts to the fp32 raw IWE -- bit for bit the image one rank computes from all the events.
+ * The backward per rank is mpc_event_splat_bwd on its own rows (a partial dL/dLUT; summed across ranks in fp32). */
+int mpc_event_splat_fwd_fixed(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
+                              int64_t *iwe_fixed, void *ws, void *stream);
+int mpc_iwe_from_fixed(const int64_t *iwe_fixed, float *iwe_raw, int64_t count, void *stream);
+
 /* ---- A8 blur + A9 objective (event_image_converter.py:170-175, loss.py:4-27,58-87)
  * iwe_blur [B*T][P][H][W] (out) ; grad_iwe [B*T][P][H][W] or NULL (out: UNSCALED adjoint image
  * Blur^T Sobel^T u, or Blur^T (x - mean) for the variance objective; multiply by

@@ -376,7 +376,9 @@ __device__ __forceinline__ void record_taps(float y, float x, float w, int H, in
     if (r1 && c1) f(y0 + 1, x0 + 1, fy * fx * w);
 }
 
-// grid NF, 1024 threads, dynamic LDS = SR * W * 8 bytes
+// grid NF, 1024 threads, dynamic LDS = SR * W * 8 bytes.  FIXED: the accumulators themselves (Q33.30, int64) are the
+// output -- partial images of event shards add up exactly, in any order (mpc_event_splat_fwd_fixed)
+template <bool FIXED>
 __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__restrict__ iwe, int H, int W) {
     extern __shared__ unsigned long long s_acc[];
     const int tid = threadIdx.x;
@@ -407,8 +409,17 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
         }
     }
     __syncthreads();
-    float *dst = iwe + ((size_t)img * H + row0) * W;
-    for (int i = tid; i < npix; i += 1024) dst[i] = ev_from_fixed((long long)s_acc[i]);
+    if (FIXED) {
+        long long *dst = reinterpret_cast<long long *>(iwe) + ((size_t)img * H + row0) * W;
+        for (int i = tid; i < npix; i += 1024) dst[i] = (long long)s_acc[i];
+    } else {
+        float *dst = iwe + ((size_t)img * H + row0) * W;
+        for (int i = tid; i < npix; i += 1024) dst[i] = ev_from_fixed((long long)s_acc[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iwe_from_fixed(const long long *__restrict__ src, float *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = ev_from_fixed(src[i]);
 }
 
 struct __attribute__((packed, aligned(4))) pair4 { float x, y; };
@@ -573,8 +584,35 @@ extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, cons
     return mpc_event_splat_fwd_ex(s, events, flow_lut, t_ref, iwe_raw, ws, stream, 0);
 }
 
+static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
+                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed);
+
+// Event-axis sharding ("optional finer split" for batches smaller than the number of ranks): the raw IWE of
+// THIS rank's events as the Q33.30 accumulators themselves; integer partial images sum exactly, so an all-reduce(SUM) of
+// them followed by mpc_iwe_from_fixed gives, bit for bit, the image a single rank computes from all the events.
+extern "C" int mpc_event_splat_fwd_fixed(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
+                                         int64_t *iwe_fixed, void *ws, void *stream) {
+    MPC_CHECK_ARG(s && iwe_fixed && ws, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(!(s->flags & MPC_F_ATOMIC_PATH) && s->T == 1, MPC_E_UNSUPPORTED, "fixed-point images come from the LDS-tiled path (num_tref == 1)");
+    return splat_fwd_impl(s, events, flow_lut, t_ref, reinterpret_cast<float *>(iwe_fixed), ws, stream, 0, true);
+}
+
+extern "C" int mpc_iwe_from_fixed(const int64_t *iwe_fixed, float *iwe_raw, int64_t count, void *stream) {
+    MPC_CHECK_ARG((iwe_fixed && iwe_raw) || count == 0, MPC_E_NULL, "null argument");
+    if (count <= 0) return 0;
+    const int64_t blocks = (count + 255) / 256 < 8192 ? (count + 255) / 256 : 8192;
+    MPC_LAUNCH(k_iwe_from_fixed, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long long *>(iwe_fixed), iwe_raw, (size_t)count);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed) {
+    return splat_fwd_impl(s, events, flow_lut, t_ref, iwe_raw, ws, stream, counters_zeroed, false);
+}
+
+static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
+                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed) {
     MPC_CHECK_ARG(s && iwe_raw && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) || flow_lut, MPC_E_NULL, "flow_lut is null");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
@@ -585,7 +623,8 @@ int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float 
     if (use_tiled(s, L)) {
         static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
         if (attr_once.need()) {
-            if ((rc = set_max_lds_ev((const void *)k_iwe_accum, __func__))) return rc;
+            if ((rc = set_max_lds_ev((const void *)k_iwe_accum<false>, __func__))) return rc;
+            if ((rc = set_max_lds_ev((const void *)k_iwe_accum<true>, __func__))) return rc;
             if ((rc = set_max_lds_ev((const void *)k_lut_accum<false>, __func__))) return rc;
             if ((rc = set_max_lds_ev((const void *)k_lut_accum<true>, __func__))) return rc;
             attr_once.mark();
@@ -602,11 +641,13 @@ int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float 
             MPC_CHECK_LAUNCH();
         }
         if (L.nfb > 0) {
-            MPC_LAUNCH(k_iwe_accum, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
+            if (fixed) MPC_LAUNCH(k_iwe_accum<true>, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
+            else MPC_LAUNCH(k_iwe_accum<false>, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
             MPC_CHECK_LAUNCH();
         }
         return 0;
     }
+    MPC_CHECK_ARG(!fixed, MPC_E_UNSUPPORTED, "fixed-point images need the LDS-tiled path");
     const size_t img_bytes = (size_t)L.nimg * s->H * s->W * sizeof(float);
     const int e = mpc_zero_async(iwe_raw, img_bytes, st);
     if (e) return e;

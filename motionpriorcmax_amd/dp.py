@@ -98,3 +98,138 @@ def sum_over_ranks(value: float, device=None, force_collective: bool = False) ->
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------
+# Event-axis sharding: a batch smaller than the number of ranks ("optional finer split"; the reference has
+# batch DDP only, scripts/flow_training.py:125-128).  Every rank holds ALL trajectories and 1/world of every sample's event
+# rows.  Exchange steps: one all-reduce(SUM) of the raw IWE as int64 Q33.30 accumulators before the blur (integer sums:
+# the image, and with it the loss, is bit for bit the single-rank one), one all-reduce(SUM) of dL/dLUT in the backward.
+# ------------------------------------------------------------------------------------------
+def _all_reduce_sum(t: torch.Tensor, group=None):
+    """all-reduce(SUM) in place.  RCCL takes the device tensor as it is; the gloo debugging backend (ranks sharing one GPU,
+    CPU tests) gets a host copy of a device tensor."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def shard_event_rows(events: torch.Tensor, num_pos: int, rank: int, world: int):
+    """Rows of `events` [B, M, 6] this rank warps: every world-th row of the positive block, then every world-th row of the
+    negative block (the polarity split is by row index, focus.py:216-227).  Returns (local events, local num_pos)."""
+    M = events.shape[1]
+    if num_pos < 0:
+        return events[:, rank:M:world].contiguous(), -1
+    pos = events[:, rank:num_pos:world]
+    neg = events[:, num_pos + rank:M:world]
+    return torch.cat((pos, neg), dim=1).contiguous(), pos.shape[1]
+
+
+class _HipStages:
+    """The stage calls of the library (ops.py) the sharded loss is built from."""
+
+    def __init__(self, cfg, B, M, Mp, n, device):
+        from . import ops
+        self.ops, self.cfg = ops, cfg
+        self.shape = ops.make_shape(cfg, B, M, Mp, n)
+        self.ws = ops.alloc_workspace(self.shape, device)
+
+    def knn_fwd(self, traj):
+        lut, nxt, state, _ = self.ops.knn_lut_fwd(self.cfg, self.shape, traj, self.ws)
+        return lut, nxt, state
+
+    def smooth(self, field, nimg, C_, want_grad):
+        return self.ops.lut_smooth(self.shape, field, nimg, C_, self.cfg.smooth_weight, self.ws, want_grad)
+
+    def splat_fixed(self, ev, lut, tr):
+        return self.ops.event_splat_fwd_fixed(self.shape, ev, lut, tr, self.ws)
+
+    def from_fixed(self, fixed):
+        return self.ops.iwe_from_fixed(fixed)
+
+    def contrast(self, raw, want_grad):
+        return self.ops.contrast_fwd(self.shape, raw, self.ws, want_grad)
+
+    def finalize(self, nimg, C_, device):
+        return self.ops.finalize(self.shape, nimg, C_, self.cfg.smooth_weight, self.ws, device)
+
+    def splat_bwd(self, ev, lut, tr, gimg, scal, g):
+        g_lut = torch.empty_like(lut)
+        self.ops.event_splat_bwd(self.shape, ev, lut, tr, gimg, scal, g, g_lut, None, self.ws)
+        return g_lut
+
+    def scale(self, x, a):
+        return self.ops.scale(x, a)
+
+    def knn_bwd(self, traj, g_lut, g_next, state):
+        return self.ops.knn_lut_bwd(self.shape, traj, g_lut, g_next, state, self.ws)
+
+
+class EventShardedFocusFn(torch.autograd.Function):
+    """FocusLoss.calc (reference focus.py:66-113) with the EVENT axis sharded over the ranks of `group`."""
+
+    @staticmethod
+    def forward(ctx, trajectories, events_local, t_ref, cfg, num_pos_local, group, stages_factory):
+        traj = trajectories.detach().float().contiguous()
+        ev = events_local.detach().float().contiguous()
+        tr = t_ref.detach().float().to(traj.device).contiguous()
+        B, M = ev.shape[0], ev.shape[1]
+        Mp = num_pos_local if cfg.polarity_split else M
+        need_grad = trajectories.requires_grad
+        K = (stages_factory or _HipStages)(cfg, B, M, Mp, traj.shape[2], traj.device)
+        lut, nxt, state = K.knn_fwd(traj)                          # replicated: every rank has all trajectories
+        g_field, s_nimg, s_C = None, 0, 0
+        if cfg.smooth_weight > 0:
+            field, s_nimg, s_C = (nxt, B * (cfg.num_bins - 1), 2) if cfg.smooth_on_next else (lut, B * cfg.num_bins, 2 * cfg.num_tref)
+            if s_nimg > 0:
+                g_field = K.smooth(field, s_nimg, s_C, need_grad)
+        fixed = K.splat_fixed(ev, lut, tr)                         # this rank's rows only
+        _all_reduce_sum(fixed, group)                              # exchange step 1: int64, exact
+        raw = K.from_fixed(fixed)
+        blur, gimg = K.contrast(raw, need_grad)
+        scal = K.finalize(s_nimg, s_C, traj.device)
+        ctx.K, ctx.cfg, ctx.group = K, cfg, group
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(traj, ev, tr, lut, state, gimg, scal, g_field)
+        out = scal[:3].clone()
+        loss, focus, smooth = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(focus, smooth, blur)
+        return loss, focus, smooth, blur
+
+    @staticmethod
+    def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
+        if g_loss is None:
+            return (None,) * 7
+        K, cfg = ctx.K, ctx.cfg
+        traj, ev, tr, lut, state, gimg, scal, g_field = ctx.saved_tensors
+        g = g_loss.reshape(1).float().contiguous()
+        g_lut = K.splat_bwd(ev, lut, tr, gimg, scal, g)            # partial: this rank's rows
+        _all_reduce_sum(g_lut, ctx.group)                          # exchange step 2
+        g_next = None
+        if g_field is not None:                                    # the smoothness gradient is replicated: added once, after the sum
+            if cfg.smooth_on_next:
+                g_next = K.scale(g_field, g)
+            else:
+                g_lut = g_lut + K.scale(g_field, g)
+        return K.knn_bwd(traj, g_lut, g_next, state), None, None, None, None, None, None
+
+
+def event_sharded_calc(loss_obj, trajectories, times, local_batch, group=None, stages_factory=None):
+    """`loss_obj.calc(trajectories, times, batch)` for a batch whose EVENT rows are sharded over the ranks (local_batch from
+    shard_event_rows): same return contract as FocusLoss.calc; loss, focus term and IWEs equal the unsharded ones bit for
+    bit, the gradient up to the fp32 rounding of one sum over ranks."""
+    cfg = loss_obj._cfg
+    assert cfg.num_tref == 1, 'event-axis sharding serves num_tref == 1 (the shipped configurations)'
+    num_pos = int(local_batch['num_pos_events']) if 'num_pos_events' in local_batch else -1
+    loss, focus, smooth, iwes = EventShardedFocusFn.apply(trajectories, local_batch['events'], times[:cfg.num_tref], cfg, num_pos,
+                                                          group, stages_factory)
+    h, w = cfg.image_shape
+    b = local_batch['events'].shape[0]
+    iwes = iwes.reshape(b, 1, 2, h, w) if cfg.polarity_split else iwes.reshape(b, 1, h, w)
+    return loss, {'focus_loss': focus.detach(), 'smoothness_loss': smooth.detach()}, {'iwes': iwes.detach()}

@@ -209,6 +209,24 @@ def event_splat_fwd(shape, events, flow_lut, t_ref, ws):
     return raw
 
 
+def event_splat_fwd_fixed(shape, events, flow_lut, t_ref, ws):
+    """mpc_event_splat_fwd_fixed: the raw IWE of these event rows as Q33.30 accumulators (int64), for an exact sum over shards."""
+    dev = events.device
+    P = 2 if shape.flags & C.F_POLARITY_SPLIT else 1
+    fixed = torch.empty((shape.B * shape.T, P, shape.H, shape.W), dtype=torch.int64, device=dev)
+    with _stage('mpc_event_splat_fwd_fixed', dev):
+        C.check(C.lib().mpc_event_splat_fwd_fixed(ctypes.byref(shape), _ptr(events), _ptr(flow_lut), _ptr(t_ref),
+                                                  _ptr(fixed), _ptr(ws), _stream(dev)), 'mpc_event_splat_fwd_fixed')
+    return fixed
+
+
+def iwe_from_fixed(fixed):
+    raw = torch.empty(fixed.shape, dtype=torch.float32, device=fixed.device)
+    with _stage('mpc_iwe_from_fixed', fixed.device):
+        C.check(C.lib().mpc_iwe_from_fixed(_ptr(fixed), _ptr(raw), fixed.numel(), _stream(fixed.device)), 'mpc_iwe_from_fixed')
+    return raw
+
+
 def contrast_fwd(shape, raw, ws, want_grad):
     blur = torch.empty_like(raw)
     gimg = torch.empty_like(raw) if want_grad else None

@@ -119,6 +119,10 @@ def main():
             iwes=misc2['iwes'].numpy(), focus_loss=focus.item(), smooth_loss=float(smooth),
             loss=loss.item(), grad_trajectories=traj.grad.numpy(),
             grad_flow_lut=flow_lut.grad.numpy(), grad_coeff_grid_abs_sum=coeff_grid.grad.abs().sum().item(),
+            # the whole gradient of the coefficient grid (trajectory_net.py:101-119,142-161): it is non-zero at the tile
+            # centres only (the mask of get_optical_flow_tile_mask), stored there as [b, 1, 2k, tiles]
+            grad_coeff_grid_at_tiles=coeff_grid.grad[..., rutils.get_optical_flow_tile_mask(shape, patch)].numpy(),
+            grad_coeff_grid_off_tiles_abs_max=coeff_grid.grad[..., ~rutils.get_optical_flow_tile_mask(shape, patch)].abs().max().item(),
         )
         if flow_next is not None:
             out['flow_next'] = flow_next.detach().numpy()

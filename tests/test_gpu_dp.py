@@ -67,3 +67,81 @@ def test_bench_two_ranks_control_flow_over_gloo():
     assert d['n_gpus'] == 2 and d['rccl_ranks'] == 0 and d['scaling'] == 'weak' and d['config']['global_batch'] == 2 and d['value'] > 0
     assert len(d['blocks_ms_per_step']) == 3
     assert d['dp_with_grad_allreduce']['grad_allreduce_MB'] > 100 and d['dp_with_grad_allreduce']['value'] > 0
+
+
+def test_event_shards_sum_to_the_single_rank_image_bit_for_bit():
+    """SURVEY.md 8e, optional finer split (dp.event_sharded_calc): on the device, the Q33.30 images of the row shards of a
+    batch add up -- as integers, in any order -- to the image of all rows, and mpc_iwe_from_fixed of the sum is the fp32 raw
+    IWE of mpc_event_splat_fwd bit for bit; the sharded loss with no process group equals FocusLoss.calc."""
+    import torch
+    import bench
+    from motionpriorcmax_amd import LossFactory, dp, ops
+    dev = torch.device('cuda:0')
+    wl = dict(bench.WORKLOADS['C2'])
+    ev, num_pos, traj, times = bench.synth_inputs(wl, seed=9)
+    L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+    cfg = L._cfg
+    evd, trajd, td = ev.to(dev), traj.to(dev), times.to(dev)
+    shape = ops.make_shape(cfg, 1, ev.shape[1], num_pos, traj.shape[2])
+    ws = ops.alloc_workspace(shape, dev)
+    lut, _, _, _ = ops.knn_lut_fwd(cfg, shape, trajd, ws)
+    raw = ops.event_splat_fwd(shape, evd, lut, td[:1], ws)
+    full = ops.event_splat_fwd_fixed(shape, evd, lut, td[:1], ws)
+    assert torch.equal(ops.iwe_from_fixed(full), raw)
+    for world in (2, 3):
+        acc = torch.zeros_like(full)
+        for r in reversed(range(world)):
+            e, npos = dp.shard_event_rows(evd, num_pos, r, world)
+            sh = ops.make_shape(cfg, 1, e.shape[1], npos, traj.shape[2])
+            acc += ops.event_splat_fwd_fixed(sh, e, lut, td[:1], ops.alloc_workspace(sh, dev))
+        assert torch.equal(acc, full), world
+    # the sharded loss without a process group = the plain loss
+    t1 = trajd.clone().requires_grad_(True); t2 = trajd.clone().requires_grad_(True)
+    l1, log1, m1 = L.calc(t1, td, {'events': evd, 'num_pos_events': num_pos}); l1.backward()
+    l2, log2, m2 = dp.event_sharded_calc(L, t2, td, {'events': evd, 'num_pos_events': num_pos}); l2.backward()
+    assert torch.equal(l1.detach(), l2.detach()) and torch.equal(m1['iwes'], m2['iwes'])
+    assert float((t1.grad - t2.grad).norm() / t1.grad.norm()) < 1e-6
+
+
+SHARD_CHILD = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, '.')
+import bench
+from motionpriorcmax_amd import LossFactory, dp
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+wl = dict(bench.WORKLOADS['C2'])
+ev, num_pos, traj, times = bench.synth_inputs(wl, seed=11)
+L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+evd, td = ev.to(dev), times.to(dev)
+e, npos = dp.shard_event_rows(evd, num_pos, rank, world)
+t = traj.to(dev).requires_grad_(True)
+loss, log, misc = dp.event_sharded_calc(L, t, td, {'events': e, 'num_pos_events': npos})
+loss.backward()
+t1 = traj.to(dev).requires_grad_(True)
+l1, _, m1 = L.calc(t1, td, {'events': evd, 'num_pos_events': num_pos})
+l1.backward()
+torch.cuda.synchronize()
+assert torch.equal(loss.detach(), l1.detach()), (loss.item(), l1.item())
+assert torch.equal(misc['iwes'], m1['iwes'])
+rel = float((t.grad - t1.grad).norm() / t1.grad.norm())
+assert rel < 1e-5, rel
+dist.barrier()
+dist.destroy_process_group()
+print('shard-ok', rank)
+'''
+
+
+def test_event_axis_split_two_ranks_on_one_gpu():
+    """B = 1 on two ranks (configs[1] cannot use a second GPU by batch sharding): both ranks share cuda:0 here, the two
+    exchange steps run over gloo; loss and IWEs equal the single-rank ones bit for bit, the gradient to fp32 rounding."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29671', RANK=str(r), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', SHARD_CHILD], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f'shard-ok {r}' in so, (so[-500:], se[-1500:])

@@ -185,6 +185,76 @@ def test_c4_full_size_bezier_on_device_flow_to_next():
     assert _rel_l2(params.grad, p2.grad) < 2e-3          # ('l1' norm: sign flips of near-zero responses, see above)
 
 
+def test_c4_at_the_yaml_training_batch_of_six():
+    """configs[3] at the batch size its yaml trains with (`...Tab2L5.yaml` training.batch_size: 6; SURVEY.md 8d "B=1 (and 6)"):
+    6 x 500k events, 41 bins, smoothness on flow_to_next.  Every sample must equal its own B = 1 run bit for bit (LUT,
+    flow_to_next, IWEs, gradient of its trajectories up to the 1/val factor shared by the batch), the LUT is checked against
+    brute force on sampled cells of every sample, and the global-atomic event kernels give the same loss and gradient."""
+    import bench
+    from motionpriorcmax_amd import ops, utils, LossFactory
+    from oracle import focus_oracle as O
+    from motionpriorcmax_amd.utils.synth import synth_events, bin_mid_times
+    dev = _dev()
+    wl = bench.WORKLOADS['C4']
+    cfg = bench.loss_config(wl)
+    B = 6
+    L = LossFactory.get_loss_calculator('FOCUS', cfg)
+    ev, num_pos = synth_events(B, wl['M'], (480, 640), 41, seed=13, pad_frac=0.02, time_sorted=True)
+    g = torch.Generator().manual_seed(17)
+    params = (torch.randn(B, 20, 120, 160, generator=g) * 2.0).to(dev)
+    times = torch.cat((torch.tensor([0.41]), bin_mid_times(41)))
+    timesd, evd = times.to(dev), ev.to(dev)
+    traj, _ = utils.trajectories_from_bezier(params, timesd, 4, (480, 640))
+    traj = traj.detach().contiguous()
+    # stage level: LUT and flow_to_next of the batch against brute force, every sample
+    shape = ops.make_shape(L._cfg, B, 0, 0, 19200)
+    ws = ops.alloc_workspace(shape, dev)
+    lut, nxt, _, _ = ops.knn_lut_fwd(L._cfg, shape, traj, ws)
+    assert _fail_fraction(L, shape, ws) < 0.01
+    grid, hq, wq = O.lut_grid_points((480, 640), 4)
+    sel = torch.cat((torch.randperm(hq * wq, generator=g)[:96], torch.tensor([0, 159, 160 * 119, 160 * 120 - 1])))
+    q = grid[sel].to(dev)
+    for b in range(B):
+        for t in (0, 23, 40):
+            f, fn = _brute_lut(traj[b], q, 32, t)
+            assert (lut[b, t].reshape(-1, 2)[sel.to(dev)] - f).abs().max().item() < 1e-5
+            if t < 40:
+                assert (nxt[b, t].reshape(-1, 2)[sel.to(dev)] - fn).abs().max().item() < 1e-5
+    del ws
+    # the whole loss at B = 6, and sample 4 alone
+    tg = traj.clone().requires_grad_(True)
+    loss, log, misc = L.calc(tg, timesd, {'events': evd, 'num_pos_events': num_pos})
+    loss.backward()
+    b1 = 4
+    t1 = traj[b1:b1 + 1].clone().requires_grad_(True)
+    l1, log1, misc1 = L.calc(t1, timesd, {'events': evd[b1:b1 + 1].contiguous(), 'num_pos_events': num_pos})
+    l1.backward()
+    assert torch.equal(misc['iwes'][b1], misc1['iwes'][0])
+    # focus = 1 / mean over ALL images of the batch: the per-sample gradients of the focus term differ by the ratio of the
+    # squared values; the smoothness term is a mean over the batch as well (ratio B).  Compare directions on the focus-only part:
+    Lf = LossFactory.get_loss_calculator('FOCUS', dict(cfg, smooth_weight=0.0))
+    tgf = traj.clone().requires_grad_(True); lf, _, _ = Lf.calc(tgf, timesd, {'events': evd, 'num_pos_events': num_pos}); lf.backward()
+    t1f = traj[b1:b1 + 1].clone().requires_grad_(True); l1f, _, _ = Lf.calc(t1f, timesd, {'events': evd[b1:b1 + 1].contiguous(), 'num_pos_events': num_pos}); l1f.backward()
+    # d(1/val)/dx = -(1/val^2) dval/dx, val = mean over B*P images: grad_batch[b] = grad_single * (val_single^2 / val_batch^2) / B
+    ratio = (lf.item() ** 2) / (l1f.item() ** 2) / B
+    assert _rel_l2(tgf.grad[b1], t1f.grad[0] * ratio) < 1e-5
+    # oracle: event path and smoothness on the GPU LUT of the batch (one sample's IWEs compared; all enter the loss)
+    Lo = O.FocusLossOracle(**cfg)
+    fo, iwo, _ = Lo.event_path(ev, lut.cpu(), times[:1], num_pos)
+    so = Lo.smooth_loss(lut.cpu(), nxt.cpu())
+    assert abs(log['focus_loss'].item() - fo.item()) <= 1e-5 * abs(fo.item())
+    assert abs(log['smoothness_loss'].item() - so.item()) <= 1e-5 * abs(so.item())
+    assert abs(loss.item() - (fo + so).item()) <= 1e-5 * abs((fo + so).item())
+    np.testing.assert_allclose(misc['iwes'][2, 0].cpu().numpy(), iwo[2].detach().numpy(), atol=1e-5 * float(iwo.max()))
+    # second implementation of the event kernels
+    La = LossFactory.get_loss_calculator('FOCUS', dict(cfg, debug_atomic_path=True))
+    ta = traj.clone().requires_grad_(True)
+    la, _, _ = La.calc(ta, timesd, {'events': evd, 'num_pos_events': num_pos})
+    la.backward()
+    assert abs(la.item() - loss.item()) <= 2e-6 * abs(loss.item())
+    assert _rel_l2(tg.grad, ta.grad) < 2e-3
+
+
 @pytest.mark.parametrize('name,B', [('C2', 1), ('C3', 2), ('C4', 1)])
 def test_strip_kernel_serves_the_benchmark_shapes(name, B):
     """The KNN fast path (strip kernel) must serve nearly every query of the shapes the benchmark times; what it hands to
@@ -230,3 +300,16 @@ def test_training_step_on_device_matches_reference_gradient(name):
     got = float(cg.grad.abs().sum())
     want = float(g['grad_coeff_grid_abs_sum'])
     assert abs(got - want) <= 1e-3 * want, (got, want)
+    # the WHOLE gradient of the grid against the reference's autograd (stored at the tile centres, zero elsewhere): by
+    # relative L2, and element by element under the accounting rule of tests/test_gpu_grad_accounting.py -- 2e-5 of the
+    # maximum + 1e-4 relative, with at most 0.1 % of the elements beyond it (a vote next to a pixel whose Sobel response is
+    # zero up to rounding may take the other sign() in the two implementations)
+    gc = cg.grad.cpu().numpy()
+    m = mask.cpu().numpy()
+    ref = g['grad_coeff_grid_at_tiles']
+    assert np.abs(gc[..., ~m]).max() == 0.0
+    d = gc[..., m] - ref
+    rel = np.linalg.norm(d) / np.linalg.norm(ref)
+    bad = np.abs(d) > 2e-5 * np.abs(ref).max() + 1e-4 * np.abs(ref)
+    assert rel < 1e-3, rel
+    assert bad.mean() <= 1e-3, (bad.mean(), rel)

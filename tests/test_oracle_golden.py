@@ -56,6 +56,13 @@ def test_oracle_matches_reference(name):
     assert np.linalg.norm(gt - g['grad_trajectories']) / denom < 1e-5
     assert abs(r['cg'].grad.abs().sum().item() - g['grad_coeff_grid_abs_sum']) <= \
         1e-4 * g['grad_coeff_grid_abs_sum']
+    # the whole coefficient-grid gradient (trajectory_net.py:101-119,142-161): non-zero at the tile centres only
+    from oracle import focus_oracle as O
+    mask = O.tile_mask(tuple(g['cfg']['image_shape']), int(g['patch']))
+    gc = r['cg'].grad.numpy()
+    want = g['grad_coeff_grid_at_tiles']
+    assert np.linalg.norm(gc[..., mask.numpy()] - want) / (np.linalg.norm(want) + 1e-30) < 1e-5
+    assert np.abs(gc[..., ~mask.numpy()]).max() == 0.0 == float(g['grad_coeff_grid_off_tiles_abs_max'])
 
 
 @pytest.mark.parametrize('name', GOLDEN_CASES)
