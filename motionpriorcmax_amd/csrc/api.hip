@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -158,14 +159,22 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
         L.cstrip_rows = mpc_cdiv(s->hq, L.n_cstrips);
         L.nfb = s->B * L.P * L.n_strips;
         L.nbb = s->B * s->nb * L.n_cstrips;
-        // a bucket holds whatever can reach it: every event of a polarity block may vote into one image strip, every
-        // event of a sample may lie in one (bin, LUT strip).  Address space only: untouched slots cost nothing.
+        // FORWARD buckets (image strip of the WARPED position: flow dependent, cannot be sized ahead): a bucket holds
+        // whatever can reach it -- every event of a polarity block may vote into one image strip.  This memory is
+        // committed (the caller's torch.empty is a hipMalloc), nfb * fcap * 16 bytes: 0.7 GB at C3.
+        // BACKWARD buckets (the event's own LUT cell: flow independent): none for a forward-only call or bucket-ordered
+        // events (MPC_F_NO_BWD_RECORDS: the backward reads the event rows themselves).  Otherwise either every bucket holds
+        // all M rows of its sample (nbb * M * 16 bytes: 4.7 GB at C3), or -- where that exceeds MPC_EV_EXACT_ABOVE_MB
+        // (default 6144: 2 % of the 288 GB) -- the buckets are sized EXACTLY by a counting pass over the events
+        // (ev_count_device.h), M records per sample in all, at the price of that pass (+11 us per C3 step when forced).
         const int64_t mpol = (L.P == 2) ? (s->Mp > s->M - s->Mp ? s->Mp : s->M - s->Mp) : s->M;
         L.fcap = (int)(mpol > 0 ? mpol : 1);
-        L.bcap = (int)(s->M > 0 ? s->M : 1);
-        L.off_fcount = off; off += mpc_align((int64_t)(L.nfb + L.nbb + 8) * sizeof(int32_t));
+        L.bcap = (int)(s->M > 0 ? s->M : 1);                 // records of one bucket, or (b_exact) of one SAMPLE
+        static const int64_t exact_above = (getenv("MPC_EV_EXACT_ABOVE_MB") ? atoll(getenv("MPC_EV_EXACT_ABOVE_MB")) : 6144) << 20;
+        L.b_exact = ((int64_t)L.nbb * L.bcap * 16 > exact_above) ? 1 : 0;
+        L.off_fcount = off; off += mpc_align((int64_t)(L.nfb + 3 * L.nbb + 8) * sizeof(int32_t));      // fill counters, marker, capacities, first records
         L.off_frec = off;   off += mpc_align((int64_t)L.nfb * L.fcap * 16);
-        L.off_brec = off;   off += mpc_align((int64_t)L.nbb * L.bcap * 16);
+        L.off_brec = off;   off += (s->flags & MPC_F_NO_BWD_RECORDS) ? 0 : mpc_align((int64_t)(L.b_exact ? s->B : L.nbb) * L.bcap * 16);
     } else {
         L.strip_rows = L.cstrip_rows = 0;
     }
@@ -199,7 +208,11 @@ extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {
 extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream) {
     MPC_CHECK_ARG(s && io && ws, MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(io->traj && io->flow_lut && io->knn_state && io->iwe_raw && io->iwe_blur && io->scal, MPC_E_NULL, "null buffer");
-    int rc = mpc_knn_lut_fwd_ex(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream, 1);
+    // the KNN forward's kernels also zero the event bucket counters and (unless the backward reads the rows themselves) count
+    // the rows per backward bucket: `done` says what of that happened (bit 0 zeroed, bit 1 counted)
+    const bool rec_bwd = io->grad_iwe && !io->event_offsets && !(s->flags & MPC_F_NO_BWD_RECORDS);
+    int done = 0;
+    int rc = mpc_knn_lut_fwd_ex(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream, 1, rec_bwd ? io->events : nullptr, &done);
     if (rc) return rc;
     int s_nimg = 0, s_C = 0;
     if (io->smooth_weight > 0.f) {
@@ -216,7 +229,7 @@ extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, vo
         // ordered events: no record per event for the backward (it reads the rows themselves)
         mpc_shape sf = *s;
         if (io->event_offsets) sf.flags |= MPC_F_NO_BWD_RECORDS;
-        if ((rc = mpc_event_splat_fwd_ex(&sf, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, 1))) return rc;
+        if ((rc = mpc_event_splat_fwd_ex(&sf, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, done))) return rc;
     }
     if ((rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream))) return rc;
     return mpc_finalize(s, s_nimg, s_C, io->smooth_weight, io->scal, ws, stream);

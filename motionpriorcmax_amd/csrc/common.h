@@ -81,13 +81,14 @@ struct mpc_ws_layout {
     int64_t off_knn_fbits;   // uint32 [B*nb][hq][ceil(wq/32)]
     int64_t off_knn_gacc;    // uint64 [1 or 2][B*nb][n]  accumulators of workgroups whose points do not fit their LDS
     // event partition (LDS-tiled path)
-    int64_t off_fcount;      // int32 [nfb + nbb + 8]  bucket fill counters, marker
+    int64_t off_fcount;      // int32 [nfb + nbb + 8] bucket fill counters, marker; then [nbb] capacities and [nbb] first records of the backward buckets
     int64_t off_frec;        // float4 [nfb][fcap]
-    int64_t off_brec;        // float4 [nbb][bcap]
+    int64_t off_brec;        // float4 [B][bcap = M]: the backward buckets of a sample back to back, each as large as its count of rows
     int32_t P, nimg, G;
     int32_t strip_rows, n_strips;   // destination strips of the IWE (forward buckets)
     int32_t cstrip_rows, n_cstrips; // source strips of LUT cell rows (backward buckets)
     int32_t nfb, nbb, fcap, bcap;
+    int32_t b_exact;          // backward buckets sized by the counting pass (bcap = records of a SAMPLE) instead of M per bucket
     int64_t total;
 };
 
@@ -105,7 +106,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s);
 // internal variants of two entry points used by mpc_focus_fwd (api.hip): the KNN forward's first kernel zeroes the event
 // bucket counters, so that the event forward can skip its own zeroing launch
 int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
-                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters);
+                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done);
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed);
 int mpc_validate_shape(const mpc_shape *s);

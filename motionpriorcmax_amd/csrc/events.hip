@@ -5,6 +5,7 @@
 // Arithmetic follows SURVEY.md Appendix A op for op (fp32, no FMA contraction: this file is
 // compiled with -ffp-contract=off).
 #include "common.h"
+#include "ev_count_device.h"
 
 struct EvParams {
     int B, M, Mp, nb, T, H, W, sp, hq, wq, P;
@@ -195,9 +196,10 @@ __global__ __launch_bounds__(256) void k_splat_bwd_atomic(const mpc_shape s,
 #define EV_MARKER 0x6d706331   // 'mpc1': backward records of this workspace are valid
 
 struct BinLayout {
-    int SR, NS, CSR, NCS, NF, NBk, fcap, bcap, P;
+    int SR, NS, CSR, NCS, NF, NBk, fcap, bcap, P, exact;
     int *gcount;            // [NF + NBk + 8]
-    float4 *frec, *brec;    // bucket storage
+    int *bcapcnt;           // [NBk] rows of the sample in each backward bucket (ev_count_device.h): its capacity; then [NBk] first records
+    float4 *frec, *brec;    // bucket storage: frec [NF][fcap]; brec [B][bcap = M], a sample's backward buckets back to back
 };
 
 __device__ __forceinline__ long long ev_to_fixed_small(float v) {   // |v| < 2
@@ -231,8 +233,10 @@ __device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, i
         const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
         L.frec[(size_t)g * L.fcap + slot] = rec;
     } else {
-        const int gb = b * p.nb * L.NCS + (lb - nf_loc);
-        L.brec[(size_t)gb * L.bcap + slot] = rec;
+        // (exact buckets: `slot` counts from the sample's first record -- the bucket starts behind the rows of the buckets
+        // before it; else every bucket has room for all the rows of its sample)
+        const size_t base = L.exact ? (size_t)b : (size_t)(b * p.nb * L.NCS + (lb - nf_loc));
+        L.brec[base * L.bcap + slot] = rec;
     }
 }
 
@@ -305,9 +309,10 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     for (int i = tid; i < nloc; i += 256) {
         const int c = s_cnt[i];
         int g;
+        int first = 0;            // backward bucket: its first record among the sample's (ev_prefix_block, before this kernel)
         if (i < nf_loc) g = (b * p.P + i / L.NS) * L.NS + (i % L.NS);
-        else g = L.NF + b * p.nb * L.NCS + (i - nf_loc);
-        s_base[i] = c > 0 ? atomicAdd(&L.gcount[g], c) : 0;
+        else { g = L.NF + b * p.nb * L.NCS + (i - nf_loc); if (L.exact) first = L.bcapcnt[L.NBk + b * p.nb * L.NCS + (i - nf_loc)]; }
+        s_base[i] = (c > 0 ? atomicAdd(&L.gcount[g], c) : 0) + first;
     }
     // Local exclusive prefix of the counts: the records are first laid out in LDS bucket by bucket and then
     // written out in that order, so that neighbouring lanes store to neighbouring slots of the same bucket
@@ -507,7 +512,9 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         o_neg = min(max(ob[NK + 1 + key], 0), p.M);
         n = n_pos + min(max(ob[NK + 1 + key + 1] - o_neg, 0), p.M - o_neg);
     } else n = valid ? L.gcount[L.NF + g] : 0;
-    const float4 *rec = L.brec + (size_t)g * L.bcap;
+    // the bucket's records: behind those of the sample's buckets before it (first records: ev_prefix_block)
+    const float4 *rec = L.brec;
+    if (!ORDERED) rec = L.exact ? L.brec + (size_t)b * L.bcap + L.bcapcnt[L.NBk + (size_t)b * NK + key] : L.brec + (size_t)g * L.bcap;
     const float tref = (ORDERED && (p.flags & MPC_F_SCALE_BY_DT)) ? t_ref[0] : 0.f;
     // record r of this bucket: from the forward's list, or rebuilt from event row r of the ordered tensor
     auto fetch = [&](int r) -> float4 {
@@ -558,14 +565,39 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
     }
 }
 
+// the counting pass of ev_count_device.h as a launch of its own (stage entry points; the fused forward lets spare
+// workgroups of the KNN strip kernel do it).  grid ev_count_blocks(a), 256 threads, dynamic LDS nb * NCS ints
+__global__ __launch_bounds__(256) void k_ev_count(const EvCountArgs a) {
+    extern __shared__ int s_ec[];
+    ev_count_block(a, blockIdx.x, s_ec);
+}
+// grid B, 256 threads
+__global__ __launch_bounds__(256) void k_ev_prefix(const EvCountArgs a) {
+    __shared__ int s_tmp[4];
+    ev_prefix_block(a, blockIdx.x, s_tmp);
+}
+
 static BinLayout bin_layout(const mpc_shape *s, const mpc_ws_layout &L, void *ws) {
     BinLayout B;
     B.SR = L.strip_rows; B.NS = L.n_strips; B.CSR = L.cstrip_rows; B.NCS = L.n_cstrips;
-    B.NF = L.nfb; B.NBk = L.nbb; B.fcap = L.fcap; B.bcap = L.bcap; B.P = L.P;
+    B.NF = L.nfb; B.NBk = L.nbb; B.fcap = L.fcap; B.bcap = L.bcap; B.P = L.P; B.exact = L.b_exact;
     B.gcount = (int *)((char *)ws + L.off_fcount);
+    B.bcapcnt = B.gcount + L.nfb + L.nbb + 8;
     B.frec = (float4 *)((char *)ws + L.off_frec);
     B.brec = (float4 *)((char *)ws + L.off_brec);
     return B;
+}
+
+// what the counting pass needs (null events: nothing to count -- no tiled path, no backward records wanted)
+EvCountArgs mpc_event_count_args(const mpc_shape *s, const float *events, void *ws) {
+    EvCountArgs a{};
+    const mpc_ws_layout L = mpc_layout(s);
+    const bool tiled = !(s->flags & MPC_F_ATOMIC_PATH) && s->T == 1 && L.strip_rows > 0 && L.cstrip_rows > 0;
+    if (!tiled || !L.b_exact || (s->flags & (MPC_F_NO_WARP | MPC_F_NO_BWD_RECORDS)) || s->B <= 0 || s->M <= 0 || !events) return a;
+    a.events = events;
+    a.cap = (int *)((char *)ws + L.off_fcount) + L.nfb + L.nbb + 8;
+    a.B = s->B; a.M = s->M; a.nb = s->nb; a.sp = s->sp; a.hq = s->hq; a.CSR = L.cstrip_rows; a.NCS = L.n_cstrips;
+    return a;
 }
 
 static bool use_tiled(const mpc_shape *s, const mpc_ws_layout &L) { return !(s->flags & MPC_F_ATOMIC_PATH) && s->T == 1 && L.strip_rows > 0 && L.cstrip_rows > 0; }
@@ -631,10 +663,18 @@ static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *
         }
         const BinLayout BL = bin_layout(s, L, ws);
         const int want_bwd = (s->flags & (MPC_F_NO_WARP | MPC_F_NO_BWD_RECORDS)) ? 0 : 1;
-        if (!counters_zeroed && (rc = mpc_zero_async(BL.gcount, (size_t)(L.nfb + L.nbb + 8) * sizeof(int), st))) return rc;
+        // counters_zeroed: bit 0 = the counters were zeroed, bit 1 = the backward capacities were counted (mpc_focus_fwd: by the
+        // KNN forward's kernels)
+        if (!(counters_zeroed & 1) && (rc = mpc_zero_async(BL.gcount, (size_t)(L.nfb + 2 * L.nbb + 8) * sizeof(int), st))) return rc;
         if (s->B > 0 && s->M > 0) {
             const int nblk = mpc_cdiv(s->M, 256 * EV_PER_THREAD) * s->B;
             const dim3 grid(((nblk + 7) / 8) * 8);
+            if (want_bwd && L.b_exact && !(counters_zeroed & 2)) {
+                const EvCountArgs ca = mpc_event_count_args(s, events, ws);
+                MPC_LAUNCH(k_ev_count, dim3(ev_count_blocks(ca)), dim3(256), (size_t)s->nb * L.n_cstrips * sizeof(int), st, ca);
+                MPC_LAUNCH(k_ev_prefix, dim3(s->B), dim3(256), 0, st, ca);
+                MPC_CHECK_LAUNCH();
+            }
             const int nloc = L.P * L.n_strips + s->nb * L.n_cstrips;
             const size_t lds = (size_t)(((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3) * sizeof(int) + (size_t)EV_STAGE * 16;
             MPC_LAUNCH(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);

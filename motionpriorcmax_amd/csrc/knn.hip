@@ -11,6 +11,7 @@
 // No index tensor is materialised: the backward re-derives membership from the saved K-th key.
 #include "common.h"
 #include "knn_device.h"
+#include "ev_count_device.h"
 #include <stdlib.h>
 
 
@@ -987,12 +988,15 @@ static int set_max_lds(const void *fn, const char *who) {
 
 extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                                float *knn_state, int32_t *idx_out, void *ws, void *stream) {
-    return mpc_knn_lut_fwd_ex(s, traj, flow_lut, flow_next, knn_state, idx_out, ws, stream, 0);
+    return mpc_knn_lut_fwd_ex(s, traj, flow_lut, flow_next, knn_state, idx_out, ws, stream, 0, nullptr, nullptr);
 }
 
-// zero_event_counters: the first kernel also zeroes the bucket counters of mpc_event_splat_fwd (mpc_focus_fwd: one launch less)
+// zero_event_counters: the first kernel also zeroes the bucket counters of mpc_event_splat_fwd (mpc_focus_fwd: one launch less);
+// events (with it): the strip kernel also counts these event rows per backward bucket (ev_count_device.h).  *done receives
+// what of the two was done: bit 0 zeroed, bit 1 counted.
 int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
-                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters) {
+                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done) {
+    if (done) *done = 0;
     MPC_CHECK_ARG(s && traj && flow_lut && knn_state && ws, MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(!(s->flags & MPC_F_WANT_NEXT) || flow_next, MPC_E_NULL, "flow_next is null");
     int rc = mpc_validate_shape(s);
@@ -1010,7 +1014,9 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     int *fail = (int *)((char *)ws + L.off_knn_fail);
     const int ntiles = mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16);
     int *zero_ptr = (int *)((char *)ws + L.off_fcount);
-    const int zero_words = (zero_event_counters && L.strip_rows > 0) ? L.nfb + L.nbb + 8 : 0;
+    const int zero_words = (zero_event_counters && L.strip_rows > 0) ? L.nfb + 2 * L.nbb + 8 : 0;
+    EvCountArgs evc = (zero_words > 0) ? mpc_event_count_args(s, events, ws) : EvCountArgs{};
+    if (s->B > 256) evc = EvCountArgs{};      // (the fallback kernel's first B workgroups finish the count)
     KnnLeanBufs lean{nullptr, nullptr, nullptr};
     if (L.knn_lean) {
         lean.masks = (unsigned *)((char *)ws + L.off_knn_mask);
@@ -1056,8 +1062,12 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     const int r_init = mpc_knn_r_init(s);
     // fast path (num_tref == 1, the shipped configurations): strip kernel + per-query fallback (knn_strip.hip)
     if (tune.strip && !tune.global_mode && idx_out == nullptr && mpc_knn_strip_usable(s, r_init))
-        return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init,
-                                    L.knn_lean ? &lean : nullptr, st);
+    {
+        rc = mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init,
+                                  L.knn_lean ? &lean : nullptr, evc.events ? &evc : nullptr, st);
+        if (!rc && done) *done = (zero_words > 0 ? 1 : 0) | (evc.events ? 2 : 0);
+        return rc;
+    }
     // (idx_out wanted where the scatter backward applies: the tile kernel below writes the indices, then the strip
     // kernels run as well so that the state the backward expects exists -- a diagnostics path)
     const bool also_strip = L.knn_lean && idx_out != nullptr;
@@ -1107,8 +1117,11 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         MPC_LAUNCH(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
                            flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
     MPC_CHECK_LAUNCH();
-    if (also_strip)
-        return mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, &lean, st);
+    if (also_strip) {
+        rc = mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, &lean, nullptr, st);
+        if (rc) return rc;
+    }
+    if (done) *done = zero_words > 0 ? 1 : 0;
     return 0;
 }
 

@@ -506,9 +506,10 @@ bool mpc_knn_strip_geom(const mpc_shape *s, int r_init, KnnStripGeom *g);
 //   rowtab int2   [B*nb][gy*gx][NR + 1]   {first bucketed point, first slot | points << 16} of every region row; then {slots, 0}
 //   fbits  uint32 [B*nb][hq][ceil(wq/32)] queries served by the fallback kernel (zeroed by the bucket kernels)
 struct KnnLeanBufs { unsigned *masks; int2 *rowtab; unsigned *fbits; };
+struct EvCountArgs;      // ev_count_device.h: event rows to count per backward bucket in spare workgroups of the strip kernel, or null
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
-                         const KnnLeanBufs *lean, hipStream_t st);
+                         const KnnLeanBufs *lean, const EvCountArgs *evc, hipStream_t st);
 // true where the backward of this shape is the scatter kernel (MPC_KNN_BWD_SCATTER=1 and: strip forward, num_tref == 1, 'mean')
 bool mpc_knn_lean(const mpc_shape *s);
 bool mpc_knn_bwd_scatter_usable(const mpc_shape *s);

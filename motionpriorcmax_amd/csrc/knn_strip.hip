@@ -20,6 +20,7 @@
 // staging area) is appended to a list and searched by k_knn_fallback, one wavefront per query: the result is the
 // exact K-nearest set for any input, ties to the lowest index.
 #include "knn_device.h"
+#include "ev_count_device.h"
 #include <stdlib.h>
 
 #define KS_NT 256
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                      int *__restrict__ fail, int r_init, int cap, int gx, int gy,
                                                      unsigned *__restrict__ mask_out, int2 *__restrict__ rowtab_out,
-                                                     unsigned *__restrict__ fbits) {
+                                                     unsigned *__restrict__ fbits, const EvCountArgs evc, int n_evc, int evc_stride) {
     constexpr int TH = KS_NT / WS;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
@@ -65,8 +66,23 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
 #ifdef KS_STAMP
     const unsigned long long st0 = wall_clock64();      // diagnostics build: per-workgroup durations (tools/strip_stamp_probe.py)
 #endif
+    // mpc_focus_fwd: some workgroups do not search -- they count the event rows per backward bucket for the event kernels
+    // that follow (ev_count_device.h).  This kernel is bound by vector-instruction issue and leaves HBM idle, so the 67 MB of
+    // C3's events are read beside it.  The counting workgroups come in groups of 8 (one per XCD: the search workgroups keep
+    // their XCD mapping), a group every `evc_stride` workgroups -- thinly spread: all at the front they held 45 % of the
+    // workgroup slots for the ~25 us a bandwidth-bound start takes (+12 us); spread they hold ~4 % at any time.
+    int pblk = (int)blockIdx.x;
+    if (n_evc > 0) {
+        const int grp = pblk / evc_stride, in_grp = pblk - grp * evc_stride, ngrp = n_evc >> 3;
+        if (grp < ngrp && in_grp < 8) {
+            const int cb = grp * 8 + in_grp;
+            if (cb < ev_count_blocks(evc)) ev_count_block(evc, cb, reinterpret_cast<int *>(s_dyn));
+            return;
+        }
+        pblk -= 8 * min(grp + 1, ngrp);
+    }
     const int nblk = gx * gy * p.B * p.nb;
-    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    const int lblk = (pblk & 7) * ((nblk + 7) >> 3) + (pblk >> 3);
     if (lblk >= nblk) return;
     const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
     const int sy = bxy / gx, sx = bxy - sy * gx;
@@ -710,8 +726,11 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
                                                       const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                       float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                       float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                      const int *__restrict__ fail, int r_init) {
+                                                      const int *__restrict__ fail, int r_init, const EvCountArgs evc) {
     __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
+    // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B workgroups turn
+    // the counts of their sample into first records (the event kernels follow on the stream)
+    if (evc.events != nullptr && (int)blockIdx.x < evc.B) ev_prefix_block(evc, (int)blockIdx.x, reinterpret_cast<int *>(&s_hist[0][0]));
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     // (the first entry is read together with the length, not after it: the list has room for every query, so the
     // address is valid whatever the length turns out to be)
@@ -767,15 +786,21 @@ bool mpc_knn_strip_geom(const mpc_shape *s, int r_init, KnnStripGeom *g) {
 template <int WS>
 static void launch_strip(const KnnParams &p, const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos,
                          const int *sidx, float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail,
-                         int r_init, int cap, size_t lds, const KnnLeanBufs *lean, hipStream_t st) {
+                         int r_init, int cap, size_t lds, const KnnLeanBufs *lean, const EvCountArgs *evc, hipStream_t st) {
     const int TH = KS_NT / WS;
     const int gx = mpc_cdiv(s->wq, WS), gy = mpc_cdiv(s->hq, TH);
-    const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
+    EvCountArgs ec{};
+    if (evc && (size_t)evc->nb * evc->NCS * sizeof(int) <= lds) ec = *evc;
+    const int n_evc = (ev_count_blocks(ec) + 7) / 8 * 8;
+    const int64_t total = ((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8 + n_evc;
+    int evc_stride = n_evc > 0 ? (int)(total / (n_evc >> 3) / 8 * 8) : 8;       // a group of 8 counting workgroups every `stride` workgroups
+    if (evc_stride < 8) evc_stride = 8;
+    const dim3 grid((unsigned)total);
     unsigned *mk = lean ? lean->masks : nullptr, *fb = lean ? lean->fbits : nullptr;
     int2 *rt = lean ? lean->rowtab : nullptr;
 #define KS_LAUNCH(L1_, NEXT_, IWD_, LEAN_)                                                                                    \
     MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_, LEAN_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx, \
-                       flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy, mk, rt, fb)
+                       flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy, mk, rt, fb, ec, n_evc, evc_stride)
     const int sel = (p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0);
     if (lean) {                  // (never with 'iwd': its backward is the gather)
         switch (sel) {
@@ -802,15 +827,18 @@ static void launch_strip(const KnnParams &p, const mpc_shape *s, const float *tr
 // `lean`: buffers of the scatter backward (knn_bwd_scatter.hip), or null for the gather backward (K-th keys + tile maxima)
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
-                         const KnnLeanBufs *lean, hipStream_t st) {
+                         const KnnLeanBufs *lean, const EvCountArgs *evc, hipStream_t st) {
     const KnnParams p = knn_params(s);
     int cap = 0; size_t lds = 0;
     if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
     if (lean && p.iwd) { mpc_set_error("mpc_knn_strip_launch: the scatter backward does not serve 'iwd'"); return MPC_E_UNSUPPORTED; }
-    launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, lean, st);
+    launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, lean, evc, st);
     MPC_CHECK_LAUNCH();
+    EvCountArgs ecf{};
+    if (evc && (size_t)evc->nb * evc->NCS * sizeof(int) <= lds && evc->B <= 256) ecf = *evc;
+    else if (evc) { mpc_set_error("mpc_knn_strip_launch: event counting does not fit"); return MPC_E_UNSUPPORTED; }
     MPC_LAUNCH(k_knn_fallback, dim3(256), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
-                       knn_state, lean ? nullptr : tile_dkmax, fail, r_init);
+                       knn_state, lean ? nullptr : tile_dkmax, fail, r_init, ecf);
     MPC_CHECK_LAUNCH();
     return 0;
 }

@@ -283,7 +283,8 @@ class _Plan:
 
     def __init__(self, cfg, B, M, Mp, n, need_grad, has_offs):
         self.cfg = cfg
-        self.shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
+        # (bucket-ordered events: the backward reads the rows themselves -- no record region in the workspace either)
+        self.shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if (need_grad and not has_offs) else C.F_NO_BWD_RECORDS)
         self.shape_ref = ctypes.byref(self.shape)
         self.need_grad = need_grad
         nbytes = C.lib().mpc_workspace_bytes(self.shape_ref)
