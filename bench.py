@@ -349,6 +349,9 @@ def main():
                     help='N>1: put the overlapped 124 MB network-gradient all-reduce inside the main timed loop '
                          '(default: the loss path alone is timed -- it has no data-path collective -- and the '
                          'variant with the all-reduce is timed in a second loop and reported beside it)')
+    ap.add_argument('--events-layout', default='bucket', choices=['bucket', 'time'],
+                    help='row order of the event tensor the timed steps run on: as the library\'s ingest delivers it (rows of a polarity '
+                         'block grouped by (time bin, LUT strip) + offsets table; default) or the reference loader\'s time order')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hip-graph', action='store_true', help='skip the HIP-graph replay timing reported beside the eager one')
     ap.add_argument('--also', default='C2,C4,C4b6', help='extra workloads reported in the "also" field (N=1 only)')
@@ -391,7 +394,12 @@ def main():
         L = LossFactory.get_loss_calculator('FOCUS', loss_config(wl))
         evd, times_d = ev.to(dev), times.to(dev)
         trajd = traj.to(dev).requires_grad_(True)
-        batch = {'events': evd, 'num_pos_events': num_pos}
+        batch_time = {'events': evd, 'num_pos_events': num_pos}
+        # The layout the library's own ingest delivers (utils.ingest_events(order_for=loss), mpc_ingest_scatter_ordered: the
+        # rows of each polarity block grouped by (time bin, LUT strip) as ingest writes them + the offsets table) is the
+        # default input of the timed steps; the reference loader's time-ordered tensor is timed beside it
+        # (`time_ordered_events`).  Same loss and gradient bit for bit (tests/test_gpu_event_order.py).
+        batch = L.order_events(batch_time) if args.events_layout == 'bucket' else batch_time
         valid_local = float(ev[..., 5].sum())
         reducer = dp.GradAllReducer(device=comm_dev) if (with_comm and world > 1) else None
 
@@ -545,18 +553,20 @@ def main():
         # SURVEY.md 8f-1, layout half: the same steps on a batch whose rows ingest ordered by (bin, LUT strip)
         # (FocusLoss.order_events, once per batch, outside the step) -- reported beside the headline, which stays on the
         # reference's time-ordered tensor
+        # the other event layout beside the headline: the reference loader's time-ordered tensor when the headline runs on
+        # bucket-ordered events (and the other way round), plus what the ordering costs ingest
         ordered = None
         if instrument and world == 1:
-            ob = L.order_events(batch)
+            other = batch_time if args.events_layout == 'bucket' else L.order_events(batch_time)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
-                L.order_events(batch)
+                L.order_events(batch_time)
             torch.cuda.synchronize()
             order_ms = 1e3 * (time.perf_counter() - t0) / 10
 
             def ostep():
-                lo_, _, _ = L.calc(trajd, times_d, ob)
+                lo_, _, _ = L.calc(trajd, times_d, other)
                 lo_.backward()
                 trajd.grad = None
                 return lo_
@@ -570,15 +580,17 @@ def main():
                     lo_ = ostep()
                 torch.cuda.synchronize()
                 ots.append(time.perf_counter() - t0)
-            ordered = {'ms_per_step': round(1e3 * sorted(ots)[1] / steps, 4), 'order_events_ms': round(order_ms, 4),
-                       'loss_equal': bool(lo_.item() == last.item())}
+            oms = 1e3 * sorted(ots)[1] / steps
+            ordered = {'layout': 'time' if args.events_layout == 'bucket' else 'bucket', 'ms_per_step': round(oms, 4),
+                       'value': round(valid_local / (oms * 1e-3) / 1e6, 3), 'unit': 'Mevents/s',
+                       'order_events_standalone_ms': round(order_ms, 4), 'loss_equal': bool(lo_.item() == last.item())}
         # one cross-check of the number the timed steps computed, outside the timed region: the same step through the
         # in-library global-atomic event kernels (a second implementation of warp + vote + backward)
         check = None
         if instrument:
             La = LossFactory.get_loss_calculator('FOCUS', dict(loss_config(wl), debug_atomic_path=True))
             ta = trajd.detach().clone().requires_grad_(True)
-            la, _, _ = La.calc(ta, times_d, batch)
+            la, _, _ = La.calc(ta, times_d, batch_time)       # (the debugging path takes the plain tensor; the layouts agree bit for bit)
             la.backward()
             tb = trajd.detach().clone().requires_grad_(True)
             lb, _, _ = L.calc(tb, times_d, batch)
@@ -670,13 +682,13 @@ def main():
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
         'blocks_ms_per_step': [round(1e3 * x / r['steps'], 4) for x in r['blocks']], 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f"{args.workload}: {wl['desc']}", 'batch_per_gpu': wl['B'],
+        'config': {'workload': f"{args.workload}: {wl['desc']}", 'batch_per_gpu': wl['B'], 'events_layout': args.events_layout,
                    'global_batch': wl['B'] * world, 'events_per_sample': wl['M'], 'num_bins': wl['nb'],
                    'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
         'rccl_ranks': rccl_ranks, 'per_rank': r.get('per_rank'),
         'loss': r['loss'], 'loss_check': r.get('check'),
-        'bucket_ordered_events': r.get('ordered'),
+        'other_event_layout': r.get('ordered'),
         'static_shapes': r.get('static'),
         'roofline': roofline_of(r, args.workload),
     }
@@ -699,13 +711,14 @@ def main():
             # (sized by the main workload) otherwise frees/reallocates inside the child's timed steps
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--steps', str(args.steps),
-                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--also', '']
+                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--also', '', '--events-layout', args.events_layout]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 dj = json.loads(r.stdout.strip().splitlines()[-1])
                 also[name] = {'value': dj['value'], 'ms_per_step': dj['ms_per_step'],
                               'hip_graph_ms_per_step': dj.get('hip_graph', {}).get('ms_per_step'),
                               'static_shapes_ms_per_step': (dj.get('static_shapes') or {}).get('ms_per_step'),
+                              'time_ordered_ms_per_step': (dj.get('other_event_layout') or {}).get('ms_per_step'),
                               'path_frac': dj['roofline']['path']['frac'],
                               'stages_us_per_step': dj['roofline']['stages_us_per_step']}
             except Exception as e:      # informational field: never fail the main line

@@ -251,6 +251,16 @@ int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, const float *y
                        const float *p, const int32_t *counts, int32_t max_pos, int32_t max_neg,
                        float *events, float *xytp, void *ws, void *stream);
 
+/* Ingest straight into the bucket-ordered layout: the outputs of mpc_ingest_scatter followed by mpc_event_bucket_order for
+ * the loss shape `loss` (its B, nb, H, W, sp, hq, wq, flags; M = max_pos + max_neg, Mp = max_pos), without the extra pass
+ * over the event tensor -- the (time bin, LUT strip) of an event is known when its row is written.  offsets
+ * [B][2][nb * S + 1] as documented at mpc_event_bucket_order.  ws: the workspace mpc_ingest_count used (unchanged since);
+ * ws_order: mpc_ingest_ordered_workspace_bytes(s, loss) bytes. */
+int64_t mpc_ingest_ordered_workspace_bytes(const mpc_ingest_shape *s, const mpc_shape *loss);
+int mpc_ingest_scatter_ordered(const mpc_ingest_shape *s, const mpc_shape *loss, const float *x, const float *y,
+                               const int64_t *t_us, const float *p, const int32_t *counts, int32_t max_pos, int32_t max_neg,
+                               float *events, int32_t *offsets, float *xytp, void *ws, void *ws_order, void *stream);
+
 /* ---- next row: dense flow from tile trajectories and flow error metrics.
  * mpc_dense_flow = reference src/utils/flow.py:12-16 (dense_flow_from_traj): list_to_grid
  *   (src/utils/trajectories.py:54-76) at pixel_positions // patch, then the anti-aliased bicubic resize

@@ -29,7 +29,8 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
            'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
-           'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed']
+           'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
+           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered']
 
 
 class Shape(ctypes.Structure):
@@ -112,6 +113,9 @@ def lib():
     L.mpc_ingest_workspace_bytes.restype = i64
     L.mpc_ingest_count.argtypes = [isp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_ingest_scatter.argtypes = [isp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.mpc_ingest_ordered_workspace_bytes.argtypes = [isp, sp]
+    L.mpc_ingest_ordered_workspace_bytes.restype = i64
+    L.mpc_ingest_scatter_ordered.argtypes = [isp, sp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mpc_dense_flow.argtypes = [ctypes.POINTER(FlowShape), vp, vp, vp, vp, vp]
     L.mpc_flow_error_workspace_bytes.argtypes = [ctypes.POINTER(ErrShape)]
     L.mpc_flow_error_workspace_bytes.restype = i64

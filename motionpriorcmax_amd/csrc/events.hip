@@ -869,6 +869,15 @@ __global__ __launch_bounds__(256) void k_evo_scatter(const mpc_shape s, const Ev
     }
 }
 
+// the two scans of the counting sort, for a counts array [b][pol][key][chunk] someone else filled (ingest.hip)
+int mpc_evo_scans(const mpc_shape *loss, int NCS, int CSR, int *kcounts, int *totals, int32_t *offsets, int chunks, hipStream_t st) {
+    const EvoKey k{NCS, CSR, loss->nb * NCS};
+    MPC_LAUNCH(k_evo_scan_chunks, dim3(mpc_cdiv(k.NK + 1, 4), 2 * loss->B), dim3(256), 0, st, k, kcounts, totals, chunks);
+    MPC_LAUNCH(k_evo_scan_keys, dim3(2 * loss->B), dim3(256), 0, st, *loss, k, totals, (int *)offsets);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int32_t mpc_event_lut_strips(const mpc_shape *s) {
     if (!s || mpc_validate_shape(s)) return MPC_E_SHAPE;
     return mpc_layout(s).n_cstrips;

@@ -184,6 +184,88 @@ __global__ __launch_bounds__(256) void k_ingest_scatter(const mpc_ingest_shape s
     }
 }
 
+// ---- ingest straight into the bucket-ordered layout (both halves in one) -----------------------------
+// The rows of each polarity block ordered by (time bin, LUT strip) -- the key of the loss's backward buckets
+// (events.hip: mpc_event_bucket_order) -- as ingest WRITES them: the key of an event is known the moment its row is
+// built, so ordering costs no pass over the event tensor of its own (ingest + mpc_event_bucket_order read and wrote the
+// tensor once more: 175 + 50 us at 14 x 200k events).  Counting sort: per-chunk counts of (polarity, key) -> the scans of
+// the bucket-order kernels (events.hip) -> scatter.  Order inside a bucket is not defined and need not be.
+struct IngKey { int NCS, CSR, NK, sp, hq; };
+
+__device__ __forceinline__ int ing_key(const mpc_ingest_shape &s, const IngKey &k, float yv, double tn) {
+    const int it = min(max(bin_index(tn, s.nb), 0), s.nb - 1);
+    const int iy = min(max((int)floorf(yv / (float)k.sp), 0), k.hq - 1);          // as warp_cell (events.hip)
+    return it * k.NCS + iy / k.CSR;
+}
+
+// grid (nchunks, B), 256 threads, dynamic LDS 2 * (NK + 1) ints: counts[b][pol][key][chunk]
+__global__ __launch_bounds__(256) void k_ingest_keycount(const mpc_ingest_shape s, const IngLayout L, const IngKey k,
+                                                         const float *__restrict__ x, const float *__restrict__ y,
+                                                         const long long *__restrict__ t, const float *__restrict__ p,
+                                                         const int *__restrict__ counts, int *__restrict__ kcounts) {
+    extern __shared__ int s_k[];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int n = min(counts[b], s.N);
+    const size_t base = (size_t)b * s.N;
+    const long long tmin = L.tminmax[b * 2], tmax = L.tminmax[b * 2 + 1];
+    const double span = (double)(tmax - tmin);
+    for (int i = tid; i < 2 * (k.NK + 1); i += 256) s_k[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = chunk * ING_CHUNK + tid * 4 + u;
+        if (i >= n) continue;
+        const int c = classify(x[base + i], y[base + i], p[base + i], s.H, s.W);
+        if (c == 0) continue;
+        const double tn = (double)(t[base + i] - tmin) / span;
+        atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, y[base + i], tn)], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * (k.NK + 1); i += 256) {
+        const int pol = i / (k.NK + 1), key = i - pol * (k.NK + 1);
+        kcounts[((size_t)(b * 2 + pol) * (k.NK + 1) + key) * L.nchunks + chunk] = s_k[i];
+    }
+}
+
+// grid (nchunks, B), 256 threads, dynamic LDS 2 * (NK + 1) ints.  kcounts (scanned in place) = first row of this chunk's
+// share inside every (polarity, key); offsets [B][2][NK + 1] = first row of every key
+__global__ __launch_bounds__(256) void k_ingest_scatter_ordered(const mpc_ingest_shape s, const IngLayout L, const IngKey k,
+                                                                const float *__restrict__ x, const float *__restrict__ y,
+                                                                const long long *__restrict__ t, const float *__restrict__ p,
+                                                                const int *__restrict__ counts, int M,
+                                                                const int *__restrict__ kcounts, const int *__restrict__ offsets,
+                                                                float *__restrict__ events, float *__restrict__ xytp) {
+    extern __shared__ int s_k[];
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int n = min(counts[b], s.N);
+    const size_t base = (size_t)b * s.N;
+    const long long tmin = L.tminmax[b * 2], tmax = L.tminmax[b * 2 + 1];
+    const double span = (double)(tmax - tmin);
+    for (int i = tid; i < 2 * (k.NK + 1); i += 256) {
+        const int pol = i / (k.NK + 1), key = i - pol * (k.NK + 1);
+        const size_t o = (size_t)(b * 2 + pol) * (k.NK + 1) + key;
+        s_k[i] = offsets[o] + kcounts[o * L.nchunks + chunk];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = chunk * ING_CHUNK + tid * 4 + u;
+        if (i >= n) continue;
+        const long long tv = t[base + i];
+        if (xytp != nullptr) {
+            const float tf = (float)(tv - tmin) / (float)(tmax - tmin);
+            reinterpret_cast<float4 *>(xytp)[base + i] = make_float4(x[base + i], y[base + i], tf, p[base + i]);
+        }
+        const int c = classify(x[base + i], y[base + i], p[base + i], s.H, s.W);
+        if (c == 0) continue;
+        const double tn = (double)(tv - tmin) / span;
+        const int row = atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, y[base + i], tn)], 1);
+        float *e = events + ((size_t)b * M + row) * 6;
+        e[0] = y[base + i]; e[1] = x[base + i]; e[2] = (float)tn; e[3] = p[base + i];
+        e[4] = (float)bin_index(tn, s.nb); e[5] = 1.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 static int ing_validate(const mpc_ingest_shape *s) {
     MPC_CHECK_ARG(s->B >= 0 && s->N >= 0 && s->H >= 1 && s->W >= 1 && s->nb >= 1, MPC_E_SHAPE, "bad ingest shape");
@@ -251,6 +333,60 @@ extern "C" int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, con
     const IngLayout L = ing_layout(s, ws).L;
     MPC_LAUNCH(k_ingest_scatter, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
                        reinterpret_cast<const long long *>(t_us), p, counts, max_pos, max_neg, events, xytp);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// the scans of the bucket-order kernels (events.hip)
+int mpc_evo_scans(const mpc_shape *loss, int NCS, int CSR, int *kcounts, int *totals, int32_t *offsets, int chunks, hipStream_t st);
+
+extern "C" int64_t mpc_ingest_ordered_workspace_bytes(const mpc_ingest_shape *s, const mpc_shape *loss) {
+    if (!s || !loss) { mpc_set_error("mpc_ingest_ordered_workspace_bytes: null shape"); return MPC_E_NULL; }
+    int rc = ing_validate(s);
+    if (rc) return rc;
+    const int32_t ncs = mpc_event_lut_strips(loss);
+    if (ncs <= 0) { mpc_set_error("mpc_ingest_ordered_workspace_bytes: no bucketed event layout for this loss shape"); return MPC_E_UNSUPPORTED; }
+    const int64_t nk1 = (int64_t)loss->nb * ncs + 1;
+    const int64_t nch = mpc_cdiv(s->N > 0 ? s->N : 1, ING_CHUNK);
+    return mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 2 * nk1 * (nch + 1) * 4);
+}
+
+// Same outputs as mpc_ingest_scatter followed by mpc_event_bucket_order for the loss shape `loss` (B, nb, H, W, sp, hq, wq,
+// flags of the FocusLoss; M = max_pos + max_neg, Mp = max_pos): `events` with the rows of every polarity block grouped by
+// (time bin, LUT strip) and the table `offsets` [B][2][nb * strips + 1].  `ws` = the workspace of mpc_ingest_count
+// (unchanged since that call), `ws_order` = mpc_ingest_ordered_workspace_bytes.
+extern "C" int mpc_ingest_scatter_ordered(const mpc_ingest_shape *s, const mpc_shape *loss, const float *x, const float *y,
+                                          const int64_t *t_us, const float *p, const int32_t *counts, int32_t max_pos,
+                                          int32_t max_neg, float *events, int32_t *offsets, float *xytp, void *ws, void *ws_order,
+                                          void *stream) {
+    MPC_CHECK_ARG(s && loss && counts && ws && ws_order && offsets && ((x && y && t_us && p) || s->N == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(max_pos >= 0 && max_neg >= 0 && (events || max_pos + max_neg == 0 || s->B == 0), MPC_E_NULL, "events is null");
+    int rc = ing_validate(s);
+    if (rc) return rc;
+    if ((rc = mpc_validate_shape(loss))) return rc;
+    MPC_CHECK_ARG(loss->B == s->B && loss->nb == s->nb && loss->H == s->H && loss->W == s->W && loss->M == max_pos + max_neg && loss->Mp == max_pos,
+                  MPC_E_SHAPE, "loss shape does not match the ingest shape / the block sizes");
+    const mpc_ws_layout LL = mpc_layout(loss);
+    MPC_CHECK_ARG(LL.n_cstrips > 0, MPC_E_UNSUPPORTED, "no bucketed event layout for this loss shape");
+    if (s->B == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)max_pos + max_neg;
+    const IngKey k{LL.n_cstrips, LL.cstrip_rows, loss->nb * LL.n_cstrips, loss->sp, loss->hq};
+    if (M > 0) {
+        const int e = mpc_zero_async(events, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows
+        if (e) return e;
+    }
+    const IngLayout L = ing_layout(s, ws).L;
+    int *kcounts = (int *)ws_order;
+    int *totals = kcounts + (size_t)2 * s->B * (k.NK + 1) * L.nchunks;
+    const size_t lds = (size_t)2 * (k.NK + 1) * sizeof(int);
+    if (s->N == 0) return mpc_zero_async(offsets, (size_t)s->B * 2 * (k.NK + 1) * sizeof(int32_t), st);
+    MPC_LAUNCH(k_ingest_keycount, dim3(L.nchunks, s->B), dim3(256), lds, st, *s, L, k, x, y, reinterpret_cast<const long long *>(t_us), p, counts, kcounts);
+    MPC_CHECK_LAUNCH();
+    if ((rc = mpc_evo_scans(loss, k.NCS, k.CSR, kcounts, totals, offsets, L.nchunks, st))) return rc;
+    MPC_LAUNCH(k_ingest_scatter_ordered, dim3(L.nchunks, s->B), dim3(256), lds, st, *s, L, k, x, y, reinterpret_cast<const long long *>(t_us), p,
+               counts, (int)M, kcounts, (const int *)offsets, events, xytp);
     MPC_CHECK_LAUNCH();
     return 0;
 }

@@ -384,11 +384,17 @@ def event_bucket_order(cfg: PathConfig, events, num_pos):
     return out, offs
 
 
+_NCS_CACHE = {}
+
+
 def _check_offsets(offs, cfg, shape, device):
     if offs is None:
         return None
     _require_gpu(offs, "batch['event_offsets']")
-    ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+    key = (cfg, shape.B, shape.flags)
+    ncs = _NCS_CACHE.get(key)
+    if ncs is None:
+        ncs = _NCS_CACHE[key] = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
     want = (shape.B, 2, cfg.num_bins * ncs + 1)
     if ncs <= 0 or offs.dtype != torch.int32 or tuple(offs.shape) != want or offs.device != device:
         raise ValueError(f"event_offsets must be int32 {want} on {device} (from event_bucket_order with this configuration), "

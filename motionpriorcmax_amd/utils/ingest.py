@@ -35,6 +35,21 @@ def ingest_events(x, y, t_us, p, counts, image_shape, num_bins, want_voxel_input
     max_pos, max_neg = (int(v) for v in out_max.tolist())          # the collate's host decision
     events = torch.empty((B, max_pos + max_neg, 6), dtype=torch.float32, device=dev)
     xytp = torch.empty((B, N, 4), dtype=torch.float32, device=dev) if want_voxel_input else None
+    if order_for is not None:
+        # the rows are written in bucket order right away (mpc_ingest_scatter_ordered): no ordering pass over the tensor
+        from ..ops import make_shape
+        cfg = order_for._cfg
+        lshape = make_shape(cfg, B, max_pos + max_neg, max_pos if cfg.polarity_split else max_pos + max_neg, 1)
+        ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(lshape)))
+        if ncs > 0 and cfg.polarity_split and tuple(cfg.image_shape) == (int(image_shape[0]), int(image_shape[1])) and cfg.num_bins == int(num_bins):
+            nb2 = int(C.lib().mpc_ingest_ordered_workspace_bytes(ctypes.byref(shape), ctypes.byref(lshape)))
+            ws2 = torch.empty(max(nb2, 256), dtype=torch.uint8, device=dev)
+            offs = torch.empty((B, 2, cfg.num_bins * ncs + 1), dtype=torch.int32, device=dev)
+            with _stage('mpc_ingest_scatter_ordered', dev):
+                C.check(C.lib().mpc_ingest_scatter_ordered(ctypes.byref(shape), ctypes.byref(lshape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p),
+                                                           _ptr(cnt), max_pos, max_neg, _ptr(events), _ptr(offs), _ptr(xytp), _ptr(ws),
+                                                           _ptr(ws2), st), 'mpc_ingest_scatter_ordered')
+            return {'events': events, 'num_pos_events': max_pos, 'xytp': xytp, 'event_offsets': offs}
     with _stage('mpc_ingest_scatter', dev):
         C.check(C.lib().mpc_ingest_scatter(ctypes.byref(shape), _ptr(x), _ptr(y), _ptr(t_us), _ptr(p), _ptr(cnt),
                                            max_pos, max_neg, _ptr(events), _ptr(xytp), _ptr(ws), st), 'mpc_ingest_scatter')

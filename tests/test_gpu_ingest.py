@@ -58,6 +58,23 @@ def test_ingest_full_size_ragged_vs_oracle_and_feeds_the_loss():
     dev = torch.device('cuda:0')
     ordered = ingest_events(*(torch.from_numpy(a).to(dev) for a in (x, y, t, p)), torch.tensor(ns, dtype=torch.int32), (H, W), nb, order_for=L)
     assert ordered['num_pos_events'] == num_pos and 'event_offsets' in ordered
+    # ... written in bucket order by ingest itself (mpc_ingest_scatter_ordered): the same table, and bucket by bucket the same
+    # rows, as ordering the time-ordered tensor afterwards (mpc_event_bucket_order); padding rows stay zero
+    two = L.order_events({'events': out['events'], 'num_pos_events': num_pos})
+    assert torch.equal(ordered['event_offsets'], two['event_offsets'])
+    offs = ordered['event_offsets'].cpu().numpy()
+    ea, eb = ordered['events'].cpu().numpy(), two['events'].cpu().numpy()
+    M = ea.shape[1]
+    for b in range(len(ns)):
+        for pol in range(2):
+            o = offs[b, pol]
+            end = num_pos if pol == 0 else M
+            assert (np.diff(o) >= 0).all() and o[0] == (0 if pol == 0 else num_pos) and o[-1] <= end
+            assert not ea[b, o[-1]:end].any() and not eb[b, o[-1]:end].any()
+            for k in np.nonzero(np.diff(o))[0]:
+                ra, rb = ea[b, o[k]:o[k + 1]], eb[b, o[k]:o[k + 1]]
+                ia = np.lexsort(ra.T[::-1]); ib = np.lexsort(rb.T[::-1])
+                assert np.array_equal(ra[ia], rb[ib]), (b, pol, k)
     res = []
     for batch in ({'events': out['events'], 'num_pos_events': num_pos}, ordered):
         tg = traj.cuda().requires_grad_(True)
