@@ -144,7 +144,7 @@ def profile_kernels(workload):
     return out, os.path.relpath(files[-1], ROOT)
 
 
-def pmc_traffic(workload, stage):
+def pmc_traffic(workload, stage, launches=None):
     """HBM-side bytes per step of `stage` from the committed rocprofv3 PMC summary of this workload
     (profiles/traffic_<workload>.json, tools/summarize_pmc.py: separate FETCH_SIZE and WRITE_SIZE passes), summed over
     the kernels the kernel-trace summary attributes to the stage.  Returns (upper, lower): the read counter doubled as the
@@ -158,7 +158,7 @@ def pmc_traffic(workload, stage):
     up = lo = 0.0
     for k, _, _, calls in ks[stage]:
         if k in d:
-            per_step = d[k].get('launches_per_step', 1)
+            per_step = (launches or {}).get(k, 1)         # launches of the kernel per step, from the live kernel timer
             up += per_step * (d[k]['hbm_bytes_upper'] if 'hbm_bytes_upper' in d[k] else d[k]['hbm_bytes_per_launch'])
             lo += per_step * (d[k]['hbm_bytes_lower'] if 'hbm_bytes_lower' in d[k] else d[k]['hbm_bytes_per_launch_raw'])
     return (round(up), round(lo)) if up > 0 else (None, None)
@@ -195,6 +195,14 @@ def knn_ceiling(workload, stages, B, nb):
                 prof[key] = {'valu_wave_instr_per_launch': k['valu_insts'], 'kernel_us_in_profile': k['kernel_us'],
                              'valu_issue_frac': round(k['valu_insts'] * 4.0 / (k['kernel_us'] * 1e-6 * ghz * 1e9 * simds), 3),
                              'wait_any_frac': k.get('wait_any_frac')}
+        # the counters belong to the library they were taken with: say so when the loaded one differs (stale figures)
+        import hashlib
+        libp = os.path.join(ROOT, 'motionpriorcmax_amd', 'libmpcmax.so')
+        cur = 'libmpcmax.so sha256 ' + hashlib.sha256(open(libp, 'rb').read()).hexdigest()[:16] if os.path.exists(libp) else None
+        if d.get('_library') != cur:
+            out['from_committed_profile'] = {'file': os.path.relpath(files[-1], ROOT), 'library': d.get('_library'), 'loaded_library': cur,
+                                             'stale': True, 'note': 'taken with another build of the library: counters omitted'}
+            return out
         out['from_committed_profile'] = {'file': os.path.relpath(files[-1], ROOT), 'library': d.get('_library'),
                                          'assumes': f'{simds} SIMDs at {ghz:.2f} GHz, 4 cycles per vector instruction',
                                          'kernels': prof}
@@ -645,7 +653,7 @@ def main():
             d['us_per_step'] = live[dom_k]['us_per_launch'] * live[dom_k]['launches_per_step']
             ach = d['algorithmic_MB'] * 1e6 / (d['us_per_step'] * 1e-6) / 1e9 if d['us_per_step'] > 0 else 0.0
             in_stage = [k for k in live if live[k]['stage'] == dom]
-        t_up, t_lo = pmc_traffic(wname, dom) if wname else (None, None)
+        t_up, t_lo = pmc_traffic(wname, dom, {k: v['launches_per_step'] for k, v in live.items()}) if wname else (None, None)
         ev_path = event_path_roofline(per_step, wl_)
         if live:
             # the per-kernel times supersede the stage brackets for the sums (a stage bracket also holds the gaps between its

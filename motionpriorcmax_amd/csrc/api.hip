@@ -161,7 +161,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
         L.nbb = s->B * s->nb * L.n_cstrips;
         // FORWARD buckets (image strip of the WARPED position: flow dependent, cannot be sized ahead): a bucket holds
         // whatever can reach it -- every event of a polarity block may vote into one image strip.  This memory is
-        // committed (the caller's torch.empty is a hipMalloc), nfb * fcap * 16 bytes: 0.7 GB at C3.
+        // committed (the caller's torch.empty is a hipMalloc), nfb * fcap * 12 bytes: 0.54 GB at C3.
         // BACKWARD buckets (the event's own LUT cell: flow independent): none for a forward-only call or bucket-ordered
         // events (MPC_F_NO_BWD_RECORDS: the backward reads the event rows themselves).  Otherwise either every bucket holds
         // all M rows of its sample (nbb * M * 16 bytes: 4.7 GB at C3), or -- where that exceeds MPC_EV_EXACT_ABOVE_MB
@@ -173,7 +173,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
         static const int64_t exact_above = (getenv("MPC_EV_EXACT_ABOVE_MB") ? atoll(getenv("MPC_EV_EXACT_ABOVE_MB")) : 6144) << 20;
         L.b_exact = ((int64_t)L.nbb * L.bcap * 16 > exact_above) ? 1 : 0;
         L.off_fcount = off; off += mpc_align((int64_t)(L.nfb + 3 * L.nbb + 8) * sizeof(int32_t));      // fill counters, marker, capacities, first records
-        L.off_frec = off;   off += mpc_align((int64_t)L.nfb * L.fcap * 16);
+        L.off_frec = off;   off += mpc_align((int64_t)L.nfb * L.fcap * 12);
         L.off_brec = off;   off += (s->flags & MPC_F_NO_BWD_RECORDS) ? 0 : mpc_align((int64_t)(L.b_exact ? s->B : L.nbb) * L.bcap * 16);
     } else {
         L.strip_rows = L.cstrip_rows = 0;

@@ -116,6 +116,12 @@ void mpc_knn_lean_sizes(const mpc_shape *s, int64_t *mask_bytes, int64_t *rowtab
 
 // ---- device helpers ---------------------------------------------------------------------
 #ifdef __HIPCC__
+// v / sp in fp32 exactly as the division gives it, without the ~10-instruction IEEE division sequence when sp is a power of
+// two (the shipped configurations: 4): the reciprocal is then exact and the product is the same scaling of the exponent.
+// The branch is uniform (sp is a launch constant).
+__device__ __forceinline__ float mpc_div_sp(float v, int sp) {
+    return ((sp & (sp - 1)) == 0) ? v * (1.f / (float)sp) : v / (float)sp;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

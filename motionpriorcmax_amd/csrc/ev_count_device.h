@@ -47,7 +47,7 @@ __device__ __forceinline__ void ev_count_block(const EvCountArgs &a, int blk, in
             if (i0 + u * 256 >= r1) continue;
             // the cell exactly as warp_cell (events.hip) computes it
             int it = (int)bn[u].x;
-            int iy = (int)floorf(ya[u].x / (float)a.sp);
+            int iy = (int)floorf(mpc_div_sp(ya[u].x, a.sp));
             it = min(max(it, 0), a.nb - 1);
             iy = min(max(iy, 0), a.hq - 1);
             const int cst = (int)(((float)iy + 0.5f) * inv_CSR);

@@ -34,8 +34,8 @@ __device__ __forceinline__ EvParams make_params(const mpc_shape s) {
 // LUT cell of an event (focus.py:184-191): it = int(bin), iy = int(y // sp), ix = int(x // sp)
 __device__ __forceinline__ void warp_cell(const EvParams &p, const float e[6], int b, int tr, Warped &o) {
     int it = (int)e[4];
-    int iy = (int)floorf(e[0] / (float)p.sp);
-    int ix = (int)floorf(e[1] / (float)p.sp);
+    int iy = (int)floorf(mpc_div_sp(e[0], p.sp));
+    int ix = (int)floorf(mpc_div_sp(e[1], p.sp));
     // torch indexing would raise on out-of-range indices; clamp instead of faulting
     it = min(max(it, 0), p.nb - 1);
     iy = min(max(iy, 0), p.hq - 1);
@@ -199,8 +199,10 @@ struct BinLayout {
     int SR, NS, CSR, NCS, NF, NBk, fcap, bcap, P, exact;
     int *gcount;            // [NF + NBk + 8]
     int *bcapcnt;           // [NBk] rows of the sample in each backward bucket (ev_count_device.h): its capacity; then [NBk] first records
-    float4 *frec, *brec;    // bucket storage: frec [NF][fcap]; brec [B][bcap = M], a sample's backward buckets back to back
+    float4 *frec, *brec;    // bucket storage: frec [NF][fcap] of 12-byte records {y, x, w} (the image is implied by the bucket); brec: 16-byte records
 };
+
+struct __attribute__((packed, aligned(4))) rec3 { float y, x, w; };       // forward record (one 12-byte store / load)
 
 __device__ __forceinline__ long long ev_to_fixed_small(float v) {   // |v| < 2
     return (long long)(int)(v * (float)(1 << EV_FIX_SHIFT));
@@ -231,7 +233,7 @@ __device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, i
                                         float4 rec) {
     if (lb < nf_loc) {
         const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
-        L.frec[(size_t)g * L.fcap + slot] = rec;
+        reinterpret_cast<rec3 *>(L.frec)[(size_t)g * L.fcap + slot] = rec3{rec.x, rec.y, rec.z};
     } else {
         // (exact buckets: `slot` counts from the sample's first record -- the bucket starts behind the rows of the buckets
         // before it; else every bucket has room for all the rows of its sample)
@@ -393,9 +395,9 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
     for (int i = tid; i < npix; i += 1024) s_acc[i] = 0ull;
     __syncthreads();
     const int n = L.gcount[g];
-    const float4 *rec = L.frec + (size_t)g * L.fcap;
+    const rec3 *rec = reinterpret_cast<const rec3 *>(L.frec) + (size_t)g * L.fcap;
     for (int r0 = tid; r0 < n; r0 += 4 * 1024) {           // four record loads in flight per thread
-        float4 e[4];
+        rec3 e[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) e[u] = rec[min(r0 + u * 1024, n - 1)];
 #pragma unroll
@@ -403,12 +405,12 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
             if (r0 + u * 1024 >= n) continue;
             // |tap| <= (1 + 1e-6)^2 |w|: the one-conversion form is exact below 2, any other weight (create_iwe(weight=
             // tensor), a weighted `valid` column; event_image_converter.py:45-74 accepts any) takes the hi/lo split
-            if (fabsf(e[u].z) <= 1.5f)
-                record_taps(e[u].x, e[u].y, e[u].z, H, W, row0, row1, [&](int yy, int xx, float v) {
+            if (fabsf(e[u].w) <= 1.5f)
+                record_taps(e[u].y, e[u].x, e[u].w, H, W, row0, row1, [&](int yy, int xx, float v) {
                     atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed_small(v));
                 });
             else
-                record_taps(e[u].x, e[u].y, e[u].z, H, W, row0, row1, [&](int yy, int xx, float v) {
+                record_taps(e[u].y, e[u].x, e[u].w, H, W, row0, row1, [&](int yy, int xx, float v) {
                     atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed(v));
                 });
         }
@@ -771,7 +773,7 @@ struct EvoKey { int NCS, CSR, NK; };
 __device__ __forceinline__ int evo_key(const EvParams &p, const EvoKey &k, const float e[6]) {
     if (e[5] == 0.f && !(p.flags & MPC_F_UNIT_WEIGHT)) return k.NK;   // padding row (weight 0: it votes for nothing)
     const int it = min(max((int)e[4], 0), p.nb - 1);
-    const int iy = min(max((int)floorf(e[0] / (float)p.sp), 0), p.hq - 1);      // as warp_event
+    const int iy = min(max((int)floorf(mpc_div_sp(e[0], p.sp)), 0), p.hq - 1);      // as warp_event
     return it * k.NCS + iy / k.CSR;
 }
 

@@ -194,7 +194,7 @@ struct IngKey { int NCS, CSR, NK, sp, hq; };
 
 __device__ __forceinline__ int ing_key(const mpc_ingest_shape &s, const IngKey &k, float yv, double tn) {
     const int it = min(max(bin_index(tn, s.nb), 0), s.nb - 1);
-    const int iy = min(max((int)floorf(yv / (float)k.sp), 0), k.hq - 1);          // as warp_cell (events.hip)
+    const int iy = min(max((int)floorf(mpc_div_sp(yv, k.sp)), 0), k.hq - 1);          // as warp_cell (events.hip)
     return it * k.NCS + iy / k.CSR;
 }
 

@@ -43,7 +43,7 @@ static KnnParams knn_params(const mpc_shape *s) {
 
 __device__ __forceinline__ int cell_of(float v, int sp, int ncell) {
     // cells are centred on the query points: cell c covers [c*sp - 0.5, (c+1)*sp - 0.5)
-    const float c = floorf((v + 0.5f) / (float)sp);
+    const float c = floorf(mpc_div_sp(v + 0.5f, sp));
     return (int)fminf(fmaxf(c, 0.f), (float)(ncell - 1));
 }
 

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Round-2 evidence run on the GPU box: bench line, kernel-trace stats and SQ counters per workload, PMC traffic with the
-# FETCH_SIZE calibration.  Everything lands in gpurun_out/r02_*; the summaries are copied into profiles/ afterwards.
+# Evidence run of a round (R=r03 below) on the GPU box: bench line, kernel-trace stats and SQ counters per workload, PMC traffic with the
+# FETCH_SIZE calibration.  Everything lands in gpurun_out/${R}_*; the summaries are copied into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out
-python bench.py > $O/r02_bench_C3.json 2> $O/r02_bench_err.log; tail -c 400 $O/r02_bench_C3.json
+R=${R:-r03}
+python bench.py > $O/${R}_bench_C3.json 2> $O/${R}_bench_err.log; tail -c 400 $O/${R}_bench_C3.json
 for wl in C3 C2 C4; do
-  tools/sq_profile.sh r02_$wl bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --steps 10 > /dev/null 2>&1
-  python3 tools/sq_to_json.py $O/r02_${wl}_sq.csv $O/r02_${wl}_kstats.csv $O/r02_sq_$wl.json > /dev/null
+  tools/sq_profile.sh ${R}_$wl bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --steps 10 > /dev/null 2>&1
+  python3 tools/sq_to_json.py $O/${R}_${wl}_sq.csv $O/${R}_${wl}_kstats.csv $O/${R}_sq_$wl.json > /dev/null
 done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_f -- tools/ubench/fetch_calib.bin > $O/r02_fetch_calib.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cal_f -- tools/ubench/fetch_calib.bin > $O/${R}_fetch_calib.txt 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cal_w -- tools/ubench/fetch_calib.bin > /dev/null 2>&1
 for wl in C3 C2 C4; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf_$wl -- python3 bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --steps 10 > /dev/null 2>&1
