@@ -214,6 +214,14 @@ int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *events, const i
                                 const float *t_ref, const float *grad_iwe, const float *scal, const float *grad_out,
                                 float *grad_flow_lut, const float *add_term, void *ws, void *stream);
 
+/* UNPINNED EXTENSION, default off (FocusLoss(pyramid_levels > 1)): helpers of an IWE pyramid, which BASELINE.json's
+ * configs[2] names and the reference does not have.  mpc_pool2_fwd: out [nimg][H/2][W/2] = 2x2 average of in [nimg][H][W].
+ * mpc_pool2_bwd_add: big[y][x] += (coef_small[0] / coef_big[0]) * 0.25 * small[y/2][x/2] (the adjoint of the pooling applied
+ * to adjoint images that are kept in units of their own level's MPC_SCAL_GCOEF; both coefficients are device scalars). */
+int mpc_pool2_fwd(const float *in, float *out, int32_t nimg, int32_t H, int32_t W, void *stream);
+int mpc_pool2_bwd_add(const float *small, const float *coef_small, float *big, const float *coef_big, int32_t nimg,
+                      int32_t H, int32_t W, void *stream);
+
 /* y[i] = a[0] * x[i] (device scalar a; used to scale the smoothness gradient by grad_out). */
 int mpc_scale(const float *x, const float *a, float *y, int64_t count, void *stream);
 

@@ -30,7 +30,7 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
            'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
-           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered']
+           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add']
 
 
 class Shape(ctypes.Structure):
@@ -122,6 +122,8 @@ def lib():
     L.mpc_flow_error.argtypes = [ctypes.POINTER(ErrShape), vp, vp, vp, vp, vp, vp, vp]
     L.mpc_event_splat_fwd_fixed.argtypes = [sp, vp, vp, vp, vp, vp, vp]
     L.mpc_iwe_from_fixed.argtypes = [vp, vp, i64, vp]
+    L.mpc_pool2_fwd.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.mpc_pool2_bwd_add.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.mpc_profile_start.argtypes = []
     L.mpc_profile_stop.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(f32), i32]
     if L.mpc_version() != 103:

@@ -787,3 +787,53 @@ extern "C" int mpc_scale(const float *x, const float *a, float *y, int64_t count
     MPC_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- UNPINNED EXTENSION (default off): IWE pyramid (BASELINE.json configs[2] names one; the reference has none, SURVEY.md
+// Appendix C).  Level l + 1 = 2x2 average of level l; the objective of every level is the reference's
+// calculate_focus_loss on that level (src/utils/loss.py:4-27), the focus term their sum.  Two helpers: the pooling and its
+// adjoint, which carries the coarser level's adjoint image (in units of ITS 1 / val^2 coefficient) into the finer one's.
+__global__ __launch_bounds__(256) void k_pool2_fwd(const float *__restrict__ in, float *__restrict__ out, int nimg, int H, int W) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const size_t n = (size_t)nimg * H2 * W2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % W2), y = (int)((i / W2) % H2);
+        const size_t img = i / ((size_t)W2 * H2);
+        const float *p = in + (img * H + 2 * y) * W + 2 * x;
+        out[i] = 0.25f * ((p[0] + p[1]) + (p[W] + p[W + 1]));
+    }
+}
+// big[y][x] += (coef_small / coef_big) * 0.25 * small[y / 2][x / 2]     (coefficients: device scalars)
+__global__ __launch_bounds__(256) void k_pool2_bwd_add(const float *__restrict__ small, const float *__restrict__ coef_small,
+                                                       float *__restrict__ big, const float *__restrict__ coef_big, int nimg, int H, int W) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const float r = 0.25f * (coef_small[0] / coef_big[0]);
+    const size_t n = (size_t)nimg * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const size_t img = i / ((size_t)W * H);
+        if ((y >> 1) < H2 && (x >> 1) < W2) big[i] += r * small[(img * H2 + (y >> 1)) * W2 + (x >> 1)];
+    }
+}
+
+extern "C" int mpc_pool2_fwd(const float *in, float *out, int32_t nimg, int32_t H, int32_t W, void *stream) {
+    MPC_CHECK_ARG(in && out, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(nimg >= 0 && H >= 2 && W >= 2, MPC_E_SHAPE, "image smaller than a pooling window");
+    const int64_t n = (int64_t)nimg * (H / 2) * (W / 2);
+    if (n == 0) return 0;
+    MPC_LAUNCH(k_pool2_fwd, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream, in, out, nimg, H, W);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_pool2_bwd_add(const float *small, const float *coef_small, float *big, const float *coef_big, int32_t nimg,
+                                 int32_t H, int32_t W, void *stream) {
+    MPC_CHECK_ARG(small && coef_small && big && coef_big, MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(nimg >= 0 && H >= 2 && W >= 2, MPC_E_SHAPE, "image smaller than a pooling window");
+    const int64_t n = (int64_t)nimg * H * W;
+    if (n == 0) return 0;
+    MPC_LAUNCH(k_pool2_bwd_add, dim3((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream,
+               small, coef_small, big, coef_big, nimg, H, W);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}

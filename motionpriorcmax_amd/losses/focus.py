@@ -26,6 +26,8 @@ class FocusLoss(base.TrajectoryLossBase):
         smooth_type (str): 'on_flow_to_tref' or 'on_flow_to_next'.
         loss_type (str, build-side extension): 'gradient_magnitude' (what the reference hard-codes,
             focus.py:90-91) or 'variance' (reference src/utils/loss.py:14-16).
+        pyramid_levels (int, UNPINNED extension, default 1 = the reference): IWE pyramid of that many levels (2x2 averages of the
+            raw IWE), the focus term summed over the levels (`ops.PyramidFocusFn`); BASELINE.json names one, the reference has none.
         static_shapes (bool, build-side extension, default False): capture `calc` + backward once per input shape into HIP
             graphs and replay them (ops.StaticFocusPlan): for small batches, whose eager step is bound by the host.
             `misc_metadata['iwes']` is then only valid until the next `calc`.
@@ -35,7 +37,7 @@ class FocusLoss(base.TrajectoryLossBase):
                  lut_superpixel_size, focus_loss_norm, dist_norm,
                  scale_iwe_by_dt, mask_image_border, polarity_aware_batching,
                  interpolation_scheme, smooth_type, loss_type='gradient_magnitude', profiler=None,
-                 static_shapes=False, **kwargs):
+                 static_shapes=False, pyramid_levels=1, **kwargs):
         super().__init__()
         self.image_shape = image_shape
         self.num_tref = num_tref
@@ -53,6 +55,9 @@ class FocusLoss(base.TrajectoryLossBase):
         self.loss_type = loss_type
         self.profiler = profiler
         self.static_shapes = bool(static_shapes)
+        self.pyramid_levels = int(pyramid_levels)      # UNPINNED extension (ops.PyramidFocusFn); 1 = the reference's single scale
+        if self.pyramid_levels < 1 or (self.pyramid_levels > 1 and (num_tref != 1 or loss_type != 'gradient_magnitude')):
+            raise ValueError('pyramid_levels > 1 needs num_tref == 1 and the gradient-magnitude objective')
         self._static_plans = {}
         self.is_needing_offsets = True
         self.imager = EventImageConverter(self.image_shape)
@@ -115,7 +120,9 @@ class FocusLoss(base.TrajectoryLossBase):
 
         t_ref = times[:self.num_tref]
         offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events (optional)
-        if self.static_shapes and ops.STAGE_TIMER is None and not torch.cuda.is_current_stream_capturing():
+        if self.pyramid_levels > 1:
+            out = ops.PyramidFocusFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), self.pyramid_levels)
+        elif self.static_shapes and ops.STAGE_TIMER is None and not torch.cuda.is_current_stream_capturing():
             out = ops.StaticFocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets, self._static_plans)
         elif self.profiler is not None:
             with torch.profiler.record_function('mpcmax::FocusLoss.calc'):

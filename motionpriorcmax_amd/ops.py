@@ -515,6 +515,85 @@ class FocusCalcFn(torch.autograd.Function):
         return g_traj, None, None, None, None, None
 
 
+class PyramidFocusFn(torch.autograd.Function):
+    """UNPINNED EXTENSION, default off (FocusLoss(pyramid_levels=L > 1)): FocusLoss.calc with an IWE pyramid -- BASELINE.json's
+    configs[2] names one, the reference has none (focus.py:90-91 evaluates one scale), so this is a definition, not a port:
+    level l + 1 is the 2x2 average of the RAW level-l IWE, every level goes through the reference's own blur + gradient-magnitude
+    objective (mpc_contrast_fwd on a shape of that level's size), and the focus term is the sum of the levels' 1 / val.
+    Stage calls (no fused path); `iwes` are the blurred level-0 images."""
+
+    @staticmethod
+    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, levels: int):
+        B, M, Mp, n, dev, traj, ev, tr = _calc_inputs(trajectories, events, t_ref, cfg, num_pos)
+        H, W = cfg.image_shape
+        if H % (1 << (levels - 1)) or W % (1 << (levels - 1)) or min(H, W) >> (levels - 1) < 3:
+            raise ValueError(f'pyramid_levels={levels}: image shape {H}x{W} must be divisible by {1 << (levels - 1)} and stay >= 3 pixels')
+        need_grad = trajectories.requires_grad
+        shape = make_shape(cfg, B, M, Mp, n, extra_flags=0 if need_grad else C.F_NO_BWD_RECORDS)
+        ws = alloc_workspace(shape, dev)
+        flow_lut, flow_next, state, _ = knn_lut_fwd(cfg, shape, traj, ws)
+        g_field, s_nimg, s_C = None, 0, 0
+        if cfg.smooth_weight > 0:
+            field, s_nimg, s_C = (flow_next, B * (cfg.num_bins - 1), 2) if cfg.smooth_on_next else (flow_lut, B * cfg.num_bins, 2 * cfg.num_tref)
+            if s_nimg > 0:
+                g_field = lut_smooth(shape, field, s_nimg, s_C, cfg.smooth_weight, ws, need_grad)
+        raw = event_splat_fwd(shape, ev, flow_lut, tr, ws)
+        nimg = raw.shape[0] * raw.shape[1]
+        blur0, gimg0 = contrast_fwd(shape, raw, ws, need_grad)
+        scal0 = finalize(shape, s_nimg, s_C, cfg.smooth_weight, ws, dev)
+        gimgs, scals, sizes = [gimg0], [scal0], [(H, W)]
+        focus_total = scal0[C.SCAL_FOCUS].clone()
+        cur, h, w = raw, H, W
+        for lv in range(1, levels):
+            nxt = torch.empty((raw.shape[0], raw.shape[1], h // 2, w // 2), dtype=torch.float32, device=dev)
+            with _stage('mpc_pool2_fwd', dev):
+                C.check(C.lib().mpc_pool2_fwd(_ptr(cur), _ptr(nxt), nimg, h, w, _stream(dev)), 'mpc_pool2_fwd')
+            h, w = h // 2, w // 2
+            cfg_l = PathConfig(**{**cfg.__dict__, 'image_shape': (h, w), 'smooth_weight': 0.0})
+            sh_l = make_shape(cfg_l, B, 0, 0, 0, K=0)
+            ws_l = alloc_workspace(sh_l, dev)
+            _, g_l = contrast_fwd(sh_l, nxt, ws_l, need_grad)
+            sc_l = finalize(sh_l, 0, 0, 0.0, ws_l, dev)
+            gimgs.append(g_l); scals.append(sc_l); sizes.append((h, w))
+            focus_total = focus_total + sc_l[C.SCAL_FOCUS]
+            cur = nxt
+        ctx.cfg, ctx.shape, ctx.ws, ctx.nimg, ctx.sizes = cfg, shape, ws, nimg, sizes
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(traj, ev, tr, flow_lut, state, g_field, *scals, *([g for g in gimgs] if need_grad else []))
+        ctx.levels = levels
+        smooth = scal0[C.SCAL_SMOOTH].clone()
+        loss = focus_total + smooth
+        ctx.mark_non_differentiable(focus_total, smooth, blur0)
+        return loss, focus_total, smooth, blur0
+
+    @staticmethod
+    def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
+        if g_loss is None:
+            return None, None, None, None, None, None
+        cfg, shape, ws, L = ctx.cfg, ctx.shape, ctx.ws, ctx.levels
+        saved = ctx.saved_tensors
+        traj, ev, tr, flow_lut, state, g_field = saved[:6]
+        scals, gimgs = saved[6:6 + L], list(saved[6 + L:6 + 2 * L])
+        dev = traj.device
+        g = _f32c(g_loss.reshape(1))
+        # the coarser levels' adjoint images into the finer ones, each in units of its own level's 1 / val^2 coefficient
+        for lv in range(L - 1, 0, -1):
+            h, w = ctx.sizes[lv - 1]
+            with _stage('mpc_pool2_bwd_add', dev):
+                C.check(C.lib().mpc_pool2_bwd_add(_ptr(gimgs[lv]), ctypes.c_void_p(scals[lv].data_ptr() + 4 * C.SCAL_GCOEF), _ptr(gimgs[lv - 1]),
+                                                  ctypes.c_void_p(scals[lv - 1].data_ptr() + 4 * C.SCAL_GCOEF), ctx.nimg, h, w, _stream(dev)),
+                        'mpc_pool2_bwd_add')
+        g_lut = torch.empty_like(flow_lut)
+        g_next = None
+        if g_field is not None and not cfg.smooth_on_next:
+            event_splat_bwd(shape, ev, flow_lut, tr, gimgs[0], scals[0], g, g_lut, g_field, ws)
+        else:
+            event_splat_bwd(shape, ev, flow_lut, tr, gimgs[0], scals[0], g, g_lut, None, ws)
+            if g_field is not None:
+                g_next = scale(g_field, g)
+        return knn_lut_bwd(shape, traj, g_lut, g_next, state, ws), None, None, None, None, None
+
+
 class StaticFocusPlan:
     """FocusLoss(static_shapes=True): `calc` + backward of ONE shape captured once into two HIP graphs (forward; backward)
     over buffers that never move, and replayed from then on -- what a B = 1 step costs on the host drops from two eager

@@ -59,3 +59,50 @@ def trajectories_from_bezier(params, times, tile_size, image_shape, scale=1.0):
     assert pos.shape[0] == h * w, 'image shape must be a multiple of the tile size'
     disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), dim=-1).reshape(B, bm.shape[0], h * w, 2)
     return disp + pos.to(params.device, params.dtype)[None, None], pos
+
+
+def bspline_basis(times, num_ctrl, degree=3):
+    """[n_t] -> [n_t, num_ctrl - 1]: the clamped (open uniform) B-spline basis functions N_1 .. N_{m-1} of `degree` on [0, 1]
+    (control point 0 is fixed at zero, as P0 of the reference's Bezier curves: the flow from the reference time vanishes at
+    t = 0).  Cox-de Boor in float64, then fp32.  UNPINNED EXTENSION: the reference has no B-spline curve
+    (src/models/raft_spline/curves holds Bezier and polynomial curves only) -- BASELINE.json's configs[3]
+    names a cubic B-spline, so the basis is provided, default OFF, and checked against scipy.interpolate.BSpline."""
+    m, p = int(num_ctrl), int(degree)
+    assert m >= p + 1, 'need at least degree + 1 control points'
+    t = np.clip(np.asarray(times, dtype=np.float64).reshape(-1), 0.0, 1.0)
+    inner = np.linspace(0.0, 1.0, m - p + 1)
+    knots = np.concatenate((np.zeros(p), inner, np.ones(p)))            # m + p + 1 knots
+    # degree 0
+    N = np.zeros((t.size, m + p))
+    for i in range(m + p):
+        lo, hi = knots[i], knots[i + 1]
+        if hi > lo:
+            N[:, i] = ((t >= lo) & (t < hi)) | ((t == 1.0) & (hi == 1.0))
+    for q in range(1, p + 1):
+        Nn = np.zeros((t.size, m + p - q))
+        for i in range(m + p - q):
+            a = knots[i + q] - knots[i]
+            b = knots[i + q + 1] - knots[i + 1]
+            if a > 0:
+                Nn[:, i] += (t - knots[i]) / a * N[:, i]
+            if b > 0:
+                Nn[:, i] += (knots[i + q + 1] - t) / b * N[:, i + 1]
+        N = Nn
+    return torch.from_numpy(N[:, 1:m]).float()
+
+
+def trajectories_from_bspline(params, times, tile_size, image_shape, scale=1.0, degree=3):
+    """As trajectories_from_bezier, for a clamped uniform B-spline flow curve (cubic by default) with control points
+    P_1 .. P_{m-1} = params [B, 2*(m-1), h, w] ((x, y) channel order) and P_0 = 0.  UNPINNED EXTENSION (see bspline_basis)."""
+    from .trajectories import get_optical_flow_tile_mask
+    B, c2, h, w = params.shape
+    H, W = (int(v) for v in image_shape)
+    assert c2 % 2 == 0 and h == H // tile_size and w == W // tile_size, (params.shape, image_shape, tile_size)
+    d = c2 // 2
+    t = times.detach().cpu().numpy() if torch.is_tensor(times) else times
+    bm = bspline_basis(t, d + 1, degree).to(params.device, params.dtype)             # [n_t, d]
+    flow = torch.einsum('bcdhw,td->btchw', params.view(B, 2, d, h, w), bm) * scale
+    pos = torch.nonzero(get_optical_flow_tile_mask((H, W), tile_size))
+    assert pos.shape[0] == h * w, 'image shape must be a multiple of the tile size'
+    disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), dim=-1).reshape(B, bm.shape[0], h * w, 2)
+    return disp + pos.to(params.device, params.dtype)[None, None], pos

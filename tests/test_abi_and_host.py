@@ -135,3 +135,32 @@ def test_bezier_adapter_matches_reference_curves():
     np.testing.assert_allclose(disp[:, -1, ..., 1].detach().numpy(), g['flow_t1'][:, 0], rtol=1e-6, atol=1e-6)
     traj.sum().backward()
     assert params.grad is not None and float(params.grad.abs().sum()) > 0
+
+
+def test_cubic_bspline_adapter_matches_scipy():
+    """UNPINNED extension (BASELINE.json configs[3] names a cubic B-spline; the reference has none): the clamped uniform
+    B-spline basis against scipy.interpolate.BSpline, partition of unity, zero flow at the anchor, autograd to the control points."""
+    import numpy as np
+    import torch
+    from scipy.interpolate import BSpline
+    from motionpriorcmax_amd import utils
+    rng = np.random.default_rng(0)
+    for m, p in ((4, 3), (7, 3), (11, 3), (6, 2)):
+        t = np.concatenate(([0.0, 1.0], rng.random(40)))
+        inner = np.linspace(0, 1, m - p + 1)
+        knots = np.concatenate((np.zeros(p), inner, np.ones(p)))
+        ref = np.stack([BSpline(knots, np.eye(m)[i], p, extrapolate=False)(np.minimum(t, 1 - 1e-15)) for i in range(m)], 1)
+        got = utils.bspline_basis(t, m, p).numpy()
+        np.testing.assert_allclose(got, ref[:, 1:], atol=2e-6)
+        np.testing.assert_allclose(got.sum(1) + ref[:, 0], 1.0, atol=2e-6)            # partition of unity with N_0
+        assert np.all(got[0] == 0) and got[1, -1] == 1.0                                # t = 0: only N_0; t = 1: only N_{m-1}
+    params = torch.randn(2, 2 * 6, 6, 8, requires_grad=True)
+    times = torch.tensor([0.0, 0.3, 0.77, 1.0])
+    traj, pos = utils.trajectories_from_bspline(params, times, 4, (24, 32))
+    assert traj.shape == (2, 4, 48, 2)
+    assert torch.equal(traj[:, 0], pos.float()[None].expand(2, -1, -1))               # zero flow at the anchor
+    last = params.view(2, 2, 6, 6, 8)[:, :, -1]                                        # t = 1: the last control point, (x, y) -> (y, x)
+    want = torch.stack((last[:, 1], last[:, 0]), -1).reshape(2, 48, 2) + pos.float()[None]
+    assert torch.allclose(traj[:, 3], want, atol=1e-6)
+    traj.sum().backward()
+    assert torch.isfinite(params.grad).all() and float(params.grad.abs().sum()) > 0
