@@ -108,7 +108,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s);
 int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
                        int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done);
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                           float *iwe_raw, void *ws, void *stream, int counters_zeroed);
+                           float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets);
 int mpc_validate_shape(const mpc_shape *s);
 // KNN: does the scatter backward serve this shape, and the sizes of what the forward leaves for it (knn.hip, knn_strip.hip)
 bool mpc_knn_lean(const mpc_shape *s);

@@ -246,7 +246,8 @@ __device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, i
 __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayout L,
                                                 const float *__restrict__ events,
                                                 const float *__restrict__ lut,
-                                                const float *__restrict__ t_ref, int want_bwd) {
+                                                const float *__restrict__ t_ref, int want_bwd,
+                                                const int *__restrict__ offsets) {
     extern __shared__ __align__(16) int s_cnt[];          // [nloc] local counts, [nloc] global bases, [nloc+1] local offsets, ids, records
     __shared__ int s_wsum[4];
     const EvParams p = make_params(s);
@@ -254,6 +255,19 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
     const int lblk = xcd_swizzle(blockIdx.x, chunks * p.B);
     if (lblk >= chunks * p.B) return;
     const int tid = threadIdx.x, b = lblk / chunks, chunk = lblk - b * chunks;
+    // bucket-ordered events (offsets table of ingest / mpc_event_bucket_order): the last entry of a polarity block's table is its
+    // first PADDING row -- rows from there to the end of the block are zero rows that vote for nothing: not even read
+    int pad0 = p.M, pad1 = p.M, blk1 = p.M;                // [pad0, blk1) and [pad1, M) are padding
+    if (offsets != nullptr) {
+        const int nk1 = p.nb * L.NCS + 1;
+        const int *ob = offsets + (size_t)b * 2 * nk1;
+        blk1 = p.Mp;                                        // the two blocks are [0, Mp) and [Mp, M) whatever P is
+        pad0 = min(max(ob[nk1 - 1], 0), blk1);
+        pad1 = min(max(ob[2 * nk1 - 1], blk1), p.M);
+        const int c0 = chunk * EV_PER_THREAD * 256, c1 = min(c0 + EV_PER_THREAD * 256, p.M);
+        const bool all_pad = (c0 >= pad0 && c1 <= blk1) || c0 >= pad1;
+        if (all_pad) return;                                  // (the marker of the backward records is not this workgroup's to write: ordered events have none)
+    }
     const int nf_loc = p.P * L.NS, nb_loc = want_bwd ? p.nb * L.NCS : 0, nloc = nf_loc + nb_loc;
     int *s_base = s_cnt + nloc;
     const int stage_off = ((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3;     // in ints; 16-byte aligned record area
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
         const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
-        live[k] = warp_event(p, ev[k], b, 0, lut, tref, wo[k]) && (i < p.M);
+        live[k] = warp_event(p, ev[k], b, 0, lut, tref, wo[k]) && (i < p.M) && !((i >= pad0 && i < blk1) || i >= pad1);
     }
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
@@ -615,11 +629,11 @@ static int set_max_lds_ev(const void *fn, const char *who) {
 // ------------------------------------------------------------------------------------------
 extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, const float *flow_lut,
                                    const float *t_ref, float *iwe_raw, void *ws, void *stream) {
-    return mpc_event_splat_fwd_ex(s, events, flow_lut, t_ref, iwe_raw, ws, stream, 0);
+    return mpc_event_splat_fwd_ex(s, events, flow_lut, t_ref, iwe_raw, ws, stream, 0, nullptr);
 }
 
 static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed);
+                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed, const int32_t *offsets = nullptr);
 
 // Event-axis sharding ("optional finer split" for batches smaller than the number of ranks): the raw IWE of
 // THIS rank's events as the Q33.30 accumulators themselves; integer partial images sum exactly, so an all-reduce(SUM) of
@@ -641,12 +655,12 @@ extern "C" int mpc_iwe_from_fixed(const int64_t *iwe_fixed, float *iwe_raw, int6
 }
 
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                           float *iwe_raw, void *ws, void *stream, int counters_zeroed) {
-    return splat_fwd_impl(s, events, flow_lut, t_ref, iwe_raw, ws, stream, counters_zeroed, false);
+                           float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets) {
+    return splat_fwd_impl(s, events, flow_lut, t_ref, iwe_raw, ws, stream, counters_zeroed, false, offsets);
 }
 
 static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed) {
+                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed, const int32_t *offsets) {
     MPC_CHECK_ARG(s && iwe_raw && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) || flow_lut, MPC_E_NULL, "flow_lut is null");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
@@ -679,7 +693,7 @@ static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *
             }
             const int nloc = L.P * L.n_strips + s->nb * L.n_cstrips;
             const size_t lds = (size_t)(((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3) * sizeof(int) + (size_t)EV_STAGE * 16;
-            MPC_LAUNCH(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd);
+            MPC_LAUNCH(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd, want_bwd ? nullptr : offsets);
             MPC_CHECK_LAUNCH();
         }
         if (L.nfb > 0) {
