@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
                                                       const float *__restrict__ knn_state,
                                                       const float *__restrict__ tile_dkmax,
                                                       float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
+                                                      float2 *__restrict__ gtraj_direct,
                                                       int gx, int gy, int bd
 #ifdef KNN_BW_STAMP
                                                       , int *__restrict__ stamp
@@ -853,8 +854,14 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
             }
         }
         if (act) {
-            tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
-            if (gnext != nullptr) tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
+            // no flow_to_next term: d traj(t_mid)[t] = -g goes straight to its place in the trajectory gradient (the value
+            // k_knn_bwd_combine would write: -g + 0 - 0); k_knn_bwd_combine_direct then only adds the bins up
+            if (gtraj_direct != nullptr)
+                gtraj_direct[((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i] = make_float2(-(invK * ay) + 0.f, -(invK * ax) + 0.f);
+            else {
+                tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
+                if (gnext != nullptr) tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
+            }
         }
     }
 #ifdef KNN_BW_STAMP
@@ -913,6 +920,23 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
     }
 }
 
+// num_tref == 1 without the flow_to_next term, after a k_knn_bwd_tile that wrote d traj(t_mid) in place: only
+//   d traj(t_ref)[i] = sum_t g[t][i] = sum_t -(d traj(t_mid)[t][i])    (same order, same bits: a - (-g) == a + g)
+// is left -- 15 coalesced reads and one write per point instead of 15 + 16.
+__global__ __launch_bounds__(256) void k_knn_bwd_combine_direct(const KnnParams p, float *__restrict__ gtraj) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= (size_t)p.B * p.n) return;
+    const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
+    float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (1 + p.nb) * p.n;
+    float sy = 0.f, sx = 0.f;
+#pragma unroll 5
+    for (int t = 0; t < p.nb; ++t) {
+        const float2 m = g2[(size_t)(1 + t) * p.n + i];
+        sy -= m.x; sx -= m.y;
+    }
+    g2[i] = make_float2(sy, sx);
+}
+
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
@@ -928,12 +952,13 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 //   MPC_KNN_BWD_FUSED=0     backward as k_knn_reach + k_knn_bwd_points also where k_knn_bwd_tile applies [1]
 //   MPC_KNN_BWD_SCATTER=1   query-centric scatter backward (knn_bwd_scatter.hip) where it applies; measured slower   [0]
 //   MPC_KNN_BWD_G=<g>       strips per workgroup of the scatter backward                               [by grid size]
+//   MPC_KNN_BWD_DIRECT=0    k_knn_bwd_tile writes per-bin partials for k_knn_bwd_combine instead of d traj(t_mid) in place [1]
 struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s, bwd_scatter;
+    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s, bwd_scatter, bwd_direct;
 };
 static const KnnTuning &knn_tuning() {
     static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0, 0};
+        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0, 0, 1};
         const char *e;
         if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
         if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
@@ -946,6 +971,7 @@ static const KnnTuning &knn_tuning() {
         if ((e = getenv("MPC_KNN_BWD_FUSED"))) v.bwd_fused = atoi(e) != 0;
         if ((e = getenv("MPC_KNN_BUCKET_S"))) v.bucket_s = atoi(e);
         if ((e = getenv("MPC_KNN_BWD_SCATTER"))) v.bwd_scatter = atoi(e) != 0;
+        if ((e = getenv("MPC_KNN_BWD_DIRECT"))) v.bwd_direct = atoi(e) != 0;
         return v;
     }();
     return t;
@@ -1170,6 +1196,7 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         const size_t ldsb = ((size_t)RWm * RWm + KNN_BW_WMAX) * (16 + (grad_flow_next ? 8 : 0));      // RWm >= 32: covers pitch 32 too
         const int gxb = mpc_cdiv(s->wq, 16), gyb = mpc_cdiv(s->hq, 16);
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
+        float2 *direct = (grad_flow_next == nullptr && knn_tuning().bwd_direct) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
 #ifdef KNN_BW_STAMP
 #define KB_STAMP_ARG , (int *)((char *)ws + L.off_knn_fail)
 #else
@@ -1177,13 +1204,14 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
 #endif
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
         MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH
         MPC_CHECK_LAUNCH();
         const int64_t totalb = (int64_t)s->B * s->n;
-        MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
+        if (direct) MPC_LAUNCH(k_knn_bwd_combine_direct, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, grad_traj);
+        else MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
                            grad_flow_next ? tmp_a : nullptr, grad_traj);
         MPC_CHECK_LAUNCH();
         return 0;
