@@ -149,7 +149,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     const int64_t lds_budget = 150 * 1024;
     L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));
     if (L.strip_rows > s->H) L.strip_rows = s->H;
-    L.cstrip_rows = (int)((48 * 1024) / ((int64_t)s->wq * 16));      // ~3 workgroups of the backward per CU
+    static const int64_t cstrip_kb = getenv("MPC_EV_CSTRIP_KB") ? atoll(getenv("MPC_EV_CSTRIP_KB")) : 48;      // (tuning)
+    L.cstrip_rows = (int)((cstrip_kb * 1024) / ((int64_t)s->wq * 16));      // ~3 workgroups of the backward per CU
     if (L.cstrip_rows < 1) L.cstrip_rows = (int)(lds_budget / ((int64_t)s->wq * 16));
     if (L.cstrip_rows > s->hq) L.cstrip_rows = s->hq;
     if (L.strip_rows > 0 && L.cstrip_rows > 0 && s->T == 1 && s->B > 0 && !(s->flags & MPC_F_ATOMIC_PATH)) {

@@ -497,6 +497,13 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
                                                     const float *__restrict__ events, const float *__restrict__ lut,
                                                     const float *__restrict__ t_ref, const int *__restrict__ offsets) {
     extern __shared__ unsigned long long s_acc[];
+#ifdef EV_LA_STAMP
+    __shared__ unsigned s_stp[8];         // (in LDS, not registers: eight live 64-bit values took the kernel from 47 to > 64 VGPRs -- one workgroup per CU)
+#define LA_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) s_stp[k] = (unsigned)wall_clock64(); } while (0)
+    if (threadIdx.x < 8) s_stp[threadIdx.x] = (unsigned)wall_clock64();
+#else
+#define LA_STAMP(k) do { } while (0)
+#endif
     constexpr int NT = ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS, NIF = ORDERED ? EV_LUT_INFLIGHT_ORD : EV_LUT_INFLIGHT;
     const EvParams p = make_params(s);
     const int tid = threadIdx.x;
@@ -518,6 +525,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         for (int i = tid; i < ncell; i += NT) s_lut[i] = src[i];
     }
     __syncthreads();
+    LA_STAMP(1);
     const bool valid = ORDERED || L.gcount[L.NF + L.NBk + 2] == EV_MARKER;
     const int NK = p.nb * L.NCS, key = it * L.NCS + cst;
     int n, n_pos = 0, o_pos = 0, o_neg = 0;
@@ -528,6 +536,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         o_neg = min(max(ob[NK + 1 + key], 0), p.M);
         n = n_pos + min(max(ob[NK + 1 + key + 1] - o_neg, 0), p.M - o_neg);
     } else n = valid ? L.gcount[L.NF + g] : 0;
+    LA_STAMP(2);
     // the bucket's records: behind those of the sample's buckets before it (first records: ev_prefix_block)
     const float4 *rec = L.brec;
     if (!ORDERED) rec = L.exact ? L.brec + (size_t)b * L.bcap + L.bcapcnt[L.NBk + (size_t)b * NK + key] : L.brec + (size_t)g * L.bcap;
@@ -554,12 +563,14 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         float4 e[NIF];
 #pragma unroll
         for (int u = 0; u < NIF; ++u) e[u] = fetch(min(r0 + u * NT, n - 1));
+        LA_STAMP(3);
         float gy[NIF], gx[NIF];
 #pragma unroll
         for (int u = 0; u < NIF; ++u) {
             const int pol = (int)(__float_as_uint(e[u].w) >> 31);
             record_grad(e[u].x, e[u].y, e[u].z, gimg + (size_t)(b * p.P + pol) * p.H * p.W, p.H, p.W, gy[u], gx[u]);
         }
+        LA_STAMP(4);
 #pragma unroll
         for (int u = 0; u < NIF; ++u) {
             if (r0 + u * NT < n && (!ORDERED || e[u].z != 0.f)) {
@@ -570,6 +581,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         }
     }
     __syncthreads();
+    LA_STAMP(5);
     const float gout = grad_out ? grad_out[0] : 1.f;
     const float coef = valid ? scal[MPC_SCAL_GCOEF] * gout : __int_as_float(0x7fc00000);
     float2 *dst = reinterpret_cast<float2 *>(glut) + ((size_t)bt * p.hq + crow0) * p.wq;
@@ -579,6 +591,15 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         if (add) { const float2 o = add[i]; v.x += gout * o.x; v.y += gout * o.y; }
         dst[i] = v;
     }
+#ifdef EV_LA_STAMP
+    LA_STAMP(6);
+    __syncthreads();
+    if (tid == 0) {       // diagnostics build (tools/lut_accum_stamp_probe.py): phase stamps of wavefront 0 over the first cells of the strip
+        unsigned *d = reinterpret_cast<unsigned *>(dst);
+        for (int k = 0; k < 7; ++k) d[k] = s_stp[k] - s_stp[0];
+        d[7] = (unsigned)n; d[8] = s_stp[0];
+    }
+#endif
 }
 
 // the counting pass of ev_count_device.h as a launch of its own (stage entry points; the fused forward lets spare
