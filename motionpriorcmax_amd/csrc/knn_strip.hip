@@ -7,13 +7,16 @@
 //     columns +- r are staged row by row, so the candidates of a query -- the rows [cy - r, cy + r] of the strip --
 //     are ONE contiguous slot range (points outside the query's square are farther than the ring bound and drop out
 //     by the same `d < upper` test that makes the search exact);
-//   * pass 1 walks the range in groups of eight slots with a wave-uniform trip count and keeps a distance LEVEL of
-//     every slot (64 levels over [upper / 2, upper), a monotone map of the exact fp32 distance) as one byte of a
-//     register array (statically indexed: the loop is fully unrolled);
-//   * the level holding the K-th smallest is found by bisection with SWAR byte compares on those registers
-//     (count(level < beta) = popcount(((beta + 127) * 0x01010101 - w) & 0x80808080) per word) -- no LDS histogram,
+//   * pass 1 walks the range in groups of eight slots with a wave-uniform trip count and keeps a NEARNESS byte of
+//     every slot (a monotone, DEcreasing map of the exact fp32 distance: 63 levels over [upper / 2, upper), one more
+//     for everything nearer, 0 for anything at or beyond the ring bound -- the float -> byte conversion saturates
+//     negative values to 0, so the map needs no clamp instruction) in a register array (statically indexed: the loop
+//     is fully unrolled);
+//   * the level holding the K-th nearest is found by bisection with SWAR byte compares on those registers
+//     (count(byte >= beta) = popcount((w + (128 - beta) * 0x01010101) & 0x80808080) per word) -- no LDS histogram,
 //     no atomics, no second distance evaluation;
-//   * pass 2 re-reads the bytes: levels below the K-th level add their flow (a 0/1 fma: fma(1, a, b) == a + b),
+//   * pass 2 re-reads the bytes: slots nearer than the K-th level add their flow (the SWAR flag byte 0x80 / 0 converted
+//     to 128.0 / 0.0 is the weight of an fma; the factor 128 is a power of two, every rounding is that of the plain sum),
 //     slots at the K-th level are noted in a bit mask and ranked afterwards by exact (distance, index).
 // A query the fast path cannot serve (fewer than K candidates below the ring bound, more slots or more keys at
 // the K-th level than the registers hold, a square that covers the whole grid, a strip whose points overflow the
@@ -26,7 +29,7 @@
 #define KS_NT 256
 #define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
-#define KS_NLEV 64                  // distance levels over [upper / 2, upper) (clipped squares: [upper / 4, upper)); byte value 64 = not a candidate
+#define KS_NLEV 64                  // nearness levels: 1 .. 63 over [upper / 2, upper) (clipped squares: [upper / 4, upper)), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
 #define KS_TAIL (4 * KS_MAXCH + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
@@ -262,19 +265,25 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     // anything outside the square is at least lb away along one axis
     const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
     const float upper = L1 ? lb : lb * lb;
-    // level of a distance: (d - lo) * NLEV / (upper - lo) saturated to [0, NLEV]: a monotone map (that is all exactness
-    // needs: a slot at a higher level is farther than every slot at a lower one); level NLEV <=> not below the ring
-    // bound (or a dummy slot).  lo = upper / 2: the K-th distance of an unclipped square sits near 0.83 upper; a
-    // clipped square was enlarged by whole rings, its K-th distance can be as low as upper / 2: lo = upper / 4.
+    // NEARNESS of a slot, one byte: (upper - d) * (NLEV - 1) / (upper - lo) converted with saturation -- a monotone map of the
+    // exact fp32 distance (that is all exactness needs: a slot with a smaller byte is at least as far as every slot with a
+    // larger one).  0 <=> not below the ring bound (or a dummy slot: the conversion saturates negative values to 0, which
+    // is why the map runs downwards -- no clamp instruction per slot); 1 .. NLEV - 1 resolve [lo, upper); everything nearer
+    // than lo lands in NLEV .. 127 and counts as ONE level (NLEV).  lo = upper / 2: the K-th distance of an unclipped
+    // square sits near 0.83 upper; a clipped square was enlarged by whole rings, its K-th distance can be as low as
+    // upper / 2: lo = upper / 4.  Largest byte: upper * (NLEV - 1) / (upper - lo) = 126 or 84 -- bytes stay below 128, which
+    // the SWAR compares rely on.  (A candidate within half a level of the ring bound converts to 0: it is treated as
+    // outside, which only makes the fast path give up earlier -- the byte of anything at or beyond the bound is 0 for sure:
+    // the rounding of the fma is ~1e-5 of a level.)
     const float lo_d = (r == r_init) ? 0.5f * upper : 0.25f * upper;
-    const float scale = (float)KS_NLEV / (upper - lo_d), loff = -lo_d * scale;
+    const float nscale = -(float)(KS_NLEV - 1) / (upper - lo_d), loff = -upper * nscale;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
     const float2 *pp = lpos + s;
-    // pass 1: level of every slot, one byte each; groups of 8 slots whose loads are issued together
+    // pass 1: nearness byte of every slot; groups of 8 slots whose loads are issued together
     unsigned w[KS_MAXCH];
 #pragma unroll
     for (int g = 0; g < KS_MAXCH / 2; ++g) {
-        w[2 * g] = w[2 * g + 1] = 0x01010101u * KS_NLEV;
+        w[2 * g] = w[2 * g + 1] = 0u;
         if (8 * g < nmax) {
             float2 pj[8];
 #pragma unroll
@@ -285,24 +294,23 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float d = pair_dist(qy, qx, pj[4 * h + u].x, pj[4 * h + u].y, L1);
-                    const float lvf = fminf(fmaf(d, scale, loff), (float)KS_NLEV);
-                    acc = __builtin_amdgcn_cvt_pk_u8_f32(lvf, u, acc);       // saturating: negative -> 0
+                    acc = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, nscale, loff), u, acc);       // saturating: negative -> 0
                 }
                 w[2 * g + h] = acc;
             }
         }
     }
-    // number of slots below level beta (1 <= beta <= NLEV): bytes are <= NLEV < 128, so (beta + 127 - byte) keeps
-    // bit 7 exactly when byte < beta, and no borrow crosses a byte (words of groups not visited hold level NLEV)
-    auto count_lt = [&](unsigned beta) {
-        const unsigned C = (beta + 127u) * 0x01010101u;
+    // number of slots with byte >= beta (1 <= beta <= 128): bytes are <= 127, so (byte + 128 - beta) has bit 7 exactly when
+    // byte >= beta, and no carry crosses a byte (words of groups not visited hold 0)
+    auto count_ge = [&](unsigned beta) {
+        const unsigned C = (128u - beta) * 0x01010101u;
         // (two v_bcnt_u32_b32 accumulate chains: the compiler's own form is bcnt + a tree of adds, half an instruction
         // more per word)
         int acc = 0, acc1 = 0;
 #pragma unroll
         for (int c = 0; c < KS_BASECH; c += 2) {
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"((C - w[c]) & 0x80808080u));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc1) : "v"((C - w[c + 1]) & 0x80808080u));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"((w[c] + C) & 0x80808080u));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc1) : "v"((w[c + 1] + C) & 0x80808080u));
         }
         acc += acc1;
         // (an inner query has 7 rows of 9 slots; only wavefronts next to the image border, whose rows are wider, get
@@ -310,45 +318,49 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         if (nmax > 4 * KS_BASECH) {
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int c = KS_BASECH; c < KS_BASECH + 4; ++c) acc += __popc((C - w[c]) & 0x80808080u);
+            for (int c = KS_BASECH; c < KS_BASECH + 4; ++c) acc += __popc((w[c] + C) & 0x80808080u);
             if (nmax > 4 * KS_BASECH + 16) {
                 asm volatile("" ::: "memory");
 #pragma unroll
-                for (int c = KS_BASECH + 4; c < KS_MAXCH; ++c) acc += __popc((C - w[c]) & 0x80808080u);
+                for (int c = KS_BASECH + 4; c < KS_MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
             }
         }
         return acc;
     };
     int bstar = 0, before = 0, inbin = 0;
     if (valid && !failed) {
-        int lo = 0, clo = 0, hi = KS_NLEV, chi = -1;      // count_lt(lo) < K <= count_lt(hi) -- assumed for hi = NLEV, checked below
+        // the level of the K-th nearest = the largest beta in [1, NLEV] with count_ge(beta) >= K  (NLEV and everything above
+        // it is one level: `hi` starts behind it with "nothing is nearer")
+        int lo = 1, clo = -1, hi = KS_NLEV + 1, chi = 0;      // count_ge(lo) >= K > count_ge(hi) -- assumed for lo = 1, checked below
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
             const int mid = (lo + hi) >> 1;
-            const int cm = count_lt((unsigned)mid);
-            if (cm >= p.K) { hi = mid; chi = cm; } else { lo = mid; clo = cm; }
+            const int cm = count_ge((unsigned)mid);
+            if (cm >= p.K) { lo = mid; clo = cm; } else { hi = mid; chi = cm; }
         }
-        // the number of candidates below the ring bound is only needed when the search ends at the top level (rare)
-        if (chi < 0) {
-            chi = count_lt(KS_NLEV);
-            if (chi < p.K) failed = true;          // fewer than K candidates below the ring bound: the square must grow
+        // the number of candidates below the ring bound is only needed when the search ends at the bottom level (rare)
+        if (clo < 0) {
+            clo = count_ge(1u);
+            if (clo < p.K) failed = true;          // fewer than K candidates below the ring bound: the square must grow
         }
-        bstar = lo; before = clo; inbin = chi - clo;     // level of the K-th smallest, slots below it, slots in it
+        bstar = lo; before = chi; inbin = clo - chi;     // level of the K-th nearest, slots nearer than it, slots in it
     }
     const bool live = valid && !failed;
-    // pass 2: flows of the levels below bstar (flag = clamp(bstar - level, 0, 1)); slots at level bstar into a bit mask
+    // pass 2: flows of the slots NEARER than level bstar, slots AT level bstar into a bit mask.  Per word of four bytes:
+    // ge1 = bit 7 of (byte + 128 - bstar) <=> byte >= bstar; ge2 likewise for bstar + 1 (for bstar = NLEV -- the one level of
+    // everything nearer than lo -- nothing is nearer: beta 128).  ge2's bytes are 0x80 / 0: converted to 128.0 / 0.0 they are
+    // the weight of the slot's flow, so the sums below carry a factor of 128 (a power of two: every rounding is that of the
+    // plain sum) which the final division removes.  Dead lanes: beta 128 twice -- no slot anywhere.
     const bool do_next = NEXT && (t < p.nb - 1);
     float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
     unsigned E[(KS_MAXCH + 7) / 8];
     unsigned Mm[(KS_MAXCH + 7) / 8];     // LEAN: the neighbours of the query, same bit <-> slot map as E
 #pragma unroll
     for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) { E[e] = 0u; Mm[e] = 0u; }
-    const unsigned cl4 = ((live ? (unsigned)bstar : 0u) + 127u) * 0x01010101u;      // bit 7 of (cl4 - byte) <=> level < bstar
-    const float ubf = live ? (float)bstar : 0.f;             // dead lanes: nothing is below level 0 ...
-    // slots AT level bstar, by a SWAR zero-byte test per word: z = w ^ (bstar in every byte) has bytes <= 127, so
-    // (0x80 - byte) keeps bit 7 exactly for byte == 0 and no borrow crosses a byte.  The four flags of word j (of the
-    // eight words of a mask) go to bits j, 8 + j, 16 + j, 24 + j: slot 32 m + 4 j + u <-> bit j + 8 u of E[m].
-    const unsigned ue4 = (live ? (unsigned)bstar : 0x7fu) * 0x01010101u;      // (dead lanes: no level is 127)
+    const unsigned beta2 = (live && bstar < KS_NLEV) ? (unsigned)bstar + 1u : 128u;
+    const unsigned c1 = (128u - (live ? (unsigned)bstar : 128u)) * 0x01010101u, c2 = (128u - beta2) * 0x01010101u;
+    // The four flags of word j (of the eight words of a mask) go to bits j, 8 + j, 16 + j, 24 + j: slot 32 m + 4 j + u <->
+    // bit j + 8 u of E[m].
     const float2 *pf = lflow + s, *pn = lnext + s;
 #pragma unroll
     for (int g = 0; g < KS_MAXCH / 2; ++g) {
@@ -356,28 +368,33 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
             float2 fj[8], gj[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { fj[u] = pf[8 * g + u]; if (NEXT) gj[u] = pn[8 * g + u]; }
+            unsigned near4[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int j = (2 * g + h) & 7;
-                const unsigned f7 = 0x80808080u - (w[2 * g + h] ^ ue4);
-                E[g / 4] |= (f7 >> (7 - j)) & (0x01010101u << j);
-                if (LEAN) Mm[g / 4] |= ((cl4 - w[2 * g + h]) >> (7 - j)) & (0x01010101u << j);
+                const unsigned ge1 = w[2 * g + h] + c1, ge2 = w[2 * g + h] + c2;
+                near4[h] = ge2 & 0x80808080u;
+                E[g / 4] |= ((ge1 ^ ge2) >> (7 - j)) & (0x01010101u << j);      // (ge2 implies ge1: the xor is "at level bstar")
+                if (LEAN) Mm[g / 4] |= (ge2 >> (7 - j)) & (0x01010101u << j);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const unsigned lv = (w[2 * g + (u >> 2)] >> (8 * (u & 3))) & 0xffu;
                 if (IWD) {
-                    if ((float)lv < ubf) {
-                        if (live) {
-                            const float2 pj = pp[8 * g + u];
-                            const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                            const float wgt = 1.f / (d + 1e-9f);                  // focus.py:159-161
-                            sy_ += wgt * fj[u].x; sx_ += wgt * fj[u].y; sw_ += wgt;
-                            if (do_next) { ny_ += gj[u].x; nx_ += gj[u].y; }
-                        }
+                    if (((near4[u >> 2] >> (8 * (u & 3))) & 0x80u) != 0u) {
+                        const float2 pj = pp[8 * g + u];
+                        const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                        const float wgt = 1.f / (d + 1e-9f);                  // focus.py:159-161
+                        sy_ += wgt * fj[u].x; sx_ += wgt * fj[u].y; sw_ += wgt;
+                        if (do_next) { ny_ += 128.f * gj[u].x; nx_ += 128.f * gj[u].y; }
                     }
                 } else {
-                    const float flag = fminf(fmaxf(ubf - (float)lv, 0.f), 1.f);
+                    // byte u & 3 of the word as a float, 128.0 or 0.0 (spelled out: with the bytes known to be 0x80 / 0 the
+                    // compiler rewrites the shift-and-mask form into a shift, an SDWA and, and a conversion of byte 0)
+                    float flag;
+                    if ((u & 3) == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    else if ((u & 3) == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    else if ((u & 3) == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
                     sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_);
                     if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
                 }
@@ -424,8 +441,8 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                 if (light && a < inbin && rank < need) {
                     const float2 f = pf[jj[a]];
                     if (IWD) { const float wgt = 1.f / (dd[a] + 1e-9f); sy_ += wgt * f.x; sx_ += wgt * f.y; sw_ += wgt; }
-                    else { sy_ += f.x; sx_ += f.y; }
-                    if (do_next) { const float2 g2 = pn[jj[a]]; ny_ += g2.x; nx_ += g2.y; }
+                    else { sy_ = fmaf(128.f, f.x, sy_); sx_ = fmaf(128.f, f.y, sx_); }       // (the sums carry the factor 128 of pass 2)
+                    if (do_next) { const float2 g2 = pn[jj[a]]; ny_ = fmaf(128.f, g2.x, ny_); nx_ = fmaf(128.f, g2.y, nx_); }
                     if (rank == need - 1) { dK = dd[a]; iK = ii[a]; }
                     if (LEAN) {
                         const unsigned bit = 1u << (kraw[a] & 31);
@@ -494,7 +511,12 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
                 cdk = fmaxf(cdk, __shfl_xor(cdk, o2, 64)); cik = max(cik, __shfl_xor(cik, o2, 64));
             }
             const bool htie = __ballot((b0 && d0 == cdk && i0 > cik) || (b1 && d1 == cdk && i1 > cik)) != 0ull;
-            if (lane == h) { sy_ += cy_; sx_ += cx_; sw_ += cw_; ny_ += cny; nx_ += cnx; dK = cdk; iK = cik; tie = htie; }
+            if (lane == h) {
+                if (IWD) { sy_ += cy_; sx_ += cx_; sw_ += cw_; }
+                else { sy_ = fmaf(128.f, cy_, sy_); sx_ = fmaf(128.f, cx_, sx_); }
+                ny_ = fmaf(128.f, cny, ny_); nx_ = fmaf(128.f, cnx, nx_);
+                dK = cdk; iK = cik; tie = htie;
+            }
             if (LEAN) {
                 // the selected slots as mask bits: bit `l` of a word belongs to slot 4 (l & 7) + (l >> 3) of its 32 slots,
                 // i.e. to the lane of that number: fetch that lane's flag, then a ballot is the word
@@ -511,10 +533,10 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         const size_t BQ = (size_t)p.B * p.nb * p.G;
         float2 ov; float norm = 0.f;
         if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
-        else { ov.x = sy_ / (float)p.K; ov.y = sx_ / (float)p.K; }
+        else { ov.x = (sy_ * 0.0078125f) / (float)p.K; ov.y = (sx_ * 0.0078125f) / (float)p.K; }       // (1 / 128: exact)
         reinterpret_cast<float2 *>(flow_lut)[q] = ov;
         if (do_next) {
-            float2 on; on.x = ny_ / (float)p.K; on.y = nx_ / (float)p.K;
+            float2 on; on.x = (ny_ * 0.0078125f) / (float)p.K; on.y = (nx_ * 0.0078125f) / (float)p.K;
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
         if (!LEAN) {
