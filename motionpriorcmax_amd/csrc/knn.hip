@@ -610,6 +610,10 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
         const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
         const float *rdk = ldk + (cyr - ry0) * RP + xb;
         const float2 *rg = lg + (cyr - ry0) * RP + xb, *rown = lgn + (cyr - ry0) * RP + xb;
+        // (the compiler pairs the gradients of neighbouring cells into ds_read2_b64, which the LDS serves at half the rate of
+        // two ds_read_b64; forcing single reads -- volatile loads, or inline asm with its own s_waitcnt -- costs registers
+        // the 64-VGPR budget does not have: 72-108 bytes of scratch per lane, 135 / 147 us against 133.  One 16-byte cell
+        // {K-th distance, gradient, index} read as ds_read_b128: 164 us)
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             const float d = dy2 + dx2[c];
@@ -634,6 +638,9 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 // grid: 1-D, XCD-contiguous, 256 threads, dynamic LDS (RWmax^2 float4 + KNN_BW_WMAX of slack [+ float2 per cell])
 // ------------------------------------------------------------------------------------------
 #define KNN_BW_WMAX 16
+#ifndef KNN_BW_PITCH
+#define KNN_BW_PITCH 48   // row pitch (cells) of the staged arrays without the flow_to_next gradient; >= 16 + 2 * KNN_RQ_MAX
+#endif
 #ifndef KNN_BW_OCC
 #define KNN_BW_OCC 8      // workgroups per CU the register budget is set for (8 -> 64 VGPRs)
 #endif
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_rowbase[TS + 1];
     __shared__ int s_rowg[TS];
-    __shared__ float s_wr[4];
+    __shared__ float s_wr[1];
     __shared__ int s_tiew[4];
     const int tid = threadIdx.x;
     const int nblk = gx * gy * p.B * p.nb;
@@ -671,47 +678,72 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
     const int *cs = cell_start + (size_t)bt * (p.G + 1);
     // ---- phase 1: reach of this tile = the largest linear K-th distance among the tiles whose queries can touch it
     //      (Chebyshev gap between this tile's cell area and their query centres); bucketed ranges of the tile rows --
-    {
+    // Wavefront 0 alone.  Step A: the largest K-th distance of ANY class of ANY tile of the slice (coalesced reads).  A
+    // source tile k tile rings away has its query centres at least (k - 1) * 16 cells from this tile's area, so only the tiles
+    // within D = floor(linmax / (16 sp)) + 1 rings can touch it -- D = 1 in practice: the 3 x 3 tiles around this one.
+    // Step B tests those 45 (tile, class) pairs on 45 lanes.  (Before: every tile of the slice on a lane of its own in a loop
+    // over the classes -- ~300 vector instructions for one or two wavefronts of the workgroup, the maximum of each class a
+    // dependent round trip behind the loop's `continue`.  With step A on all four wavefronts and a barrier before step B the
+    // kernel was slower than that: 142 vs 139 us.)  Wavefront 1 meanwhile looks up the bucketed ranges of the tile rows.
+    if (tid < 64) {
         const int ntx = gx, nty = gy, nt = ntx * nty;
+        float m = 0.f;
+        for (int i = tid; i < nt * KNN_NCLS; i += 64) m = fmaxf(m, tile_dkmax[(size_t)bt * nt * KNN_NCLS + i]);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+        const float linmax = (L1 ? m : sqrtf(m)) * 1.0001f + 0.01f;
+        const int D = (int)fminf(linmax / (float)(16 * p.sp), 1.0e6f) + 1;
         const float ay0 = (float)(by_ * 16 * p.sp) - 0.5f, ay1 = (float)(min(by_ * 16 + 16, p.hq) * p.sp) - 0.5f;
         const float ax0 = (float)(bx_ * 16 * p.sp) - 0.5f, ax1 = (float)(min(bx_ * 16 + 16, p.wq) * p.sp) - 0.5f;
         float r = 0.f;
-        for (int tb = tid; tb < nt; tb += 256) {
-            const int sy = tb / ntx, sx = tb - sy * ntx;
+        // one (source tile, class) pair: its K-th distance counts if its queries can reach this tile's area
+        auto pair_reach = [&](int sy, int sx, int c) {
+            const int tb = sy * ntx + sx;
             const int ty0 = sy * 16, ty1 = min(ty0 + 16, p.hq) - 1, tx0 = sx * 16, tx1 = min(tx0 + 16, p.wq) - 1;
+            // cells of the source tile that can hold queries of class c (knn_device.h)
+            int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
+            if (c == 1) cy1 = min(cy1, bd - 1);
+            if (c == 2) cy0 = max(cy0, p.hq - bd);
+            if (c == 3) cx1 = min(cx1, bd - 1);
+            if (c == 4) cx0 = max(cx0, p.wq - bd);
+            if (cy0 > cy1 || cx0 > cx1) return;
+            const float dk = tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c];
+            const float lin = (L1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
+            const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
+            const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
+            const float gyv = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1)), gxv = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
+            if (dk > 0.f && lin >= fmaxf(gyv, gxv)) r = fmaxf(r, lin);
+        };
+        if (D == 1) {
+            if (tid < 9 * KNN_NCLS) {
+                const int nbr = tid / KNN_NCLS, c = tid - nbr * KNN_NCLS;
+                const int sy = by_ + nbr / 3 - 1, sx = bx_ + (nbr % 3) - 1;
+                if (sy >= 0 && sy < nty && sx >= 0 && sx < ntx) pair_reach(sy, sx, c);
+            }
+        } else {
+            for (int tb = tid; tb < nt; tb += 64) {
+                const int sy = tb / ntx, sx = tb - sy * ntx;
+                if (abs(sy - by_) > D || abs(sx - bx_) > D) continue;
 #pragma unroll
-            for (int c = 0; c < KNN_NCLS; ++c) {
-                // cells of the source tile that can hold queries of class c (knn_device.h)
-                int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
-                if (c == 1) cy1 = min(cy1, bd - 1);
-                if (c == 2) cy0 = max(cy0, p.hq - bd);
-                if (c == 3) cx1 = min(cx1, bd - 1);
-                if (c == 4) cx0 = max(cx0, p.wq - bd);
-                if (cy0 > cy1 || cx0 > cx1) continue;
-                const float dk = tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c];
-                const float lin = (L1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
-                const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
-                const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
-                const float gyv = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1)), gxv = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
-                if (dk > 0.f && lin >= fmaxf(gyv, gxv)) r = fmaxf(r, lin);
+                for (int c = 0; c < KNN_NCLS; ++c) pair_reach(sy, sx, c);
             }
         }
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) r = fmaxf(r, __shfl_xor(r, o2, 64));
-        if ((tid & 63) == 0) s_wr[tid >> 6] = r;
-    }
-    if (tid < 64) {
+        if (tid == 0) s_wr[0] = r;
+    } else if (tid < 128) {
+        const int ln = tid - 64;
         int gs = 0, ge = 0;
-        const int yy = by_ * TS + tid;
-        if (tid < TS && yy < p.hq) {
+        const int yy = by_ * TS + ln;
+        if (ln < TS && yy < p.hq) {
             const int xa = bx_ * TS, xb = min(xa + TS, p.wq);
             gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
         }
         int run = ge - gs;
 #pragma unroll
-        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
-        if (tid < TS) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
-        if (tid == 0) s_rowbase[0] = 0;
+        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (ln >= o2) run += v; }
+        if (ln < TS) { s_rowg[ln] = gs; s_rowbase[ln + 1] = run; }
+        if (ln == 0) s_rowbase[0] = 0;
     }
     // ---- phase 2 (after the reach is known; staging a guessed halo before it, so that the loads of the two phases
     //      travel together, measured slower: too many tiles stage twice): the K-th distance, K-th index | tie flag and
@@ -723,17 +755,27 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
     auto stage = [&]() {
         RW = TS + 2 * RQ;
-        // row pitch of the staged arrays: 32 entries where the region fits (consecutive rows then start on the same
-        // banks and the points of a cell row read consecutive words)
-        RP = RW <= 32 ? 32 : RW;
+        // Row pitch of the staged arrays.  The window loop reads one K-th distance (4 bytes) and one gradient (8 bytes) per
+        // lane and cell; the LDS serves 32 lanes per cycle -- two cell rows of ~16 points each, whose windows start at about
+        // the same column one row apart.  At a pitch of 32 entries (round 2) both rows sit on the same banks: a 2-way
+        // conflict on every read (SQ_LDS_BANK_CONFLICT: 18.6 M cycles per C3 launch, a quarter of the kernel).  48 entries
+        // put consecutive rows 16 banks (4-byte array: 32 banks) resp. 32 banks (8-byte array: 64 banks) apart: no conflict.
+        // The K-th INDEX (only read on the exact path, for a tie) stays in global memory then, which keeps the workgroup
+        // at 19.5 KB -- eight per CU as before.  With the flow_to_next gradient (8 more bytes per cell) the pitch stays 32.
+        RP = NEXT ? (RW <= 32 ? 32 : RW) : KNN_BW_PITCH;
         ry0 = by_ * TS - RQ; rx0 = bx_ * TS - RQ;
         // separate arrays (the hot loop reads the K-th distance and the gradient only; neighbouring lanes then read
-        // neighbouring 4- and 8-byte words): K-th distance, K-th index, dL/dLUT, dL/dflow_next
+        // neighbouring 4- and 8-byte words): K-th distance, [K-th index,] dL/dLUT, [dL/dflow_next]
         const size_t ncell = (size_t)RW * RP + KNN_BW_WMAX;
         ldk = reinterpret_cast<float *>(s_dyn);
-        lik = reinterpret_cast<int *>(s_dyn + ncell * 4);
-        lg = reinterpret_cast<float2 *>(s_dyn + ncell * 8);
-        lgn = reinterpret_cast<float2 *>(s_dyn + ncell * 16);
+        if (NEXT) {
+            lik = reinterpret_cast<int *>(s_dyn + ncell * 4);
+            lg = reinterpret_cast<float2 *>(s_dyn + ncell * 8);
+            lgn = reinterpret_cast<float2 *>(s_dyn + ncell * 16);
+        } else {
+            lik = nullptr; lgn = nullptr;
+            lg = reinterpret_cast<float2 *>(s_dyn + ncell * 4);          // (ncell is even: 8-byte aligned)
+        }
         int tie = 0;
         for (int rr = tid >> 5; rr < RW; rr += 8) {
             const int yy = ry0 + rr;
@@ -750,20 +792,20 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
                     tie |= ik & KNN_TIE_FLAG;
                     ik &= ~KNN_TIE_FLAG;
                 }
-                ldk[rr * RP + cc] = dk; lik[rr * RP + cc] = ik; lg[rr * RP + cc] = g;
-                if (NEXT) lgn[rr * RP + cc] = gn;
+                ldk[rr * RP + cc] = dk; lg[rr * RP + cc] = g;
+                if (NEXT) { lik[rr * RP + cc] = ik; lgn[rr * RP + cc] = gn; }
             }
         }
         if (tid < KNN_BW_WMAX) {                    // slack behind the last row: never a member
-            ldk[RW * RP + tid] = -1.f; lik[RW * RP + tid] = -1; lg[RW * RP + tid] = make_float2(0.f, 0.f);
-            if (NEXT) lgn[RW * RP + tid] = make_float2(0.f, 0.f);
+            ldk[RW * RP + tid] = -1.f; lg[RW * RP + tid] = make_float2(0.f, 0.f);
+            if (NEXT) { lik[RW * RP + tid] = -1; lgn[RW * RP + tid] = make_float2(0.f, 0.f); }
         }
         const bool wt = __ballot(tie != 0) != 0ull;
         if ((tid & 63) == 0) s_tiew[tid >> 6] = wt ? 1 : 0;
     };
     if ((tid & 63) == 0) s_tiew[tid >> 6] = 0;
     __syncthreads();
-    const float R = fmaxf(fmaxf(s_wr[0], s_wr[1]), fmaxf(s_wr[2], s_wr[3]));
+    const float R = s_wr[0];
     const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo the reach asks for, in cells
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
     if (use_lds) {
@@ -827,7 +869,9 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
                         const float dx = ((float)(cx * p.sp) + p.off) - pt.y;
                         const float d = dy2 + (L1 ? fabsf(dx) : dx * dx);
                         const float dk = ldk[ro + cx];
-                        const bool in = (d < dk) || (d == dk && i <= lik[ro + cx]);
+                        // (the K-th index: staged only with the flow_to_next gradient, else read where it lives -- a tie is rare)
+                        const bool in = (d < dk) || (d == dk && i <= (NEXT ? lik[ro + cx]
+                                                                            : (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & ~KNN_TIE_FLAG)));
                         if (in) {
                             const float2 e = lg[ro + cx];
                             ay += e.x; ax += e.y;
@@ -1193,7 +1237,8 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
     const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
     if (s->T == 1 && !p.iwd && knn_tuning().bwd_ts == 16 && knn_tuning().bwd_fused) {
         const int RWm = 16 + 2 * KNN_RQ_MAX;
-        const size_t ldsb = ((size_t)RWm * RWm + KNN_BW_WMAX) * (16 + (grad_flow_next ? 8 : 0));      // RWm >= 32: covers pitch 32 too
+        const size_t ldsb = grad_flow_next ? ((size_t)RWm * RWm + KNN_BW_WMAX) * 24                 // RWm >= 32: covers pitch 32 too
+                                           : ((size_t)RWm * KNN_BW_PITCH + KNN_BW_WMAX) * 12;
         const int gxb = mpc_cdiv(s->wq, 16), gyb = mpc_cdiv(s->hq, 16);
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
         float2 *direct = (grad_flow_next == nullptr && knn_tuning().bwd_direct) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
