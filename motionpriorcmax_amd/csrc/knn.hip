@@ -13,6 +13,9 @@
 #include "knn_device.h"
 #include "ev_count_device.h"
 #include <stdlib.h>
+#ifndef KNN_BW_CH
+#define KNN_BW_CH 4       // bwd_window_fast: cells of a window row whose LDS reads are issued together
+#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -610,17 +613,34 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
         const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
         const float *rdk = ldk + (cyr - ry0) * RP + xb;
         const float2 *rg = lg + (cyr - ry0) * RP + xb, *rown = lgn + (cyr - ry0) * RP + xb;
-        // (the compiler pairs the gradients of neighbouring cells into ds_read2_b64, which the LDS serves at half the rate of
-        // two ds_read_b64; forcing single reads -- volatile loads, or inline asm with its own s_waitcnt -- costs registers
-        // the 64-VGPR budget does not have: 72-108 bytes of scratch per lane, 135 / 147 us against 133.  One 16-byte cell
-        // {K-th distance, gradient, index} read as ds_read_b128: 164 us)
+        // The gradients as ONE ds_read_b64 each (knn_lds_f2: a volatile load the compiler may not pair).  Left alone it pairs
+        // the reads of neighbouring cells into ds_read2_b64, which the LDS serves at half the rate of two single reads (8
+        // cycles per pair: MI355X_MICROARCH.md, LDS table) -- and this loop lives on the LDS (SQ_LDS_IDX_ACTIVE: 76 % of the
+        // kernel's cycles).  (Inline asm with its own s_waitcnt: 147 us; one 16-byte cell {K-th distance, gradient, index}
+        // read as ds_read_b128: 164 us.)
+        // (the loads of four cells first, then their arithmetic: a volatile load is a scheduling barrier for every other
+        // memory operation, so in load-use-load-use order each cell would wait for its own LDS round trip)
 #pragma unroll
-        for (int c = 0; c < CW; ++c) {
-            const float d = dy2 + dx2[c];
-            const float w = (d <= rdk[c]) ? 1.f : 0.f;
-            const float2 e = rg[c];
-            ay = fmaf(w, e.x, ay); ax = fmaf(w, e.y, ax);
-            if (NEXT) { const float2 gq = rown[c]; an.x = fmaf(w, gq.x, an.x); an.y = fmaf(w, gq.y, an.y); }
+        for (int c0 = 0; c0 < CW; c0 += KNN_BW_CH) {
+            float2 e[KNN_BW_CH], gq[KNN_BW_CH];
+            float dkc[KNN_BW_CH];
+#pragma unroll
+            for (int c = 0; c < KNN_BW_CH; ++c) {
+                if (c0 + c < CW) {
+                    e[c] = knn_lds_f2(rg + c0 + c);
+                    if (NEXT) gq[c] = knn_lds_f2(rown + c0 + c);
+                    dkc[c] = rdk[c0 + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KNN_BW_CH; ++c) {
+                if (c0 + c < CW) {
+                    const float d = dy2 + dx2[c0 + c];
+                    const float w = (d <= dkc[c]) ? 1.f : 0.f;
+                    ay = fmaf(w, e[c].x, ay); ax = fmaf(w, e[c].y, ax);
+                    if (NEXT) { an.x = fmaf(w, gq[c].x, an.x); an.y = fmaf(w, gq[c].y, an.y); }
+                }
+            }
         }
     }
 }
@@ -638,6 +658,9 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 // grid: 1-D, XCD-contiguous, 256 threads, dynamic LDS (RWmax^2 float4 + KNN_BW_WMAX of slack [+ float2 per cell])
 // ------------------------------------------------------------------------------------------
 #define KNN_BW_WMAX 16
+#ifndef KNN_BW_CH
+#define KNN_BW_CH 4       // cells of a window row whose LDS reads are issued together
+#endif
 #ifndef KNN_BW_PITCH
 #define KNN_BW_PITCH 48   // row pitch (cells) of the staged arrays without the flow_to_next gradient; >= 16 + 2 * KNN_RQ_MAX
 #endif
@@ -851,11 +874,18 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
                 const int xb = min(x0, rx0 + RW - 1) - rx0;
                 // (a point far outside the image sits in a border cell with an EMPTY window whose x0 lies beyond the
                 // staged region: the unconditional reads must stay inside it -- xb, cyr)
+                // windows wider than 8 columns (border tiles: clipped queries reach twice as far) go in two column chunks, 8 +
+                // 2 / 5 / 8: the squared column offsets of 16 columns, live across the row loop, do not fit the 64-register
+                // budget beside the single-read form of the gradient loads (bwd_window_fast)
                 if (nxmax <= 7) bwd_window_fast<7, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
-                else if (nxmax <= 8) bwd_window_fast<8, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
-                else if (nxmax <= 10) bwd_window_fast<10, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
-                else if (nxmax <= 13) bwd_window_fast<13, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
-                else bwd_window_fast<KNN_BW_WMAX, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                else {
+                    bwd_window_fast<8, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                    if (nxmax > 8) {
+                        if (nxmax <= 10) bwd_window_fast<2, L1, NEXT>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
+                        else if (nxmax <= 13) bwd_window_fast<5, L1, NEXT>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
+                        else bwd_window_fast<8, L1, NEXT>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
+                    }
+                }
             } else if (act) {
 #ifdef KNN_BW_STAMP
                 st_slow = 1;
