@@ -604,15 +604,16 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
     float dx2[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
-        const float dx = ((float)((x0 + c) * p.sp) + p.off) - pt.y;
+        const float dx = ((float)__mul24(x0 + c, p.sp) + p.off) - pt.y;      // (24-bit multiplies: full rate; v_mul_lo_u32 is quarter rate)
         dx2[c] = (c < nxw) ? (L1 ? fabsf(dx) : dx * dx) : INFINITY;
     }
     for (int r = 0; r < nymax; ++r) {
         const int cyr = min(max(y0 + r, ry0), ry0 + RW - 1);
-        const float dy = ((float)(cyr * p.sp) + p.off) - pt.x;
+        const float dy = ((float)__mul24(cyr, p.sp) + p.off) - pt.x;
         const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
-        const float *rdk = ldk + (cyr - ry0) * RP + xb;
-        const float2 *rg = lg + (cyr - ry0) * RP + xb, *rown = lgn + (cyr - ry0) * RP + xb;
+        const int ro = __mul24(cyr - ry0, RP) + xb;
+        const float *rdk = ldk + ro;
+        const float2 *rg = lg + ro, *rown = lgn + ro;
         // The gradients as ONE ds_read_b64 each (knn_lds_f2: a volatile load the compiler may not pair).  Left alone it pairs
         // the reads of neighbouring cells into ds_read2_b64, which the LDS serves at half the rate of two single reads (8
         // cycles per pair: MI355X_MICROARCH.md, LDS table) -- and this loop lives on the LDS (SQ_LDS_IDX_ACTIVE: 76 % of the
@@ -635,8 +636,13 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 #pragma unroll
             for (int c = 0; c < KNN_BW_CH; ++c) {
                 if (c0 + c < CW) {
+                    // member <=> d <= K-th distance, as ARITHMETIC: t = dk - d has the exact sign of the comparison (a
+                    // difference of two floats is 0 only if they are equal, and it cannot round across 0), so
+                    // clamp(t * 2^100 + 1, 0, 1) is 1 for t >= 0 and 0 for any t < 0 (|t| >= one ulp of a squared distance;
+                    // d = inf and the dk = -1 of a cell that is no query give -inf / negative).  Two fp32 instructions, which
+                    // this chip issues at twice the rate of the compare + select they replace (profiles/r02_ubench_valu_rate.txt).
                     const float d = dy2 + dx2[c0 + c];
-                    const float w = (d <= dkc[c]) ? 1.f : 0.f;
+                    const float w = fminf(fmaxf(fmaf(dkc[c] - d, 0x1p100f, 1.f), 0.f), 1.f);
                     ay = fmaf(w, e[c].x, ay); ax = fmaf(w, e[c].y, ax);
                     if (NEXT) { an.x = fmaf(w, gq[c].x, an.x); an.y = fmaf(w, gq[c].y, an.y); }
                 }
