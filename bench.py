@@ -168,8 +168,8 @@ def knn_ceiling(workload, stages, B, nb):
     """The KNN stages against the ceiling that applies to them (VALU issue, not HBM): queries per second from the LIVE stage
     times; and, clearly marked as FROM THE COMMITTED PROFILE (not re-measured by this run, and only valid for the library
     that profile was taken with), the share of the chip's vector-instruction issue slots their dominant kernels used
-    (profiles/r<NN>_sq_<workload>.json: SQ_INSTS_VALU per launch x 4 cycles / (duration x SIMDs x clock); SIMD count and
-    clock from the device properties when a GPU is present)."""
+    (profiles/r<NN>_sq_<workload>.json: SIMD cycles available per SQ_INSTS_VALU = duration x SIMDs x clock / instructions; SIMD
+    count and clock from the device properties when a GPU is present)."""
     import glob
     Q = (H // SP) * (W // SP)
     out = {}
@@ -192,9 +192,14 @@ def knn_ceiling(workload, stages, B, nb):
         prof = {}
         for key, k in d.items():
             if isinstance(k, dict) and stage_of_kernel(key) in ('mpc_knn_lut_fwd', 'mpc_knn_lut_bwd') and k.get('kernel_us', 0) > 20:
+                # SIMD cycles (at the nominal clock) the launch had per vector instruction it issued.  Measured issue
+                # costs on this chip (profiles/r02_ubench_valu_rate.txt, nominal-clock cycles): fp32 add/mul/fma 2.7,
+                # integer/SWAR 3.5-3.9, compare + select 4.6, packed fp32 5.1 -- a kernel near 3-4 is bound by what it issues
+                slots = k['kernel_us'] * 1e-6 * ghz * 1e9 * simds
                 prof[key] = {'valu_wave_instr_per_launch': k['valu_insts'], 'kernel_us_in_profile': k['kernel_us'],
-                             'valu_issue_frac': round(k['valu_insts'] * 4.0 / (k['kernel_us'] * 1e-6 * ghz * 1e9 * simds), 3),
-                             'wait_any_frac': k.get('wait_any_frac')}
+                             'simd_cycles_per_valu_instr': round(slots / k['valu_insts'], 2),
+                             'valu_issue_frac_at_4_cycles': round(k['valu_insts'] * 4.0 / slots, 3),
+                             'lds_active_frac': k.get('lds_active_frac'), 'wait_any_frac': k.get('wait_any_frac')}
         # the counters belong to the library they were taken with: say so when the loaded one differs (stale figures)
         import hashlib
         libp = os.path.join(ROOT, 'motionpriorcmax_amd', 'libmpcmax.so')
@@ -204,7 +209,8 @@ def knn_ceiling(workload, stages, B, nb):
                                              'stale': True, 'note': 'taken with another build of the library: counters omitted'}
             return out
         out['from_committed_profile'] = {'file': os.path.relpath(files[-1], ROOT), 'library': d.get('_library'),
-                                         'assumes': f'{simds} SIMDs at {ghz:.2f} GHz, 4 cycles per vector instruction',
+                                         'assumes': f'{simds} SIMDs at {ghz:.2f} GHz (nominal); valu_issue_frac_at_4_cycles can exceed 1: fp32 '
+                                                    'instructions issue in fewer than 4 cycles',
                                          'kernels': prof}
     return out
 

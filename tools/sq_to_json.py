@@ -22,6 +22,12 @@ def main():
         out[name] = {'valu_insts': float(r['SQ_INSTS_VALU']), 'waves': float(r['SQ_WAVES']), 'kernel_us': ks[name],
                      'valu_per_wave': float(r['valu_per_wave'] or 0), 'wait_any_frac': float(r['wait_any_frac'] or 0),
                      'wait_inst_frac': float(r['wait_inst_frac'] or 0), 'lds_per_wave': float(r['lds_per_wave'] or 0)}
+        # share of the kernel's cycles in which a CU's LDS was busy (SQ_BUSY_CYCLES is summed over the 32 shader engines of 8 CUs
+        # each, SQ_LDS_IDX_ACTIVE over the CUs), and the share of those cycles that were bank-conflict cycles
+        busy, act = float(r.get('SQ_BUSY_CYCLES') or 0), float(r.get('SQ_LDS_IDX_ACTIVE') or 0)
+        if busy > 0:
+            out[name]['lds_active_frac'] = round(act / busy / 8.0, 3)
+            out[name]['lds_conflict_frac'] = round(float(r.get('SQ_LDS_BANK_CONFLICT') or 0) / act, 3) if act > 0 else 0.0
     # which library the counters belong to: bench.py prints it beside the figures it takes from this file
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'motionpriorcmax_amd', 'libmpcmax.so')
     if os.path.exists(lib):
