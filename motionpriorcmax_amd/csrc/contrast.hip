@@ -619,6 +619,9 @@ __global__ void k_scale(const float *__restrict__ x, const float *__restrict__ a
 // grid (ceil(wq/60), ceil(hq/MPC_SM_H), nimg*C/2), 64 threads
 // ------------------------------------------------------------------------------------------
 // TH rows per band: MPC_SM_H (16), or half of it for small fields (smooth_band_rows below)
+#ifndef MPC_SM_PF
+#define MPC_SM_PF 2
+#endif
 template <int TH>
 __global__ __launch_bounds__(64) void k_lut_smooth_march(const float *__restrict__ field, float *__restrict__ gfield,
                                                          double *__restrict__ part, int hq, int wq, int C, float gscale) {
@@ -637,19 +640,21 @@ __global__ __launch_bounds__(64) void k_lut_smooth_march(const float *__restrict
     float2 f1 = make_float2(0.f, 0.f), f2r = f1, hd1 = f1, hd2 = f1;          // f and hd at rows y-1, y-2
     float2 hx2 = f1, hx3 = f1, vy2 = f1, vy3 = f1;                              // hx and vy at rows y-2, y-3
     double a0 = 0.0, a1 = 0.0;
-    float2 f_next[2];
+    // rows requested MPC_SM_PF iterations ahead of their use (rolling window in registers: the loop is fully unrolled)
+    constexpr int PF = MPC_SM_PF;
+    float2 f_next[PF];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PF; ++k) {
         const int y = y0 - 2 + k;
-        f_next[k] = (xin && y >= 0 && y < hq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
+        f_next[k] = (k < TH + 4 && xin && y >= 0 && y < hq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int it = 0; it < TH + 4; ++it) {
         const int y = y0 - 2 + it;
-        const float2 f0 = f_next[it & 1];
+        const float2 f0 = f_next[it % PF];
         {
-            const int yn = y + 2;
-            f_next[it & 1] = (it + 2 < TH + 4 && xin && yn >= 0 && yn < hq) ? f2[base + ((size_t)yn * wq + x) * C2] : make_float2(0.f, 0.f);
+            const int yn = y + PF;
+            f_next[it % PF] = (it + PF < TH + 4 && xin && yn >= 0 && yn < hq) ? f2[base + ((size_t)yn * wq + x) * C2] : make_float2(0.f, 0.f);
         }
         const float2 hd0 = make_float2(lane_right(f0.x) - lane_left(f0.x), lane_right(f0.y) - lane_left(f0.y));
         // row y - 1: Sobel -> charbonnier terms and their derivatives

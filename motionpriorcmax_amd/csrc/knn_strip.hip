@@ -206,7 +206,7 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         // item -> (row, slot of the row) with a reciprocal multiply: (it + 0.5) / pitch is at least 0.5 / pitch away from
         // an integer, far more than the rounding of the product (it < 2^14)
         const int items = NR * pitch;
-        const float inv_pitch = 1.f / (float)pitch;
+        const float inv_pitch = __builtin_amdgcn_rcpf((float)pitch);        // (1 ulp: the margin below is 0.5 / pitch)
         for (int base = 0; base < items; base += KS_NT * KS_SB) {
             int slot[KS_SB], id[KS_SB];
             bool in[KS_SB], real[KS_SB];
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     // outside, which only makes the fast path give up earlier -- the byte of anything at or beyond the bound is 0 for sure:
     // the rounding of the fma is ~1e-5 of a level.)
     const float lo_d = (r == r_init) ? 0.5f * upper : 0.25f * upper;
-    const float nscale = -(float)(KS_NLEV - 1) / (upper - lo_d), loff = -upper * nscale;
+    // (hardware reciprocal, 1 ulp: any constant near this one gives a monotone map; the largest byte stays below 127.5)
+    const float nscale = -(float)(KS_NLEV - 1) * __builtin_amdgcn_rcpf(upper - lo_d), loff = -upper * nscale;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
     const float2 *pp = lpos + s;
     // pass 1: nearness byte of every slot; groups of 8 slots whose loads are issued together
@@ -535,10 +536,18 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
         const size_t BQ = (size_t)p.B * p.nb * p.G;
         float2 ov; float norm = 0.f;
         if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
-        else { ov.x = (sy_ * 0.0078125f) / (float)p.K; ov.y = (sx_ * 0.0078125f) / (float)p.K; }       // (1 / 128: exact)
+        // mean = sum / K (focus.py:166) with the factor 128 of pass 2 taken out first (exact).  K a power of two (the shipped
+        // 32): the division is a multiplication by an exact reciprocal -- same bits, a tenth of the instructions
+        const bool kpow2 = (p.K & (p.K - 1)) == 0;
+        const float rK = __int_as_float((120 - (__ffs(p.K) - 1)) << 23);        // 2^-(7 + log2 K), built from its exponent (used if kpow2)
+        if (IWD) { }
+        else if (kpow2) { ov.x = sy_ * rK; ov.y = sx_ * rK; }
+        else { ov.x = (sy_ * 0.0078125f) / (float)p.K; ov.y = (sx_ * 0.0078125f) / (float)p.K; }
         reinterpret_cast<float2 *>(flow_lut)[q] = ov;
         if (do_next) {
-            float2 on; on.x = (ny_ * 0.0078125f) / (float)p.K; on.y = (nx_ * 0.0078125f) / (float)p.K;
+            float2 on;
+            if (kpow2) { on.x = ny_ * rK; on.y = nx_ * rK; }
+            else { on.x = (ny_ * 0.0078125f) / (float)p.K; on.y = (nx_ * 0.0078125f) / (float)p.K; }
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
         if (!LEAN) {
