@@ -27,7 +27,8 @@
 // grid B*nb*S, 1024 threads, dynamic LDS = ceil(hq/S)*wq * 4 + n * 2 bytes
 // ------------------------------------------------------------------------------------------
 #define KNN_BUCKET_NPT 24
-template <bool CACHED>
+// NPT: points per thread held in registers (CACHED), a multiple of 4 >= ceil(n / 1024): 20 for the 19 200 points of a DSEC grid
+template <bool CACHED, int NPT>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start,
                                                      float2 *__restrict__ spos, int *__restrict__ sidx, int S,
@@ -38,6 +39,13 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     __shared__ int s_wave[16];
     __shared__ int s_low[16];
     const int tid = threadIdx.x;
+#ifdef KNN_BK_STAMP
+    __shared__ unsigned s_stp[8];       // diagnostics build (tools/bucket_stamp_probe.py): phase stamps of thread 0, 10 ns units
+#define BK_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) s_stp[k] = (unsigned)wall_clock64(); } while (0)
+#else
+#define BK_STAMP(k) do { } while (0)
+#endif
+    BK_STAMP(0);
     const int bt = blockIdx.x / S, part = blockIdx.x - bt * S, b = bt / p.nb, t = bt - b * p.nb;
     // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
     // atomicMax and its fallback list is appended to (knn_strip.hip)
@@ -48,26 +56,29 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     const int rows_per = (p.hq + S - 1) / S;
     const int g_lo = min(part * rows_per, p.hq) * p.wq, g_hi = min((part + 1) * rows_per, p.hq) * p.wq, Gp = g_hi - g_lo;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
-    int qc[CACHED ? KNN_BUCKET_NPT : 1];
+    int qc[CACHED ? NPT : 1];
     int below = 0;                                  // points of this thread in cells before the range
     if (CACHED) {
-        float2 q[KNN_BUCKET_NPT];
+        float2 q[NPT];
 #pragma unroll
         // (slots beyond n read point 0, which always exists: n >= K >= 1; reading pts[tid] there ran past the end
         // of the trajectory tensor for the last (sample, bin) whenever n < 1024)
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : 0]; }
+        for (int u = 0; u < NPT; ++u) { const int i = tid + u * 1024; q[u] = pts[i < p.n ? i : 0]; }
+        // (skipping the rounds beyond the last point by a wave-uniform test instead of a compile-time count was measured:
+        // 41.7 -> 45.5 us, the branches break up the batch of loads)
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u) {
+        for (int u = 0; u < NPT; ++u) {
             qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
             if (tid + u * 1024 >= p.n) qc[u] = 0x7fffffff;          // not a point
             below += qc[u] < g_lo;
         }
     }
+    BK_STAMP(1);
     for (int g = tid; g < Gp; g += 1024) s_cnt[g] = 0;
     __syncthreads();
     if (CACHED) {
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u)
+        for (int u = 0; u < NPT; ++u)
             if (qc[u] >= g_lo && qc[u] < g_hi) atomicAdd(&s_cnt[qc[u] - g_lo], 1);
     } else {
         for (int i = tid; i < p.n; i += 1024) {
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     for (int o = 32; o > 0; o >>= 1) below += __shfl_down(below, o, 64);
     if ((tid & 63) == 0) s_low[tid >> 6] = below;
     __syncthreads();
+    BK_STAMP(2);
     int base = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) base += s_low[w];
@@ -106,10 +118,12 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         run += c;
     }
     __syncthreads();
+    BK_STAMP(3);
     int *cs = cell_start + (size_t)bt * (p.G + 1);
     for (int g = tid; g < Gp; g += 1024) cs[g_lo + g] = base + s_cnt[g];      // coalesced
     if (tid == 0 && part == S - 1) cs[p.G] = p.n;
     __syncthreads();
+    BK_STAMP(4);
     float2 *sp_ = spos + (size_t)bt * p.n + base;
     int *si_ = sidx + (size_t)bt * p.n + base;
     // scatter the INDICES into LDS first: the slots inside a cell are handed out in the order the LDS atomics
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     unsigned short *l_idx = reinterpret_cast<unsigned short *>(s_cnt + Gp);
     if (CACHED) {
 #pragma unroll
-        for (int u = 0; u < KNN_BUCKET_NPT; ++u)
+        for (int u = 0; u < NPT; ++u)
             if (qc[u] >= g_lo && qc[u] < g_hi) l_idx[atomicAdd(&s_cnt[qc[u] - g_lo], 1)] = (unsigned short)(tid + u * 1024);
     } else {
         for (int i = tid; i < p.n; i += 1024) {
@@ -129,6 +143,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         }
     }
     __syncthreads();
+    BK_STAMP(5);
     for (int g = tid; g < Gp; g += 1024) {          // s_cnt[g] is now the END of cell g
         const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0;
         for (int i = a + 1; i < e; ++i) {
@@ -139,22 +154,31 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         }
     }
     __syncthreads();
+    BK_STAMP(6);
     const int own = Gp > 0 ? s_cnt[Gp - 1] : 0;
-    // (eight gathers of a thread in flight together: one after the other they were ~19 dependent L2 round trips)
-    for (int sl0 = tid; sl0 < own; sl0 += 8 * 1024) {
-        int i[8];
-        float2 v[8];
+    // (all gathers of a thread in flight together -- one batch of NPT with the points in registers, eight otherwise: one after
+    // the other they were ~19 dependent L2 round trips, in batches of eight three)
+    constexpr int GB = CACHED ? NPT : 8;
+    for (int sl0 = tid; sl0 < own; sl0 += GB * 1024) {
+        int i[GB];
+        float2 v[GB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) i[u] = (sl0 + u * 1024 < own) ? (int)l_idx[sl0 + u * 1024] : 0;
+        for (int u = 0; u < GB; ++u) i[u] = (sl0 + u * 1024 < own) ? (int)l_idx[sl0 + u * 1024] : 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = pts[i[u]];
+        for (int u = 0; u < GB; ++u) v[u] = pts[i[u]];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < GB; ++u) {
             const int sl = sl0 + u * 1024;
             if (sl < own) { si_[sl] = i[u]; sp_[sl] = v[u]; }
         }
     }
+#ifdef KNN_BK_STAMP
+    BK_STAMP(7);
+    __syncthreads();
+    if (tid < 8) fail[1 + 100000 + 8 * blockIdx.x + tid] = (int)(s_stp[tid] - s_stp[0]);
+#endif
 }
+
 
 // ------------------------------------------------------------------------------------------
 // LUT grids beyond the LDS sort (G > 38 400 cells, e.g. 1280x720 at superpixel 4): the same counting sort with
@@ -1133,8 +1157,11 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     const int lean_fwords = L.knn_lean ? s->hq * ((s->wq + 31) / 32) : 0;
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
-        if ((rc = set_max_lds((const void *)k_knn_bucket<true>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_bucket<false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<true, 8>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<true, 16>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<true, 20>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<true, 24>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bucket<false, 1>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query<256>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
         attr_once.mark();
@@ -1157,10 +1184,15 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         MPC_LAUNCH(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
         MPC_LAUNCH(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         MPC_LAUNCH(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
-    } else if (s->n <= KNN_BUCKET_NPT * 1024)
-        MPC_LAUNCH(k_knn_bucket<true>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
-    else
-        MPC_LAUNCH(k_knn_bucket<false>, dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
+    } else {
+#define KB_LAUNCH(C_, N_) MPC_LAUNCH((k_knn_bucket<C_, N_>), dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords)
+        if (s->n <= 8 * 1024) KB_LAUNCH(true, 8);
+        else if (s->n <= 16 * 1024) KB_LAUNCH(true, 16);
+        else if (s->n <= 20 * 1024) KB_LAUNCH(true, 20);
+        else if (s->n <= KNN_BUCKET_NPT * 1024) KB_LAUNCH(true, 24);
+        else KB_LAUNCH(false, 1);
+#undef KB_LAUNCH
+    }
     MPC_CHECK_LAUNCH();
     // smallest square that can hold K points at the mean point density and pass the ring bound
     const double dens = (double)s->n / (double)p.G;
