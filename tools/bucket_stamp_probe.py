@@ -32,9 +32,13 @@ off = C.lib().mpc_knn_fail_list_offset(ctypes.byref(shape))
 nb = cfg.num_bins
 S = max(1, min(8, 256 // (B * nb)))
 nwg = B * nb * S
-st = ws[off + 4 * 100001: off + 4 * 100001 + 32 * nwg].view(torch.int32).cpu().numpy().reshape(nwg, 8) / 100.0
+raw = ws[off + 4 * 100001: off + 4 * 100001 + 32 * nwg].view(torch.int32).cpu().numpy().reshape(nwg, 8).astype(np.int64)
+t0 = (raw[:, 0] - raw[:, 0].min()) % (1 << 32) / 100.0          # start of every workgroup after the first one's
+st = raw / 100.0
+st[:, 0] = 0.0
 ph = np.diff(st, axis=1)
 names = ['point loads + cells', 'zero + count atomics + barrier', 'scan', 'cell_start written', 'rank atomics + index scatter', 'per-cell index order', 'gather + write']
 print(f'{name} B={B}: {nwg} workgroups ({S} per (sample, bin)); lifetime us mean {st[:, 7].mean():.2f} max {st[:, 7].max():.2f}')
 for k, nm in enumerate(names):
     print(f'  {nm:34s} mean {ph[:, k].mean():6.2f} us   max {ph[:, k].max():6.2f}')
+print(f'  workgroup starts after the first: median {np.median(t0):.2f} us, p90 {np.percentile(t0, 90):.2f}, max {t0.max():.2f}; last end {np.max(t0 + st[:, 7]):.2f} us after the first start')
