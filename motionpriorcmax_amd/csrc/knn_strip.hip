@@ -35,6 +35,9 @@
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
 #define KS_FB_SLOTS 4               // fallback: candidates per lane (64 * 4 per query)
+#ifndef KS_FB_GROW0
+#define KS_FB_GROW0 1                // fallback: rings added to a square that held too few candidates, first time
+#endif
 
 // value of lane `l` (wave-uniform l): v_readlane, no LDS round trip
 __device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -632,7 +635,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
     int r = query_radius(p, cy, cx, r_init);
-    if (grow_first) r += 1 + (r >> 2);
+    if (grow_first) r += KS_FB_GROW0 + (r >> 2);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS];
     float2 pq[KS_FB_SLOTS];
     bool serial = false;
