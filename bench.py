@@ -193,8 +193,9 @@ def knn_ceiling(workload, stages, B, nb):
         for key, k in d.items():
             if isinstance(k, dict) and stage_of_kernel(key) in ('mpc_knn_lut_fwd', 'mpc_knn_lut_bwd') and k.get('kernel_us', 0) > 20:
                 # SIMD cycles (at the nominal clock) the launch had per vector instruction it issued.  Measured issue
-                # costs on this chip (profiles/r02_ubench_valu_rate.txt, nominal-clock cycles): fp32 add/mul/fma 2.7,
-                # integer/SWAR 3.5-3.9, compare + select 4.6, packed fp32 5.1 -- a kernel near 3-4 is bound by what it issues
+                # costs on this chip in shader-clock cycles (profiles/r03_ubench_op_cycles.txt): 1.65 for plain fp32 / integer
+                # add, sub, mul, and, xor; 2.9 for nearly everything else (fma with three registers 2.5); 5.5 for rcp / sqrt --
+                # a kernel near 3-4 nominal cycles per instruction (the clock under load is below nominal) is bound by what it issues
                 slots = k['kernel_us'] * 1e-6 * ghz * 1e9 * simds
                 prof[key] = {'valu_wave_instr_per_launch': k['valu_insts'], 'kernel_us_in_profile': k['kernel_us'],
                              'simd_cycles_per_valu_instr': round(slots / k['valu_insts'], 2),
