@@ -155,6 +155,29 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     if (L.cstrip_rows > s->hq) L.cstrip_rows = s->hq;
     if (L.strip_rows > 0 && L.cstrip_rows > 0 && s->T == 1 && s->B > 0 && !(s->flags & MPC_F_ATOMIC_PATH)) {
         L.n_strips = mpc_cdiv(s->H, L.strip_rows);
+        {
+            // k_iwe_accum holds ONE workgroup per CU (its strip of 64-bit accumulators fills the LDS), so it costs (rounds of
+            // workgroups) x (rows of a strip): a few more, thinner strips can save a partly filled round (C3: 448 workgroups =
+            // 1.75 rounds of 30 rows -> 504 = 1.97 rounds of 27 rows).  MPC_EV_STRIPS=<n> forces a count (tuning).
+            static const int ncu = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+                    (void)hipGetLastError();
+                    n = 256;
+                }
+                return n;
+            }();
+            static const int forced = getenv("MPC_EV_STRIPS") ? atoi(getenv("MPC_EV_STRIPS")) : 0;
+            const int n0 = L.n_strips;
+            int best = n0;
+            int64_t best_cost = (int64_t)mpc_cdiv((int64_t)s->B * L.P * n0, ncu) * mpc_cdiv(s->H, n0);
+            for (int n = n0 + 1; n <= 2 * n0 && mpc_cdiv(s->H, n) >= 8; ++n) {
+                const int64_t cost = (int64_t)mpc_cdiv((int64_t)s->B * L.P * n, ncu) * mpc_cdiv(s->H, n);
+                if (cost < best_cost) { best_cost = cost; best = n; }
+            }
+            if (forced >= n0 && forced <= s->H) best = forced;
+            L.n_strips = best;
+        }
         L.strip_rows = mpc_cdiv(s->H, L.n_strips);          // equalise the strips
         L.n_cstrips = mpc_cdiv(s->hq, L.cstrip_rows);
         L.cstrip_rows = mpc_cdiv(s->hq, L.n_cstrips);
