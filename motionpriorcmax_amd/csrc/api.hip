@@ -267,8 +267,9 @@ extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, co
     const bool smooth = io->smooth_weight > 0.f && io->smooth_grad != nullptr;
     // the smoothness gradient on flow_to_tref is folded into the event backward; on flow_to_next it is a separate
     // gradient of the KNN backward, scaled by grad_out
-    int rc = mpc_event_splat_bwd_ordered(s, io->events, io->event_offsets, io->flow_lut, io->t_ref, io->grad_iwe, io->scal, grad_out,
-                                         grad_lut_scratch, (smooth && !on_next) ? io->smooth_grad : nullptr, ws, stream);
+    int reach_done = 0;       // (the event backward's kernel computes the tile reaches of the KNN backward on the side)
+    int rc = mpc_event_splat_bwd_job(s, io->events, io->event_offsets, io->flow_lut, io->t_ref, io->grad_iwe, io->scal, grad_out,
+                                     grad_lut_scratch, (smooth && !on_next) ? io->smooth_grad : nullptr, ws, stream, io->knn_state, &reach_done);
     if (rc) return rc;
     const float *g_next = nullptr;
     if (smooth && on_next && s->nb > 1) {
@@ -277,5 +278,5 @@ extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, co
         if (grad_out) { if ((rc = mpc_scale(io->smooth_grad, grad_out, grad_next_scratch, cnt, stream))) return rc; g_next = grad_next_scratch; }
         else g_next = io->smooth_grad;
     }
-    return mpc_knn_lut_bwd(s, io->traj, grad_lut_scratch, g_next, io->knn_state, grad_traj, ws, stream);
+    return mpc_knn_lut_bwd_ex(s, io->traj, grad_lut_scratch, g_next, io->knn_state, grad_traj, ws, stream, reach_done);
 }

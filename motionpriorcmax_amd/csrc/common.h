@@ -107,6 +107,12 @@ mpc_ws_layout mpc_layout(const mpc_shape *s);
 // bucket counters, so that the event forward can skip its own zeroing launch
 int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
                        int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done);
+int mpc_event_splat_bwd_job(const mpc_shape *s, const float *events, const int32_t *offsets, const float *flow_lut,
+                            const float *t_ref, const float *grad_iwe, const float *scal,
+                            const float *grad_out, float *grad_flow_lut, const float *add_term,
+                            void *ws, void *stream, const float *knn_state, int *reach_done);
+int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut, const float *grad_flow_next,
+                       const float *knn_state, float *grad_traj, void *ws, void *stream, int reach_ready);
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets);
 int mpc_validate_shape(const mpc_shape *s);

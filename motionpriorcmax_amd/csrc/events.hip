@@ -6,6 +6,7 @@
 // compiled with -ffp-contract=off).
 #include "common.h"
 #include "ev_count_device.h"
+#include "knn_device.h"
 
 struct EvParams {
     int B, M, Mp, nb, T, H, W, sp, hq, wq, P;
@@ -495,7 +496,8 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
                                                     float *__restrict__ glut,
                                                     const float *__restrict__ add_term,
                                                     const float *__restrict__ events, const float *__restrict__ lut,
-                                                    const float *__restrict__ t_ref, const int *__restrict__ offsets) {
+                                                    const float *__restrict__ t_ref, const int *__restrict__ offsets,
+                                                    const KnnReachJob job) {
     extern __shared__ unsigned long long s_acc[];
 #ifdef EV_LA_STAMP
     __shared__ unsigned s_stp[8];         // (in LDS, not registers: eight live 64-bit values took the kernel from 47 to > 64 VGPRs -- one workgroup per CU)
@@ -516,6 +518,14 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
     const int g = bt * L.NCS + cst;                   // bucket id: (b*nb + it)*NCS + cstrip
     const int crow0 = cst * L.CSR, crow1 = min(crow0 + L.CSR, p.hq);
     const int ncell = (crow1 - crow0) * p.wq;
+    // mpc_focus_bwd: the KNN backward follows on the stream and needs the reach of every 16x16 tile of every (sample, bin); the
+    // first workgroup of each (sample, bin) here works it out on the side (knn_device.h) -- this kernel leaves the vector pipes
+    // almost idle, and the gather that follows loses two dependent round trips per workgroup (132 -> 117 us at C3)
+    if (job.on && cst == 0) {
+        if (job.p.l1) knn_reach_slice<true>(job.p, job.tile_dkmax, job.reach, bt, job.gx, job.gy, job.bd, reinterpret_cast<float *>(s_acc));
+        else knn_reach_slice<false>(job.p, job.tile_dkmax, job.reach, bt, job.gx, job.gy, job.bd, reinterpret_cast<float *>(s_acc));
+        __syncthreads();
+    }
     for (int i = tid; i < 2 * ncell; i += NT) s_acc[i] = 0ull;
     // ORDERED: the bucket's strip of the table goes to LDS (coalesced, while the event rows are on their way), so the
     // warp costs no dependent round trip of its own
@@ -747,6 +757,16 @@ extern "C" int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *even
                                            const float *t_ref, const float *grad_iwe, const float *scal,
                                            const float *grad_out, float *grad_flow_lut, const float *add_term,
                                            void *ws, void *stream) {
+    return mpc_event_splat_bwd_job(s, events, offsets, flow_lut, t_ref, grad_iwe, scal, grad_out, grad_flow_lut, add_term, ws, stream, nullptr, nullptr);
+}
+
+// knn_state != nullptr (mpc_focus_bwd): k_lut_accum also computes the tile reaches of the KNN backward that follows; *reach_done
+// tells the caller whether it did
+int mpc_event_splat_bwd_job(const mpc_shape *s, const float *events, const int32_t *offsets, const float *flow_lut,
+                            const float *t_ref, const float *grad_iwe, const float *scal,
+                            const float *grad_out, float *grad_flow_lut, const float *add_term,
+                            void *ws, void *stream, const float *knn_state, int *reach_done) {
+    if (reach_done) *reach_done = 0;
     MPC_CHECK_ARG(s && flow_lut && grad_iwe && scal && grad_flow_lut && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(!(s->flags & MPC_F_NO_WARP), MPC_E_UNSUPPORTED, "no LUT to differentiate with MPC_F_NO_WARP");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
@@ -761,13 +781,18 @@ extern "C" int mpc_event_splat_bwd_ordered(const mpc_shape *s, const float *even
         if (L.nbb > 0) {
             MPC_CHECK_ARG(!offsets || (size_t)L.cstrip_rows * s->wq * 24 <= 160 * 1024 - 512, MPC_E_UNSUPPORTED,
                           "LUT too wide for the ordered backward (use mpc_event_splat_bwd)");
+            KnnReachJob job{};
+            const size_t lds_acc = (size_t)L.cstrip_rows * s->wq * (offsets ? 24 : 16);
+            if (knn_state && mpc_knn_reach_job(s, knn_state, ws, &job) &&
+                ((size_t)job.gx * job.gy * (KNN_NCLS + 1) + 16) * sizeof(float) > lds_acc) job.on = 0;      // (does not fit this kernel's LDS)
             if (offsets)
-                MPC_LAUNCH(k_lut_accum<true>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS_ORD), (size_t)L.cstrip_rows * s->wq * 24, st, *s, BL,
-                                   grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets);
+                MPC_LAUNCH(k_lut_accum<true>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS_ORD), lds_acc, st, *s, BL,
+                                   grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets, job);
             else
-                MPC_LAUNCH(k_lut_accum<false>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), (size_t)L.cstrip_rows * s->wq * 16, st, *s, BL,
-                                   grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets);
+                MPC_LAUNCH(k_lut_accum<false>, dim3(((L.nbb + 7) / 8) * 8), dim3(EV_LUT_THREADS), lds_acc, st, *s, BL,
+                                   grad_iwe, scal, grad_out, grad_flow_lut, add_term, events, flow_lut, t_ref, offsets, job);
             MPC_CHECK_LAUNCH();
+            if (reach_done) *reach_done = job.on;
         }
         return 0;
     }

@@ -700,48 +700,12 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 #ifndef KNN_BW_OCC
 #define KNN_BW_OCC 8      // workgroups per CU the register budget is set for (8 -> 64 VGPRs)
 #endif
-template <bool L1, bool NEXT>
-__global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
-                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
-                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
-                                                      const float *__restrict__ knn_state,
-                                                      const float *__restrict__ tile_dkmax,
-                                                      float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
-                                                      float2 *__restrict__ gtraj_direct,
-                                                      int gx, int gy, int bd
-#ifdef KNN_BW_STAMP
-                                                      , int *__restrict__ stamp
-#endif
-                                                      ) {
-    constexpr int TS = 16;
-#ifdef KNN_BW_STAMP
-    const unsigned long long st0 = wall_clock64();
-    int st_slow = 0;
-#endif
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_rowbase[TS + 1];
-    __shared__ int s_rowg[TS];
-    __shared__ float s_wr[1];
-    __shared__ int s_tiew[4];
-    const int tid = threadIdx.x;
-    const int nblk = gx * gy * p.B * p.nb;
-    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
-    if (lblk >= nblk) return;
-    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
-    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
-    const int b = bt / p.nb, t = bt - b * p.nb;
-    const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
-    // ---- phase 1: reach of this tile = the largest linear K-th distance among the tiles whose queries can touch it
-    //      (Chebyshev gap between this tile's cell area and their query centres); bucketed ranges of the tile rows --
-    // Wavefront 0 alone.  Step A: the largest K-th distance of ANY class of ANY tile of the slice (coalesced reads).  A
-    // source tile k tile rings away has its query centres at least (k - 1) * 16 cells from this tile's area, so only the tiles
-    // within D = floor(linmax / (16 sp)) + 1 rings can touch it -- D = 1 in practice: the 3 x 3 tiles around this one.
-    // Step B tests those 45 (tile, class) pairs on 45 lanes.  (Before: every tile of the slice on a lane of its own in a loop
-    // over the classes -- ~300 vector instructions for one or two wavefronts of the workgroup, the maximum of each class a
-    // dependent round trip behind the loop's `continue`.  With step A on all four wavefronts and a barrier before step B the
-    // kernel was slower than that: 142 vs 139 us.)  Wavefront 1 meanwhile looks up the bucketed ranges of the tile rows.
-    if (tid < 64) {
+// Reach of one 16x16 tile, computed by ONE wavefront (lane = threadIdx.x & 63, all 64 lanes call): step A, the largest K-th
+// distance of any class of any tile of the slice; step B, the (tile, class) pairs within its D rings -- see k_knn_bwd_tile.
+template <bool L1>
+__device__ __forceinline__ float knn_tile_reach(const KnnParams &p, const float *__restrict__ tile_dkmax, int bt, int by_, int bx_,
+                                                int gx, int gy, int bd) {
+    const int tid = threadIdx.x & 63;
         const int ntx = gx, nty = gy, nt = ntx * nty;
         float m = 0.f;
         for (int i = tid; i < nt * KNN_NCLS; i += 64) m = fmaxf(m, tile_dkmax[(size_t)bt * nt * KNN_NCLS + i]);
@@ -786,6 +750,62 @@ __global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParam
         }
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) r = fmaxf(r, __shfl_xor(r, o2, 64));
+        return r;
+}
+
+// The reaches of all tiles from a launch of its own (the stage entry point mpc_knn_lut_bwd on large problems; mpc_focus_bwd lets
+// the event backward's kernel do it on the side): knn_reach_slice, knn_device.h.  grid B * nb, 256 threads, dynamic LDS
+// (nt * (KNN_NCLS + 1) + 16) floats
+template <bool L1>
+__global__ __launch_bounds__(256) void k_knn_reach_tiles(const KnnParams p, const float *__restrict__ tile_dkmax, float *__restrict__ reach,
+                                                         int gx, int gy, int bd) {
+    extern __shared__ float s_reach_mem[];
+    knn_reach_slice<L1>(p, tile_dkmax, reach, blockIdx.x, gx, gy, bd, s_reach_mem);
+}
+
+template <bool L1, bool NEXT>
+__global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
+                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
+                                                      const float *__restrict__ knn_state,
+                                                      const float *__restrict__ tile_dkmax,
+                                                      float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
+                                                      float2 *__restrict__ gtraj_direct, const float *__restrict__ reach_in,
+                                                      int gx, int gy, int bd
+#ifdef KNN_BW_STAMP
+                                                      , int *__restrict__ stamp
+#endif
+                                                      ) {
+    constexpr int TS = 16;
+#ifdef KNN_BW_STAMP
+    const unsigned long long st0 = wall_clock64();
+    int st_slow = 0;
+#endif
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ int s_rowbase[TS + 1];
+    __shared__ int s_rowg[TS];
+    __shared__ float s_wr[1];
+    __shared__ int s_tiew[4];
+    const int tid = threadIdx.x;
+    const int nblk = gx * gy * p.B * p.nb;
+    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (lblk >= nblk) return;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
+    const size_t BQ = (size_t)p.B * p.nb * p.G;
+    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    // ---- phase 1: reach of this tile = the largest linear K-th distance among the tiles whose queries can touch it
+    //      (Chebyshev gap between this tile's cell area and their query centres); bucketed ranges of the tile rows --
+    // Wavefront 0 alone.  Step A: the largest K-th distance of ANY class of ANY tile of the slice (coalesced reads).  A
+    // source tile k tile rings away has its query centres at least (k - 1) * 16 cells from this tile's area, so only the tiles
+    // within D = floor(linmax / (16 sp)) + 1 rings can touch it -- D = 1 in practice: the 3 x 3 tiles around this one.
+    // Step B tests those 45 (tile, class) pairs on 45 lanes.  (Before: every tile of the slice on a lane of its own in a loop
+    // over the classes -- ~300 vector instructions for one or two wavefronts of the workgroup, the maximum of each class a
+    // dependent round trip behind the loop's `continue`.  With step A on all four wavefronts and a barrier before step B the
+    // kernel was slower than that: 142 vs 139 us.)  Wavefront 1 meanwhile looks up the bucketed ranges of the tile rows.
+    if (tid < 64) {
+        const float r = reach_in ? reach_in[(size_t)bt * gx * gy + bxy] : knn_tile_reach<L1>(p, tile_dkmax, bt, by_, bx_, gx, gy, bd);
         if (tid == 0) s_wr[0] = r;
     } else if (tid < 128) {
         const int ln = tid - 64;
@@ -1266,9 +1286,38 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     return 0;
 }
 
+// true where the backward of this shape is k_knn_bwd_tile (the gather with per-tile reaches)
+static bool knn_bwd_is_tile(const mpc_shape *s, const mpc_ws_layout &L) {
+    return !L.knn_lean && s->B > 0 && s->T == 1 && !((s->flags & MPC_F_SCHEME_IWD) && s->K > 1) && knn_tuning().bwd_ts == 16 && knn_tuning().bwd_fused;
+}
+
+bool mpc_knn_reach_job(const mpc_shape *s, const float *knn_state, void *ws, KnnReachJob *job) {
+    job->on = 0;
+    static const int reach_forced = getenv("MPC_KNN_BWD_REACH") ? (atoi(getenv("MPC_KNN_BWD_REACH")) != 0 ? 1 : 0) : -1;
+    if (!s || !knn_state || !ws || mpc_validate_shape(s) || reach_forced == 0) return false;
+    const mpc_ws_layout L = mpc_layout(s);
+    if (!knn_bwd_is_tile(s, L)) return false;
+    job->p = knn_params(s);
+    job->tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * job->p.G;
+    job->reach = (float *)((char *)ws + L.off_knn_reach);
+    job->gx = mpc_cdiv(s->wq, 16); job->gy = mpc_cdiv(s->hq, 16);
+    job->bd = knn_band_depth(mpc_knn_r_init(s));
+    // (below one round of the gather's workgroups the side job costs the host kernel more than the gather gains: C2, B = 1 x 15
+    // bins = 1 200 workgroups: +3.5 us on k_lut_accum's slowest workgroup for -1.5 on the gather; C4, 3 280: +3.7 / -6)
+    job->on = (reach_forced == 1 || (int64_t)job->gx * job->gy * s->B * s->nb >= 2048) ? 1 : 0;
+    return job->on != 0;
+}
+
 extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                                const float *grad_flow_next, const float *knn_state, float *grad_traj,
                                void *ws, void *stream) {
+    return mpc_knn_lut_bwd_ex(s, traj, grad_flow_lut, grad_flow_next, knn_state, grad_traj, ws, stream, 0);
+}
+
+// reach_ready: the reaches of the tiles are in the workspace already (the event backward's kernel computed them: mpc_focus_bwd)
+int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
+                       const float *grad_flow_next, const float *knn_state, float *grad_traj,
+                       void *ws, void *stream, int reach_ready) {
     MPC_CHECK_ARG(s && traj && grad_flow_lut && knn_state && grad_traj && ws, MPC_E_NULL, "null argument");
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
@@ -1313,6 +1362,21 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
         const int gxb = mpc_cdiv(s->wq, 16), gyb = mpc_cdiv(s->hq, 16);
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
         float2 *direct = (grad_flow_next == nullptr && knn_tuning().bwd_direct) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
+        // The reach of every tile NOT as the first phase of every workgroup: the gather is a chain of phases per workgroup at
+        // eight workgroups per CU -- 8.1 of a workgroup's 14.6 us pass before its window loop (tools/bwd_stamp_probe.py) -- and
+        // without the two dependent round trips of the reach phase it runs 132 -> 117 us at C3.  mpc_focus_bwd has the event
+        // backward's kernel compute the reaches on the side (reach_ready); called alone, a launch of its own does it (~6-8 us)
+        // where that pays: from about four rounds of workgroups (C3: 8.2; B = 1: 0.6 -- there it would cost 3 us).
+        // MPC_KNN_BWD_REACH=0 / 1 forces both off / the launch on.
+        static const int reach_forced = getenv("MPC_KNN_BWD_REACH") ? (atoi(getenv("MPC_KNN_BWD_REACH")) != 0 ? 1 : 0) : -1;
+        const bool reach_launch = !reach_ready && (reach_forced >= 0 ? reach_forced == 1 : (int64_t)gxb * gyb * s->B * s->nb >= 4 * 2048);
+        const float *reach_pre = reach_ready ? reach : nullptr;
+        if (reach_launch) {
+            const size_t rl = ((size_t)gxb * gyb * (KNN_NCLS + 1) + 16) * sizeof(float);
+            if (p.l1) MPC_LAUNCH(k_knn_reach_tiles<true>, dim3(s->B * s->nb), dim3(256), rl, st, p, tile_dkmax, reach, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)));
+            else MPC_LAUNCH(k_knn_reach_tiles<false>, dim3(s->B * s->nb), dim3(256), rl, st, p, tile_dkmax, reach, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)));
+            reach_pre = reach;
+        }
 #ifdef KNN_BW_STAMP
 #define KB_STAMP_ARG , (int *)((char *)ws + L.off_knn_fail)
 #else
@@ -1320,7 +1384,7 @@ extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const floa
 #endif
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
         MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH

@@ -33,3 +33,7 @@ print(f'  border tiles ({border.sum()}): mean {dur[border].mean():.1f} max {dur[
 print(f'  global path {((fl & 256) != 0).sum()}, tie tiles {((fl & 512) != 0).sum()}, tiles with an exact-loop wavefront {((fl & 1024) != 0).sum()}; points per tile mean {tot.mean():.0f} max {tot.max()}')
 for name_, m in (('corner', ((by == 0) | (by == gy - 1)) & ((bx == 0) | (bx == gx - 1))), ('top/bottom', ((by == 0) | (by == gy - 1)) & ~((bx == 0) | (bx == gx - 1))), ('left/right', ~((by == 0) | (by == gy - 1)) & ((bx == 0) | (bx == gx - 1)))):
     print(f'  {name_}: n {m.sum()} mean {dur[m].mean():.1f} max {dur[m].max():.1f} RQ {(fl[m] & 255).mean():.2f} slow {((fl[m] & 1024) != 0).mean():.2f}')
+full = (by < gy - 1) | (shape.hq % 16 == 0)
+for name_, m in (('full tiles, <= 256 points', full & (tot <= 256)), ('full tiles, > 256 points (second round of points)', full & (tot > 256))):
+    if m.sum():
+        print(f'  {name_}: n {m.sum()} mean {dur[m].mean():.1f} us  inner only {dur[m & ~border].mean() if (m & ~border).sum() else float("nan"):.1f}')
