@@ -698,7 +698,11 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 #define KNN_BW_PITCH 48   // row pitch (cells) of the staged arrays without the flow_to_next gradient; >= 16 + 2 * KNN_RQ_MAX
 #endif
 #ifndef KNN_BW_OCC
-#define KNN_BW_OCC 8      // workgroups per CU the register budget is set for (8 -> 64 VGPRs)
+#define KNN_BW_OCC 7      // workgroups per CU the register budget is set for (7 -> 72 VGPRs, 8 -> 64).  Round 2 needed all eight (the
+#endif                    // kernel waited for its LDS conflicts); without them, and with the reach phase gone, seven workgroups that
+                          // spill 12 instead of 48 bytes per lane are faster: 118 -> 114 us at C3.  With the flow_to_next
+#ifndef KNN_BW_OCC_NEXT   // gradient (C4: its own, larger register set) eight remain better: 57.3 against 58.4 us
+#define KNN_BW_OCC_NEXT 8
 #endif
 // Reach of one 16x16 tile, computed by ONE wavefront (lane = threadIdx.x & 63, all 64 lanes call): step A, the largest K-th
 // distance of any class of any tile of the slice; step B, the (tile, class) pairs within its D rings -- see k_knn_bwd_tile.
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(256) void k_knn_reach_tiles(const KnnParams p, cons
 }
 
 template <bool L1, bool NEXT>
-__global__ __launch_bounds__(256, KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
                                                       const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                       const float *__restrict__ glut, const float *__restrict__ gnext,
                                                       const float *__restrict__ knn_state,
