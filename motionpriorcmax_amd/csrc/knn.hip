@@ -697,11 +697,14 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 #ifndef KNN_BW_PITCH
 #define KNN_BW_PITCH 48   // row pitch (cells) of the staged arrays without the flow_to_next gradient; >= 16 + 2 * KNN_RQ_MAX
 #endif
+// Workgroups per CU the register budget is set for (7 -> 72 VGPRs, 8 -> 64).  Round 2 needed all eight (the kernel waited for its
+// LDS conflicts); without them, and with the reach phase gone, seven workgroups that spill 12 instead of 48 bytes per lane are
+// faster: 118 -> 114 us at C3.  With the flow_to_next gradient (C4: a larger register set of its own) eight remain better: 57.3
+// against 58.4 us.
 #ifndef KNN_BW_OCC
-#define KNN_BW_OCC 7      // workgroups per CU the register budget is set for (7 -> 72 VGPRs, 8 -> 64).  Round 2 needed all eight (the
-#endif                    // kernel waited for its LDS conflicts); without them, and with the reach phase gone, seven workgroups that
-                          // spill 12 instead of 48 bytes per lane are faster: 118 -> 114 us at C3.  With the flow_to_next
-#ifndef KNN_BW_OCC_NEXT   // gradient (C4: its own, larger register set) eight remain better: 57.3 against 58.4 us
+#define KNN_BW_OCC 7
+#endif
+#ifndef KNN_BW_OCC_NEXT
 #define KNN_BW_OCC_NEXT 8
 #endif
 // Reach of one 16x16 tile, computed by ONE wavefront (lane = threadIdx.x & 63, all 64 lanes call): step A, the largest K-th
@@ -710,51 +713,51 @@ template <bool L1>
 __device__ __forceinline__ float knn_tile_reach(const KnnParams &p, const float *__restrict__ tile_dkmax, int bt, int by_, int bx_,
                                                 int gx, int gy, int bd) {
     const int tid = threadIdx.x & 63;
-        const int ntx = gx, nty = gy, nt = ntx * nty;
-        float m = 0.f;
-        for (int i = tid; i < nt * KNN_NCLS; i += 64) m = fmaxf(m, tile_dkmax[(size_t)bt * nt * KNN_NCLS + i]);
+    const int ntx = gx, nty = gy, nt = ntx * nty;
+    float m = 0.f;
+    for (int i = tid; i < nt * KNN_NCLS; i += 64) m = fmaxf(m, tile_dkmax[(size_t)bt * nt * KNN_NCLS + i]);
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
-        const float linmax = (L1 ? m : sqrtf(m)) * 1.0001f + 0.01f;
-        const int D = (int)fminf(linmax / (float)(16 * p.sp), 1.0e6f) + 1;
-        const float ay0 = (float)(by_ * 16 * p.sp) - 0.5f, ay1 = (float)(min(by_ * 16 + 16, p.hq) * p.sp) - 0.5f;
-        const float ax0 = (float)(bx_ * 16 * p.sp) - 0.5f, ax1 = (float)(min(bx_ * 16 + 16, p.wq) * p.sp) - 0.5f;
-        float r = 0.f;
-        // one (source tile, class) pair: its K-th distance counts if its queries can reach this tile's area
-        auto pair_reach = [&](int sy, int sx, int c) {
-            const int tb = sy * ntx + sx;
-            const int ty0 = sy * 16, ty1 = min(ty0 + 16, p.hq) - 1, tx0 = sx * 16, tx1 = min(tx0 + 16, p.wq) - 1;
-            // cells of the source tile that can hold queries of class c (knn_device.h)
-            int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
-            if (c == 1) cy1 = min(cy1, bd - 1);
-            if (c == 2) cy0 = max(cy0, p.hq - bd);
-            if (c == 3) cx1 = min(cx1, bd - 1);
-            if (c == 4) cx0 = max(cx0, p.wq - bd);
-            if (cy0 > cy1 || cx0 > cx1) return;
-            const float dk = tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c];
-            const float lin = (L1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
-            const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
-            const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
-            const float gyv = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1)), gxv = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
-            if (dk > 0.f && lin >= fmaxf(gyv, gxv)) r = fmaxf(r, lin);
-        };
-        if (D == 1) {
-            if (tid < 9 * KNN_NCLS) {
-                const int nbr = tid / KNN_NCLS, c = tid - nbr * KNN_NCLS;
-                const int sy = by_ + nbr / 3 - 1, sx = bx_ + (nbr % 3) - 1;
-                if (sy >= 0 && sy < nty && sx >= 0 && sx < ntx) pair_reach(sy, sx, c);
-            }
-        } else {
-            for (int tb = tid; tb < nt; tb += 64) {
-                const int sy = tb / ntx, sx = tb - sy * ntx;
-                if (abs(sy - by_) > D || abs(sx - bx_) > D) continue;
-#pragma unroll
-                for (int c = 0; c < KNN_NCLS; ++c) pair_reach(sy, sx, c);
-            }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+    const float linmax = (L1 ? m : sqrtf(m)) * 1.0001f + 0.01f;
+    const int D = (int)fminf(linmax / (float)(16 * p.sp), 1.0e6f) + 1;
+    const float ay0 = (float)(by_ * 16 * p.sp) - 0.5f, ay1 = (float)(min(by_ * 16 + 16, p.hq) * p.sp) - 0.5f;
+    const float ax0 = (float)(bx_ * 16 * p.sp) - 0.5f, ax1 = (float)(min(bx_ * 16 + 16, p.wq) * p.sp) - 0.5f;
+    float r = 0.f;
+    // one (source tile, class) pair: its K-th distance counts if its queries can reach this tile's area
+    auto pair_reach = [&](int sy, int sx, int c) {
+        const int tb = sy * ntx + sx;
+        const int ty0 = sy * 16, ty1 = min(ty0 + 16, p.hq) - 1, tx0 = sx * 16, tx1 = min(tx0 + 16, p.wq) - 1;
+        // cells of the source tile that can hold queries of class c (knn_device.h)
+        int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
+        if (c == 1) cy1 = min(cy1, bd - 1);
+        if (c == 2) cy0 = max(cy0, p.hq - bd);
+        if (c == 3) cx1 = min(cx1, bd - 1);
+        if (c == 4) cx0 = max(cx0, p.wq - bd);
+        if (cy0 > cy1 || cx0 > cx1) return;
+        const float dk = tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c];
+        const float lin = (L1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
+        const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
+        const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
+        const float gyv = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1)), gxv = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
+        if (dk > 0.f && lin >= fmaxf(gyv, gxv)) r = fmaxf(r, lin);
+    };
+    if (D == 1) {
+        if (tid < 9 * KNN_NCLS) {
+            const int nbr = tid / KNN_NCLS, c = tid - nbr * KNN_NCLS;
+            const int sy = by_ + nbr / 3 - 1, sx = bx_ + (nbr % 3) - 1;
+            if (sy >= 0 && sy < nty && sx >= 0 && sx < ntx) pair_reach(sy, sx, c);
         }
+    } else {
+        for (int tb = tid; tb < nt; tb += 64) {
+            const int sy = tb / ntx, sx = tb - sy * ntx;
+            if (abs(sy - by_) > D || abs(sx - bx_) > D) continue;
 #pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) r = fmaxf(r, __shfl_xor(r, o2, 64));
-        return r;
+            for (int c = 0; c < KNN_NCLS; ++c) pair_reach(sy, sx, c);
+        }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) r = fmaxf(r, __shfl_xor(r, o2, 64));
+    return r;
 }
 
 // The reaches of all tiles from a launch of its own (the stage entry point mpc_knn_lut_bwd on large problems; mpc_focus_bwd lets
