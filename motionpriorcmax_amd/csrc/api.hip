@@ -156,9 +156,13 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     if (L.strip_rows > 0 && L.cstrip_rows > 0 && s->T == 1 && s->B > 0 && !(s->flags & MPC_F_ATOMIC_PATH)) {
         L.n_strips = mpc_cdiv(s->H, L.strip_rows);
         {
-            // k_iwe_accum holds ONE workgroup per CU (its strip of 64-bit accumulators fills the LDS), so it costs (rounds of
-            // workgroups) x (rows of a strip): a few more, thinner strips can save a partly filled round (C3: 448 workgroups =
-            // 1.75 rounds of 30 rows -> 504 = 1.97 rounds of 27 rows).  MPC_EV_STRIPS=<n> forces a count (tuning).
+            // k_iwe_accum keeps a strip of 64-bit accumulators in LDS: one 1024-thread workgroup per CU with the largest strip
+            // that fits, two with strips of half that height.  Its time is (rounds of workgroups) x (rows of a strip + a fixed
+            // part per workgroup); thinner strips also duplicate more records (an event votes into two rows: 1 / rows of them
+            // straddle a strip border).  Among 1x .. 3x the smallest strip count the cheapest by that model is taken -- measured
+            // at C3 (14 x 2 images): 16 strips of 30 rows (448 workgroups = 1.75 rounds) 23.6 us, 18 of 27 (1.97 rounds) 22.3,
+            // 36 of 14 (two per CU, 1.97 rounds) 19.9, 54 of 9: 20.8 with k_ev_bin + 1.7; at B = 1 thin strips are the parallelism
+            // there is (C4: 16 strips 15.3 us, 32: 10.6).  MPC_EV_STRIPS=<n> forces a count (tuning).
             static const int ncu = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
@@ -169,11 +173,22 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
             }();
             static const int forced = getenv("MPC_EV_STRIPS") ? atoi(getenv("MPC_EV_STRIPS")) : 0;
             const int n0 = L.n_strips;
+            auto cost_of = [&](int n) {
+                const int rows = mpc_cdiv(s->H, n);
+                const int64_t lds = (int64_t)rows * s->W * 8 + 1280;
+                const int wpc = lds * 2 <= 160 * 1024 ? 2 : 1;
+                const int64_t rounds = mpc_cdiv((int64_t)s->B * L.P * n, (int64_t)ncu * wpc);
+                return (double)rounds * (rows + 16) * (1.0 + 1.0 / rows);
+            };
             int best = n0;
-            int64_t best_cost = (int64_t)mpc_cdiv((int64_t)s->B * L.P * n0, ncu) * mpc_cdiv(s->H, n0);
-            for (int n = n0 + 1; n <= 2 * n0 && mpc_cdiv(s->H, n) >= 8; ++n) {
-                const int64_t cost = (int64_t)mpc_cdiv((int64_t)s->B * L.P * n, ncu) * mpc_cdiv(s->H, n);
-                if (cost < best_cost) { best_cost = cost; best = n; }
+            double best_cost = cost_of(n0);
+            // (every forward bucket is sized for the worst case -- all events of its polarity block: more strips, more committed
+            // memory.  Beyond 1.5 GB of forward records the smallest count stays: C3 1.2 GB at 35 strips, 0.5 at 16)
+            const int64_t mpol_ = (L.P == 2) ? (s->Mp > s->M - s->Mp ? s->Mp : s->M - s->Mp) : s->M;
+            for (int n = n0 + 1; n <= 3 * n0 && mpc_cdiv(s->H, n) >= 8; ++n) {
+                if ((int64_t)s->B * L.P * n * (mpol_ > 0 ? mpol_ : 1) * 12 > (int64_t)1536 << 20) break;
+                const double cost = cost_of(n);
+                if (cost < best_cost * 0.999) { best_cost = cost; best = n; }
             }
             if (forced >= n0 && forced <= s->H) best = forced;
             L.n_strips = best;
@@ -185,7 +200,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
         L.nbb = s->B * s->nb * L.n_cstrips;
         // FORWARD buckets (image strip of the WARPED position: flow dependent, cannot be sized ahead): a bucket holds
         // whatever can reach it -- every event of a polarity block may vote into one image strip.  This memory is
-        // committed (the caller's torch.empty is a hipMalloc), nfb * fcap * 12 bytes: 0.54 GB at C3.
+        // committed (the caller's torch.empty is a hipMalloc), nfb * fcap * 12 bytes: 1.2 GB at C3 (35 strips).
         // BACKWARD buckets (the event's own LUT cell: flow independent): none for a forward-only call or bucket-ordered
         // events (MPC_F_NO_BWD_RECORDS: the backward reads the event rows themselves).  Otherwise either every bucket holds
         // all M rows of its sample (nbb * M * 16 bytes: 4.7 GB at C3), or -- where that exceeds MPC_EV_EXACT_ABOVE_MB
