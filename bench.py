@@ -364,10 +364,12 @@ def main():
                     help='N>1: put the overlapped 124 MB network-gradient all-reduce inside the main timed loop '
                          '(default: the loss path alone is timed -- it has no data-path collective -- and the '
                          'variant with the all-reduce is timed in a second loop and reported beside it)')
-    ap.add_argument('--events-layout', default='bucket', choices=['bucket', 'time'],
-                    help='row order of the event tensor the timed steps run on: as the library\'s ingest delivers it (rows of a polarity '
-                         'block grouped by (time bin, LUT strip) + offsets table; default) or the reference loader\'s time order')
+    ap.add_argument('--events-layout', default='time', choices=['bucket', 'time'],
+                    help='row order of the event tensor the timed steps run on: the reference loader\'s time order (default: the layout '
+                         'whose cost is counted is the one that is timed) or as the library\'s ingest can deliver it (rows of a polarity '
+                         'block grouped by (time bin, LUT strip) + offsets table; the ordering is then NOT inside the timed step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-realistic', action='store_true', help='skip the realistic-input variants reported in also.realistic_inputs')
     ap.add_argument('--no-hip-graph', action='store_true', help='skip the HIP-graph replay timing reported beside the eager one')
     ap.add_argument('--also', default='C2,C4,C4b6', help='extra workloads reported in the "also" field (N=1 only)')
     args = ap.parse_args()
@@ -410,10 +412,10 @@ def main():
         evd, times_d = ev.to(dev), times.to(dev)
         trajd = traj.to(dev).requires_grad_(True)
         batch_time = {'events': evd, 'num_pos_events': num_pos}
-        # The layout the library's own ingest delivers (utils.ingest_events(order_for=loss), mpc_ingest_scatter_ordered: the
-        # rows of each polarity block grouped by (time bin, LUT strip) as ingest writes them + the offsets table) is the
-        # default input of the timed steps; the reference loader's time-ordered tensor is timed beside it
-        # (`time_ordered_events`).  Same loss and gradient bit for bit (tests/test_gpu_event_order.py).
+        # The timed steps run on the reference loader's time-ordered tensor (the layout whose cost is counted is the layout that
+        # is timed).  The layout the library's own ingest can deliver instead (utils.ingest_events(order_for=loss): the rows of
+        # each polarity block grouped by (time bin, LUT strip) + the offsets table) is timed beside it (`other_event_layout`,
+        # the ordering outside the step); same loss and gradient bit for bit (tests/test_gpu_event_order.py).
         batch = L.order_events(batch_time) if args.events_layout == 'bucket' else batch_time
         valid_local = float(ev[..., 5].sum())
         reducer = dp.GradAllReducer(device=comm_dev) if (with_comm and world > 1) else None
@@ -565,9 +567,6 @@ def main():
                 del Lst
             except Exception as e:      # informational
                 static_ms = {'error': repr(e)[:160]}
-        # SURVEY.md 8f-1, layout half: the same steps on a batch whose rows ingest ordered by (bin, LUT strip)
-        # (FocusLoss.order_events, once per batch, outside the step) -- reported beside the headline, which stays on the
-        # reference's time-ordered tensor
         # the other event layout beside the headline: the reference loader's time-ordered tensor when the headline runs on
         # bucket-ordered events (and the other way round), plus what the ordering costs ingest
         ordered = None
@@ -726,7 +725,7 @@ def main():
             # (sized by the main workload) otherwise frees/reallocates inside the child's timed steps
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--steps', str(args.steps),
-                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--also', '', '--events-layout', args.events_layout]
+                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--no-realistic', '--also', '', '--events-layout', args.events_layout]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 dj = json.loads(r.stdout.strip().splitlines()[-1])
@@ -738,6 +737,29 @@ def main():
                               'stages_us_per_step': dj['roofline']['stages_us_per_step']}
             except Exception as e:      # informational field: never fail the main line
                 also[name] = {'error': repr(e)[:200]}
+        # the same workload on the inputs training produces instead of white-noise coefficients (smooth flow fields, zero flow,
+        # ragged batches): step time relative to the headline's inputs, share of the KNN queries handed to the fallback
+        if not args.no_realistic:
+            try:
+                import subprocess
+                import tempfile
+                with tempfile.NamedTemporaryFile(suffix='.json') as tf:
+                    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'realistic_probe.py'), '--workload', args.workload,
+                           '--steps', str(max(5, args.steps // 2)), '--layout', args.events_layout, '--json', tf.name]
+                    subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True)
+                    rows = json.load(open(tf.name))
+                also['realistic_inputs'] = {
+                    'note': 'C3-shaped steps; vs_white = step time / step time on the white-noise coefficients of the headline; '
+                            'knn_fail_frac = queries the strip kernel handed to k_knn_fallback',
+                    'variants': {r['variant']: {'ms_per_step': r['ms_per_step'], 'vs_white': r['vs_first'],
+                                                'knn_fail_frac': round(r['knn_fail_frac'], 5),
+                                                'k_knn_fallback_us': r['kernels_us_per_step'].get('k_knn_fallback'),
+                                                'k_knn_strip_us': r['kernels_us_per_step'].get('k_knn_strip'),
+                                                'k_knn_bwd_tile_us': r['kernels_us_per_step'].get('k_knn_bwd_tile'),
+                                                'k_knn_bwd_far_us': r['kernels_us_per_step'].get('k_knn_bwd_far')} for r in rows},
+                    'worst_vs_white': max(r['vs_first'] for r in rows)}
+            except Exception as e:
+                also['realistic_inputs'] = {'error': repr(e)[:300]}
         # next row 8f-2: voxel-grid builder on the same window shape (network input; not part of `value`)
         try:
             from motionpriorcmax_amd.utils import voxel_grids

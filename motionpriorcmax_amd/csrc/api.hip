@@ -127,24 +127,20 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_spart = off; off += mpc_align((int64_t)L.n_sblocks_max * 2 * sizeof(double));
     L.off_counts = off; off += mpc_align(64 + (int64_t)(L.nimg > 0 ? L.nimg : 1) * sizeof(float));
     const int64_t bt = (int64_t)(s->B > 0 ? s->B : 1) * s->nb;
-    L.off_cell_start = off; off += mpc_align(bt * (L.G + 1) * sizeof(int32_t));
+    const int km = mpc_knn_margin(s);
+    const int64_t hb = s->hq + 2 * km, wb = s->wq + 2 * km, Gb = hb * wb;
+    const int64_t ktiles = ((hb + 15) / 16) * ((wb + 15) / 16);
+    L.off_cell_start = off; off += mpc_align(bt * (Gb + 1) * sizeof(int32_t));
+    L.off_knn_sat = off;    off += mpc_align(bt * (hb + 1) * (wb + 1) * sizeof(int32_t));
     L.off_spos = off;       off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
     L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(int32_t));
     L.off_knn_tmp_g = off;  off += mpc_align(bt * (int64_t)s->n * s->T * 2 * sizeof(float));
     L.off_knn_tmp_a = off;  off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
-    const bool big_sort = L.G > MPC_KNN_LDS_SORT_CELLS || (int64_t)L.G * 4 + ((int64_t)s->n + 1) / 2 * 4 > 150 * 1024;
-    L.off_knn_cursor = off; off += big_sort ? mpc_align(bt * (int64_t)L.G * sizeof(int32_t)) : 0;
-    L.off_knn_reach = off;  off += mpc_align(bt * (int64_t)mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16) * sizeof(float));
+    L.off_knn_cursor = off; off += mpc_knn_big_sort(s) ? mpc_align(bt * Gb * sizeof(int32_t)) : 0;
+    L.off_knn_reach = off;  off += mpc_align(bt * ktiles * sizeof(float));
     L.off_knn_fail = off;   off += mpc_align((1 + bt * (int64_t)L.G) * sizeof(int32_t));
-    L.knn_lean = (s->B > 0 && mpc_knn_lean(s)) ? 1 : 0;
-    if (L.knn_lean) {
-        int64_t mb, rb, fb, gb;
-        mpc_knn_lean_sizes(s, &mb, &rb, &fb, &gb);
-        L.off_knn_mask = off;   off += mpc_align(mb);
-        L.off_knn_rowtab = off; off += mpc_align(rb);
-        L.off_knn_fbits = off;  off += mpc_align(fb);
-        L.off_knn_gacc = off;   off += mpc_align(gb);
-    }
+    L.off_knn_retry = off;  off += mpc_align((1 + bt * (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128)) * sizeof(int32_t));
+    L.off_knn_far = off;    off += mpc_knn_uses_far_list(s) ? mpc_align(bt * (1 + (int64_t)L.G) * sizeof(int32_t)) : 0;
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;
     L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));
@@ -226,7 +222,8 @@ extern "C" int64_t mpc_knn_state_floats(const mpc_shape *s) {
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     const int64_t bt = (int64_t)s->B * s->nb;
-    return 3 * bt * s->hq * s->wq + bt * mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16) * 5;
+    const int km = mpc_knn_margin(s);
+    return 3 * bt * s->hq * s->wq + bt * ((s->hq + 2 * km + 15) / 16) * ((s->wq + 2 * km + 15) / 16) * 5;
 }
 
 extern "C" int64_t mpc_knn_fail_list_offset(const mpc_shape *s) {

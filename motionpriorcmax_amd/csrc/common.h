@@ -66,20 +66,17 @@ struct mpc_ws_layout {
     int64_t off_spart;   int32_t n_sblocks_max; // [n_sblocks_max][2] double
     int64_t off_counts;                         // int32[8] : n_sblocks used, ...
     // KNN
-    int64_t off_cell_start;  // int32 [B*nb][G+1]
+    int64_t off_cell_start;  // int32 [B*nb][Gb+1]   first bucketed point of every cell of the bucket grid (query grid + margin)
+    int64_t off_knn_sat;     // int32 [B*nb][hb+1][wb+1]  summed-area table of the cell counts (strip forward only)
     int64_t off_spos;        // float2 [B*nb][n]
     int64_t off_sidx;        // int32  [B*nb][n]
     int64_t off_knn_tmp_g;   // float2 [B*nb][n][T]  backward partials
     int64_t off_knn_tmp_a;   // float2 [B*nb][n]
-    int64_t off_knn_cursor;  // int32  [B*nb][G]  fill cursors of the global-memory bucket sort (only when G*4 B exceeds the LDS sort)
-    int64_t off_knn_reach;   // float  [B*nb][ceil(hq/16)][ceil(wq/16)]  backward search reach per 16x16 tile
+    int64_t off_knn_cursor;  // int32  [B*nb][Gb]  fill cursors of the global-memory bucket sort (only when Gb*4 B exceeds the LDS sort)
+    int64_t off_knn_reach;   // float  [B*nb][tiles of the bucket grid]  backward search reach per 16x16 tile
     int64_t off_knn_fail;    // int32  [1 + B*nb*G]  queries handed from the strip kernel to the fallback kernel
-    // scatter backward of the KNN LUT (knn_lean != 0; knn_device.h: KnnLeanBufs), kept from the forward to the backward
-    int32_t knn_lean;
-    int64_t off_knn_mask;    // uint32 [B*nb][strips][3][256]
-    int64_t off_knn_rowtab;  // int2   [B*nb][strips][NR + 1]
-    int64_t off_knn_fbits;   // uint32 [B*nb][hq][ceil(wq/32)]
-    int64_t off_knn_gacc;    // uint64 [1 or 2][B*nb][n]  accumulators of workgroups whose points do not fit their LDS
+    int64_t off_knn_retry;   // int32  [1 + B*nb*ceil(wq/2)*ceil(hq/128)]  strips the strip kernel searches again in quarters (staging overflow)
+    int64_t off_knn_far;     // int32  [B*nb][1 + G]  per (sample, bin): the queries the fallback kernel served, for k_knn_bwd_far
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8] bucket fill counters, marker; then [nbb] capacities and [nbb] first records of the backward buckets
     int64_t off_frec;        // float4 [nfb][fcap]
@@ -116,9 +113,10 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets);
 int mpc_validate_shape(const mpc_shape *s);
-// KNN: does the scatter backward serve this shape, and the sizes of what the forward leaves for it (knn.hip, knn_strip.hip)
-bool mpc_knn_lean(const mpc_shape *s);
-void mpc_knn_lean_sizes(const mpc_shape *s, int64_t *mask_bytes, int64_t *rowtab_bytes, int64_t *fbits_bytes, int64_t *gacc_bytes);
+// KNN (knn.hip): margin of the bucket grid; is the points' counting sort the global-memory one; does the forward keep a far list
+int mpc_knn_margin(const mpc_shape *s);
+bool mpc_knn_big_sort(const mpc_shape *s);
+bool mpc_knn_uses_far_list(const mpc_shape *s);
 
 // ---- device helpers ---------------------------------------------------------------------
 #ifdef __HIPCC__

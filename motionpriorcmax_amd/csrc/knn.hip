@@ -24,20 +24,48 @@
 // whole kernel instead of one per point and pass.  The kernel is latency- not bandwidth-limited, so the cell
 // rows of a (sample, bin) are split over S workgroups: each reads all n points, counts those below its row
 // range (its base offset in the bucketed arrays) and sorts the ones inside it -- no exchange between them.
-// grid B*nb*S, 1024 threads, dynamic LDS = ceil(hq/S)*wq * 4 + n * 2 bytes
+// The cells are those of the BUCKET grid (knn_device.h: the query grid + a margin of p.m cells).
+// grid B*nb*S, 1024 threads, dynamic LDS = ceil(hb/S)*wb * 4 + n * 2 bytes (+ n / 8 for the bitmap of a crowded cell)
 // ------------------------------------------------------------------------------------------
 #define KNN_BUCKET_NPT 24
+#define KNN_BK_SMALL 6        // cells with up to this many points are ordered by their own thread (insertion sort)
+#define KNN_BK_WAVE 128       // ... up to this many by one wavefront (bitonic network, two keys per lane); more: by the workgroup (bitmap)
+
+// ascending bitonic sort of 128 keys held two per lane (k0 = element `lane`, k1 = element `lane + 64`)
+__device__ __forceinline__ void knn_bitonic128(unsigned &k0, unsigned &k1, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 128; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride == 64) {
+                // partners are the two keys of a lane; at size 128 every pair sorts ascending
+                const unsigned lo = min(k0, k1), hi = max(k0, k1);
+                k0 = lo; k1 = hi;
+            } else {
+                // element e (lane for k0, lane + 64 for k1): partner e ^ stride in the same half; ascending block <=> (e & size) == 0
+                const unsigned p0 = (unsigned)__shfl_xor((int)k0, stride, 64), p1 = (unsigned)__shfl_xor((int)k1, stride, 64);
+                const bool lower = (lane & stride) == 0;
+                const bool asc0 = (lane & size) == 0, asc1 = ((lane + 64) & size) == 0;
+                k0 = (lower == asc0) ? min(k0, p0) : max(k0, p0);
+                k1 = (lower == asc1) ? min(k1, p1) : max(k1, p1);
+            }
+        }
+    }
+}
+
 // NPT: points per thread held in registers (CACHED), a multiple of 4 >= ceil(n / 1024): 20 for the 19 200 points of a DSEC grid
 template <bool CACHED, int NPT>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
-                                                     int *__restrict__ cell_start,
+                                                     int *__restrict__ cell_start, int *__restrict__ sat,
                                                      float2 *__restrict__ spos, int *__restrict__ sidx, int S,
-                                                     float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail,
-                                                     int *__restrict__ zero_ptr, int zero_words,
-                                                     unsigned *__restrict__ fbits, int fwords) {
+                                                     float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail, int *__restrict__ retry,
+                                                     int *__restrict__ far, int *__restrict__ zero_ptr, int zero_words) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
     __shared__ int s_low[16];
+    __shared__ int s_nbig, s_nhuge;
+    __shared__ int s_huge[32];
+    __shared__ int s_big[1024];          // crowded cells of this workgroup (more than KNN_BK_SMALL points); the rest of them re-scan
     const int tid = threadIdx.x;
 #ifdef KNN_BK_STAMP
     __shared__ unsigned s_stp[8];       // diagnostics build (tools/bucket_stamp_probe.py): phase stamps of thread 0, 10 ns units
@@ -48,13 +76,13 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     BK_STAMP(0);
     const int bt = blockIdx.x / S, part = blockIdx.x - bt * S, b = bt / p.nb, t = bt - b * p.nb;
     // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
-    // atomicMax and its fallback list is appended to (knn_strip.hip)
+    // atomicMax and its fallback lists are appended to (knn_strip.hip)
     if (part == 0) for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;
-    if (part == 0) for (int i = tid; i < fwords; i += 1024) fbits[(size_t)bt * fwords + i] = 0u;      // (scatter backward: map of the fallback's queries)
-    if (blockIdx.x == 0 && tid == 0) fail[0] = 0;
+    if (part == 0 && tid == 0 && far != nullptr) far[(size_t)bt * (p.G + 1)] = 0;
+    if (blockIdx.x == 0 && tid == 0) { fail[0] = 0; retry[0] = 0; }
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
-    const int rows_per = (p.hq + S - 1) / S;
-    const int g_lo = min(part * rows_per, p.hq) * p.wq, g_hi = min((part + 1) * rows_per, p.hq) * p.wq, Gp = g_hi - g_lo;
+    const int rows_per = (p.hb + S - 1) / S;
+    const int g_lo = min(part * rows_per, p.hb) * p.wb, g_hi = min((part + 1) * rows_per, p.hb) * p.wb, Gp = g_hi - g_lo;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
     int qc[CACHED ? NPT : 1];
     int below = 0;                                  // points of this thread in cells before the range
@@ -68,13 +96,14 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         // 41.7 -> 45.5 us, the branches break up the batch of loads)
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
-            qc[u] = cell_of(q[u].x, p.sp, p.hq) * p.wq + cell_of(q[u].y, p.sp, p.wq);
+            qc[u] = knn_cell_index(p, q[u].x, q[u].y);
             if (tid + u * 1024 >= p.n) qc[u] = 0x7fffffff;          // not a point
             below += qc[u] < g_lo;
         }
     }
     BK_STAMP(1);
     for (int g = tid; g < Gp; g += 1024) s_cnt[g] = 0;
+    if (tid == 0) { s_nbig = 0; s_nhuge = 0; }
     __syncthreads();
     if (CACHED) {
 #pragma unroll
@@ -83,7 +112,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
-            const int c = cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq);
+            const int c = knn_cell_index(p, v.x, v.y);
             below += c < g_lo;
             if (c >= g_lo && c < g_hi) atomicAdd(&s_cnt[c - g_lo], 1);
         }
@@ -119,9 +148,15 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     }
     __syncthreads();
     BK_STAMP(3);
-    int *cs = cell_start + (size_t)bt * (p.G + 1);
+    int *cs = cell_start + (size_t)bt * (p.Gb + 1);
     for (int g = tid; g < Gp; g += 1024) cs[g_lo + g] = base + s_cnt[g];      // coalesced
-    if (tid == 0 && part == S - 1) cs[p.G] = p.n;
+    if (tid == 0 && part == S - 1) cs[p.Gb] = p.n;
+    if (sat != nullptr && S == 1) {
+        // the summed-area table of the cell counts while the first points of all cells are in LDS (one workgroup holds the
+        // whole (sample, bin); otherwise k_knn_sat follows); the scratch is the index array's space, not yet in use
+        knn_sat_build(p, [&](int y, int x) { const int g = y * p.wb + x; return g < Gp ? s_cnt[g] : p.n; },
+                      sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), s_cnt + Gp);
+    }
     __syncthreads();
     BK_STAMP(4);
     float2 *sp_ = spos + (size_t)bt * p.n + base;
@@ -138,17 +173,24 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
-            const int c = cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq);
+            const int c = knn_cell_index(p, v.x, v.y);
             if (c >= g_lo && c < g_hi) l_idx[atomicAdd(&s_cnt[c - g_lo], 1)] = (unsigned short)i;
         }
     }
     __syncthreads();
     BK_STAMP(5);
-    // (measured and not kept: the bounds of eight cells read together -0.8 us; a thread's chunk of the scan held in registers
-    // +-0; cells with more than six points ordered by a whole wavefront -- rank by counting -- instead of their thread +1.8 us:
-    // the slow workgroups of this phase, 12 us against a mean of 5, are not slow because of a few crowded cells)
+    // Order the points of every cell by trajectory index.  A cell of the lattice holds about one point and its own thread
+    // sorts it by insertion; a smooth flow field packs points (a contracting field: several per cell; the outermost ring of
+    // the margin: everything that left the image by more than the margin, a hundred per cell) -- cells with more than
+    // KNN_BK_SMALL points go on a list and are sorted by a whole wavefront (bitonic network, up to KNN_BK_WAVE keys), the few
+    // with more than that by the whole workgroup (a bitmap over the trajectory indices: any number of keys).
     for (int g = tid; g < Gp; g += 1024) {          // s_cnt[g] is now the END of cell g
         const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0;
+        if (e - a > KNN_BK_SMALL) {
+            const int k = atomicAdd(&s_nbig, 1);
+            if (k < 1024) s_big[k] = g;
+            continue;
+        }
         for (int i = a + 1; i < e; ++i) {
             const unsigned short key = l_idx[i];
             int j = i - 1;
@@ -157,6 +199,57 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         }
     }
     __syncthreads();
+    {
+        const int nbig = s_nbig;
+        const int lane = tid & 63, wv = tid >> 6;
+        // (more crowded cells than the list holds: every wavefront scans its share of the cells again instead)
+        const int nitem = nbig <= 1024 ? nbig : Gp;
+        for (int it = wv; it < nitem; it += 16) {
+            const int g = nbig <= 1024 ? s_big[it] : it;
+            const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0, c = e - a;
+            if (c <= KNN_BK_SMALL) continue;
+            if (c > KNN_BK_WAVE) { if (lane == 0) { const int k = atomicAdd(&s_nhuge, 1); if (k < 32) s_huge[k] = g; } continue; }
+            unsigned k0 = lane < c ? (unsigned)l_idx[a + lane] : 0xffffffffu;
+            unsigned k1 = lane + 64 < c ? (unsigned)l_idx[a + 64 + lane] : 0xffffffffu;
+            knn_bitonic128(k0, k1, lane);
+            if (lane < c) l_idx[a + lane] = (unsigned short)k0;
+            if (lane + 64 < c) l_idx[a + 64 + lane] = (unsigned short)k1;
+        }
+    }
+    __syncthreads();
+    if (s_nhuge > 0) {
+        // cells beyond the wavefront sort, one at a time by the whole workgroup: mark the indices of the cell in a bitmap over
+        // [0, n), then every word's bits go back in ascending order behind the bits of the words before it
+        unsigned *bm = reinterpret_cast<unsigned *>(l_idx + ((p.n + 1) & ~1));
+        const int nw = (p.n + 31) >> 5;
+        const int nhuge = s_nhuge;
+        const int nh_item = nhuge <= 32 ? nhuge : Gp;          // (more than the list holds: look at every cell)
+        for (int hi_ = 0; hi_ < nh_item; ++hi_) {
+            const int g = nhuge <= 32 ? s_huge[hi_] : hi_;
+            const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0, c = e - a;
+            if (c <= KNN_BK_WAVE) continue;                   // (workgroup-uniform)
+            for (int w = tid; w < nw; w += 1024) bm[w] = 0u;
+            __syncthreads();
+            for (int i = a + tid; i < e; i += 1024) atomicOr(&bm[l_idx[i] >> 5], 1u << (l_idx[i] & 31));
+            __syncthreads();
+            // prefix of the word popcounts: thread `tid` owns words [w0, w1)
+            const int per = (nw + 1023) / 1024, w0 = min(tid * per, nw), w1 = min(w0 + per, nw);
+            int mine = 0;
+            for (int w = w0; w < w1; ++w) mine += __popc(bm[w]);
+            int inc2 = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc2, o, 64); if ((tid & 63) >= o) inc2 += v; }
+            if ((tid & 63) == 63) s_wave[tid >> 6] = inc2;
+            __syncthreads();
+            int pos = a + inc2 - mine;
+            for (int w = 0; w < (tid >> 6); ++w) pos += s_wave[w];
+            for (int w = w0; w < w1; ++w) {
+                unsigned bits = bm[w];
+                while (bits) { const int bit = __ffs(bits) - 1; bits &= bits - 1u; l_idx[pos++] = (unsigned short)(32 * w + bit); }
+            }
+            __syncthreads();
+        }
+    }
     BK_STAMP(6);
     const int own = Gp > 0 ? s_cnt[Gp - 1] : 0;
     // (all gathers of a thread in flight together -- one batch of NPT with the points in registers, eight otherwise: one after
@@ -182,9 +275,47 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Summed-area table of the cell counts of one (sample, bin): sat[y][x] = points in cells (y', x') of the bucket grid with
+// y' < y and x' < x, (hb + 1) x (wb + 1) entries.  The strip kernel and its fallback read the number of points in a query's
+// search square from it (four loads) to choose the radius of the square.
+// Built from the first bucketed point of every cell (rowstart(y, x), x in [0, wb]: x = wb is one past the row), whose
+// differences along a row are the row prefixes; the sum over the rows in two levels: groups of 8 rows first (s_part), then
+// every (column, group) item adds up its own rows behind the groups above it.  All threads of the workgroup call.
+// ------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, int *__restrict__ S, int *s_part) {
+    const int W1 = p.wb + 1, ngrp = (p.hb + 7) >> 3, nthr = blockDim.x;
+    for (int it = threadIdx.x; it < ngrp * W1; it += nthr) {
+        const int g = it / W1, x = it - g * W1;
+        int sum = 0;
+        for (int y = g * 8; y < min(g * 8 + 8, p.hb); ++y) sum += rowstart(y, x) - rowstart(y, 0);
+        s_part[it] = sum;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < ngrp * W1; it += nthr) {
+        const int g = it / W1, x = it - g * W1;
+        int acc = 0;
+        for (int gg = 0; gg < g; ++gg) acc += s_part[gg * W1 + x];
+        if (g == 0) S[x] = 0;
+        for (int y = g * 8; y < min(g * 8 + 8, p.hb); ++y) {
+            acc += rowstart(y, x) - rowstart(y, 0);
+            S[(size_t)(y + 1) * W1 + x] = acc;
+        }
+    }
+}
+// from cell_start in global memory (the bucket sorts that do not hold a whole (sample, bin) in one workgroup's LDS)
+// grid B * nb, 1024 threads, dynamic LDS ceil(hb / 8) * (wb + 1) ints
+__global__ __launch_bounds__(1024) void k_knn_sat(const KnnParams p, const int *__restrict__ cell_start, int *__restrict__ sat) {
+    extern __shared__ int s_part[];
+    const int bt = blockIdx.x;
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    knn_sat_build(p, [&](int y, int x) { return cs[y * p.wb + x]; }, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), s_part);
+}
+
 
 // ------------------------------------------------------------------------------------------
-// LUT grids beyond the LDS sort (G > 38 400 cells, e.g. 1280x720 at superpixel 4): the same counting sort with
+// LUT grids beyond the LDS sort (Gb > 38 400 cells, e.g. 1280x720 at superpixel 4): the same counting sort with
 // the counters in global memory, as three launches (count / scan / scatter) and a fourth that orders the
 // points of every cell by trajectory index, so that the bucket order -- and with it the fp32 summation order
 // of the LUT -- does not depend on the order the atomics happened to execute in.
@@ -195,25 +326,24 @@ __global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, con
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const float2 v = reinterpret_cast<const float2 *>(traj)[((size_t)b * (p.T + p.nb) + p.T + t) * p.n + i];
-    atomicAdd(&cursor[(size_t)bt * p.G + cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+    atomicAdd(&cursor[(size_t)bt * p.Gb + knn_cell_index(p, v.x, v.y)], 1);
 }
 
 // grid B*nb, 1024 threads
 __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
                                                           int *__restrict__ cell_start,
-                                                          float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail,
-                                                          int *__restrict__ zero_ptr, int zero_words,
-                                                          unsigned *__restrict__ fbits, int fwords) {
+                                                          float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail, int *__restrict__ retry,
+                                                          int *__restrict__ far, int *__restrict__ zero_ptr, int zero_words) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, bt = blockIdx.x;
     for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;       // (see k_knn_bucket)
-    for (int i = tid; i < fwords; i += 1024) fbits[(size_t)bt * fwords + i] = 0u;
-    if (bt == 0 && tid == 0) fail[0] = 0;
+    if (tid == 0 && far != nullptr) far[(size_t)bt * (p.G + 1)] = 0;
+    if (bt == 0 && tid == 0) { fail[0] = 0; retry[0] = 0; }
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
-    int *cur = cursor + (size_t)bt * p.G;
-    int *cs = cell_start + (size_t)bt * (p.G + 1);
-    const int chunk = (p.G + 1023) / 1024;
-    const int g0 = min(tid * chunk, p.G), g1 = min(g0 + chunk, p.G);
+    int *cur = cursor + (size_t)bt * p.Gb;
+    int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const int chunk = (p.Gb + 1023) / 1024;
+    const int g0 = min(tid * chunk, p.Gb), g1 = min(g0 + chunk, p.Gb);
     int local = 0;
     for (int g = g0; g < g1; ++g) local += cur[g];
     int incl = local;
@@ -232,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
         cs[g] = run;
         run += c;
     }
-    if (tid == 0) cs[p.G] = p.n;
+    if (tid == 0) cs[p.Gb] = p.n;
 }
 
 __global__ __launch_bounds__(256) void k_knn_bucket_scatter(const KnnParams p, const float *__restrict__ traj,
@@ -242,28 +372,53 @@ __global__ __launch_bounds__(256) void k_knn_bucket_scatter(const KnnParams p, c
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
     const float2 v = reinterpret_cast<const float2 *>(traj)[((size_t)b * (p.T + p.nb) + p.T + t) * p.n + i];
-    const int pos = atomicAdd(&cursor[(size_t)bt * p.G + cell_of(v.x, p.sp, p.hq) * p.wq + cell_of(v.y, p.sp, p.wq)], 1);
+    const int pos = atomicAdd(&cursor[(size_t)bt * p.Gb + knn_cell_index(p, v.x, v.y)], 1);
     spos[(size_t)bt * p.n + pos] = v;
     sidx[(size_t)bt * p.n + pos] = i;
 }
 
-// one thread per cell: insertion sort of its (few) points by trajectory index
+// one WAVEFRONT per cell: cells of up to 128 points by the bitonic network, larger ones by rank counting (every lane
+// counts the keys below its own: quadratic, but spread over 64 lanes; the rare pile of the outermost margin ring)
 __global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, const int *__restrict__ cell_start,
-                                                          float2 *__restrict__ spos, int *__restrict__ sidx) {
-    const int bt = blockIdx.y;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= p.G) return;
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+                                                          float2 *__restrict__ spos, int *__restrict__ sidx,
+                                                          const float *__restrict__ traj) {
+    const int bt = blockIdx.y, b = bt / p.nb, t = bt - b * p.nb;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= p.Gb) return;
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
     float2 *sp_ = spos + (size_t)bt * p.n;
     int *si_ = sidx + (size_t)bt * p.n;
-    const int a = cs[g], e = cs[g + 1];
-    for (int i = a + 1; i < e; ++i) {
-        const int key = si_[i];
-        const float2 v = sp_[i];
-        int j = i - 1;
-        while (j >= a && si_[j] > key) { si_[j + 1] = si_[j]; sp_[j + 1] = sp_[j]; --j; }
-        si_[j + 1] = key; sp_[j + 1] = v;
+    const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
+    const int a = cs[g], e = cs[g + 1], c = e - a;
+    if (c <= 1) return;
+    if (c <= KNN_BK_WAVE) {
+        unsigned k0 = lane < c ? (unsigned)si_[a + lane] : 0xffffffffu;
+        unsigned k1 = lane + 64 < c ? (unsigned)si_[a + 64 + lane] : 0xffffffffu;
+        knn_bitonic128(k0, k1, lane);
+        if (lane < c) { si_[a + lane] = (int)k0; sp_[a + lane] = pts[k0]; }
+        if (lane + 64 < c) { si_[a + 64 + lane] = (int)k1; sp_[a + 64 + lane] = pts[k1]; }
+        return;
     }
+    // rank counting in rounds of 64 keys: all ranks first (reads), then the writes (the positions are re-read by index)
+    for (int i0 = 0; i0 < c; i0 += 64) {
+        const int mine = i0 + lane < c ? si_[a + i0 + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < c; ++j) rank += si_[a + j] < mine ? 1 : 0;
+        // the ranks of the keys of this round are final, but writing them now would disturb the later rounds' counts: the
+        // sorted indices go to the POSITION array's slots as bit patterns first, and are unpacked below
+        if (i0 + lane < c) reinterpret_cast<int *>(sp_ + a + rank)[0] = mine;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < c; i0 += 64) {
+        if (i0 + lane < c) {
+            const int id = __hip_atomic_load(reinterpret_cast<int *>(sp_ + a + i0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            si_[a + i0 + lane] = id;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < c; i0 += 64) if (i0 + lane < c) sp_[a + i0 + lane] = pts[__hip_atomic_load(si_ + a + i0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
 }
 
 
@@ -277,9 +432,8 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
                                                    float *__restrict__ knn_state,
                                                    int *__restrict__ idx_out,
                                                    float *__restrict__ tile_dkmax, int r_init, int RH,
-                                                   int cap, int stage_flow, int gx, int gy) {
+                                                   int cap, int stage_flow, int gx, int gy) {      // (gx x gy tiles of the QUERY grid)
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ float s_maxf[NT / 64];
     __shared__ int s_rowbase[64 + 1];   // RW <= 48
     __shared__ int s_rowg[64];
     __shared__ int s_use_lds;
@@ -305,7 +459,7 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
     unsigned short *lcs = reinterpret_cast<unsigned short *>(s_dyn + o);
 
     QueryCtx c;
-    c.cs = cell_start + (size_t)bt * (p.G + 1);
+    c.cs = cell_start + (size_t)bt * (p.Gb + 1);
     c.spos = spos + (size_t)bt * p.n;
     c.sidx = sidx + (size_t)bt * p.n;
     c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
@@ -315,11 +469,11 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
     c.rx0 = bx_ * 16 - RH;
 
     // ---- stage the region (tile + RH rings) ---------------------------------------------------
-    const int xlo = max(c.rx0, 0), xhi = min(c.rx0 + RW - 1, p.wq - 1);
+    const int xlo = max(c.rx0, -p.m), xhi = min(c.rx0 + RW - 1, p.wq + p.m - 1);
     if (tid < RWY) {
         const int yy = c.ry0 + tid;
         int gs = 0, ge = 0;
-        if (yy >= 0 && yy < p.hq) { gs = c.cs[yy * p.wq + xlo]; ge = c.cs[yy * p.wq + xhi + 1]; }
+        if (yy >= -p.m && yy < p.hq + p.m) { gs = c.cs[knn_ci(p, yy, xlo)]; ge = c.cs[knn_ci(p, yy, xhi + 1)]; }
         s_rowg[tid] = gs;
         s_rowbase[tid + 1] = ge - gs;
     }
@@ -338,9 +492,9 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
             const int rr = i / (RW + 1), cc = i - rr * (RW + 1);
             const int yy = c.ry0 + rr;
             int v = s_rowbase[rr];
-            if (yy >= 0 && yy < p.hq) {
+            if (yy >= -p.m && yy < p.hq + p.m) {
                 const int xx = min(max(c.rx0 + cc, xlo), xhi + 1);
-                v += c.cs[yy * p.wq + xx] - s_rowg[rr];
+                v += c.cs[knn_ci(p, yy, xx)] - s_rowg[rr];
             }
             lcs[i] = (unsigned short)v;
         }
@@ -373,25 +527,8 @@ __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float
             if (!done) knn_one_query<false, false, NT>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, idx_out, dK);
         }
     }
-    // largest K-th distance of this tile: bounds the backward's search windows
-    float m = dK;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_down(m, o2, 64));
-    if ((tid & 63) == 0) s_maxf[tid >> 6] = m;
-    __syncthreads();
-    // one maximum per 16x16 query tile (= 4 wavefronts), the granularity the backward works at
-    const int gy16 = (p.hq + 15) >> 4;
-    if ((tid & 255) == 0) {
-        const int ty16 = by_ * (TY / 16) + (tid >> 8);
-        if (ty16 < gy16) {
-            const int w0 = tid >> 6;
-            // (this kernel does not classify its queries: everything in class 0, whose region is the whole tile)
-            float *dst = tile_dkmax + (((size_t)bt * gy16 + ty16) * gx + bx_) * KNN_NCLS;
-            dst[0] = fmaxf(fmaxf(s_maxf[w0], s_maxf[w0 + 1]), fmaxf(s_maxf[w0 + 2], s_maxf[w0 + 3]));
-#pragma unroll
-            for (int c = 1; c < KNN_NCLS; ++c) dst[c] = 0.f;
-        }
-    }
+    // K-th distance into the tile maxima (they bound the backward's search windows)
+    if (cy < p.hq && cx < p.wq) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
 }
 
 __device__ __forceinline__ int wave_max_int(int v) {
@@ -439,28 +576,30 @@ __device__ __forceinline__ void bwd_window(const float4 *__restrict__ lq4, const
 __global__ __launch_bounds__(256) void k_knn_reach(const KnnParams p, const float *__restrict__ tile_dkmax,
                                                    float *__restrict__ reach) {
     extern __shared__ float s_lin[];          // linear K-th distance bound of every tile of this (sample, bin)
-    const int ntx = (p.wq + 15) >> 4, nty = (p.hq + 15) >> 4, nt = ntx * nty;
+    const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m), nt = ntx * nty;
     const int bt = blockIdx.x;
     for (int tb = threadIdx.x; tb < nt; tb += 256) {
         float dk = 0.f;
 #pragma unroll
         for (int c = 0; c < KNN_NCLS; ++c) dk = fmaxf(dk, tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c]);
-        s_lin[tb] = (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
+        s_lin[tb] = dk > 0.f ? (p.l1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f : -1.f;
     }
     __syncthreads();
     for (int tile = threadIdx.x; tile < nt; tile += 256) {
         const int ty = tile / ntx, tx = tile - ty * ntx;
-        const float ay0 = (float)(ty * 16 * p.sp) - 0.5f, ay1 = (float)(min(ty * 16 + 16, p.hq) * p.sp) - 0.5f;
-        const float ax0 = (float)(tx * 16 * p.sp) - 0.5f, ax1 = (float)(min(tx * 16 + 16, p.wq) * p.sp) - 0.5f;
+        float ay0, ay1, ax0, ax1;
+        knn_tile_area(p, ty, tx, ay0, ay1, ax0, ax1);
         float r = 0.f;
         for (int by = 0; by < nty; ++by) {
-            const float qy0 = (float)(by * 16 * p.sp) + p.off, qy1 = (float)((min(by * 16 + 16, p.hq) - 1) * p.sp) + p.off;
-            const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
             for (int bx = 0; bx < ntx; ++bx) {
+                int cy0, cy1, cx0, cx1;
+                if (!knn_tile_class_cells(p, by, bx, 0, 0, cy0, cy1, cx0, cx1)) continue;
                 const float lin = s_lin[by * ntx + bx];
-                const float qx0 = (float)(bx * 16 * p.sp) + p.off, qx1 = (float)((min(bx * 16 + 16, p.wq) - 1) * p.sp) + p.off;
+                const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
+                const float gy = fmaxf(0.f, fmaxf(qy0 - ay1, ay0 - qy1));
+                const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
                 const float gx = fmaxf(0.f, fmaxf(qx0 - ax1, ax0 - qx1));
-                if (lin >= fmaxf(gy, gx)) r = fmaxf(r, lin);
+                if (lin > 0.f && lin >= fmaxf(gy, gx)) r = fmaxf(r, lin);
             }
         }
         reach[(size_t)bt * nt + tile] = r;
@@ -504,20 +643,21 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
     const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    // (tiles of the BUCKET grid: knn_tile_of)
     // phase 1 (independent loads): reach of the 16x16 sub-tiles; per tile row the contiguous range of
     // the bucketed arrays, turned into a running offset by a wavefront scan
     if (tid < SUB * SUB) {
-        const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
+        const int gx16 = knn_tiles_x(p.wq, p.m), gy16 = knn_tiles_y(p.hq, p.m);
         const int ty = by_ * SUB + tid / SUB, tx = bx_ * SUB + tid % SUB;
         s_Rsub[tid] = (ty < gy16 && tx < gx16) ? reach[((size_t)bt * gy16 + ty) * gx16 + tx] : 0.f;
     }
     if (tid < 64) {
         int gs = 0, ge = 0;
-        const int yy = by_ * TS + tid;
-        if (tid < TS && yy < p.hq) {
-            const int xa = bx_ * TS, xb = min(xa + TS, p.wq);
-            gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
+        const int yq = by_ * TS - KNN_TILE_OFF + tid;      // cell row of the tile (query numbering)
+        if (tid < TS && yq >= -p.m && yq < p.hq + p.m) {
+            const int xa = max(bx_ * TS - KNN_TILE_OFF, -p.m), xb = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m);
+            if (xa < xb) { gs = cs[knn_ci(p, yq, xa)]; ge = cs[knn_ci(p, yq, xb)]; }
         }
         int run = ge - gs;                               // inclusive scan over the lanes
 #pragma unroll
@@ -533,7 +673,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
     const int RQ = use_lds ? RQ_need : 0;
     const int RW = TS + 2 * RQ;
-    const int ry0 = by_ * TS - RQ, rx0 = bx_ * TS - RQ;
+    const int ry0 = by_ * TS - KNN_TILE_OFF - RQ, rx0 = bx_ * TS - KNN_TILE_OFF - RQ;      // (query-grid coordinates)
     // LDS: only the fast path (num_tref == 1, 'mean') stages anything: one float4 per query cell
     // {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} (+ float2 of the flow_to_next gradient)
     float4 *lq4 = reinterpret_cast<float4 *>(s_dyn);
@@ -551,7 +691,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
             if (yy >= 0 && yy < p.hq && xx >= 0 && xx < p.wq) {
                 const size_t q = (size_t)bt * p.G + (size_t)yy * p.wq + xx;
                 dk = knn_state[q];
-                ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & ~KNN_TIE_FLAG;
+                ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & KNN_IDX_MASK;
                 g = gl2[(size_t)yy * p.wq + xx];
                 if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
             }
@@ -570,7 +710,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
         const int g = s_rowg[lo] + (pi - s_rowbase[lo]);
         const float2 pt = sp_[g];
         const int i = si_[g];
-        if (SUB > 1) R = s_Rsub[(lo >> 4) * SUB + ((cell_of(pt.y, p.sp, p.wq) - bx_ * TS) >> 4)];
+        if (SUB > 1) R = s_Rsub[(lo >> 4) * SUB + ((cell_of(pt.y, p.sp, p.wq, p.m) + KNN_TILE_OFF - bx_ * TS) >> 4)];
         // query cells within reach: |q - p| <= R per axis.  R already carries a 0.01 px + 1e-4 relative
         // margin, which dominates the rounding of these four expressions, so no extra cell is added.
         // (a reciprocal multiply instead of four divisions: its 1e-7 relative error is far inside that margin too)
@@ -606,7 +746,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
                     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
                     const float dk = knn_state[q];
                     if (d > dk) continue;
-                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & ~KNN_TIE_FLAG;
+                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & KNN_IDX_MASK;
                     if (d == dk && i > ik) continue;
                     const float nm = p.iwd ? knn_state[2 * BQ + q] : 1.f;
                     const float2 gq = gl2[((size_t)cy * p.wq + cx) * p.T + tr];
@@ -720,20 +860,14 @@ __device__ __forceinline__ float knn_tile_reach(const KnnParams &p, const float 
     for (int o2 = 32; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
     const float linmax = (L1 ? m : sqrtf(m)) * 1.0001f + 0.01f;
     const int D = (int)fminf(linmax / (float)(16 * p.sp), 1.0e6f) + 1;
-    const float ay0 = (float)(by_ * 16 * p.sp) - 0.5f, ay1 = (float)(min(by_ * 16 + 16, p.hq) * p.sp) - 0.5f;
-    const float ax0 = (float)(bx_ * 16 * p.sp) - 0.5f, ax1 = (float)(min(bx_ * 16 + 16, p.wq) * p.sp) - 0.5f;
+    float ay0, ay1, ax0, ax1;
+    knn_tile_area(p, by_, bx_, ay0, ay1, ax0, ax1);
     float r = 0.f;
     // one (source tile, class) pair: its K-th distance counts if its queries can reach this tile's area
     auto pair_reach = [&](int sy, int sx, int c) {
         const int tb = sy * ntx + sx;
-        const int ty0 = sy * 16, ty1 = min(ty0 + 16, p.hq) - 1, tx0 = sx * 16, tx1 = min(tx0 + 16, p.wq) - 1;
-        // cells of the source tile that can hold queries of class c (knn_device.h)
-        int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
-        if (c == 1) cy1 = min(cy1, bd - 1);
-        if (c == 2) cy0 = max(cy0, p.hq - bd);
-        if (c == 3) cx1 = min(cx1, bd - 1);
-        if (c == 4) cx0 = max(cx0, p.wq - bd);
-        if (cy0 > cy1 || cx0 > cx1) return;
+        int cy0, cy1, cx0, cx1;
+        if (!knn_tile_class_cells(p, sy, sx, c, bd, cy0, cy1, cx0, cx1)) return;
         const float dk = tile_dkmax[((size_t)bt * nt + tb) * KNN_NCLS + c];
         const float lin = (L1 ? dk : sqrtf(dk)) * 1.0001f + 0.01f;
         const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
@@ -801,7 +935,8 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
     const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    // (tiles of the BUCKET grid: knn_tile_of)
     // ---- phase 1: reach of this tile = the largest linear K-th distance among the tiles whose queries can touch it
     //      (Chebyshev gap between this tile's cell area and their query centres); bucketed ranges of the tile rows --
     // Wavefront 0 alone.  Step A: the largest K-th distance of ANY class of ANY tile of the slice (coalesced reads).  A
@@ -817,10 +952,10 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     } else if (tid < 128) {
         const int ln = tid - 64;
         int gs = 0, ge = 0;
-        const int yy = by_ * TS + ln;
-        if (ln < TS && yy < p.hq) {
-            const int xa = bx_ * TS, xb = min(xa + TS, p.wq);
-            gs = cs[yy * p.wq + xa]; ge = cs[yy * p.wq + xb];
+        const int yq = by_ * TS - KNN_TILE_OFF + ln;       // cell row of the tile (query numbering)
+        if (ln < TS && yq >= -p.m && yq < p.hq + p.m) {
+            const int xa = max(bx_ * TS - KNN_TILE_OFF, -p.m), xb = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m);
+            if (xa < xb) { gs = cs[knn_ci(p, yq, xa)]; ge = cs[knn_ci(p, yq, xb)]; }
         }
         int run = ge - gs;
 #pragma unroll
@@ -832,7 +967,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     //      travel together, measured slower: too many tiles stage twice): the K-th distance, K-th index | tie flag and
     //      dL/dLUT of the tile's query cells and the halo the reach asks for ------------------------------------------
     float *ldk; int *lik; float2 *lg, *lgn;
-    int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS, rx0 = bx_ * TS;
+    int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS - KNN_TILE_OFF, rx0 = bx_ * TS - KNN_TILE_OFF;      // (query-grid coordinates)
     const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
@@ -846,7 +981,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
         // The K-th INDEX (only read on the exact path, for a tie) stays in global memory then, which keeps the workgroup
         // at 19.5 KB -- eight per CU as before.  With the flow_to_next gradient (8 more bytes per cell) the pitch stays 32.
         RP = NEXT ? (RW <= 32 ? 32 : RW) : KNN_BW_PITCH;
-        ry0 = by_ * TS - RQ; rx0 = bx_ * TS - RQ;
+        ry0 = by_ * TS - KNN_TILE_OFF - RQ; rx0 = bx_ * TS - KNN_TILE_OFF - RQ;
         // separate arrays (the hot loop reads the K-th distance and the gradient only; neighbouring lanes then read
         // neighbouring 4- and 8-byte words): K-th distance, [K-th index,] dL/dLUT, [dL/dflow_next]
         const size_t ncell = (size_t)RW * RP + KNN_BW_WMAX;
@@ -872,8 +1007,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                     ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
                     g = gl2[(size_t)yy * p.wq + xx];
                     if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
-                    tie |= ik & KNN_TIE_FLAG;
-                    ik &= ~KNN_TIE_FLAG;
+                    if (ik & KNN_FAR_FLAG) dk = -1.f;        // served by the fallback kernel: k_knn_bwd_far adds its gradient
+                    else tie |= ik & KNN_TIE_FLAG;
+                    ik &= KNN_IDX_MASK;
                 }
                 ldk[rr * RP + cc] = dk; lg[rr * RP + cc] = g;
                 if (NEXT) { lik[rr * RP + cc] = ik; lgn[rr * RP + cc] = gn; }
@@ -888,6 +1024,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     };
     if ((tid & 63) == 0) s_tiew[tid >> 6] = 0;
     __syncthreads();
+    if (s_rowbase[TS] == 0) return;          // (a tile of the margin ring that holds no point: workgroup-uniform)
     const float R = s_wr[0];
     const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo the reach asks for, in cells
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
@@ -961,7 +1098,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                         const float dk = ldk[ro + cx];
                         // (the K-th index: staged only with the flow_to_next gradient, else read where it lives -- a tie is rare)
                         const bool in = (d < dk) || (d == dk && i <= (NEXT ? lik[ro + cx]
-                                                                            : (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & ~KNN_TIE_FLAG)));
+                                                                            : (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & KNN_IDX_MASK)));
                         if (in) {
                             const float2 e = lg[ro + cx];
                             ay += e.x; ax += e.y;
@@ -979,8 +1116,8 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
                     const float dk = knn_state[q];
                     if (d > dk) continue;
-                    const int ik = reinterpret_cast<const int *>(knn_state)[BQ + q] & ~KNN_TIE_FLAG;
-                    if (d == dk && i > ik) continue;
+                    const int ikf = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                    if ((ikf & KNN_FAR_FLAG) || (d == dk && i > (ikf & KNN_IDX_MASK))) continue;
                     const float2 gq = gl2[(size_t)cy * p.wq + cx];
                     ay += gq.x; ax += gq.y;
                     if (has_next) { const float2 gnq = gn2[(size_t)cy * p.wq + cx]; an.x += gnq.x; an.y += gnq.y; }
@@ -1007,6 +1144,176 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
         stamp[4 * lblk + 2] = RQ | (use_lds ? 0 : 256) | (anytie ? 512 : 0) | (anyslow ? 1024 : 0); stamp[4 * lblk + 3] = total;
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of the FAR queries (the ones the forward's fallback kernel served: fewer than K points within the largest square
+// of the strip kernel -- queries inside a band the flow field emptied, whose K neighbours lie in a thin segment of a disc
+// tens of pixels away).  Counting them in the tile maxima would make every point of the tiles around such a band search a
+// window of hundreds of query cells for the few dozen of them that hold it; k_knn_bwd_tile therefore leaves them out, and
+// here the search runs the other way round, as in the forward: one thread per far query walks the cell rows of the tile
+// that its disc (centre, K-th distance) touches, tests the bucketed points of the chord and adds dL/dLUT to the
+// accumulators of the members -- 64-bit fixed point in LDS (scaled by a power of two from the largest gradient of the list:
+// integer sums, any order, bitwise reproducible), then added to what the gather wrote for the point.
+// grid: as k_knn_bwd_tile (one workgroup per tile of the bucket grid and (sample, bin)); returns at once when the list of
+// the (sample, bin) is empty (the white-noise benchmark: ~1 query per slice)
+// ------------------------------------------------------------------------------------------
+#define KNN_FAR_CAP 512       // points of a tile per round of accumulators
+template <bool L1, bool NEXT>
+__global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const int *__restrict__ cell_start,
+                                                     const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                     const float *__restrict__ glut, const float *__restrict__ gnext,
+                                                     const float *__restrict__ knn_state, const int *__restrict__ far,
+                                                     float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
+                                                     float2 *__restrict__ gtraj_direct, int gx, int gy) {
+    constexpr int TS = 16;
+    __shared__ unsigned long long s_acc[KNN_FAR_CAP * (NEXT ? 4 : 2)];
+    __shared__ int s_rowbase[TS + 1];
+    __shared__ int s_rowg[TS];
+    __shared__ float s_wm[4];
+    const int tid = threadIdx.x;
+    const int nblk = gx * gy * p.B * p.nb;
+    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (lblk >= nblk) return;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
+    const int *fl = far + (size_t)bt * (p.G + 1);
+    const int nfar = min(fl[0], p.G);
+    if (nfar <= 0) return;
+    const size_t BQ = (size_t)p.B * p.nb * p.G;
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const float2 *sp_ = spos + (size_t)bt * p.n;
+    const int *si_ = sidx + (size_t)bt * p.n;
+    const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
+    const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
+    const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
+    const float *dks = knn_state + (size_t)bt * p.G;
+    const int *iks = reinterpret_cast<const int *>(knn_state) + BQ + (size_t)bt * p.G;
+    // pixel extent of the tile's cells; the outermost cells also hold what lies beyond the margin: open on that side
+    float ay0, ay1, ax0, ax1;
+    knn_tile_area(p, by_, bx_, ay0, ay1, ax0, ax1);
+    const int ty0 = max(by_ * TS - KNN_TILE_OFF, -p.m), tx0 = max(bx_ * TS - KNN_TILE_OFF, -p.m);      // first / last cell row and column of the tile (query numbering)
+    const int ty1 = min(by_ * TS - KNN_TILE_OFF + TS, p.hq + p.m) - 1, tx1 = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m) - 1;
+    if (ty0 == -p.m) ay0 = -INFINITY;
+    if (ty1 == p.hq + p.m - 1) ay1 = INFINITY;
+    if (tx0 == -p.m) ax0 = -INFINITY;
+    if (tx1 == p.wq + p.m - 1) ax1 = INFINITY;
+    {   // does the disc of any far query touch this tile?  (the lattice-like point sets of the benchmark have a handful of far
+        // queries per (sample, bin): nearly every workgroup ends here)
+        int any = 0;
+        for (int e = tid; e < nfar; e += 256) {
+            const int cell = fl[1 + e];
+            const int cy = cell / p.wq, cx = cell - cy * p.wq;
+            const float dk = dks[cell];
+            const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+            const float gy_ = fmaxf(0.f, fmaxf(qy - ay1, ay0 - qy)), gx_ = fmaxf(0.f, fmaxf(qx - ax1, ax0 - qx));
+            any |= ((L1 ? gy_ + gx_ : gy_ * gy_ + gx_ * gx_) <= dk) ? 1 : 0;
+        }
+        if (!__syncthreads_or(any)) return;
+    }
+    // bucketed ranges of the tile rows
+    if (tid < 64) {
+        int gs = 0, ge = 0;
+        const int yq = by_ * TS - KNN_TILE_OFF + tid;
+        if (tid < TS && yq >= -p.m && yq < p.hq + p.m) {
+            const int xa = max(bx_ * TS - KNN_TILE_OFF, -p.m), xb = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m);
+            if (xa < xb) { gs = cs[knn_ci(p, yq, xa)]; ge = cs[knn_ci(p, yq, xb)]; }
+        }
+        int run = ge - gs;
+#pragma unroll
+        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
+        if (tid < TS) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
+        if (tid == 0) s_rowbase[0] = 0;
+    }
+    // largest gradient of the list -> the power of two that scales the fixed-point sums (values below 2^40, up to 2^20 of them)
+    float gm = 0.f;
+    for (int e = tid; e < nfar; e += 256) {
+        const int cell = fl[1 + e];
+        const float2 g = gl2[cell];
+        gm = fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y)));
+        if (has_next) { const float2 gn = gn2[cell]; gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o2, 64));
+    if ((tid & 63) == 0) s_wm[tid >> 6] = gm;
+    __syncthreads();
+    gm = fmaxf(fmaxf(s_wm[0], s_wm[1]), fmaxf(s_wm[2], s_wm[3]));
+    const int total = s_rowbase[TS];
+    if (total == 0 || !(gm > 0.f) || !(gm < INFINITY)) return;          // (no point to receive anything / nothing to add)
+    int ex;
+    (void)frexpf(gm, &ex);                                              // gm = f * 2^ex, f in [0.5, 1)
+    const double scale = ldexp(1.0, 40 - ex), inv_scale = ldexp(1.0, ex - 40);
+    const float invK = 1.f / (float)p.K;
+    constexpr int NA = NEXT ? 4 : 2;
+    for (int c0 = 0; c0 < total; c0 += KNN_FAR_CAP) {
+        for (int i = tid; i < KNN_FAR_CAP * NA; i += 256) s_acc[i] = 0ull;
+        __syncthreads();
+        for (int e = tid; e < nfar; e += 256) {
+            const int cell = fl[1 + e];
+            const int cy = cell / p.wq, cx = cell - cy * p.wq;
+            const float dk = dks[cell];
+            const int ik = iks[cell] & KNN_IDX_MASK;
+            const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+            // does the disc of the query touch the tile's area at all?
+            const float gy_ = fmaxf(0.f, fmaxf(qy - ay1, ay0 - qy)), gx_ = fmaxf(0.f, fmaxf(qx - ax1, ax0 - qx));
+            if ((L1 ? gy_ + gx_ : gy_ * gy_ + gx_ * gx_) > dk) continue;
+            const float2 g = gl2[cell];
+            const float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
+            const long long fy = __double2ll_rn((double)g.x * scale), fx = __double2ll_rn((double)g.y * scale);
+            const long long fny = __double2ll_rn((double)gn.x * scale), fnx = __double2ll_rn((double)gn.y * scale);
+            for (int yq = ty0; yq <= ty1; ++yq) {
+                // a point of cell row yq is at least dyc away along y (none for the open side of an outermost row); along x
+                // it then lies within wx of the query
+                float dyc = fmaxf((float)abs(yq - cy) - 0.5f, 0.f) * (float)p.sp;
+                const float w2 = L1 ? dk - dyc : dk - dyc * dyc;
+                if (w2 < 0.f) continue;
+                const int xr = (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1;
+                int xa = max(cx - xr, tx0), xb = min(cx + xr, tx1);
+                if (cx - xr <= -p.m) xa = tx0;                   // (the outermost column holds everything beyond it)
+                if (cx + xr >= p.wq + p.m - 1) xb = tx1;
+                if (xa > xb) continue;
+                const int rr = yq - (by_ * TS - KNN_TILE_OFF);
+                const int js = cs[knn_ci(p, yq, xa)], je = cs[knn_ci(p, yq, xb + 1)];
+                for (int j = js; j < je; ++j) {
+                    const float2 pj = sp_[j];
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                    if (d > dk || (d == dk && si_[j] > ik)) continue;
+                    const int li = s_rowbase[rr] + (j - s_rowg[rr]) - c0;
+                    if (li < 0 || li >= KNN_FAR_CAP) continue;
+                    atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fy);
+                    atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fx);
+                    if (NEXT && has_next) { atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fny); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fnx); }
+                }
+            }
+        }
+        __syncthreads();
+        for (int li = tid; li < min(KNN_FAR_CAP, total - c0); li += 256) {
+            const long long ay = (long long)s_acc[li * NA + 0], ax = (long long)s_acc[li * NA + 1];
+            const long long any_ = NEXT ? (long long)s_acc[li * NA + 2] : 0ll, anx = NEXT ? (long long)s_acc[li * NA + 3] : 0ll;
+            if ((ay | ax | any_ | anx) == 0ll) continue;
+            const int pi = c0 + li;
+            int lo = 0, hi = TS;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
+            const int i = si_[s_rowg[lo] + (pi - s_rowbase[lo])];
+            const float vy = invK * (float)((double)ay * inv_scale), vx = invK * (float)((double)ax * inv_scale);
+            if (gtraj_direct != nullptr) {
+                float2 *dst = gtraj_direct + ((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i;
+                const float2 o = *dst;
+                *dst = make_float2(o.x - vy, o.y - vx);
+            } else {
+                float2 *dst = tmp_g + (size_t)bt * p.n + i;
+                const float2 o = *dst;
+                *dst = make_float2(o.x + vy, o.y + vx);
+                if (NEXT && gnext != nullptr) {
+                    float2 *da = tmp_a + (size_t)bt * p.n + i;
+                    const float2 oa = *da;
+                    *da = make_float2(oa.x + invK * (float)((double)any_ * inv_scale), oa.y + invK * (float)((double)anx * inv_scale));
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // backward, step 2: one thread per (sample, trajectory point): combine the per-bin partials.
@@ -1074,71 +1381,47 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine_direct(const KnnParams 
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
-// Tuning switches for A/B measurements, read once per process from the environment (defaults in brackets):
-//   MPC_KNN_MODE=global     nothing staged in LDS, every query searches the global arrays     [thread]
-//   MPC_KNN_BLOCKS=<n>      force the LDS share of the query kernel to n workgroups per CU    [largest that fits]
-//   MPC_KNN_STAGE_FLOW=0    gather the flows from global memory instead of staging them       [1]
-//   MPC_KNN_NT=256|512      query workgroup size (16x16 or 16x32 queries)                     [by occupancy]
-//   MPC_KNN_R0=<d>          offset of the initial search radius                               [0]
-//   MPC_KNN_BWD_TS=16|32    tile side of the backward gather                                  [16]
-//   MPC_KNN_HALO=<h>        rings staged beyond the initial radius by the query kernel        [1]
-//   MPC_KNN_STRIP=0         tile query kernel (k_knn_query) also where the strip kernel applies  [1]
-//   MPC_KNN_BWD_FUSED=0     backward as k_knn_reach + k_knn_bwd_points also where k_knn_bwd_tile applies [1]
-//   MPC_KNN_BWD_SCATTER=1   query-centric scatter backward (knn_bwd_scatter.hip) where it applies; measured slower   [0]
-//   MPC_KNN_BWD_G=<g>       strips per workgroup of the scatter backward                               [by grid size]
-//   MPC_KNN_BWD_DIRECT=0    k_knn_bwd_tile writes per-bin partials for k_knn_bwd_combine instead of d traj(t_mid) in place [1]
-struct KnnTuning {
-    int global_mode, blocks, stage_flow, nt, r0, bwd_ts, halo, strip, bwd_fused, bucket_s, bwd_scatter, bwd_direct;
-};
-static const KnnTuning &knn_tuning() {
-    static const KnnTuning t = [] {
-        KnnTuning v{0, 0, 1, 0, 0, 16, 0, 1, 1, 0, 0, 1};
-        const char *e;
-        if ((e = getenv("MPC_KNN_MODE"))) v.global_mode = (e[0] == 'g');
-        if ((e = getenv("MPC_KNN_BLOCKS"))) v.blocks = atoi(e);
-        if ((e = getenv("MPC_KNN_STAGE_FLOW"))) v.stage_flow = atoi(e) != 0;
-        if ((e = getenv("MPC_KNN_NT"))) v.nt = atoi(e);
-        if ((e = getenv("MPC_KNN_R0"))) v.r0 = atoi(e);
-        if ((e = getenv("MPC_KNN_BWD_TS"))) v.bwd_ts = atoi(e) == 32 ? 32 : 16;
-        if ((e = getenv("MPC_KNN_HALO"))) v.halo = atoi(e);
-        if ((e = getenv("MPC_KNN_STRIP"))) v.strip = atoi(e) != 0;
-        if ((e = getenv("MPC_KNN_BWD_FUSED"))) v.bwd_fused = atoi(e) != 0;
-        if ((e = getenv("MPC_KNN_BUCKET_S"))) v.bucket_s = atoi(e);
-        if ((e = getenv("MPC_KNN_BWD_SCATTER"))) v.bwd_scatter = atoi(e) != 0;
-        if ((e = getenv("MPC_KNN_BWD_DIRECT"))) v.bwd_direct = atoi(e) != 0;
-        return v;
-    }();
-    return t;
-}
-
-// smallest square that can hold K points at the mean point density and pass the ring bound
+// search radius of a query (cells) at the MEAN point density: the smallest square that can hold K points and pass the ring
+// bound.  The strip kernel starts from it (and chooses every query's own radius from the summed-area table of the cell
+// counts: a flow field thins the points out where it diverges and packs them where it converges); it is also the depth of the
+// border classes of the tile maxima.
 int mpc_knn_r_init(const mpc_shape *s) {
     const double dens = (double)s->n / ((double)s->hq * s->wq);
     int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
-    r_init += knn_tuning().r0;
     return r_init < 1 ? 1 : r_init;
 }
 
-// The backward of this shape is the query-centric scatter (knn_bwd_scatter.hip): the strip kernel serves the forward
-// (whatever idx_out), one reference time, 'mean' interpolation.
-bool mpc_knn_lean(const mpc_shape *s) {
-    const KnnTuning &t = knn_tuning();
-    if (!t.bwd_scatter || !t.strip || t.global_mode) return false;
-    if (s->T != 1 || ((s->flags & MPC_F_SCHEME_IWD) && s->K > 1)) return false;
-    if (s->n < s->K || s->K < 1) return false;
-    return mpc_knn_strip_usable(s, mpc_knn_r_init(s)) && mpc_knn_bwd_scatter_usable(s);
-}
+// margin of the bucket grid (knn_device.h): the strip kernel never reaches the outermost ring
+int mpc_knn_margin(const mpc_shape *) { return KNN_MARGIN; }
 
-void mpc_knn_lean_sizes(const mpc_shape *s, int64_t *mask_bytes, int64_t *rowtab_bytes, int64_t *fbits_bytes, int64_t *gacc_bytes) {
-    KnnStripGeom g;
-    *mask_bytes = *rowtab_bytes = *fbits_bytes = *gacc_bytes = 0;
-    if (!mpc_knn_strip_geom(s, mpc_knn_r_init(s), &g)) return;
-    const int64_t bt = (int64_t)s->B * s->nb, strips = (int64_t)g.gx * g.gy;
-    *mask_bytes = bt * strips * 3 * 256 * 4;
-    *rowtab_bytes = bt * strips * (g.NR + 1) * 8;
-    *fbits_bytes = bt * s->hq * ((s->wq + 31) / 32) * 4;
-    *gacc_bytes = bt * (int64_t)s->n * 8 * ((s->flags & MPC_F_WANT_NEXT) ? 2 : 1);
+// true where the forward is the strip kernel + fallback (num_tref == 1: the shipped configurations)
+static bool knn_fwd_is_strip(const mpc_shape *s, const int32_t *idx_out) {
+    return idx_out == nullptr && mpc_knn_strip_usable(s, mpc_knn_r_init(s));
 }
+// true where the backward of this shape is k_knn_bwd_tile + k_knn_bwd_far (the gather with per-tile reaches)
+static bool knn_bwd_is_tile(const mpc_shape *s) {
+    return s->B > 0 && s->T == 1 && !((s->flags & MPC_F_SCHEME_IWD) && s->K > 1);
+}
+// the fallback kernel lists the queries it served for k_knn_bwd_far (and keeps them out of the tile maxima)
+bool mpc_knn_uses_far_list(const mpc_shape *s) { return knn_bwd_is_tile(s) && knn_fwd_is_strip(s, nullptr); }
+
+// The counting sort of the points of a (sample, bin): S workgroups per (sample, bin) with the counters in LDS -- as many as
+// keep the launch within one workgroup per CU (measured at C3: 210 workgroups 39 us, split three ways 68 us; at B = 1: 15
+// workgroups 33 us, split eight ways 19 us) -- or, returned as true, the global-memory sort (bucket grids beyond the LDS).
+static bool knn_sort_plan(const mpc_shape *s, int *S_out, size_t *lds_out) {
+    const int m = mpc_knn_margin(s), hb = s->hq + 2 * m, wb = s->wq + 2 * m;
+    int S = 256 / ((s->B > 0 ? s->B : 1) * s->nb);
+    if (S > 8) S = 8;
+    if (S > hb) S = hb;
+    if (S < 1) S = 1;
+    size_t tail = (size_t)((s->n + 1) / 2 * 2) * 2 + (size_t)((s->n + 31) / 32) * 4;              // index array + bitmap of a crowded cell
+    const size_t sat_tmp = (size_t)((hb + 7) / 8) * (wb + 1) * 4;                                   // scratch of the summed-area table (S == 1)
+    if (S == 1 && sat_tmp > tail) tail = sat_tmp;
+    const size_t lds = (size_t)((hb + S - 1) / S) * wb * 4 + tail;
+    *S_out = S; *lds_out = lds;
+    return (int64_t)hb * wb > MPC_KNN_LDS_SORT_CELLS || lds > 145 * 1024;
+}
+bool mpc_knn_big_sort(const mpc_shape *s) { int S; size_t l; return knn_sort_plan(s, &S, &l); }
 
 static int set_max_lds(const void *fn, const char *who) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1168,23 +1451,20 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
     int *cell_start = (int *)((char *)ws + L.off_cell_start);
+    int *sat = (int *)((char *)ws + L.off_knn_sat);
     float2 *spos = (float2 *)((char *)ws + L.off_spos);
     int *sidx = (int *)((char *)ws + L.off_sidx);
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     int *fail = (int *)((char *)ws + L.off_knn_fail);
-    const int ntiles = mpc_cdiv(s->hq, 16) * mpc_cdiv(s->wq, 16);
+    int *retry = (int *)((char *)ws + L.off_knn_retry);
+    int *far = mpc_knn_uses_far_list(s) ? (int *)((char *)ws + L.off_knn_far) : nullptr;
+    const int ntiles = knn_tiles_x(s->wq, p.m) * knn_tiles_y(s->hq, p.m);
     int *zero_ptr = (int *)((char *)ws + L.off_fcount);
     const int zero_words = (zero_event_counters && L.strip_rows > 0) ? L.nfb + 2 * L.nbb + 8 : 0;
     EvCountArgs evc = (zero_words > 0) ? mpc_event_count_args(s, events, ws) : EvCountArgs{};
-    if (s->B > 256) evc = EvCountArgs{};      // (the fallback kernel's first B workgroups finish the count)
-    KnnLeanBufs lean{nullptr, nullptr, nullptr};
-    if (L.knn_lean) {
-        lean.masks = (unsigned *)((char *)ws + L.off_knn_mask);
-        lean.rowtab = (int2 *)((char *)ws + L.off_knn_rowtab);
-        lean.fbits = (unsigned *)((char *)ws + L.off_knn_fbits);
-    }
-    unsigned *lean_fbits = lean.fbits;
-    const int lean_fwords = L.knn_lean ? s->hq * ((s->wq + 31) / 32) : 0;
+    const bool strip = knn_fwd_is_strip(s, idx_out);
+    // (the fallback kernel's first B workgroups finish the count; the count rides in workgroups of the strip kernel)
+    if (s->B > 256 || !strip || !mpc_knn_strip_counts_events(s, &evc)) evc = EvCountArgs{};
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bucket<true, 8>, __func__))) return rc;
@@ -1196,26 +1476,20 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         if ((rc = set_max_lds((const void *)k_knn_query<512>, __func__))) return rc;
         attr_once.mark();
     }
-    // workgroups per (sample, bin) of the LDS sort: as many as keep the launch within one workgroup per CU
-    // (measured at C3: 210 workgroups 39 us, split three ways 68 us; at B = 1: 15 workgroups 33 us, split
-    // eight ways 19 us)
-    int S = 256 / (s->B * s->nb);
-    if (S > 8) S = 8;
-    if (knn_tuning().bucket_s > 0) S = knn_tuning().bucket_s;
-    if (S > s->hq) S = s->hq;
-    if (S < 1) S = 1;
-    const size_t sort_lds = (size_t)((s->hq + S - 1) / S) * s->wq * 4 + (size_t)((s->n + 1) / 2 * 2) * 2;
-    if (p.G > MPC_KNN_LDS_SORT_CELLS || sort_lds > 150 * 1024) {
+    int S; size_t sort_lds;
+    bool sat_launch = true;          // (the LDS sort of a whole (sample, bin) builds the summed-area table itself)
+    if (knn_sort_plan(s, &S, &sort_lds)) {
         int *cursor = (int *)((char *)ws + L.off_knn_cursor);
-        const int e = mpc_zero_async(cursor, (size_t)s->B * s->nb * p.G * sizeof(int), st);
+        const int e = mpc_zero_async(cursor, (size_t)s->B * s->nb * p.Gb * sizeof(int), st);
         if (e) return e;
-        const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.G, 256), s->B * s->nb);
+        const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.Gb, 4), s->B * s->nb);
         MPC_LAUNCH(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
-        MPC_LAUNCH(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords);
+        MPC_LAUNCH(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, retry, far, zero_ptr, zero_words);
         MPC_LAUNCH(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
-        MPC_LAUNCH(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx);
+        MPC_LAUNCH(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx, traj);
     } else {
-#define KB_LAUNCH(C_, N_) MPC_LAUNCH((k_knn_bucket<C_, N_>), dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, spos, sidx, S, tile_dkmax, ntiles, fail, zero_ptr, zero_words, lean_fbits, lean_fwords)
+        sat_launch = S != 1;
+#define KB_LAUNCH(C_, N_) MPC_LAUNCH((k_knn_bucket<C_, N_>), dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, strip ? sat : nullptr, spos, sidx, S, tile_dkmax, ntiles, fail, retry, far, zero_ptr, zero_words)
         if (s->n <= 8 * 1024) KB_LAUNCH(true, 8);
         else if (s->n <= 16 * 1024) KB_LAUNCH(true, 16);
         else if (s->n <= 20 * 1024) KB_LAUNCH(true, 20);
@@ -1224,23 +1498,22 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
 #undef KB_LAUNCH
     }
     MPC_CHECK_LAUNCH();
-    // smallest square that can hold K points at the mean point density and pass the ring bound
-    const double dens = (double)s->n / (double)p.G;
-    const KnnTuning &tune = knn_tuning();
     const int r_init = mpc_knn_r_init(s);
-    // fast path (num_tref == 1, the shipped configurations): strip kernel + per-query fallback (knn_strip.hip)
-    if (tune.strip && !tune.global_mode && idx_out == nullptr && mpc_knn_strip_usable(s, r_init))
-    {
-        rc = mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init,
-                                  L.knn_lean ? &lean : nullptr, evc.events ? &evc : nullptr, st);
+    // fast path (num_tref == 1, the shipped configurations): strip kernel + fallback (knn_strip.hip)
+    if (strip) {
+        if (sat_launch) {
+            MPC_LAUNCH(k_knn_sat, dim3(s->B * s->nb), dim3(1024), (size_t)((p.hb + 7) / 8) * (p.wb + 1) * sizeof(int), st, p, cell_start, sat);
+            MPC_CHECK_LAUNCH();
+        }
+        rc = mpc_knn_strip_launch(s, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, retry, far, r_init,
+                                  evc.events ? &evc : nullptr, st);
         if (!rc && done) *done = (zero_words > 0 ? 1 : 0) | (evc.events ? 2 : 0);
         return rc;
     }
-    // (idx_out wanted where the scatter backward applies: the tile kernel below writes the indices, then the strip
-    // kernels run as well so that the state the backward expects exists -- a diagnostics path)
-    const bool also_strip = L.knn_lean && idx_out != nullptr;
-    const int want_blocks = tune.blocks, want_nt = tune.nt;
-    int RH = r_init + (tune.halo > 0 ? tune.halo : 1);     // halo of the staged region: one ring of slack by default
+    // everything else (num_tref > 1, idx_out wanted, K or densities the strip kernel does not hold): the tile kernel, one
+    // thread per query with a per-thread radix histogram (knn_one_query)
+    const double dens = (double)s->n / (double)p.G;
+    int RH = r_init + 1;                                   // halo of the staged region: one ring of slack
     if (RH > 16) RH = 16;
     const int RW = 16 + 2 * RH;
     // LDS per workgroup decides how many wavefronts a CU holds, and the kernel is latency bound: measured at
@@ -1248,22 +1521,20 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     // what is left of the per-workgroup share after the histogram columns, provided it still holds 1.25x the
     // mean region; 16x32-query workgroups (512 threads) carry less halo per query and are used when they
     // reach more wavefronts per CU.
-    const int stage_flow = tune.stage_flow;
-    const size_t per_pt = 8 + 2 + ((s->T == 1 && stage_flow) ? 8 : 0) + (p.want_next ? 8 : 0);
+    const size_t per_pt = 8 + 2 + (s->T == 1 ? 8 : 0) + (p.want_next ? 8 : 0);
     int best_nt = 256, best_cap = 64, best_waves = 0;
     for (int nt = 256; nt <= 512; nt *= 2) {
-        if (want_nt > 0 && nt != want_nt) continue;
-        if (nt == 512 && s->hq <= 16 && want_nt == 0) continue;
+        if (nt == 512 && s->hq <= 16) continue;
         const int RWY = nt / 16 + 2 * RH;
         const size_t fixed = (size_t)KNN_HW * nt * 4 + (size_t)RWY * (RW + 1) * 2 + 64;
         const double mean_pts = dens * RW * RWY;
-        for (int blocks = want_blocks > 0 ? want_blocks : 2048 / nt; blocks >= 1; --blocks) {
+        for (int blocks = 2048 / nt; blocks >= 1; --blocks) {
             const size_t share = (size_t)160 * 1024 / blocks;
             const size_t budget = (share > 64 * 1024 ? 64 * 1024 : share) - 1024;  // static LDS + allocation granule
             if (budget <= fixed) continue;
             int c = (int)((budget - fixed) / per_pt / 64 * 64);
             if (c > 65472) c = 65472;                                              // 16-bit staged offsets
-            if (c >= (int)(1.25 * mean_pts) + 64 || blocks == 1 || want_blocks > 0) {
+            if (c >= (int)(1.25 * mean_pts) + 64 || blocks == 1) {
                 const int full = ((int)(1.5 * mean_pts) + 128 + 63) / 64 * 64;
                 if (blocks == 1 && c > full) c = full;
                 if (c < 64) c = 64;
@@ -1272,46 +1543,35 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
             }
         }
     }
-    int cap = best_cap;
-    if (tune.global_mode) cap = 0;             // nothing staged: every query searches the global arrays
+    const int cap = best_cap;
     const int RWYb = best_nt / 16 + 2 * RH;
     const size_t lds = (size_t)KNN_HW * best_nt * 4 + (size_t)RWYb * (RW + 1) * 2 + 64 + per_pt * cap;
     const int gx = mpc_cdiv(s->wq, 16), gy = mpc_cdiv(s->hq, best_nt / 16);
     const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
     if (best_nt == 512)
         MPC_LAUNCH(k_knn_query<512>, grid, dim3(512), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, 1, gx, gy);
     else
         MPC_LAUNCH(k_knn_query<256>, grid, dim3(256), lds, st, p, traj, cell_start, spos, sidx, flow_lut,
-                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, stage_flow, gx, gy);
+                           flow_next, knn_state, idx_out, tile_dkmax, r_init, RH, cap, 1, gx, gy);
     MPC_CHECK_LAUNCH();
-    if (also_strip) {
-        rc = mpc_knn_strip_launch(s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, &lean, nullptr, st);
-        if (rc) return rc;
-    }
     if (done) *done = zero_words > 0 ? 1 : 0;
     return 0;
 }
 
-// true where the backward of this shape is k_knn_bwd_tile (the gather with per-tile reaches)
-static bool knn_bwd_is_tile(const mpc_shape *s, const mpc_ws_layout &L) {
-    return !L.knn_lean && s->B > 0 && s->T == 1 && !((s->flags & MPC_F_SCHEME_IWD) && s->K > 1) && knn_tuning().bwd_ts == 16 && knn_tuning().bwd_fused;
-}
-
 bool mpc_knn_reach_job(const mpc_shape *s, const float *knn_state, void *ws, KnnReachJob *job) {
     job->on = 0;
-    static const int reach_forced = getenv("MPC_KNN_BWD_REACH") ? (atoi(getenv("MPC_KNN_BWD_REACH")) != 0 ? 1 : 0) : -1;
-    if (!s || !knn_state || !ws || mpc_validate_shape(s) || reach_forced == 0) return false;
+    if (!s || !knn_state || !ws || mpc_validate_shape(s)) return false;
     const mpc_ws_layout L = mpc_layout(s);
-    if (!knn_bwd_is_tile(s, L)) return false;
+    if (!knn_bwd_is_tile(s)) return false;
     job->p = knn_params(s);
     job->tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * job->p.G;
     job->reach = (float *)((char *)ws + L.off_knn_reach);
-    job->gx = mpc_cdiv(s->wq, 16); job->gy = mpc_cdiv(s->hq, 16);
+    job->gx = knn_tiles_x(s->wq, job->p.m); job->gy = knn_tiles_y(s->hq, job->p.m);
     job->bd = knn_band_depth(mpc_knn_r_init(s));
     // (below one round of the gather's workgroups the side job costs the host kernel more than the gather gains: C2, B = 1 x 15
     // bins = 1 200 workgroups: +3.5 us on k_lut_accum's slowest workgroup for -1.5 on the gather; C4, 3 280: +3.7 / -6)
-    job->on = (reach_forced == 1 || (int64_t)job->gx * job->gy * s->B * s->nb >= 2048) ? 1 : 0;
+    job->on = ((int64_t)job->gx * job->gy * s->B * s->nb >= 2048) ? 1 : 0;
     return job->on != 0;
 }
 
@@ -1342,41 +1602,25 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<16>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_bwd_points<32>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, false>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, true>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, false>, __func__))) return rc;
         if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, true>, __func__))) return rc;
         attr_once.mark();
     }
-    if (L.knn_lean) {
-        // scatter backward: every query adds dLUT / K to its neighbours, read from the bit masks the strip kernel left
-        KnnLeanBufs lean{(unsigned *)((char *)ws + L.off_knn_mask), (int2 *)((char *)ws + L.off_knn_rowtab),
-                         (unsigned *)((char *)ws + L.off_knn_fbits)};
-        if ((rc = mpc_knn_bwd_scatter_launch(s, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, knn_state, &lean,
-                                             (unsigned long long *)((char *)ws + L.off_knn_gacc), tmp_g, tmp_a, st))) return rc;
-        const int64_t totalb = (int64_t)s->B * s->n;
-        MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
-                           grad_flow_next ? tmp_a : nullptr, grad_traj);
-        MPC_CHECK_LAUNCH();
-        return 0;
-    }
-    const int ntiles = mpc_cdiv(s->wq, 16) * mpc_cdiv(s->hq, 16);
-    if (s->T == 1 && !p.iwd && knn_tuning().bwd_ts == 16 && knn_tuning().bwd_fused) {
+    const int gxb = knn_tiles_x(s->wq, p.m), gyb = knn_tiles_y(s->hq, p.m), ntiles = gxb * gyb;
+    if (knn_bwd_is_tile(s)) {
         const int RWm = 16 + 2 * KNN_RQ_MAX;
         const size_t ldsb = grad_flow_next ? ((size_t)RWm * RWm + KNN_BW_WMAX) * 24                 // RWm >= 32: covers pitch 32 too
                                            : ((size_t)RWm * KNN_BW_PITCH + KNN_BW_WMAX) * 12;
-        const int gxb = mpc_cdiv(s->wq, 16), gyb = mpc_cdiv(s->hq, 16);
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
-        float2 *direct = (grad_flow_next == nullptr && knn_tuning().bwd_direct) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
+        float2 *direct = (grad_flow_next == nullptr) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
         // The reach of every tile NOT as the first phase of every workgroup: the gather is a chain of phases per workgroup at
         // eight workgroups per CU -- 8.1 of a workgroup's 14.6 us pass before its window loop (tools/bwd_stamp_probe.py) -- and
         // without the two dependent round trips of the reach phase it runs 132 -> 117 us at C3.  mpc_focus_bwd has the event
         // backward's kernel compute the reaches on the side (reach_ready); called alone, a launch of its own does it (~6-8 us)
         // where that pays: from about four rounds of workgroups (C3: 8.2; B = 1: 0.6 -- there it would cost 3 us).
-        // MPC_KNN_BWD_REACH=0 / 1 forces both off / the launch on.
-        static const int reach_forced = getenv("MPC_KNN_BWD_REACH") ? (atoi(getenv("MPC_KNN_BWD_REACH")) != 0 ? 1 : 0) : -1;
-        const bool reach_launch = !reach_ready && (reach_forced >= 0 ? reach_forced == 1 : (int64_t)gxb * gyb * s->B * s->nb >= 4 * 2048);
+        const bool reach_launch = !reach_ready && (int64_t)gxb * gyb * s->B * s->nb >= 4 * 2048;
         const float *reach_pre = reach_ready ? reach : nullptr;
         if (reach_launch) {
             const size_t rl = ((size_t)gxb * gyb * (KNN_NCLS + 1) + 16) * sizeof(float);
@@ -1396,6 +1640,17 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH
         MPC_CHECK_LAUNCH();
+        if (mpc_knn_uses_far_list(s)) {
+            // the queries the forward's fallback kernel served (left out of the gather above)
+            const int *far = (const int *)((char *)ws + L.off_knn_far);
+#define KF_LAUNCH(L1_, NEXT_)                                                                                            \
+            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), gridb, dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
+                               knn_state, far, tmp_g, tmp_a, direct, gxb, gyb)
+            if (p.l1) { if (grad_flow_next) KF_LAUNCH(true, true); else KF_LAUNCH(true, false); }
+            else { if (grad_flow_next) KF_LAUNCH(false, true); else KF_LAUNCH(false, false); }
+#undef KF_LAUNCH
+            MPC_CHECK_LAUNCH();
+        }
         const int64_t totalb = (int64_t)s->B * s->n;
         if (direct) MPC_LAUNCH(k_knn_bwd_combine_direct, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, grad_traj);
         else MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
@@ -1403,20 +1658,14 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         MPC_CHECK_LAUNCH();
         return 0;
     }
+    // num_tref > 1 or 'iwd': the general gather, one thread per bucketed point and tile (k_knn_bwd_points)
     MPC_LAUNCH(k_knn_reach, dim3(s->B * s->nb), dim3(256), (size_t)ntiles * sizeof(float), st, p, tile_dkmax, reach);
     MPC_CHECK_LAUNCH();
-    // (32x32-cell tiles with 1024 threads measured slower at C3: 296 vs 229 us)
-    const int ts = knn_tuning().bwd_ts;
-    const int RWmax = ts + 2 * KNN_RQ_MAX;
+    const int RWmax = 16 + 2 * KNN_RQ_MAX;
     const size_t lds = (s->T == 1 && !p.iwd) ? (size_t)RWmax * RWmax * (16 + (grad_flow_next ? 8 : 0)) : 0;
-    const int gx = mpc_cdiv(s->wq, ts), gy = mpc_cdiv(s->hq, ts);
-    const dim3 grid(((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8);
-    if (ts == 32)
-        MPC_LAUNCH(k_knn_bwd_points<32>, grid, dim3(1024), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
-                           grad_flow_next, knn_state, reach, tmp_g, tmp_a, gx, gy);
-    else
-        MPC_LAUNCH(k_knn_bwd_points<16>, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
-                           grad_flow_next, knn_state, reach, tmp_g, tmp_a, gx, gy);
+    const dim3 grid(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
+    MPC_LAUNCH(k_knn_bwd_points<16>, grid, dim3(256), lds, st, p, cell_start, spos, sidx, grad_flow_lut,
+                       grad_flow_next, knn_state, reach, tmp_g, tmp_a, gxb, gyb);
     MPC_CHECK_LAUNCH();
     const int64_t total = (int64_t)s->B * s->n;
     MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g,

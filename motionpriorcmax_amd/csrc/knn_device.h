@@ -15,6 +15,10 @@
 // bit 30 of the saved K-th index: some point lies at exactly the K-th distance but was excluded (tie resolved by
 // index); without it the backward's membership test is simply `d <= K-th distance`
 #define KNN_TIE_FLAG 0x40000000
+// bit 29: the query was served by the fallback kernel and is on the far list of its (sample, bin): the backward's gather
+// skips it (its K-th distance is not in the tile maxima either) and k_knn_bwd_far adds its gradient
+#define KNN_FAR_FLAG 0x20000000
+#define KNN_IDX_MASK 0x1fffffff
 // Largest K-th distance per 16x16 cell tile, kept per CLASS of query so that the backward's search reach stays tight:
 // queries next to the image border have clipped neighbourhoods and therefore K-th distances up to 2-4x larger than
 // inner ones, but they sit in a thin band; a per-tile maximum over all of them would inflate the reach of every tile
@@ -24,16 +28,31 @@
 #define KNN_NCLS 5
 #define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
 
+// The points are bucketed into a grid of cells that extends `m` cells beyond the query grid on every side (cell (y, x),
+// y in [-m, hq + m), x in [-m, wq + m): the query cells are y in [0, hq), x in [0, wq)).  Trajectory points that a flow has
+// carried out of the image keep their own cells there; only what lies beyond the margin is clamped into the outermost ring,
+// which no search of the fast path reaches (m = KNN_RCAP + 1).  Without the margin every point outside the image piled up in
+// the border cells of the query grid (an expanding flow field: a hundred points per corner cell), and every border query
+// had to look at all of them.
 struct KnnParams {
-    int B, nb, T, n, hq, wq, sp, K, G;
+    int B, nb, T, n, hq, wq, sp, K, G;      // G = hq * wq query cells
+    int m, hb, wb, Gb;                       // margin; bucket grid hb x wb = (hq + 2m) x (wq + 2m), Gb cells
     int l1, iwd, want_next;
     float off;   // sp/2 - 0.5 : centre of cell 0 (focus.py:117)
 };
+#define KNN_RCAP 6                 // largest search radius (cells) of the strip kernel; beyond it a query goes to the fallback
+#define KNN_MARGIN 8              // > KNN_RCAP; a multiple of 8, so that 8 query rows x 2 columns of a strip lie in one 16 x 16 tile
+// smallest count of points in the (2r + 1)^2 cell square of a query for which radius r is tried (K / (pi / 4) at K = 32: the
+// disc of the ring bound holds K points if they are spread evenly over the square; calibrated on smooth flow fields)
+__host__ __device__ static inline int knn_square_need(int K) { return (int)((float)K * 1.28f + 0.5f); }
+
+int mpc_knn_margin(const mpc_shape *s);
 
 static KnnParams knn_params(const mpc_shape *s) {
     KnnParams p;
     p.B = s->B; p.nb = s->nb; p.T = s->T; p.n = s->n; p.hq = s->hq; p.wq = s->wq; p.sp = s->sp;
     p.K = s->K; p.G = s->hq * s->wq;
+    p.m = mpc_knn_margin(s); p.hb = s->hq + 2 * p.m; p.wb = s->wq + 2 * p.m; p.Gb = p.hb * p.wb;
     p.l1 = (s->flags & MPC_F_DIST_L1) ? 1 : 0;
     p.iwd = ((s->flags & MPC_F_SCHEME_IWD) && s->K > 1) ? 1 : 0;   // focus.py:145-147: K == 1 is a plain gather
     p.want_next = (s->flags & MPC_F_WANT_NEXT) ? 1 : 0;
@@ -41,10 +60,31 @@ static KnnParams knn_params(const mpc_shape *s) {
     return p;
 }
 
-__device__ __forceinline__ int cell_of(float v, int sp, int ncell) {
-    // cells are centred on the query points: cell c covers [c*sp - 0.5, (c+1)*sp - 0.5)
+__device__ __forceinline__ int cell_of(float v, int sp, int ncell, int m) {
+    // cells are centred on the query points: cell c covers [c*sp - 0.5, (c+1)*sp - 0.5); c in [-m, ncell + m), clamped
     const float c = floorf(mpc_div_sp(v + 0.5f, sp));
-    return (int)fminf(fmaxf(c, 0.f), (float)(ncell - 1));
+    return (int)fminf(fmaxf(c, (float)-m), (float)(ncell + m - 1));
+}
+// index of cell (y, x) -- query-grid coordinates, -m <= y < hq + m, -m <= x <= wq + m -- in cell_start
+__device__ __forceinline__ int knn_ci(const KnnParams &p, int y, int x) { return (y + p.m) * p.wb + (x + p.m); }
+// bucket cell of a point
+__device__ __forceinline__ int knn_cell_index(const KnnParams &p, float py, float px) {
+    return knn_ci(p, cell_of(py, p.sp, p.hq, p.m), cell_of(px, p.sp, p.wq, p.m));
+}
+// 16 x 16 cell tiles of the bucket grid (the backward's workgroups; the tile maxima of the K-th distance).  Tile t holds the
+// cells 16 t - 16 .. 16 t - 1 (query numbering): the tiles of the query grid are the same with and without the margin, and
+// the margin cells above / left of the image have a ring of tiles of their own (mostly empty: those workgroups return at once).
+#define KNN_TILE_OFF 16
+static_assert(KNN_MARGIN <= KNN_TILE_OFF, "the margin lies within one ring of tiles");
+__host__ __device__ static inline int knn_tile_of(int c) { return (c + KNN_TILE_OFF) >> 4; }
+__host__ __device__ static inline int knn_tiles_x(int wq, int m) { return knn_tile_of(wq + m - 1) + 1; }
+__host__ __device__ static inline int knn_tiles_y(int hq, int m) { return knn_tile_of(hq + m - 1) + 1; }
+// summed-area table of the cell counts: sat[(y + m) * (wb + 1) + (x + m)] = points in cells (y', x') with y' < y and x' < x
+__device__ __forceinline__ int knn_square_count(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r) {
+    const int y0 = max(cy - r, -p.m) + p.m, y1 = min(cy + r, p.hq + p.m - 1) + p.m + 1;
+    const int x0 = max(cx - r, -p.m) + p.m, x1 = min(cx + r, p.wq + p.m - 1) + p.m + 1;
+    const int W1 = p.wb + 1;
+    return sat[y1 * W1 + x1] - sat[y0 * W1 + x1] - sat[y1 * W1 + x0] + sat[y0 * W1 + x0];
 }
 
 __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float px, int l1) {
@@ -89,8 +129,8 @@ struct Acc {
             js = row[x0 - c.rx0];
             je = row[x1 + 1 - c.rx0];
         } else {
-            js = c.cs[yy * p.wq + x0];
-            je = c.cs[yy * p.wq + x1 + 1];
+            js = c.cs[knn_ci(p, yy, x0)];
+            je = c.cs[knn_ci(p, yy, x1 + 1)];
         }
     }
     __device__ __forceinline__ float2 pos(int j) const { return LDS ? c.lpos[j] : c.spos[j]; }
@@ -108,36 +148,54 @@ struct Acc {
 };
 
 // Returns false if the search needs more rings than the LDS halo holds (LDS variant only).
-template <bool LDS, bool L1, int NT>
+// r_init: first radius of the search square (cells).  DISC (global-array variant, the bulk fallback of the strip kernel): the
+// cells of a row that lie wholly beyond the ring bound are skipped -- a query deep inside an empty band (a flow field that
+// carried the points away from an image border) has its K neighbours in a thin segment of a large disc, and the corners of
+// the square hold as many points again; `flag_or` is OR-ed into the saved K-th index (KNN_FAR_FLAG).
+template <bool LDS, bool L1, int NT, bool DISC = false>
 __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int t, int cy, int cx,
                               int r_init, unsigned (*s_hist)[NT], float *__restrict__ flow_lut,
                               float *__restrict__ flow_next, float *__restrict__ knn_state,
-                              int *__restrict__ idx_out, float &dK_out) {
+                              int *__restrict__ idx_out, float &dK_out, int flag_or = 0) {
     const Acc<LDS> A{p, c, t};
     const int tid = threadIdx.x;
     const int bt = b * p.nb + t;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+    const int ylo = -p.m, yhi = p.hq + p.m - 1, xlo = -p.m, xhi = p.wq + p.m - 1;      // the bucket grid
     // ---- 1. grow the search square until K candidates are provably the nearest ---------------
     int r = r_init, y0, y1, x0, x1, cnt;
-    {   // next to the image border the square is clipped: start with one of the same cell count
+    if (!DISC) {   // next to the border of the bucket grid the square is clipped: start with one of the same cell count
         const int want = (2 * r_init + 1) * (2 * r_init + 1);
         for (;;) {
-            const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
-            const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
-            if (hh * ww >= want || (hh == p.hq && ww == p.wq) || (LDS && r >= c.RH)) break;
+            const int hh = min(cy + r, yhi) - max(cy - r, ylo) + 1;
+            const int ww = min(cx + r, xhi) - max(cx - r, xlo) + 1;
+            if (hh * ww >= want || (hh == p.hb && ww == p.wb) || (LDS && r >= c.RH)) break;
             ++r;
         }
     }
-    float upper, scale;
+    float upper = INFINITY, scale;
     bool whole;
+    // bucketed range of row yy of the search square; DISC: only the cells that can hold a point below the ring bound
+    auto row_range = [&](int yy, int &js, int &je) {
+        int xa = x0, xb = x1;
+        if (DISC && upper < INFINITY) {
+            // a point of cell row yy is at least dyc away along y; along x it must then lie within wx of the query
+            const float dyc = fmaxf((float)abs(yy - cy) - 0.5f, 0.f) * (float)p.sp;
+            const float w2 = L1 ? upper - dyc : upper - dyc * dyc;
+            if (!(w2 > 0.f)) { js = je = 0; return; }
+            const int xr = (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1;      // (+1: rounding of the square root)
+            xa = max(xa, cx - xr); xb = min(xb, cx + xr);
+        }
+        A.range(yy, xa, xb, js, je);
+    };
     for (;;) {
-        y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
-        x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
+        y0 = max(cy - r, ylo); y1 = min(cy + r, yhi);
+        x0 = max(cx - r, xlo); x1 = min(cx + r, xhi);
         // the LDS variant serves any square that lies inside the staged region: next to the image border a
         // grown square is wider than the halo but, clipped, still inside the tile (otherwise such queries finish
         // on the global arrays, one dependent L2 round trip per step: the tail of small launches)
         if (LDS && (y0 < c.ry0 || y1 >= c.ry0 + c.RWY || x0 < c.rx0 || x1 >= c.rx0 + c.RW)) return false;
-        whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
+        whole = (y0 == ylo && x0 == xlo && y1 == yhi && x1 == xhi);
         if (whole) {
             if (LDS) return false;
             // every point is a candidate: range of the histogram = largest distance
@@ -160,10 +218,10 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
         // software pipeline: the candidate positions of the next step and the cell range of the next row are
         // requested before the current ones are consumed (the wavefront otherwise parks on every LDS round trip)
         int njs, nje;
-        A.range(y0, x0, x1, njs, nje);
+        row_range(y0, njs, nje);
         for (int yy = y0; yy <= y1; ++yy) {
             const int js = njs, je = nje;
-            A.range(min(yy + 1, y1), x0, x1, njs, nje);
+            row_range(min(yy + 1, y1), njs, nje);
             if (js >= je) continue;
             float2 q[KNN_BATCH];
 #pragma unroll
@@ -228,10 +286,10 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
     const float fb = (float)bstar, fb1 = (bstar == KNN_BINS - 1) ? INFINITY : (float)(bstar + 1);
     int m = 0;
     int njs, nje;
-    A.range(y0, x0, x1, njs, nje);
+    row_range(y0, njs, nje);
     for (int yy = y0; yy <= y1; ++yy) {
         const int js = njs, je = nje;
-        A.range(min(yy + 1, y1), x0, x1, njs, nje);
+        row_range(min(yy + 1, y1), njs, nje);
         if (js >= je) continue;
         float2 qq[KNN_BATCH];
 #pragma unroll
@@ -322,7 +380,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
         int mm = 0;
         for (int yy = y0; yy <= y1; ++yy) {
             int js, je;
-            A.range(yy, x0, x1, js, je);
+            row_range(yy, js, je);
             for (int j = js; j < je; ++j) {
                 const float2 pj = A.pos(j);
                 const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
@@ -363,7 +421,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             float bd = INFINITY; int bi = 0x7fffffff;
             for (int yy = y0; yy <= y1; ++yy) {
                 int js, je;
-                A.range(yy, x0, x1, js, je);
+                row_range(yy, js, je);
                 for (int j = js; j < je; ++j) {
                     const float2 pj = A.pos(j);
                     const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
@@ -397,7 +455,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             const bool do_next = (tr == 0) && do_next0;
             for (int yy = y0; yy <= y1; ++yy) {
                 int js, je;
-                A.range(yy, x0, x1, js, je);
+                row_range(yy, js, je);
                 for (int j = js; j < je; ++j) {
                     const float2 pj = A.pos(j);
                     const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
@@ -427,7 +485,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
         }
     }
     knn_state[q] = dK;
-    reinterpret_cast<int *>(knn_state)[BQ + q] = iK | KNN_TIE_FLAG;      // (this routine does not look for excluded ties: flagged conservatively)
+    reinterpret_cast<int *>(knn_state)[BQ + q] = iK | KNN_TIE_FLAG | flag_or;      // (this routine does not look for excluded ties: flagged conservatively)
     knn_state[2 * BQ + q] = norm;
     // ---- 5. optional: the K indices in ascending (distance, index) order ---------------------
     if (idx_out != nullptr) {
@@ -436,7 +494,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
             float bd = INFINITY; int bi = 0x7fffffff;
             for (int yy = y0; yy <= y1; ++yy) {
                 int js, je;
-                A.range(yy, x0, x1, js, je);
+                row_range(yy, js, je);
                 for (int j = js; j < je; ++j) {
                     const float2 pj = A.pos(j);
                     const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
@@ -456,7 +514,7 @@ __device__ bool knn_one_query(const KnnParams &p, const QueryCtx &c, int b, int 
 
 // band depth (cells) of the border classes of the tile maxima
 __host__ __device__ static inline int knn_band_depth(int r_init) { return r_init + 1; }
-// first search radius of a query (cells), from the point density; shared by the forward and the backward
+// search radius of a query at the MEAN point density (cells): the first radius tried, and the depth of the border classes
 int mpc_knn_r_init(const mpc_shape *s);
 
 #ifdef __HIPCC__
@@ -465,64 +523,46 @@ __device__ __forceinline__ unsigned knn_query_classes(const KnnParams &p, int cy
     const unsigned m = (cy < bd ? 2u : 0u) | (cy >= p.hq - bd ? 4u : 0u) | (cx < bd ? 8u : 0u) | (cx >= p.wq - bd ? 16u : 0u);
     return m ? m : 1u;
 }
-// one query's K-th distance into the tile maxima (atomicMax on the bits of a non-negative float)
+// one query's K-th distance into the tile maxima (atomicMax on the bits of a non-negative float); tiles of the bucket grid
 __device__ __forceinline__ void knn_tile_max_add(float *__restrict__ tile_dkmax, const KnnParams &p, int bt, int cy, int cx,
                                                  int bd, float dK) {
-    if (tile_dkmax == nullptr) return;          // scatter backward: no tile maxima
-    const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
-    int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4)) * KNN_NCLS;
+    if (tile_dkmax == nullptr) return;
+    const int gx16 = knn_tiles_x(p.wq, p.m), gy16 = knn_tiles_y(p.hq, p.m);
+    int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + knn_tile_of(cy)) * gx16 + knn_tile_of(cx)) * KNN_NCLS;
     const unsigned m = knn_query_classes(p, cy, cx, bd);
 #pragma unroll
     for (int c = 0; c < KNN_NCLS; ++c) if ((m >> c) & 1u) atomicMax(dst + c, __float_as_int(dK));
 }
-#endif
-
-#ifdef __HIPCC__
-// search square of a query (the rule of knn_one_query): next to the image border the clipped square starts with the
-// cell count of an unclipped one
-__device__ __forceinline__ int query_radius(const KnnParams &p, int cy, int cx, int r_init) {
-    const int want = (2 * r_init + 1) * (2 * r_init + 1);
-    int r = r_init;
-    for (;;) {
-        const int hh = min(cy + r, p.hq - 1) - max(cy - r, 0) + 1;
-        const int ww = min(cx + r, p.wq - 1) - max(cx - r, 0) + 1;
-        if (hh * ww >= want || (hh == p.hq && ww == p.wq)) break;
-        ++r;
-    }
+// Search radius of a query from the summed-area table of the cell counts: the smallest r in [rmin, KNN_RCAP] whose square
+// of (2r + 1)^2 cells (clipped to the bucket grid) holds at least `need` points; KNN_RCAP + 1 if none does.
+__device__ __forceinline__ int knn_sat_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int rmin, int need) {
+    int r = rmin;
+    while (r <= KNN_RCAP && knn_square_count(p, sat, cy, cx, r) < need) ++r;
     return r;
 }
 #endif
 
 // ---- strip kernel (knn_strip.hip): the fast path of the forward for num_tref == 1 ---------------------------
 // `fail` = int [1 + B*nb*G]: fail[0] counts the queries handed to the fallback kernel (zeroed, like tile_dkmax, by the
-// bucket kernels), fail[1..] lists them.
+// bucket kernels), fail[1..] lists them (bits 0..29 the query, bits 30..31 why).
+// `retry` = int [1 + strips]: strips whose points overflowed the staging area (k_knn_strip_retry searches them in quarters).
+// `far`  = int [B*nb][1 + G]: per (sample, bin) the number and the cells (cy * wq + cx) of the queries the fallback kernel
+// served, for k_knn_bwd_far (counters zeroed by the bucket kernels); null where the backward is not the tile gather.
 bool mpc_knn_strip_usable(const mpc_shape *s, int r_init);
-// geometry of the strip kernel's launch: strips of WS query columns x TH rows, gx x gy of them per (sample, bin), NR region
-// rows and `cap` staged slots per strip
-struct KnnStripGeom { int WS, TH, gx, gy, NR, cap; size_t lds; };
-bool mpc_knn_strip_geom(const mpc_shape *s, int r_init, KnnStripGeom *g);
-// what the strip kernel leaves for the scatter backward (knn_bwd_scatter.hip), all in the workspace:
-//   masks  uint32 [B*nb][gy*gx][3][256]   neighbours of every query as bits over its slot range (query = row-major in the strip)
-//   rowtab int2   [B*nb][gy*gx][NR + 1]   {first bucketed point, first slot | points << 16} of every region row; then {slots, 0}
-//   fbits  uint32 [B*nb][hq][ceil(wq/32)] queries served by the fallback kernel (zeroed by the bucket kernels)
-struct KnnLeanBufs { unsigned *masks; int2 *rowtab; unsigned *fbits; };
+bool mpc_knn_uses_far_list(const mpc_shape *s);
 struct EvCountArgs;      // ev_count_device.h: event rows to count per backward bucket in spare workgroups of the strip kernel, or null
-int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
-                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
-                         const KnnLeanBufs *lean, const EvCountArgs *evc, hipStream_t st);
-// true where the backward of this shape is the scatter kernel (MPC_KNN_BWD_SCATTER=1 and: strip forward, num_tref == 1, 'mean')
-bool mpc_knn_lean(const mpc_shape *s);
-bool mpc_knn_bwd_scatter_usable(const mpc_shape *s);
-int mpc_knn_bwd_scatter_launch(const mpc_shape *s, const int *cell_start, const float2 *spos, const int *sidx,
-                               const float *grad_flow_lut, const float *grad_flow_next, const float *knn_state,
-                               const KnnLeanBufs *lean, unsigned long long *gacc, float2 *tmp_g, float2 *tmp_a, hipStream_t st);
+int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const int *sat, const float2 *spos, const int *sidx,
+                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int *retry, int *far, int r_init,
+                         const EvCountArgs *evc, hipStream_t st);
+bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc);
 
 // ------------------------------------------------------------------------------------------
 // Reach of every 16x16 tile of ONE (sample, bin) for the backward gather (k_knn_bwd_tile): the largest linear K-th distance
 // among the (tile, class) pairs whose queries can touch the tile's cell area (Chebyshev gap between that area and their
-// query centres; classes: knn_query_classes).  Step A: the linear bounds of all pairs into LDS and the largest of them -- a
-// source tile k tile rings away has its query centres at least (k - 1) * 16 cells from a tile's area, so only D =
-// floor(linmax / (16 sp)) + 1 rings matter (one, in practice).  Step B: one (tile, neighbour tile) item per thread and round.
+// query centres; classes: knn_query_classes).  Tiles are those of the BUCKET grid (tile (ty, tx) = cells 16 ty - m ...).
+// Step A: the linear bounds of all pairs into LDS and the largest of them -- a source tile k tile rings away has its query
+// centres at least (k - 1) * 16 cells from a tile's area, so only D = floor(linmax / (16 sp)) + 1 rings matter (one, in
+// practice).  Step B: one (tile, neighbour tile) item per thread and round.
 // Called by all threads of a workgroup of any size (<= 1024); s_mem: nt * (KNN_NCLS + 1) + 16 floats of LDS; the caller
 // synchronises before it reuses s_mem.  Hosts: k_knn_reach_tiles (a launch of its own), k_lut_accum (the event backward's
 // kernel, which runs just before the gather in mpc_focus_bwd: one workgroup per slice does it on the side).
@@ -533,6 +573,24 @@ struct KnnReachJob {
     float *reach;
     int gx, gy, bd, on;
 };
+
+#ifdef __HIPCC__
+// query cells of class c inside tile (sy, sx) of the bucket grid: false if there are none
+__device__ __forceinline__ bool knn_tile_class_cells(const KnnParams &p, int sy, int sx, int c, int bd, int &cy0, int &cy1, int &cx0, int &cx1) {
+    cy0 = max(sy * 16 - KNN_TILE_OFF, 0); cy1 = min(sy * 16 + 16 - KNN_TILE_OFF, p.hq) - 1;
+    cx0 = max(sx * 16 - KNN_TILE_OFF, 0); cx1 = min(sx * 16 + 16 - KNN_TILE_OFF, p.wq) - 1;
+    if (c == 1) cy1 = min(cy1, bd - 1);
+    if (c == 2) cy0 = max(cy0, p.hq - bd);
+    if (c == 3) cx1 = min(cx1, bd - 1);
+    if (c == 4) cx0 = max(cx0, p.wq - bd);
+    return cy0 <= cy1 && cx0 <= cx1;
+}
+// pixel extent of the cells of tile (ty, tx) of the bucket grid (its bucketed points lie inside, or -- clamped into the
+// outermost ring -- farther out, which only makes them farther from every query)
+__device__ __forceinline__ void knn_tile_area(const KnnParams &p, int ty, int tx, float &ay0, float &ay1, float &ax0, float &ax1) {
+    ay0 = (float)(max(ty * 16 - KNN_TILE_OFF, -p.m) * p.sp) - 0.5f; ay1 = (float)(min(ty * 16 + 16 - KNN_TILE_OFF, p.hq + p.m) * p.sp) - 0.5f;
+    ax0 = (float)(max(tx * 16 - KNN_TILE_OFF, -p.m) * p.sp) - 0.5f; ax1 = (float)(min(tx * 16 + 16 - KNN_TILE_OFF, p.wq + p.m) * p.sp) - 0.5f;
+}
 
 template <bool L1>
 __device__ __forceinline__ void knn_reach_slice(const KnnParams &p, const float *__restrict__ tile_dkmax, float *__restrict__ reach,
@@ -562,20 +620,14 @@ __device__ __forceinline__ void knn_reach_slice(const KnnParams &p, const float 
         const int by_ = tile / ntx, bx_ = tile - by_ * ntx;
         const int sy = by_ + nbr / W - D, sx = bx_ + nbr % W - D;
         if (sy < 0 || sy >= nty || sx < 0 || sx >= ntx) continue;
-        const float ay0 = (float)(by_ * 16 * p.sp) - 0.5f, ay1 = (float)(min(by_ * 16 + 16, p.hq) * p.sp) - 0.5f;
-        const float ax0 = (float)(bx_ * 16 * p.sp) - 0.5f, ax1 = (float)(min(bx_ * 16 + 16, p.wq) * p.sp) - 0.5f;
+        float ay0, ay1, ax0, ax1;
+        knn_tile_area(p, by_, bx_, ay0, ay1, ax0, ax1);
         const int tb = sy * ntx + sx;
-        const int ty0 = sy * 16, ty1 = min(ty0 + 16, p.hq) - 1, tx0 = sx * 16, tx1 = min(tx0 + 16, p.wq) - 1;
         float r = 0.f;
 #pragma unroll
         for (int c = 0; c < KNN_NCLS; ++c) {
-            // cells of the source tile that can hold queries of class c
-            int cy0 = ty0, cy1 = ty1, cx0 = tx0, cx1 = tx1;
-            if (c == 1) cy1 = min(cy1, bd - 1);
-            if (c == 2) cy0 = max(cy0, p.hq - bd);
-            if (c == 3) cx1 = min(cx1, bd - 1);
-            if (c == 4) cx0 = max(cx0, p.wq - bd);
-            if (cy0 > cy1 || cx0 > cx1) continue;
+            int cy0, cy1, cx0, cx1;
+            if (!knn_tile_class_cells(p, sy, sx, c, bd, cy0, cy1, cx0, cx1)) continue;
             const float lin = s_lin[tb * KNN_NCLS + c];
             const float qy0 = (float)(cy0 * p.sp) + p.off, qy1 = (float)(cy1 * p.sp) + p.off;
             const float qx0 = (float)(cx0 * p.sp) + p.off, qx1 = (float)(cx1 * p.sp) + p.off;
@@ -587,15 +639,18 @@ __device__ __forceinline__ void knn_reach_slice(const KnnParams &p, const float 
     __syncthreads();
     for (int i = tid; i < nt; i += nthr) reach[(size_t)bt * nt + i] = __int_as_float(s_r[i]);
 }
+#endif
 // what the event backward needs to host the reach computation (on = 0: not this shape / not this backward)
 bool mpc_knn_reach_job(const mpc_shape *s, const float *knn_state, void *ws, KnnReachJob *job);
 int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut, const float *grad_flow_next,
                        const float *knn_state, float *grad_traj, void *ws, void *stream, int reach_ready);
 
+#ifdef __HIPCC__
 // One 8-byte LDS read as ONE ds_read_b64 (volatile: the compiler may not pair it with its neighbour into ds_read2_b64, which
 // the LDS serves at half the rate of two single reads -- MI355X_MICROARCH.md, LDS table).  p must point into LDS.
 __device__ __forceinline__ float2 knn_lds_f2(const float2 *p) {
     typedef const volatile __attribute__((address_space(3))) unsigned long long lds_u64;
-    const unsigned long long b = *(lds_u64 *)(unsigned)(size_t)p;        // (low half of a flat LDS address = the LDS offset)
+    const unsigned long long b = *(lds_u64 *)(uintptr_t)(unsigned)(size_t)p;        // (low half of a flat LDS address = the LDS offset)
     return make_float2(__uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
 }
+#endif

@@ -7,8 +7,13 @@
 //     columns +- r are staged row by row, so the candidates of a query -- the rows [cy - r, cy + r] of the strip --
 //     are ONE contiguous slot range (points outside the query's square are farther than the ring bound and drop out
 //     by the same `d < upper` test that makes the search exact);
+//   * EVERY QUERY HAS ITS OWN RADIUS r, read off the summed-area table of the cell counts (k_knn_sat): the smallest square
+//     that holds about K / (pi / 4) points.  A trained network's flow field thins the trajectory points out where it
+//     diverges, packs them where it converges and empties a band along the borders it moves away from; one radius from the
+//     mean density (rounds 1-3) served white-noise coefficients only.  A region row is staged as wide as the widest square
+//     that uses it;
 //   * pass 1 walks the range in groups of eight slots with a wave-uniform trip count and keeps a NEARNESS byte of
-//     every slot (a monotone, DEcreasing map of the exact fp32 distance: 63 levels over [upper / 2, upper), one more
+//     every slot (a monotone, DEcreasing map of the exact fp32 distance: 63 levels over [0.4 upper, upper), one more
 //     for everything nearer, 0 for anything at or beyond the ring bound -- the float -> byte conversion saturates
 //     negative values to 0, so the map needs no clamp instruction) in a register array (statically indexed: the loop
 //     is fully unrolled);
@@ -18,10 +23,11 @@
 //   * pass 2 re-reads the bytes: slots nearer than the K-th level add their flow (the SWAR flag byte 0x80 / 0 converted
 //     to 128.0 / 0.0 is the weight of an fma; the factor 128 is a power of two, every rounding is that of the plain sum),
 //     slots at the K-th level are noted in a bit mask and ranked afterwards by exact (distance, index).
-// A query the fast path cannot serve (fewer than K candidates below the ring bound, more slots or more keys at
-// the K-th level than the registers hold, a square that covers the whole grid, a strip whose points overflow the
-// staging area) is appended to a list and searched by k_knn_fallback, one wavefront per query: the result is the
-// exact K-nearest set for any input, ties to the lowest index.
+// A query the fast path cannot serve (no square up to KNN_RCAP cells holds enough points: the inside of an emptied band;
+// fewer than K candidates below the ring bound after all; more slots than the registers hold; a strip whose points overflow
+// the staging area even in quarters) is appended to a list and searched by k_knn_fallback -- one wavefront per query while
+// the list is short, one thread per query when it is long: the result is the exact K-nearest set for any input, ties to
+// the lowest index.
 #include "knn_device.h"
 #include "ev_count_device.h"
 #include <stdlib.h>
@@ -29,15 +35,17 @@
 #define KS_NT 256
 #define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
-#define KS_NLEV 64                  // nearness levels: 1 .. 63 over [upper / 2, upper) (clipped squares: [upper / 4, upper)), 64 = nearer than that; byte 0 = not a candidate
+#define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
 #define KS_TAIL (4 * KS_MAXCH + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
-#define KS_FB_SLOTS 4               // fallback: candidates per lane (64 * 4 per query)
-#ifndef KS_FB_GROW0
-#define KS_FB_GROW0 1                // fallback: rings added to a square that held too few candidates, first time
-#endif
+#define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
+#define KS_FB_WAVE_MAX (1 << 30)    // longest list served a wavefront per query; longer: a thread per query (measured: the per-lane
+                                    // gathers of the thread form cost 5-7 ns per query against ~2 of the wavefront form: not used)
+#define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
+#define KS_RETRY_BLOCKS 768         // workgroups of the retry kernel (3 per CU)
+static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
 
 // value of lane `l` (wave-uniform l): v_readlane, no LDS round trip
 __device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -52,28 +60,512 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// One strip (workgroup-wide): the query rows [pr0, pr1) of strip `lblk`.  SPLIT = false: the whole strip (pr0 = 0, pr1 = TH); a
+// strip whose points do not fit the staging area (a place where the flow field packs the points) goes on the retry list and
+// is searched again by k_knn_strip_retry in quarters (SPLIT = true); what does not fit a quarter goes to the fallback list.
+template <int WS, bool L1, bool NEXT, bool IWD, bool SPLIT>
+__device__ __forceinline__ void strip_body(const KnnParams &p, const float *__restrict__ traj,
+                                           const int *__restrict__ cell_start, const int *__restrict__ sat,
+                                           const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                           float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                           float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                           int *__restrict__ fail, int *__restrict__ retry, int r_init, int cap, int gx, int gy,
+                                           int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, int *s_rq) {
+    constexpr int TH = KS_NT / WS;
+    constexpr int NR = TH + 2 * KNN_RCAP;               // region rows: the strip's query rows and the largest radius above and below
+    static_assert(NR <= KS_NT, "one thread per region row");
+    const int tid = threadIdx.x;
+    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
+    const int sy = bxy / gx, sx = bxy - sy * gx;
+    const int b = bt / p.nb, t = bt - b * p.nb;
+    const int qx0 = sx * WS, qy0 = sy * TH;
+    const int qx1 = min(qx0 + WS, p.wq) - 1, qy1 = min(qy0 + TH, p.hq) - 1;
+    const int ry_base = qy0 - KNN_RCAP;          // grid row of region row 0 (may lie outside the bucket grid: an empty row)
+    // ---- LDS carve-up ----------------------------------------------------------------------------
+    int2 *s_row = reinterpret_cast<int2 *>(s_dyn);             // [NR] {first bucketed slot, points (-1: no such row)}
+    int *s_rowstart = reinterpret_cast<int *>(s_row + NR);     // [NR + 1] first slot of every region row
+    size_t o = ((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15;
+    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
+    float2 *lflow = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
+    float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL) * 8 : 0;
+    unsigned short *lidx = reinterpret_cast<unsigned short *>(s_dyn + o);
+
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const int *sat_bt = sat + (size_t)bt * (p.hb + 1) * (p.wb + 1);
+    const float2 *sp_ = spos + (size_t)bt * p.n;
+    const int *si_ = sidx + (size_t)bt * p.n;
+    const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
+
+    // ---- the query of this thread and its search radius -------------------------------------------
+    // Thread -> query: 16-row groups of the strip (a wavefront = two groups).  The queries next to the top and bottom
+    // border of the image are the expensive ones (half of their neighbourhood lies outside the image: larger squares, up to
+    // 96 slots against 63) and a wavefront pays for its most expensive lane, so the group holding the bottom border trades
+    // places with group 1: ONE wavefront of a full-height strip carries both borders, not two.
+    int grp = tid / (16 * WS);
+    if (qy0 == 0 && p.hq <= TH) {
+        const int gb = (p.hq - 1) >> 4;
+        if (gb >= 2) grp = (grp == 1) ? gb : ((grp == gb) ? 1 : grp);
+    }
+    const int cy = qy0 + grp * 16 + (tid % (16 * WS)) / WS, cx = qx0 + tid % WS;
+    const bool valid = cy <= qy1 && cx <= qx1;
+    // Radius from the summed-area table (four loads per radius tried): the smallest r whose square holds `need` points.
+    // Starts at the radius of the mean density; only a clearly denser place tries smaller ones.
+    int r = 0;
+    bool served = false;
+    if (valid) {
+        const int need = knn_square_need(p.K);
+        r = min(r_init, KNN_RCAP);
+        const int n0 = knn_square_count(p, sat_bt, cy, cx, r);
+        if (n0 >= need) {
+            if (2 * n0 >= 3 * need) while (r > 1 && knn_square_count(p, sat_bt, cy, cx, r - 1) >= need) --r;
+        } else r = knn_sat_radius(p, sat_bt, cy, cx, r + 1, need);
+        served = r <= KNN_RCAP;
+    }
+    {   // radius of the widest square of every query row (the WS lanes of a row are neighbours)
+        int rr = served ? r : 0;
+#pragma unroll
+        for (int o2 = 1; o2 < WS; o2 <<= 1) rr = max(rr, __shfl_xor(rr, o2, 64));
+        if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = rr;
+    }
+    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
+    __syncthreads();
+    // ---- column extent of every region row = the widest square (of the query rows [pr0, pr1) of the strip) that uses the
+    //      row; slots of the region rows: an exclusive scan of the row lengths; a row of even length gets one dummy slot so
+    //      that the row pitch is odd (consecutive rows then start in different LDS banks: with the 8 points per row of a
+    //      regular lattice an unpadded pitch puts every fourth row on the same banks).  Returns the slots of the region.
+    int pitch = 1;
+    auto region_rows = [&](int pr0, int pr1) -> int {
+        int len = -1, padded = 0, gs = 0;
+        if (tid < NR) {
+            const int y = ry_base + tid;
+            int R = 0;
+            const int c0 = max(tid - 2 * KNN_RCAP, pr0), c1 = min(tid, pr1 - 1);       // query rows within KNN_RCAP of this row
+            for (int c = c0; c <= c1; ++c) { const int rq = s_rq[c]; if (abs(c - (tid - KNN_RCAP)) <= rq) R = max(R, rq); }
+            if (R > 0 && y >= -p.m && y < p.hq + p.m) {
+                const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
+                gs = cs[knn_ci(p, y, xl)];
+                len = cs[knn_ci(p, y, xh + 1)] - gs;
+                padded = len + ((len & 1) ? 0 : 1);
+            }
+        }
+        int incl = padded;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if ((tid & 63) >= o2) incl += v; }
+        const int wmx = wave_max_i(padded);
+        if ((tid & 63) == 63) { s_wsum[tid >> 6] = incl; s_wmax[tid >> 6] = wmx; }
+        __syncthreads();
+        int run = incl - padded;
+        for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
+        if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int2(gs, len); }
+        if (tid == NR - 1) s_rowstart[NR] = run + padded;
+        // row pitch of the staging loop = the longest row of the region
+        pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
+        __syncthreads();
+        return s_rowstart[NR];
+    };
+    const bool inpass = valid && (cy - qy0) >= pr0 && (cy - qy0) < pr1;
+    const int total = region_rows(pr0, pr1);
+    bool overflow = false;
+    if (total > cap) {
+        if (!SPLIT) {                 // (workgroup-uniform) again in quarters: k_knn_strip_retry
+            if (tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = lblk;
+            return;
+        }
+        overflow = true;              // even a quarter of the strip does not fit: its queries go to the fallback list
+    }
+    {
+        const bool act = inpass && served && !overflow;
+        // ---- stage positions, flows and indices: item = (region row, k-th slot of the row), KS_SB items per thread
+        //      with their (dependent) global loads in flight together ----------------------------------------------
+        if (!overflow) {
+            const float2 *tref0 = traj_b;                                     // T == 1: the reference time
+            const float2 *tnext = traj_b + (size_t)(p.T + t + 1) * p.n;       // next bin (if any)
+            const bool has_next = NEXT && (t < p.nb - 1);
+            // item -> (row, slot of the row) with a reciprocal multiply: (it + 0.5) / pitch is at least 0.5 / pitch away from
+            // an integer, far more than the rounding of the product (it < 2^14)
+            const int items = NR * pitch;
+            const float inv_pitch = __builtin_amdgcn_rcpf((float)pitch);        // (1 ulp: the margin below is 0.5 / pitch)
+            for (int base = 0; base < items; base += KS_NT * KS_SB) {
+                int slot[KS_SB], id[KS_SB];
+                bool in[KS_SB], real[KS_SB];
+                float2 pj[KS_SB], f0[KS_SB], f1[KS_SB];
+#pragma unroll
+                for (int u = 0; u < KS_SB; ++u) {
+                    const int it = base + u * KS_NT + tid, rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1), k = it - rr * pitch;
+                    const int2 row = s_row[rr];                                     // {first bucketed slot, points}
+                    in[u] = it < items && row.y >= 0 && k < (row.y | 1);            // (an even row has one dummy slot: odd pitch)
+                    real[u] = in[u] && k < row.y;
+                    slot[u] = s_rowstart[rr] + k;
+                    pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
+                    if (real[u]) { pj[u] = sp_[row.x + k]; id[u] = si_[row.x + k]; }
+                }
+#pragma unroll
+                for (int u = 0; u < KS_SB; ++u) {
+                    f0[u] = f1[u] = make_float2(0.f, 0.f);
+                    if (real[u]) {
+                        const float2 a = tref0[id[u]];
+                        f0[u] = make_float2(a.x - pj[u].x, a.y - pj[u].y);      // traj(t_ref) - traj(t_mid)  focus.py:140-141
+                        if (has_next) { const float2 c = tnext[id[u]]; f1[u] = make_float2(c.x - pj[u].x, c.y - pj[u].y); }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KS_SB; ++u) {
+                    if (in[u]) {
+                        lpos[slot[u]] = pj[u];
+                        lflow[slot[u]] = f0[u];
+                        if (NEXT) lnext[slot[u]] = f1[u];
+                        lidx[slot[u]] = (unsigned short)id[u];
+                    }
+                }
+            }
+            // the tail behind the staged slots: far-away positions, zero flows (lanes whose range is shorter than the
+            // wavefront's trip count read them, flagged off)
+            for (int i = total + tid; i < total + KS_TAIL; i += KS_NT) {
+                lpos[i] = make_float2(KS_FAR, KS_FAR);
+                lflow[i] = make_float2(0.f, 0.f);
+                if (NEXT) lnext[i] = make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- search --------------------------------------------------------------------------------------
+        const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+        bool failed = (inpass && !served) || (inpass && overflow);       // no radius up to KNN_RCAP holds enough points (why 0)
+        unsigned why = (inpass && served && overflow) ? 2u : 0u;      // diagnostics: top two bits of a list entry (0 few candidates, 1 too many slots, 2 staging overflow)
+        int s = 0, nsl = 0;
+        if (act) {
+            s = s_rowstart[cy - r - ry_base];
+            nsl = s_rowstart[cy + r - ry_base + 1] - s;
+            if (nsl > 4 * KS_MAXCH) { failed = true; why = 1u; nsl = 0; s = 0; }
+        }
+        // anything outside the square is at least lb away along one axis
+        const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
+        const float upper = L1 ? lb : lb * lb;
+        // NEARNESS of a slot, one byte: (upper - d) * (NLEV - 1) / (upper - lo) converted with saturation -- a monotone map of the
+        // exact fp32 distance (that is all exactness needs: a slot with a smaller byte is at least as far as every slot with a
+        // larger one).  0 <=> not below the ring bound (or a dummy slot: the conversion saturates negative values to 0, which
+        // is why the map runs downwards -- no clamp instruction per slot); 1 .. NLEV - 1 resolve [lo, upper); everything nearer
+        // than lo lands in NLEV .. 127 and counts as ONE level (NLEV).  lo = upper / 2: the K-th distance of an unclipped
+        // square sits near 0.83 upper; a clipped square was enlarged by whole rings, its K-th distance can be as low as
+        // upper / 2: lo = upper / 4.  Largest byte: upper * (NLEV - 1) / (upper - lo) = 126 or 84 -- bytes stay below 128, which
+        // the SWAR compares rely on.  (A candidate within half a level of the ring bound converts to 0: it is treated as
+        // outside, which only makes the fast path give up earlier -- the byte of anything at or beyond the bound is 0 for sure:
+        // the rounding of the fma is ~1e-5 of a level.)
+        const float lo_d = 0.4f * upper;
+        // (hardware reciprocal, 1 ulp: any constant near this one gives a monotone map; the largest byte stays below 127.5)
+        const float nscale = -(float)(KS_NLEV - 1) * __builtin_amdgcn_rcpf(upper - lo_d), loff = -upper * nscale;
+        const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
+        const float2 *pp = lpos + s;
+        // pass 1: nearness byte of every slot; groups of 8 slots whose loads are issued together
+        unsigned w[KS_MAXCH];
+#pragma unroll
+        for (int g = 0; g < KS_MAXCH / 2; ++g) {
+            w[2 * g] = w[2 * g + 1] = 0u;
+            if (8 * g < nmax) {
+                float2 pj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pj[u] = knn_lds_f2(pp + 8 * g + u);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    unsigned acc = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float d = pair_dist(qy, qx, pj[4 * h + u].x, pj[4 * h + u].y, L1);
+                        acc = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, nscale, loff), u, acc);       // saturating: negative -> 0
+                    }
+                    w[2 * g + h] = acc;
+                }
+            }
+        }
+        // number of slots with byte >= beta (1 <= beta <= 128): bytes are <= 127, so (byte + 128 - beta) has bit 7 exactly when
+        // byte >= beta, and no carry crosses a byte (words of groups not visited hold 0)
+        auto count_ge = [&](unsigned beta) {
+            const unsigned C = (128u - beta) * 0x01010101u;
+            // (two v_bcnt_u32_b32 accumulate chains: the compiler's own form is bcnt + a tree of adds, half an instruction
+            // more per word)
+            int acc = 0, acc1 = 0;
+#pragma unroll
+            for (int c = 0; c < KS_BASECH; c += 2) {
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"((w[c] + C) & 0x80808080u));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc1) : "v"((w[c + 1] + C) & 0x80808080u));
+            }
+            acc += acc1;
+            // (an inner query has 7 rows of 9 slots; only wavefronts next to the image border, whose rows are wider, get
+            // here: real branches on the wave-uniform trip count -- the empty asm keeps them from being if-converted)
+            if (nmax > 4 * KS_BASECH) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int c = KS_BASECH; c < KS_BASECH + 4; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                if (nmax > 4 * KS_BASECH + 16) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int c = KS_BASECH + 4; c < KS_MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                }
+            }
+            return acc;
+        };
+        int bstar = 0, before = 0, inbin = 0;
+        if (act && !failed) {
+            // the level of the K-th nearest = the largest beta in [1, NLEV] with count_ge(beta) >= K  (NLEV and everything above
+            // it is one level: `hi` starts behind it with "nothing is nearer")
+            int lo = 1, clo = -1, hi = KS_NLEV + 1, chi = 0;      // count_ge(lo) >= K > count_ge(hi) -- assumed for lo = 1, checked below
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const int cm = count_ge((unsigned)mid);
+                if (cm >= p.K) { lo = mid; clo = cm; } else { hi = mid; chi = cm; }
+            }
+            // the number of candidates below the ring bound is only needed when the search ends at the bottom level (rare)
+            if (clo < 0) {
+                clo = count_ge(1u);
+                if (clo < p.K) failed = true;          // fewer than K candidates below the ring bound: the square must grow
+            }
+            bstar = lo; before = chi; inbin = clo - chi;     // level of the K-th nearest, slots nearer than it, slots in it
+        }
+        const bool live = act && !failed;
+        // pass 2: flows of the slots NEARER than level bstar, slots AT level bstar into a bit mask.  Per word of four bytes:
+        // ge1 = bit 7 of (byte + 128 - bstar) <=> byte >= bstar; ge2 likewise for bstar + 1 (for bstar = NLEV -- the one level of
+        // everything nearer than lo -- nothing is nearer: beta 128).  ge2's bytes are 0x80 / 0: converted to 128.0 / 0.0 they are
+        // the weight of the slot's flow, so the sums below carry a factor of 128 (a power of two: every rounding is that of the
+        // plain sum) which the final division removes.  Dead lanes: beta 128 twice -- no slot anywhere.
+        const bool do_next = NEXT && (t < p.nb - 1);
+        float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
+        unsigned E[(KS_MAXCH + 7) / 8];
+#pragma unroll
+        for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) E[e] = 0u;
+        const unsigned beta2 = (live && bstar < KS_NLEV) ? (unsigned)bstar + 1u : 128u;
+        const unsigned c1 = (128u - (live ? (unsigned)bstar : 128u)) * 0x01010101u, c2 = (128u - beta2) * 0x01010101u;
+        // The four flags of word j (of the eight words of a mask) go to bits j, 8 + j, 16 + j, 24 + j: slot 32 m + 4 j + u <->
+        // bit j + 8 u of E[m].
+        const float2 *pf = lflow + s, *pn = lnext + s;
+#pragma unroll
+        for (int g = 0; g < KS_MAXCH / 2; ++g) {
+            if (8 * g < nmax) {
+                float2 fj[8], gj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { fj[u] = knn_lds_f2(pf + 8 * g + u); if (NEXT) gj[u] = knn_lds_f2(pn + 8 * g + u); }
+                unsigned near4[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = (2 * g + h) & 7;
+                    const unsigned ge1 = w[2 * g + h] + c1, ge2 = w[2 * g + h] + c2;
+                    near4[h] = ge2 & 0x80808080u;
+                    E[g / 4] |= ((ge1 ^ ge2) >> (7 - j)) & (0x01010101u << j);      // (ge2 implies ge1: the xor is "at level bstar")
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (IWD) {
+                        if (((near4[u >> 2] >> (8 * (u & 3))) & 0x80u) != 0u) {
+                            const float2 pj = pp[8 * g + u];
+                            const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                            const float wgt = 1.f / (d + 1e-9f);                  // focus.py:159-161
+                            sy_ += wgt * fj[u].x; sx_ += wgt * fj[u].y; sw_ += wgt;
+                            if (do_next) { ny_ += 128.f * gj[u].x; nx_ += 128.f * gj[u].y; }
+                        }
+                    } else {
+                        // byte u & 3 of the word as a float, 128.0 or 0.0 (spelled out: with the bytes known to be 0x80 / 0 the
+                        // compiler rewrites the shift-and-mask form into a shift, an SDWA and, and a conversion of byte 0)
+                        float flag;
+                        if ((u & 3) == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                        else if ((u & 3) == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                        else if ((u & 3) == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                        else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                        sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_);
+                        if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
+                    }
+                }
+            }
+        }
+        // ---- the K-th level: rank its keys by exact (distance, index); the first `need` are neighbours -----------------
+        // Lanes with at most KS_LMAX keys there (nearly all) rank them in registers.  The others -- a lattice with little
+        // flow has shells of up to eight points at practically one distance -- are HEAVY: rare per lane but present in
+        // most wavefronts, so the whole wavefront serves them one at a time, a lane per slot (any number of keys).
+        const int need = p.K - before;
+        float dK = 0.f; int iK = -1;
+        bool tie = false;                 // a point at exactly the K-th distance that is NOT a neighbour (higher index): KNN_TIE_FLAG
+        const bool heavy = live && inbin > KS_LMAX;
+        {
+            float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX], kraw[KS_LMAX];
+            const bool light = live && !heavy;
+            const int mmax = __builtin_amdgcn_readfirstlane(wave_max_i(light ? inbin : 0));
+            unsigned long long em = ((unsigned long long)E[1] << 32) | E[0];
+            unsigned e2 = E[2];
+#pragma unroll
+            for (int a = 0; a < KS_LMAX; ++a) {
+                dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0; kraw[a] = 0;
+                if (a < mmax) {
+                    int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // a bit still in the mask ...
+                    if (em) em &= em - 1ull; else e2 &= e2 - 1u;
+                    kraw[a] = k;
+                    k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
+                    if (light && k >= 0) {
+                        const float2 pj = pp[k];
+                        jj[a] = k;
+                        dd[a] = pair_dist(qy, qx, pj.x, pj.y, L1);
+                        ii[a] = (int)lidx[s + k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < KS_LMAX; ++a) {
+                if (a < mmax) {
+                    int rank = 0;
+#pragma unroll
+                    for (int e = 0; e < KS_LMAX; ++e)
+                        if (e != a) rank += ((dd[e] < dd[a]) | ((dd[e] == dd[a]) & (ii[e] < ii[a]))) ? 1 : 0;
+                    if (light && a < inbin && rank < need) {
+                        const float2 f = pf[jj[a]];
+                        if (IWD) { const float wgt = 1.f / (dd[a] + 1e-9f); sy_ += wgt * f.x; sx_ += wgt * f.y; sw_ += wgt; }
+                        else { sy_ = fmaf(128.f, f.x, sy_); sx_ = fmaf(128.f, f.y, sx_); }       // (the sums carry the factor 128 of pass 2)
+                        if (do_next) { const float2 g2 = pn[jj[a]]; ny_ = fmaf(128.f, g2.x, ny_); nx_ = fmaf(128.f, g2.y, nx_); }
+                        if (rank == need - 1) { dK = dd[a]; iK = ii[a]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < KS_LMAX; ++a) tie = tie || (light && a < inbin && dd[a] == dK && ii[a] > iK);
+        }
+        {
+            unsigned long long hm = __ballot(heavy);
+            const int lane = tid & 63;
+            while (hm != 0ull) {                                       // wave-uniform loop over the heavy lanes
+                const int h = __ffsll((long long)hm) - 1;
+                hm &= hm - 1ull;
+                const int hs = lane_i(s, h), hneed = lane_i(need, h);
+                const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h);
+                const float hqy = lane_f(qy, h), hqx = lane_f(qx, h);
+                // this lane's two slots of the heavy query: lane and lane + 64
+                const int mybit = ((lane >> 2) & 7) + 8 * (lane & 3);            // bit of slot `lane` (and of slot 64 + lane) in its mask word
+                const bool b0 = (((lane < 32 ? h0 : h1) >> mybit) & 1u) != 0u, b1 = lane < 32 && ((h2 >> mybit) & 1u) != 0u;
+                float d0 = INFINITY, d1 = INFINITY;
+                int i0 = 0x7fffffff, i1 = 0x7fffffff, r0_ = 0, r1_ = 0;
+                if (b0) { const float2 pj = lpos[hs + lane]; d0 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i0 = (int)lidx[hs + lane]; }
+                if (b1) { const float2 pj = lpos[hs + 64 + lane]; d1 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i1 = (int)lidx[hs + 64 + lane]; }
+                unsigned long long km = ((unsigned long long)h1 << 32) | h0;
+                while (km != 0ull) {
+                    const int kb = __ffsll((long long)km) - 1;
+                    km &= km - 1ull;
+                    const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot of the bit
+                    const float kd = lane_f(d0, k); const int ki = lane_i(i0, k);
+                    r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
+                    r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
+                }
+                unsigned k2 = h2;
+                while (k2 != 0u) {
+                    const int kb = __ffs(k2) - 1;
+                    k2 &= k2 - 1u;
+                    const int k = 4 * (kb & 7) + (kb >> 3);                          // slot - 64 of the bit
+                    const float kd = lane_f(d1, k); const int ki = lane_i(i1, k);
+                    r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
+                    r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
+                }
+                float cy_ = 0.f, cx_ = 0.f, cw_ = 0.f, cny = 0.f, cnx = 0.f, cdk = 0.f;
+                int cik = -1;
+                const bool hnext = NEXT && (t < p.nb - 1);
+                if (b0 && r0_ < hneed) {
+                    const float2 f = lflow[hs + lane];
+                    if (IWD) { const float wgt = 1.f / (d0 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
+                    if (hnext) { const float2 g2 = lnext[hs + lane]; cny += g2.x; cnx += g2.y; }
+                    if (r0_ == hneed - 1) { cdk = d0; cik = i0; }
+                }
+                if (b1 && r1_ < hneed) {
+                    const float2 f = lflow[hs + 64 + lane];
+                    if (IWD) { const float wgt = 1.f / (d1 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
+                    if (hnext) { const float2 g2 = lnext[hs + 64 + lane]; cny += g2.x; cnx += g2.y; }
+                    if (r1_ == hneed - 1) { cdk = d1; cik = i1; }
+                }
+#pragma unroll
+                for (int o2 = 32; o2 > 0; o2 >>= 1) {
+                    cy_ += __shfl_xor(cy_, o2, 64); cx_ += __shfl_xor(cx_, o2, 64);
+                    if (IWD) cw_ += __shfl_xor(cw_, o2, 64);
+                    if (NEXT) { cny += __shfl_xor(cny, o2, 64); cnx += __shfl_xor(cnx, o2, 64); }
+                    cdk = fmaxf(cdk, __shfl_xor(cdk, o2, 64)); cik = max(cik, __shfl_xor(cik, o2, 64));
+                }
+                const bool htie = __ballot((b0 && d0 == cdk && i0 > cik) || (b1 && d1 == cdk && i1 > cik)) != 0ull;
+                if (lane == h) {
+                    if (IWD) { sy_ += cy_; sx_ += cx_; sw_ += cw_; }
+                    else { sy_ = fmaf(128.f, cy_, sy_); sx_ = fmaf(128.f, cx_, sx_); }
+                    ny_ = fmaf(128.f, cny, ny_); nx_ = fmaf(128.f, cnx, nx_);
+                    dK = cdk; iK = cik; tie = htie;
+                }
+            }
+        }
+        // ---- outputs ---------------------------------------------------------------------------------------
+        if (live) {
+            const size_t BQ = (size_t)p.B * p.nb * p.G;
+            float2 ov; float norm = 0.f;
+            if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
+            // mean = sum / K (focus.py:166) with the factor 128 of pass 2 taken out first (exact).  K a power of two (the shipped
+            // 32): the division is a multiplication by an exact reciprocal -- same bits, a tenth of the instructions
+            const bool kpow2 = (p.K & (p.K - 1)) == 0;
+            const float rK = __int_as_float((120 - (__ffs(p.K) - 1)) << 23);        // 2^-(7 + log2 K), built from its exponent (used if kpow2)
+            if (IWD) { }
+            else if (kpow2) { ov.x = sy_ * rK; ov.y = sx_ * rK; }
+            else { ov.x = (sy_ * 0.0078125f) / (float)p.K; ov.y = (sx_ * 0.0078125f) / (float)p.K; }
+            reinterpret_cast<float2 *>(flow_lut)[q] = ov;
+            if (do_next) {
+                float2 on;
+                if (kpow2) { on.x = ny_ * rK; on.y = nx_ * rK; }
+                else { on.x = (ny_ * 0.0078125f) / (float)p.K; on.y = (nx_ * 0.0078125f) / (float)p.K; }
+                reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
+            }
+            knn_state[q] = dK;
+            reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
+#ifdef KS_DEBUG_INBIN
+            norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
+            knn_state[2 * BQ + q] = norm;
+#else
+            if (IWD) knn_state[2 * BQ + q] = norm;         // (the 'mean' backward never reads the normaliser)
+#endif
+        }
+        {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
+            const bool push = inpass && !live;
+            const unsigned long long pm = __ballot(push);
+            if (pm != 0ull) {
+                const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
+                base = __shfl(base, first, 64);
+                if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | (why << 30));
+            }
+        }
+        // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
+        // backward): a wavefront covers 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
+        // (knn_tile_of: the tiles of the query grid start at multiples of 16).  Only wavefronts next to the image border hold
+        // anything but class 0 (knn_device.h).
+        {
+            static_assert(WS == 2, "32 lanes = one tile");
+            const int bd = knn_band_depth(r_init);
+            const unsigned cls = live ? knn_query_classes(p, cy, cx, bd) : 0u;
+            const bool plain = __ballot(cls > 1u) == 0ull;
+            const int gx16 = knn_tiles_x(p.wq, p.m), gy16 = knn_tiles_y(p.hq, p.m);
+            int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + knn_tile_of(min(cy, p.hq - 1))) * gx16 + knn_tile_of(qx0)) * KNN_NCLS;
+            const bool writer = (tid & (16 * WS - 1)) == 0 && cy <= qy1;
+#pragma unroll
+            for (int c = 0; c < KNN_NCLS; ++c) {
+                if (c > 0 && plain) break;
+                float m = ((cls >> c) & 1u) ? dK : 0.f;
+#pragma unroll
+                for (int o2 = 8 * WS; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
+                if (writer && m > 0.f) atomicMax(dst + c, __float_as_int(m));
+            }
+        }
+    }
+}
+
 // 1-D grid of gx * gy * B * nb workgroups (gx strips, gy row blocks) in XCD-contiguous order, 256 threads,
 // dynamic LDS sized by the launcher
-// LEAN: the backward is the query-centric scatter of knn_bwd_scatter.hip, which reads each query's neighbours from a
-// bit mask over its slot range (`mask_out`: three words per query, bit 8 u + j of word m <-> slot 32 m + 4 j + u) and
-// the strip's row table (`rowtab_out`) instead of re-deriving them from the K-th key: no K-th key, tie flag or tile
-// maxima are written for the queries served here; the queries handed to the fallback kernel are flagged in `fbits`.
-template <int WS, bool L1, bool NEXT, bool IWD, bool LEAN>
+template <int WS, bool L1, bool NEXT, bool IWD>
 __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
-                                                     const int *__restrict__ cell_start,
+                                                     const int *__restrict__ cell_start, const int *__restrict__ sat,
                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                     int *__restrict__ fail, int r_init, int cap, int gx, int gy,
-                                                     unsigned *__restrict__ mask_out, int2 *__restrict__ rowtab_out,
-                                                     unsigned *__restrict__ fbits, const EvCountArgs evc, int n_evc, int evc_stride) {
-    constexpr int TH = KS_NT / WS;
+                                                     int *__restrict__ fail, int *__restrict__ retry, int r_init, int cap, int gx, int gy,
+                                                     const EvCountArgs evc, int n_evc, int evc_stride) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
-    const int tid = threadIdx.x;
-#ifdef KS_STAMP
-    const unsigned long long st0 = wall_clock64();      // diagnostics build: per-workgroup durations (tools/strip_stamp_probe.py)
-#endif
+    __shared__ int s_rq[KS_NT / WS];                    // radius of the widest square of every query row of the strip (0: none)
     // mpc_focus_fwd: some workgroups do not search -- they count the event rows per backward bucket for the event kernels
     // that follow (ev_count_device.h).  This kernel is bound by vector-instruction issue and leaves HBM idle, so the 67 MB of
     // C3's events are read beside it.  The counting workgroups come in groups of 8 (one per XCD: the search workgroups keep
@@ -92,564 +584,104 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     const int nblk = gx * gy * p.B * p.nb;
     const int lblk = (pblk & 7) * ((nblk + 7) >> 3) + (pblk >> 3);
     if (lblk >= nblk) return;
-    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
-    const int sy = bxy / gx, sx = bxy - sy * gx;
-    const int b = bt / p.nb, t = bt - b * p.nb;
-    const int qx0 = sx * WS, qy0 = sy * TH;
-    const int qx1 = min(qx0 + WS, p.wq) - 1, qy1 = min(qy0 + TH, p.hq) - 1;
-    const int R2 = 2 * r_init;                   // no clipped square needs a larger radius (corner: r + 1 >= 2 r_init + 1)
-    const int ry_base = qy0 - R2;                // grid row of region row 0 (may lie outside the grid: an empty row)
-    const int NR = TH + 2 * R2;                  // region rows (launcher: NR <= KS_NT)
-    // ---- LDS carve-up ----------------------------------------------------------------------------
-    int2 *s_row = reinterpret_cast<int2 *>(s_dyn);             // [NR] {xlo, xhi} of the row, then {first bucketed slot, points (-1: no such row)}
-    int *s_rowstart = reinterpret_cast<int *>(s_row + NR);     // [NR + 1] first slot of every region row
-    size_t o = ((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15;
-    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
-    float2 *lflow = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
-    float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL) * 8 : 0;
-    unsigned short *lidx = reinterpret_cast<unsigned short *>(s_dyn + o);
+    strip_body<WS, L1, NEXT, IWD, false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, retry,
+                                         r_init, cap, gx, gy, lblk, 0, KS_NT / WS, s_dyn, s_wsum, s_wmax, s_rq);
+}
 
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
-    const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
-    const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
-
-    // ---- the query of this thread and its search square -------------------------------------------
-    // Thread -> query: 16-row groups of the strip (a wavefront = two groups = two LUT tiles of the reach bookkeeping
-    // below).  The queries next to the top and bottom border of the image are the expensive ones (enlarged squares, wider
-    // staged rows: up to 96 slots against 63) and a wavefront pays for its most expensive lane, so the group holding the
-    // bottom border trades places with group 1: ONE wavefront of a full-height strip carries both borders, not two.
-    int grp = tid / (16 * WS);
-    if (qy0 == 0 && p.hq <= TH) {
-        const int gb = (p.hq - 1) >> 4;
-        if (gb >= 2) grp = (grp == 1) ? gb : ((grp == gb) ? 1 : grp);
-    }
-    const int cy = qy0 + grp * 16 + (tid % (16 * WS)) / WS, cx = qx0 + tid % WS;
-    const bool valid = cy <= qy1 && cx <= qx1;
-    int r = r_init, y0 = 0, y1 = -1, x0 = 0, x1 = -1;
-    if (valid) {
-        r = query_radius(p, cy, cx, r_init);
-        y0 = max(cy - r, 0); y1 = min(cy + r, p.hq - 1);
-        x0 = max(cx - r, 0); x1 = min(cx + r, p.wq - 1);
-    }
-    // ---- column extent of every region row = union of the squares that use the row ---------------------
-    // queries that no border clips all have radius r_init: their rows get the default extent directly; only the
-    // (few) clipped queries widen rows with LDS atomics
-    const int icx0 = max(qx0, r_init), icx1 = min(qx1, p.wq - 1 - r_init);
-    const int icy0 = max(qy0, r_init), icy1 = min(qy1, p.hq - 1 - r_init);
-    const bool has_inner = icx0 <= icx1 && icy0 <= icy1;
-    if (tid < NR) {
-        const int y = ry_base + tid;
-        const bool dflt = has_inner && y >= icy0 - r_init && y <= icy1 + r_init;
-        s_row[tid] = make_int2(dflt ? icx0 - r_init : 0x7fffffff, dflt ? icx1 + r_init : -1);
-    }
-    __syncthreads();
-    const bool inner = valid && cx >= icx0 && cx <= icx1 && cy >= icy0 && cy <= icy1;
-    if (valid && !inner) {
-        for (int y = y0; y <= y1; ++y) {
-            atomicMin(&s_row[y - ry_base].x, x0);
-            atomicMax(&s_row[y - ry_base].y, x1);
-        }
-    }
-    __syncthreads();
-    // ---- slots of the region rows: an exclusive scan of the row lengths; a row of even length gets one dummy
-    //      slot so that the row pitch is odd (consecutive rows then start in different LDS banks: with the 8 points
-    //      per row of a regular lattice an unpadded pitch puts every fourth row on the same banks) ---------------
-    int len = -1, padded = 0, gs = 0;
-    if (tid < NR) {
-        const int y = ry_base + tid;
-        const int xl = s_row[tid].x, xh = s_row[tid].y;
-        if (y >= 0 && y < p.hq && xh >= xl) {
-            gs = cs[y * p.wq + xl];
-            len = cs[y * p.wq + xh + 1] - gs;
-            padded = len + ((len & 1) ? 0 : 1);
-        }
-    }
-    int incl = padded;
-#pragma unroll
-    for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if ((tid & 63) >= o2) incl += v; }
-    const int wmx = wave_max_i(padded);
-    if ((tid & 63) == 63) { s_wsum[tid >> 6] = incl; s_wmax[tid >> 6] = wmx; }
-    __syncthreads();
-    int run = incl - padded;
-    for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
-    if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int2(gs, len); }
-    if (tid == NR - 1) s_rowstart[NR] = run + padded;
-    if (LEAN) {      // row table of the strip for the backward: {first bucketed slot, first slot | points << 16}, then the slot total
-        int2 *rt = rowtab_out + (size_t)lblk * (NR + 1);
-        if (tid < NR) rt[tid] = make_int2(gs, (run & 0xffff) | (max(len, 0) << 16));
-        if (tid == NR - 1) rt[NR] = make_int2(run + padded, 0);
-    }
-    // row pitch of the staging loop = the longest row of the region
-    const int pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
-    __syncthreads();
-    const int total = s_rowstart[NR];
-    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
-    // LEAN: this query's place in the strip's block of the mask planes, and its bit in the map of failed queries
-    const int qi = (cy - qy0) * WS + (cx - qx0);
-    unsigned *mq = LEAN ? mask_out + (size_t)lblk * (3 * KS_NT) + qi : nullptr;
-    const int fwpr = (p.wq + 31) >> 5;
-    if (total > cap) {
-        // the points of this strip do not fit the staging area (heavily clustered input): every query goes to the list
-        if (valid) {
-            fail[1 + atomicAdd(&fail[0], 1)] = (int)((unsigned)q | (3u << 30));
-            if (LEAN) {
-                mq[0] = 0u; mq[KS_NT] = 0u; mq[2 * KS_NT] = 0u;
-                atomicOr(&fbits[((size_t)bt * p.hq + cy) * fwpr + (cx >> 5)], 1u << (cx & 31));
-            }
-        }
-        return;
-    }
-    // ---- stage positions, flows and indices: item = (region row, k-th slot of the row), KS_SB items per thread
-    //      with their (dependent) global loads in flight together ----------------------------------------------
-    {
-        const float2 *tref0 = traj_b;                                     // T == 1: the reference time
-        const float2 *tnext = traj_b + (size_t)(p.T + t + 1) * p.n;       // next bin (if any)
-        const bool has_next = NEXT && (t < p.nb - 1);
-        // item -> (row, slot of the row) with a reciprocal multiply: (it + 0.5) / pitch is at least 0.5 / pitch away from
-        // an integer, far more than the rounding of the product (it < 2^14)
-        const int items = NR * pitch;
-        const float inv_pitch = __builtin_amdgcn_rcpf((float)pitch);        // (1 ulp: the margin below is 0.5 / pitch)
-        for (int base = 0; base < items; base += KS_NT * KS_SB) {
-            int slot[KS_SB], id[KS_SB];
-            bool in[KS_SB], real[KS_SB];
-            float2 pj[KS_SB], f0[KS_SB], f1[KS_SB];
-#pragma unroll
-            for (int u = 0; u < KS_SB; ++u) {
-                const int it = base + u * KS_NT + tid, rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1), k = it - rr * pitch;
-                const int2 row = s_row[rr];                                     // {first bucketed slot, points}
-                in[u] = it < items && row.y >= 0 && k < (row.y | 1);            // (an even row has one dummy slot: odd pitch)
-                real[u] = in[u] && k < row.y;
-                slot[u] = s_rowstart[rr] + k;
-                pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
-                if (real[u]) { pj[u] = sp_[row.x + k]; id[u] = si_[row.x + k]; }
-            }
-#pragma unroll
-            for (int u = 0; u < KS_SB; ++u) {
-                f0[u] = f1[u] = make_float2(0.f, 0.f);
-                if (real[u]) {
-                    const float2 a = tref0[id[u]];
-                    f0[u] = make_float2(a.x - pj[u].x, a.y - pj[u].y);      // traj(t_ref) - traj(t_mid)  focus.py:140-141
-                    if (has_next) { const float2 c = tnext[id[u]]; f1[u] = make_float2(c.x - pj[u].x, c.y - pj[u].y); }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < KS_SB; ++u) {
-                if (in[u]) {
-                    lpos[slot[u]] = pj[u];
-                    lflow[slot[u]] = f0[u];
-                    if (NEXT) lnext[slot[u]] = f1[u];
-                    lidx[slot[u]] = (unsigned short)id[u];
-                }
-            }
-        }
-        // the tail behind the staged slots: far-away positions, zero flows (lanes whose range is shorter than the
-        // wavefront's trip count read them, flagged off)
-        for (int i = total + tid; i < total + KS_TAIL; i += KS_NT) {
-            lpos[i] = make_float2(KS_FAR, KS_FAR);
-            lflow[i] = make_float2(0.f, 0.f);
-            if (NEXT) lnext[i] = make_float2(0.f, 0.f);
-        }
-    }
-    __syncthreads();
-#ifdef KS_STAMP
-    const unsigned long long st1 = wall_clock64();
-#endif
-
-    // ---- search --------------------------------------------------------------------------------------
-    const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-    bool failed = false;
-    unsigned why = 0u;                 // diagnostics: top two bits of a list entry (0 few candidates, 1 too many slots, 2 too many keys at the K-th level, 3 staging overflow)
-    int s = 0, nsl = 0;
-    if (valid) {
-        const bool whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
-        s = s_rowstart[y0 - ry_base];
-        nsl = s_rowstart[y1 - ry_base + 1] - s;
-        if (whole || nsl > 4 * KS_MAXCH) { failed = true; why = 1u; nsl = 0; s = 0; }
-    }
-    // anything outside the square is at least lb away along one axis
-    const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
-    const float upper = L1 ? lb : lb * lb;
-    // NEARNESS of a slot, one byte: (upper - d) * (NLEV - 1) / (upper - lo) converted with saturation -- a monotone map of the
-    // exact fp32 distance (that is all exactness needs: a slot with a smaller byte is at least as far as every slot with a
-    // larger one).  0 <=> not below the ring bound (or a dummy slot: the conversion saturates negative values to 0, which
-    // is why the map runs downwards -- no clamp instruction per slot); 1 .. NLEV - 1 resolve [lo, upper); everything nearer
-    // than lo lands in NLEV .. 127 and counts as ONE level (NLEV).  lo = upper / 2: the K-th distance of an unclipped
-    // square sits near 0.83 upper; a clipped square was enlarged by whole rings, its K-th distance can be as low as
-    // upper / 2: lo = upper / 4.  Largest byte: upper * (NLEV - 1) / (upper - lo) = 126 or 84 -- bytes stay below 128, which
-    // the SWAR compares rely on.  (A candidate within half a level of the ring bound converts to 0: it is treated as
-    // outside, which only makes the fast path give up earlier -- the byte of anything at or beyond the bound is 0 for sure:
-    // the rounding of the fma is ~1e-5 of a level.)
-    const float lo_d = (r == r_init) ? 0.5f * upper : 0.25f * upper;
-    // (hardware reciprocal, 1 ulp: any constant near this one gives a monotone map; the largest byte stays below 127.5)
-    const float nscale = -(float)(KS_NLEV - 1) * __builtin_amdgcn_rcpf(upper - lo_d), loff = -upper * nscale;
-    const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
-    const float2 *pp = lpos + s;
-    // pass 1: nearness byte of every slot; groups of 8 slots whose loads are issued together
-    unsigned w[KS_MAXCH];
-#pragma unroll
-    for (int g = 0; g < KS_MAXCH / 2; ++g) {
-        w[2 * g] = w[2 * g + 1] = 0u;
-        if (8 * g < nmax) {
-            float2 pj[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pj[u] = knn_lds_f2(pp + 8 * g + u);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                unsigned acc = 0u;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float d = pair_dist(qy, qx, pj[4 * h + u].x, pj[4 * h + u].y, L1);
-                    acc = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, nscale, loff), u, acc);       // saturating: negative -> 0
-                }
-                w[2 * g + h] = acc;
-            }
-        }
-    }
-    // number of slots with byte >= beta (1 <= beta <= 128): bytes are <= 127, so (byte + 128 - beta) has bit 7 exactly when
-    // byte >= beta, and no carry crosses a byte (words of groups not visited hold 0)
-    auto count_ge = [&](unsigned beta) {
-        const unsigned C = (128u - beta) * 0x01010101u;
-        // (two v_bcnt_u32_b32 accumulate chains: the compiler's own form is bcnt + a tree of adds, half an instruction
-        // more per word)
-        int acc = 0, acc1 = 0;
-#pragma unroll
-        for (int c = 0; c < KS_BASECH; c += 2) {
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"((w[c] + C) & 0x80808080u));
-            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc1) : "v"((w[c + 1] + C) & 0x80808080u));
-        }
-        acc += acc1;
-        // (an inner query has 7 rows of 9 slots; only wavefronts next to the image border, whose rows are wider, get
-        // here: real branches on the wave-uniform trip count -- the empty asm keeps them from being if-converted)
-        if (nmax > 4 * KS_BASECH) {
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int c = KS_BASECH; c < KS_BASECH + 4; ++c) acc += __popc((w[c] + C) & 0x80808080u);
-            if (nmax > 4 * KS_BASECH + 16) {
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int c = KS_BASECH + 4; c < KS_MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
-            }
-        }
-        return acc;
-    };
-    int bstar = 0, before = 0, inbin = 0;
-    if (valid && !failed) {
-        // the level of the K-th nearest = the largest beta in [1, NLEV] with count_ge(beta) >= K  (NLEV and everything above
-        // it is one level: `hi` starts behind it with "nothing is nearer")
-        int lo = 1, clo = -1, hi = KS_NLEV + 1, chi = 0;      // count_ge(lo) >= K > count_ge(hi) -- assumed for lo = 1, checked below
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const int cm = count_ge((unsigned)mid);
-            if (cm >= p.K) { lo = mid; clo = cm; } else { hi = mid; chi = cm; }
-        }
-        // the number of candidates below the ring bound is only needed when the search ends at the bottom level (rare)
-        if (clo < 0) {
-            clo = count_ge(1u);
-            if (clo < p.K) failed = true;          // fewer than K candidates below the ring bound: the square must grow
-        }
-        bstar = lo; before = chi; inbin = clo - chi;     // level of the K-th nearest, slots nearer than it, slots in it
-    }
-    const bool live = valid && !failed;
-    // pass 2: flows of the slots NEARER than level bstar, slots AT level bstar into a bit mask.  Per word of four bytes:
-    // ge1 = bit 7 of (byte + 128 - bstar) <=> byte >= bstar; ge2 likewise for bstar + 1 (for bstar = NLEV -- the one level of
-    // everything nearer than lo -- nothing is nearer: beta 128).  ge2's bytes are 0x80 / 0: converted to 128.0 / 0.0 they are
-    // the weight of the slot's flow, so the sums below carry a factor of 128 (a power of two: every rounding is that of the
-    // plain sum) which the final division removes.  Dead lanes: beta 128 twice -- no slot anywhere.
-    const bool do_next = NEXT && (t < p.nb - 1);
-    float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
-    unsigned E[(KS_MAXCH + 7) / 8];
-    unsigned Mm[(KS_MAXCH + 7) / 8];     // LEAN: the neighbours of the query, same bit <-> slot map as E
-#pragma unroll
-    for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) { E[e] = 0u; Mm[e] = 0u; }
-    const unsigned beta2 = (live && bstar < KS_NLEV) ? (unsigned)bstar + 1u : 128u;
-    const unsigned c1 = (128u - (live ? (unsigned)bstar : 128u)) * 0x01010101u, c2 = (128u - beta2) * 0x01010101u;
-    // The four flags of word j (of the eight words of a mask) go to bits j, 8 + j, 16 + j, 24 + j: slot 32 m + 4 j + u <->
-    // bit j + 8 u of E[m].
-    const float2 *pf = lflow + s, *pn = lnext + s;
-#pragma unroll
-    for (int g = 0; g < KS_MAXCH / 2; ++g) {
-        if (8 * g < nmax) {
-            float2 fj[8], gj[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { fj[u] = knn_lds_f2(pf + 8 * g + u); if (NEXT) gj[u] = knn_lds_f2(pn + 8 * g + u); }
-            unsigned near4[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = (2 * g + h) & 7;
-                const unsigned ge1 = w[2 * g + h] + c1, ge2 = w[2 * g + h] + c2;
-                near4[h] = ge2 & 0x80808080u;
-                E[g / 4] |= ((ge1 ^ ge2) >> (7 - j)) & (0x01010101u << j);      // (ge2 implies ge1: the xor is "at level bstar")
-                if (LEAN) Mm[g / 4] |= (ge2 >> (7 - j)) & (0x01010101u << j);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (IWD) {
-                    if (((near4[u >> 2] >> (8 * (u & 3))) & 0x80u) != 0u) {
-                        const float2 pj = pp[8 * g + u];
-                        const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                        const float wgt = 1.f / (d + 1e-9f);                  // focus.py:159-161
-                        sy_ += wgt * fj[u].x; sx_ += wgt * fj[u].y; sw_ += wgt;
-                        if (do_next) { ny_ += 128.f * gj[u].x; nx_ += 128.f * gj[u].y; }
-                    }
-                } else {
-                    // byte u & 3 of the word as a float, 128.0 or 0.0 (spelled out: with the bytes known to be 0x80 / 0 the
-                    // compiler rewrites the shift-and-mask form into a shift, an SDWA and, and a conversion of byte 0)
-                    float flag;
-                    if ((u & 3) == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                    else if ((u & 3) == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                    else if ((u & 3) == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                    sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_);
-                    if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
-                }
-            }
-        }
-    }
-    // ---- the K-th level: rank its keys by exact (distance, index); the first `need` are neighbours -----------------
-    // Lanes with at most KS_LMAX keys there (nearly all) rank them in registers.  The others -- a lattice with little
-    // flow has shells of up to eight points at practically one distance -- are HEAVY: rare per lane but present in
-    // most wavefronts, so the whole wavefront serves them one at a time, a lane per slot (any number of keys).
-    const int need = p.K - before;
-    float dK = 0.f; int iK = -1;
-    bool tie = false;                 // a point at exactly the K-th distance that is NOT a neighbour (higher index): KNN_TIE_FLAG
-    const bool heavy = live && inbin > KS_LMAX;
-    {
-        float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX], kraw[KS_LMAX];
-        const bool light = live && !heavy;
-        const int mmax = __builtin_amdgcn_readfirstlane(wave_max_i(light ? inbin : 0));
-        unsigned long long em = ((unsigned long long)E[1] << 32) | E[0];
-        unsigned e2 = E[2];
-#pragma unroll
-        for (int a = 0; a < KS_LMAX; ++a) {
-            dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0; kraw[a] = 0;
-            if (a < mmax) {
-                int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // a bit still in the mask ...
-                if (em) em &= em - 1ull; else e2 &= e2 - 1u;
-                kraw[a] = k;
-                k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
-                if (light && k >= 0) {
-                    const float2 pj = pp[k];
-                    jj[a] = k;
-                    dd[a] = pair_dist(qy, qx, pj.x, pj.y, L1);
-                    ii[a] = (int)lidx[s + k];
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < KS_LMAX; ++a) {
-            if (a < mmax) {
-                int rank = 0;
-#pragma unroll
-                for (int e = 0; e < KS_LMAX; ++e)
-                    if (e != a) rank += ((dd[e] < dd[a]) | ((dd[e] == dd[a]) & (ii[e] < ii[a]))) ? 1 : 0;
-                if (light && a < inbin && rank < need) {
-                    const float2 f = pf[jj[a]];
-                    if (IWD) { const float wgt = 1.f / (dd[a] + 1e-9f); sy_ += wgt * f.x; sx_ += wgt * f.y; sw_ += wgt; }
-                    else { sy_ = fmaf(128.f, f.x, sy_); sx_ = fmaf(128.f, f.y, sx_); }       // (the sums carry the factor 128 of pass 2)
-                    if (do_next) { const float2 g2 = pn[jj[a]]; ny_ = fmaf(128.f, g2.x, ny_); nx_ = fmaf(128.f, g2.y, nx_); }
-                    if (rank == need - 1) { dK = dd[a]; iK = ii[a]; }
-                    if (LEAN) {
-                        const unsigned bit = 1u << (kraw[a] & 31);
-                        Mm[0] |= kraw[a] < 32 ? bit : 0u; Mm[1] |= (kraw[a] >= 32 && kraw[a] < 64) ? bit : 0u; Mm[2] |= kraw[a] >= 64 ? bit : 0u;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < KS_LMAX; ++a) tie = tie || (light && a < inbin && dd[a] == dK && ii[a] > iK);
-    }
-    {
-        unsigned long long hm = __ballot(heavy);
-        const int lane = tid & 63;
-        while (hm != 0ull) {                                       // wave-uniform loop over the heavy lanes
-            const int h = __ffsll((long long)hm) - 1;
-            hm &= hm - 1ull;
-            const int hs = lane_i(s, h), hneed = lane_i(need, h);
-            const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h);
-            const float hqy = lane_f(qy, h), hqx = lane_f(qx, h);
-            // this lane's two slots of the heavy query: lane and lane + 64
-            const int mybit = ((lane >> 2) & 7) + 8 * (lane & 3);            // bit of slot `lane` (and of slot 64 + lane) in its mask word
-            const bool b0 = (((lane < 32 ? h0 : h1) >> mybit) & 1u) != 0u, b1 = lane < 32 && ((h2 >> mybit) & 1u) != 0u;
-            float d0 = INFINITY, d1 = INFINITY;
-            int i0 = 0x7fffffff, i1 = 0x7fffffff, r0_ = 0, r1_ = 0;
-            if (b0) { const float2 pj = lpos[hs + lane]; d0 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i0 = (int)lidx[hs + lane]; }
-            if (b1) { const float2 pj = lpos[hs + 64 + lane]; d1 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i1 = (int)lidx[hs + 64 + lane]; }
-            unsigned long long km = ((unsigned long long)h1 << 32) | h0;
-            while (km != 0ull) {
-                const int kb = __ffsll((long long)km) - 1;
-                km &= km - 1ull;
-                const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot of the bit
-                const float kd = lane_f(d0, k); const int ki = lane_i(i0, k);
-                r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
-                r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
-            }
-            unsigned k2 = h2;
-            while (k2 != 0u) {
-                const int kb = __ffs(k2) - 1;
-                k2 &= k2 - 1u;
-                const int k = 4 * (kb & 7) + (kb >> 3);                          // slot - 64 of the bit
-                const float kd = lane_f(d1, k); const int ki = lane_i(i1, k);
-                r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
-                r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
-            }
-            float cy_ = 0.f, cx_ = 0.f, cw_ = 0.f, cny = 0.f, cnx = 0.f, cdk = 0.f;
-            int cik = -1;
-            const bool hnext = NEXT && (t < p.nb - 1);
-            if (b0 && r0_ < hneed) {
-                const float2 f = lflow[hs + lane];
-                if (IWD) { const float wgt = 1.f / (d0 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
-                if (hnext) { const float2 g2 = lnext[hs + lane]; cny += g2.x; cnx += g2.y; }
-                if (r0_ == hneed - 1) { cdk = d0; cik = i0; }
-            }
-            if (b1 && r1_ < hneed) {
-                const float2 f = lflow[hs + 64 + lane];
-                if (IWD) { const float wgt = 1.f / (d1 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
-                if (hnext) { const float2 g2 = lnext[hs + 64 + lane]; cny += g2.x; cnx += g2.y; }
-                if (r1_ == hneed - 1) { cdk = d1; cik = i1; }
-            }
-#pragma unroll
-            for (int o2 = 32; o2 > 0; o2 >>= 1) {
-                cy_ += __shfl_xor(cy_, o2, 64); cx_ += __shfl_xor(cx_, o2, 64);
-                if (IWD) cw_ += __shfl_xor(cw_, o2, 64);
-                if (NEXT) { cny += __shfl_xor(cny, o2, 64); cnx += __shfl_xor(cnx, o2, 64); }
-                cdk = fmaxf(cdk, __shfl_xor(cdk, o2, 64)); cik = max(cik, __shfl_xor(cik, o2, 64));
-            }
-            const bool htie = __ballot((b0 && d0 == cdk && i0 > cik) || (b1 && d1 == cdk && i1 > cik)) != 0ull;
-            if (lane == h) {
-                if (IWD) { sy_ += cy_; sx_ += cx_; sw_ += cw_; }
-                else { sy_ = fmaf(128.f, cy_, sy_); sx_ = fmaf(128.f, cx_, sx_); }
-                ny_ = fmaf(128.f, cny, ny_); nx_ = fmaf(128.f, cnx, nx_);
-                dK = cdk; iK = cik; tie = htie;
-            }
-            if (LEAN) {
-                // the selected slots as mask bits: bit `l` of a word belongs to slot 4 (l & 7) + (l >> 3) of its 32 slots,
-                // i.e. to the lane of that number: fetch that lane's flag, then a ballot is the word
-                const int src = (lane & 32) + 4 * (lane & 7) + ((lane & 31) >> 3);
-                const int sel0 = (b0 && r0_ < hneed) ? 1 : 0, sel1 = (b1 && r1_ < hneed) ? 1 : 0;
-                const unsigned long long w01 = __ballot(__shfl(sel0, src, 64) != 0);
-                const unsigned long long w2 = __ballot(lane < 32 && __shfl(sel1, src, 64) != 0);
-                if (lane == h) { Mm[0] |= (unsigned)w01; Mm[1] |= (unsigned)(w01 >> 32); Mm[2] |= (unsigned)w2; }
-            }
-        }
-    }
-    // ---- outputs ---------------------------------------------------------------------------------------
-    if (live) {
-        const size_t BQ = (size_t)p.B * p.nb * p.G;
-        float2 ov; float norm = 0.f;
-        if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
-        // mean = sum / K (focus.py:166) with the factor 128 of pass 2 taken out first (exact).  K a power of two (the shipped
-        // 32): the division is a multiplication by an exact reciprocal -- same bits, a tenth of the instructions
-        const bool kpow2 = (p.K & (p.K - 1)) == 0;
-        const float rK = __int_as_float((120 - (__ffs(p.K) - 1)) << 23);        // 2^-(7 + log2 K), built from its exponent (used if kpow2)
-        if (IWD) { }
-        else if (kpow2) { ov.x = sy_ * rK; ov.y = sx_ * rK; }
-        else { ov.x = (sy_ * 0.0078125f) / (float)p.K; ov.y = (sx_ * 0.0078125f) / (float)p.K; }
-        reinterpret_cast<float2 *>(flow_lut)[q] = ov;
-        if (do_next) {
-            float2 on;
-            if (kpow2) { on.x = ny_ * rK; on.y = nx_ * rK; }
-            else { on.x = (ny_ * 0.0078125f) / (float)p.K; on.y = (nx_ * 0.0078125f) / (float)p.K; }
-            reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
-        }
-        if (!LEAN) {
-            knn_state[q] = dK;
-            reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
-        }
-#ifdef KS_DEBUG_INBIN
-        norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
-        knn_state[2 * BQ + q] = norm;
-#else
-        if (IWD) knn_state[2 * BQ + q] = norm;         // (the 'mean' backward never reads the normaliser)
-#endif
-    }
-    if (LEAN && valid) {
-        mq[0] = live ? Mm[0] : 0u; mq[KS_NT] = live ? Mm[1] : 0u; mq[2 * KS_NT] = live ? Mm[2] : 0u;
-    }
-    {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
-        const bool push = valid && !live;
-        const unsigned long long pm = __ballot(push);
-        if (pm != 0ull) {
-            const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
-            int base = 0;
-            if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
-            base = __shfl(base, first, 64);
-            if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | (why << 30));
-            if (LEAN && push) atomicOr(&fbits[((size_t)bt * p.hq + cy) * fwpr + (cx >> 5)], 1u << (cx & 31));
-        }
-    }
-    // largest K-th distance per 16x16 cell tile (bounds the search windows of the gather backward): a wavefront covers
-    // 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
-    if (!LEAN) {
-        // per class of query (knn_device.h): only wavefronts next to the image border hold anything but class 0
-        const int bd = knn_band_depth(r_init);
-        const unsigned cls = live ? knn_query_classes(p, cy, cx, bd) : 0u;
-        const bool plain = __ballot(cls > 1u) == 0ull;
-        const int gx16 = (p.wq + 15) >> 4, gy16 = (p.hq + 15) >> 4;
-        int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (min(cy, p.hq - 1) >> 4)) * gx16 + (qx0 >> 4)) * KNN_NCLS;
-        const bool writer = (tid & (16 * WS - 1)) == 0 && cy <= qy1;
-#pragma unroll
-        for (int c = 0; c < KNN_NCLS; ++c) {
-            if (c > 0 && plain) break;
-            float m = ((cls >> c) & 1u) ? dK : 0.f;
-#pragma unroll
-            for (int o2 = 8 * WS; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
-            if (writer && m > 0.f) atomicMax(dst + c, __float_as_int(m));
-        }
-    }
-#ifdef KS_STAMP
-    {
-        const unsigned long long st2 = wall_clock64();      // this wavefront's end
+// The strips on the retry list, a quarter of the query rows per workgroup and round.  grid: a fixed number of workgroups (the
+// list length is only known on the device; nothing to do for the lattice-like point sets of the benchmark)
+template <int WS, bool L1, bool NEXT, bool IWD>
+__global__ __launch_bounds__(KS_NT) void k_knn_strip_retry(const KnnParams p, const float *__restrict__ traj,
+                                                           const int *__restrict__ cell_start, const int *__restrict__ sat,
+                                                           const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                           float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                                           float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                                           int *__restrict__ fail, int *__restrict__ retry, int r_init, int cap, int gx, int gy) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
+    __shared__ int s_rq[KS_NT / WS];
+    constexpr int TH = KS_NT / WS;
+    const int nwork = 4 * min(retry[0], gx * gy * p.B * p.nb);
+    for (int w = (int)blockIdx.x; w < nwork; w += (int)gridDim.x) {
+        const int lblk = retry[1 + (w >> 2)], quarter = w & 3;
+        strip_body<WS, L1, NEXT, IWD, true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, retry,
+                                            r_init, cap, gx, gy, lblk, quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq);
         __syncthreads();
-        const size_t BQ = (size_t)p.B * p.nb * p.G;
-        const size_t q0 = (size_t)bt * p.G + (size_t)qy0 * p.wq + qx0;
-        // plane 2 of the state (unused by the 'mean' backward): rows qy0 .. qy0 + 4 of the strip's first column
-        if ((tid & 63) == 0) knn_state[2 * BQ + q0 + (size_t)(1 + (tid >> 6)) * p.wq] = (float)(st2 - st0);
-        if (tid == 0) { knn_state[2 * BQ + q0] = (float)(wall_clock64() - st0); knn_state[2 * BQ + q0 + 1] = (float)(st1 - st0); }
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
-// The queries the strip kernel could not serve: ONE WAVEFRONT per query (a thread per query would spend ~100 us
-// in dependent global loads).  The square grows as in knn_one_query; the lanes take its candidates in parallel
-// (up to 64 * KS_FB_SLOTS of them), every candidate is broadcast in turn and each lane counts how many keys
-// (distance, index) are smaller than its own: rank < K <=> neighbour.  A square with more candidates than that is
-// searched by lane 0 with the generic routine.
-// grid: a fixed number of workgroups (the list length is only known on the device), 256 threads = 4 queries at a time
+// The queries the strip kernel could not serve.  Two forms, chosen by the length of the list:
+//   * short list (white-noise flows: one query in ten thousand, scattered): ONE WAVEFRONT per query -- a thread per query
+//     would spend ~100 us in dependent global loads.  The lanes take the rows of the query's search region, then its
+//     candidates (up to 64 * KS_FB_SLOTS of them), and the K-th key is found by a bitwise search with ballots;
+//   * long list (a flow field that emptied a band along an image border: every query of the band, up to a fifth of all):
+//     ONE THREAD per query, 64 neighbouring queries per wavefront, the generic two-scan search of knn_device.h on the global
+//     arrays -- 17 x fewer instructions per query than a wavefront each, and the lanes of a wavefront walk similar regions.
+// Both start from a radius read off the summed-area table and look only at the cells of each row that can hold a point
+// below the ring bound (a band query's neighbours lie in a thin segment of a large disc).
+// With `far` (the backward is the tile gather) every query served here goes on the far list of its (sample, bin), is flagged
+// KNN_FAR_FLAG and stays out of the tile maxima: k_knn_bwd_far computes its gradient (knn.hip).
+// grid: KS_FB_BLOCKS workgroups (the list length is only known on the device), 256 threads
 // ------------------------------------------------------------------------------------------
+// first radius of a fallback search: the smallest square with 1.25 x the strip kernel's count (which it has tried), growing
+// by a quarter per step
+__device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx) {
+    const int need = knn_square_need(p.K) + (knn_square_need(p.K) >> 2);
+    const int rmax = max(p.hb, p.wb);
+    int r = 2;
+    while (r < rmax && knn_square_count(p, sat, cy, cx, r) < need) r += 1 + (r >> 2);
+    return r;
+}
+
+// one entry on the far list of (sample, bin) bt; called by ONE lane
+__device__ __forceinline__ void far_list_add(const KnnParams &p, int *__restrict__ far, int bt, int cell) {
+    int *fl = far + (size_t)bt * (p.G + 1);
+    const int k = atomicAdd(&fl[0], 1);
+    fl[1 + k] = cell;
+}
+
 template <bool L1>
 __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const int *__restrict__ cell_start,
-                                   const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                   const int *__restrict__ sat, const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, int q, int r_init,
-                                   bool grow_first, unsigned (*s_hist)[256]) {
+                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, int *__restrict__ far, int q, int r_init,
+                                   unsigned (*s_hist)[256]) {
     const int lane = threadIdx.x & 63;
     const int bt = q / p.G, cell = q - bt * p.G;
     const int cy = cell / p.wq, cx = cell - cy * p.wq;
     const int b = bt / p.nb, t = bt - b * p.nb;
-    const int *cs = cell_start + (size_t)bt * (p.G + 1);
+    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const int *si_ = sidx + (size_t)bt * p.n;
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-    int r = query_radius(p, cy, cx, r_init);
-    if (grow_first) r += KS_FB_GROW0 + (r >> 2);
+    const int ylo = -p.m, yhi = p.hq + p.m - 1, xlo = -p.m, xhi = p.wq + p.m - 1;
+    int r = fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS];
     float2 pq[KS_FB_SLOTS];
     bool serial = false;
     int ns = KS_FB_SLOTS;                  // slots per lane actually in use (wave-uniform): ceil(candidates / 64)
     for (;;) {
-        const int y0 = max(cy - r, 0), y1 = min(cy + r, p.hq - 1), x0 = max(cx - r, 0), x1 = min(cx + r, p.wq - 1);
-        const bool whole = (y0 == 0 && x0 == 0 && y1 == p.hq - 1 && x1 == p.wq - 1);
+        const int y0 = max(cy - r, ylo), y1 = min(cy + r, yhi), x0 = max(cx - r, xlo), x1 = min(cx + r, xhi);
+        const bool whole = (y0 == ylo && x0 == xlo && y1 == yhi && x1 == xhi);
         const int nrows = y1 - y0 + 1;
         if (nrows > 64) { serial = true; break; }
         const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
         const float upper = whole ? INFINITY : (L1 ? lb : lb * lb);
-        // lane l < nrows: the bucketed range of row y0 + l; exclusive scan over the lanes -> flat candidate numbering
+        // lane l < nrows: the bucketed range of row y0 + l -- only the cells that can hold a point below the ring bound;
+        // exclusive scan over the lanes -> flat candidate numbering
         int js = 0, ln = 0;
-        if (lane < nrows) { js = cs[(y0 + lane) * p.wq + x0]; ln = cs[(y0 + lane) * p.wq + x1 + 1] - js; }
+        if (lane < nrows) {
+            int xa = x0, xb = x1;
+            if (!whole) {
+                const float dyc = fmaxf((float)abs(y0 + lane - cy) - 0.5f, 0.f) * (float)p.sp;
+                const float w2 = L1 ? upper - dyc : upper - dyc * dyc;
+                const int xr = w2 > 0.f ? (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1 : -1;
+                xa = max(xa, cx - xr); xb = min(xb, cx + xr);
+            }
+            if (xa <= xb) { js = cs[knn_ci(p, y0 + lane, xa)]; ln = cs[knn_ci(p, y0 + lane, xb + 1)] - js; }
+        }
         int incl = ln;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if (lane >= o2) incl += v; }
@@ -685,16 +717,18 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         if (cnt >= p.K || whole) break;
         r += 1 + (r >> 2);
     }
+    const int flag_far = far != nullptr ? KNN_FAR_FLAG : 0;
+    if (far != nullptr && lane == 0) far_list_add(p, far, bt, cell);
     if (serial) {
-        // more candidates than the lanes hold (a very dense place): the generic thread-serial search
+        // more rows or candidates than the lanes hold (a very dense place, a very deep band): the generic thread-serial search
         if (lane == 0) {
             QueryCtx c;
             c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
             c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
             c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
             float dK = 0.f;
-            knn_one_query<false, L1, 256>(p, c, b, t, cy, cx, r_init, s_hist, flow_lut, flow_next, knn_state, nullptr, dK);
-            knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+            knn_one_query<false, L1, 256, true>(p, c, b, t, cy, cx, r, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, flag_far);
+            if (far == nullptr) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
         }
         return;
     }
@@ -751,56 +785,95 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
         knn_state[q] = dK;
-        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
+        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0) | flag_far;
         knn_state[2 * BQ + q] = norm;
-        knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+        if (far == nullptr) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
     }
 }
 
 __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const float *__restrict__ traj,
-                                                      const int *__restrict__ cell_start,
+                                                      const int *__restrict__ cell_start, const int *__restrict__ sat,
                                                       const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                       float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                       float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                      const int *__restrict__ fail, int r_init, const EvCountArgs evc) {
+                                                      const int *__restrict__ fail, int *__restrict__ far, int r_init, const EvCountArgs evc) {
     __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
     // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B workgroups turn
     // the counts of their sample into first records (the event kernels follow on the stream)
-    if (evc.events != nullptr && (int)blockIdx.x < evc.B) ev_prefix_block(evc, (int)blockIdx.x, reinterpret_cast<int *>(&s_hist[0][0]));
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    // (the first entry is read together with the length, not after it: the list has room for every query, so the
-    // address is valid whatever the length turns out to be)
-    int ent = fail[1 + min(wv, p.B * p.nb * p.G - 1)];
-    const int nfail = fail[0];
-    for (int i = wv; i < nfail; i += nw) {
-        if (i != wv) ent = fail[1 + i];
-        const int q = ent & 0x3fffffff;
-        const bool grow = ((unsigned)ent >> 30) == 0u;       // too few candidates at the first radius: skip it
-        if (p.l1) fallback_one_query<true>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, grow, s_hist);
-        else fallback_one_query<false>(p, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, q, r_init, grow, s_hist);
+    if (evc.events != nullptr && (int)blockIdx.x < evc.B) {
+        ev_prefix_block(evc, (int)blockIdx.x, reinterpret_cast<int *>(&s_hist[0][0]));
+        __syncthreads();          // (s_hist was the prefix's scratch)
+    }
+    const int nq = p.B * p.nb * p.G;
+    const int nfail = min(fail[0], nq);
+    if (nfail <= KS_FB_WAVE_MAX) {
+        const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+        for (int i = wv; i < nfail; i += nw) {
+            const int q = fail[1 + i] & 0x3fffffff;
+            if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, far, q, r_init, s_hist);
+            else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, far, q, r_init, s_hist);
+        }
+        return;
+    }
+    // a thread per query; the list is in the order the strip kernel's wavefronts appended to it: the 64 entries of a wavefront
+    // are mostly neighbouring queries of one strip
+    const int flag_far = far != nullptr ? KNN_FAR_FLAG : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ((nfail + 63) & ~63); i += gridDim.x * 256) {
+        const bool on = i < nfail;
+        const int q = on ? (fail[1 + i] & 0x3fffffff) : 0;
+        const int bt = q / p.G, cell = q - bt * p.G;
+        const int cy = cell / p.wq, cx = cell - cy * p.wq;
+        const int b = bt / p.nb, t = bt - b * p.nb;
+        if (on) {
+            QueryCtx c;
+            c.cs = cell_start + (size_t)bt * (p.Gb + 1); c.spos = spos + (size_t)bt * p.n; c.sidx = sidx + (size_t)bt * p.n;
+            c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
+            c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
+            c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
+            const int r0 = fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx);
+            float dK = 0.f;
+            if (p.l1) knn_one_query<false, true, 256, true>(p, c, b, t, cy, cx, r0, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, flag_far);
+            else knn_one_query<false, false, 256, true>(p, c, b, t, cy, cx, r0, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, flag_far);
+            if (far == nullptr) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+        }
+        if (far != nullptr) {
+            // far list of every (sample, bin) among the wavefront's queries: one atomic per distinct (sample, bin)
+            const int lane = threadIdx.x & 63;
+            unsigned long long todo = __ballot(on);
+            while (todo != 0ull) {
+                const int first = __ffsll((long long)todo) - 1;
+                const int bt0 = __shfl(bt, first, 64);
+                const unsigned long long same = __ballot(on && bt == bt0) & todo;
+                int base = 0;
+                int *fl = far + (size_t)bt0 * (p.G + 1);
+                if (lane == first) base = atomicAdd(&fl[0], __popcll(same));
+                base = __shfl(base, first, 64);
+                if (on && bt == bt0) fl[1 + base + __popcll(same & ((1ull << lane) - 1ull))] = cell;
+                todo &= ~same;
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// launcher (called by mpc_knn_lut_fwd once the points are bucketed; `fail[0]` and tile_dkmax zeroed by the bucket kernel)
+// launcher (called by mpc_knn_lut_fwd once the points are bucketed; `fail[0]`, the far-list counters and tile_dkmax zeroed by
+// the bucket kernel)
 // ------------------------------------------------------------------------------------------
 static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out, size_t *lds_out) {
-    const int TH = KS_NT / WS, R2 = 2 * r_init, NR = TH + 2 * R2;
-    if (NR > KS_NT) return false;
+    const int TH = KS_NT / WS, NR = TH + 2 * KNN_RCAP;
+    if (NR > KS_NT || r_init > KNN_RCAP) return false;
     const double dens = (double)s->n / ((double)s->hq * s->wq);
     const double row_pts = dens * (WS + 2 * r_init);                       // points per region row of an inner strip
     // slots of an inner query: its rows, one dummy slot per even row; must leave room for denser places
     if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * KS_MAXCH) return false;
     const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
-    static const double slack = getenv("MPC_KS_SLACK") ? atof(getenv("MPC_KS_SLACK")) : 1.15;      // (tuning)
-    int cap = (int)(slack * rows * (row_pts + 0.5)) + 64;
+    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 64;
     cap = (cap + 15) / 16 * 16;
     const bool next = (s->flags & MPC_F_WANT_NEXT) != 0;
     const size_t lds = (((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + KS_TAIL) * 8 * (next ? 3 : 2) +
                        (size_t)cap * 2 + 16;
     if (lds > 64 * 1024) return false;
-    static const int pad_lds = getenv("MPC_KS_PADLDS") ? atoi(getenv("MPC_KS_PADLDS")) : 0;             // (tuning: occupancy experiments)
-    *cap_out = cap; *lds_out = lds + (size_t)pad_lds;
+    *cap_out = cap; *lds_out = lds;
     return true;
 }
 
@@ -811,70 +884,50 @@ bool mpc_knn_strip_usable(const mpc_shape *s, int r_init) {
     return strip_geometry(s, r_init, 2, &cap, &lds);
 }
 
-bool mpc_knn_strip_geom(const mpc_shape *s, int r_init, KnnStripGeom *g) {
+// can the strip kernel's spare workgroups count the event rows of `evc` (their LDS holds one counter per backward bucket of a sample)?
+bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc) {
     int cap; size_t lds;
-    if (!strip_geometry(s, r_init, 2, &cap, &lds)) return false;
-    g->WS = 2; g->TH = KS_NT / 2; g->gx = mpc_cdiv(s->wq, 2); g->gy = mpc_cdiv(s->hq, KS_NT / 2);
-    g->NR = g->TH + 4 * r_init; g->cap = cap; g->lds = lds;
-    return true;
+    if (!evc || !evc->events || !strip_geometry(s, mpc_knn_r_init(s), 2, &cap, &lds)) return false;
+    return (size_t)evc->nb * evc->NCS * sizeof(int) <= lds && evc->B <= 256;
 }
 
-template <int WS>
-static void launch_strip(const KnnParams &p, const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos,
-                         const int *sidx, float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail,
-                         int r_init, int cap, size_t lds, const KnnLeanBufs *lean, const EvCountArgs *evc, hipStream_t st) {
-    const int TH = KS_NT / WS;
+int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const int *sat, const float2 *spos, const int *sidx,
+                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int *retry, int *far, int r_init,
+                         const EvCountArgs *evc, hipStream_t st) {
+    const KnnParams p = knn_params(s);
+    int cap = 0; size_t lds = 0;
+    if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
+    constexpr int WS = 2, TH = KS_NT / WS;
     const int gx = mpc_cdiv(s->wq, WS), gy = mpc_cdiv(s->hq, TH);
     EvCountArgs ec{};
-    if (evc && (size_t)evc->nb * evc->NCS * sizeof(int) <= lds) ec = *evc;
+    if (evc) ec = *evc;                 // (the caller checked mpc_knn_strip_counts_events)
     const int n_evc = (ev_count_blocks(ec) + 7) / 8 * 8;
     const int64_t total = ((int64_t)gx * gy * s->B * s->nb + 7) / 8 * 8 + n_evc;
     int evc_stride = n_evc > 0 ? (int)(total / (n_evc >> 3) / 8 * 8) : 8;       // a group of 8 counting workgroups every `stride` workgroups
     if (evc_stride < 8) evc_stride = 8;
     const dim3 grid((unsigned)total);
-    unsigned *mk = lean ? lean->masks : nullptr, *fb = lean ? lean->fbits : nullptr;
-    int2 *rt = lean ? lean->rowtab : nullptr;
-#define KS_LAUNCH(L1_, NEXT_, IWD_, LEAN_)                                                                                    \
-    MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_, LEAN_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, spos, sidx, \
-                       flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, gx, gy, mk, rt, fb, ec, n_evc, evc_stride)
-    const int sel = (p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0);
-    if (lean) {                  // (never with 'iwd': its backward is the gather)
-        switch (sel) {
-        case 0: KS_LAUNCH(false, false, false, true); break;
-        case 2: KS_LAUNCH(false, true, false, true); break;
-        case 4: KS_LAUNCH(true, false, false, true); break;
-        default: KS_LAUNCH(true, true, false, true); break;
-        }
-        return;
-    }
-    switch (sel) {
-    case 0: KS_LAUNCH(false, false, false, false); break;
-    case 1: KS_LAUNCH(false, false, true, false); break;
-    case 2: KS_LAUNCH(false, true, false, false); break;
-    case 3: KS_LAUNCH(false, true, true, false); break;
-    case 4: KS_LAUNCH(true, false, false, false); break;
-    case 5: KS_LAUNCH(true, false, true, false); break;
-    case 6: KS_LAUNCH(true, true, false, false); break;
-    default: KS_LAUNCH(true, true, true, false); break;
+    // (the retry kernel: nothing to do unless a strip overflowed its staging area -- 256 workgroups that read one word)
+#define KS_LAUNCH(L1_, NEXT_, IWD_)                                                                                       \
+    do {                                                                                                                  \
+        MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, sat, spos, sidx, \
+                           flow_lut, flow_next, knn_state, tile_dkmax, fail, retry, r_init, cap, gx, gy, ec, n_evc, evc_stride); \
+        MPC_LAUNCH((k_knn_strip_retry<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS), dim3(KS_NT), lds, st, p, traj, cell_start, sat, spos, sidx, \
+                           flow_lut, flow_next, knn_state, tile_dkmax, fail, retry, r_init, cap, gx, gy);                 \
+    } while (0)
+    switch ((p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0)) {
+    case 0: KS_LAUNCH(false, false, false); break;
+    case 1: KS_LAUNCH(false, false, true); break;
+    case 2: KS_LAUNCH(false, true, false); break;
+    case 3: KS_LAUNCH(false, true, true); break;
+    case 4: KS_LAUNCH(true, false, false); break;
+    case 5: KS_LAUNCH(true, false, true); break;
+    case 6: KS_LAUNCH(true, true, false); break;
+    default: KS_LAUNCH(true, true, true); break;
     }
 #undef KS_LAUNCH
-}
-
-// `lean`: buffers of the scatter backward (knn_bwd_scatter.hip), or null for the gather backward (K-th keys + tile maxima)
-int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const float2 *spos, const int *sidx,
-                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int r_init,
-                         const KnnLeanBufs *lean, const EvCountArgs *evc, hipStream_t st) {
-    const KnnParams p = knn_params(s);
-    int cap = 0; size_t lds = 0;
-    if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
-    if (lean && p.iwd) { mpc_set_error("mpc_knn_strip_launch: the scatter backward does not serve 'iwd'"); return MPC_E_UNSUPPORTED; }
-    launch_strip<2>(p, s, traj, cell_start, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, r_init, cap, lds, lean, evc, st);
     MPC_CHECK_LAUNCH();
-    EvCountArgs ecf{};
-    if (evc && (size_t)evc->nb * evc->NCS * sizeof(int) <= lds && evc->B <= 256) ecf = *evc;
-    else if (evc) { mpc_set_error("mpc_knn_strip_launch: event counting does not fit"); return MPC_E_UNSUPPORTED; }
-    MPC_LAUNCH(k_knn_fallback, dim3(256), dim3(256), 0, st, p, traj, cell_start, spos, sidx, flow_lut, flow_next,
-                       knn_state, lean ? nullptr : tile_dkmax, fail, r_init, ecf);
+    MPC_LAUNCH(k_knn_fallback, dim3(KS_FB_BLOCKS), dim3(256), 0, st, p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next,
+                       knn_state, tile_dkmax, fail, far, r_init, ec);
     MPC_CHECK_LAUNCH();
     return 0;
 }

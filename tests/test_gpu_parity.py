@@ -297,32 +297,19 @@ def test_single_sample_single_event_and_far_out_of_bounds_flow():
     assert float(raw2.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('env', [{'MPC_KNN_MODE': 'global'}, {'MPC_KNN_STAGE_FLOW': '0'}, {'MPC_KNN_BLOCKS': '8'},
-                                 {'MPC_KNN_NT': '512', 'MPC_KNN_BWD_TS': '32'},
-                                 {'MPC_KNN_BWD_SCATTER': '1'}, {'MPC_KNN_BWD_SCATTER': '1', 'MPC_KNN_BWD_G': '3'},
-                                 {'MPC_EV_EXACT_ABOVE_MB': '0'}, {'MPC_KNN_BWD_DIRECT': '0'}, {'MPC_EV_STRIPS': '40'}, {'MPC_KNN_BWD_REACH': '1'},
-                                 {'MPC_KNN_BWD_REACH': '0'}])
-def test_alternative_knn_kernels_agree_with_goldens(env):
-    """The unstaged per-thread search, the variant that gathers the flows from global memory, a tiny LDS
-    staging capacity (tiles that overflow it finish on the global arrays), the larger workgroup shapes and the
-    query-centric scatter backward (default and with three strips per workgroup), and the backward event buckets sized by
-    the counting pass (normally only above MPC_EV_EXACT_ABOVE_MB), the backward gather writing per-bin partials for the
-    combine kernel instead of the mid-time gradient in place, a forced count of image strips in the forward event kernels, the
-    reach of the backward's tiles from a launch of its own at every size / at no size --
-    tuning switches read once per process -- must pass the same parity tests as the default: the golden,
-    odd-size and brute-force KNN tests of this file are re-run in a subprocess with the switch set."""
+@pytest.mark.parametrize('env', [{'MPC_EV_EXACT_ABOVE_MB': '0'}, {'MPC_EV_STRIPS': '40'}])
+def test_alternative_event_kernels_agree_with_goldens(env):
+    """The backward event buckets sized by the counting pass (normally only above MPC_EV_EXACT_ABOVE_MB) and a forced count of
+    image strips in the forward event kernels -- switches read once per process -- must pass the same parity tests as the
+    default: the event tests of this file are re-run in a subprocess with the switch set."""
     import os
     import subprocess
     import sys
     if os.environ.get('MPC_ALT_KNN_CHILD'):
         pytest.skip('already inside the child run')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = 'golden_full_calc or golden_stages or odd_image_sizes or knn_large_k or knn_degenerate or full_size_knn'
-    if 'MPC_KNN_BWD_SCATTER' in env or 'MPC_KNN_BWD_DIRECT' in env or 'MPC_KNN_BWD_REACH' in env:      # the scatter backward (knn_bwd_scatter.hip): also every test with a KNN gradient
-        sel += ' or many_keys or hd_sensor or bitwise_reproducible or vs_oracle_seeded or recovers_a_known_flow'
-    if 'MPC_EV_EXACT_ABOVE_MB' in env or 'MPC_EV_STRIPS' in env:    # backward event buckets sized by the counting pass at every size / 40 thin image strips: the event tests
-        sel = ('golden_full_calc or golden_stages or vs_oracle_seeded or tiled_and_atomic or all_events_in_one_bucket or odd_image_sizes '
-               'or empty_and_all_padding or single_sample_single_event or full_size_mass or full_size_event_path or bitwise_reproducible')
+    sel = ('golden_full_calc or golden_stages or vs_oracle_seeded or tiled_and_atomic or all_events_in_one_bucket or odd_image_sizes '
+           'or empty_and_all_padding or single_sample_single_event or full_size_mass or full_size_event_path or bitwise_reproducible')
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_gpu_parity.py', '-x', '-q', '-m', 'gpu', '-k', sel],
                        cwd=root, env=dict(os.environ, MPC_ALT_KNN_CHILD='1', **env), capture_output=True, text=True,
                        timeout=900)
