@@ -129,7 +129,7 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     const int64_t bt = (int64_t)(s->B > 0 ? s->B : 1) * s->nb;
     const int km = mpc_knn_margin(s);
     const int64_t hb = s->hq + 2 * km, wb = s->wq + 2 * km, Gb = hb * wb;
-    const int64_t ktiles = ((hb + 15) / 16) * ((wb + 15) / 16);
+    const int64_t ktiles = mpc_knn_tiles(s);
     L.off_cell_start = off; off += mpc_align(bt * (Gb + 1) * sizeof(int32_t));
     L.off_knn_sat = off;    off += mpc_align(bt * (hb + 1) * (wb + 1) * sizeof(int32_t));
     L.off_spos = off;       off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
@@ -140,6 +140,10 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_knn_reach = off;  off += mpc_align(bt * ktiles * sizeof(float));
     L.off_knn_fail = off;   off += mpc_align((1 + bt * (int64_t)L.G) * sizeof(int32_t));
     L.off_knn_retry = off;  off += mpc_align((1 + bt * (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128)) * sizeof(int32_t));
+    L.off_knn_farstrip = off; off += mpc_align((1 + bt * (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128)) * sizeof(int32_t));
+    L.off_knn_ftlist = off; off += mpc_knn_uses_far_list(s) ? mpc_align((1 + bt * ktiles) * sizeof(int32_t)) : 0;
+    L.off_knn_ftbits = off; off += mpc_knn_uses_far_list(s) ? mpc_align(bt * ((ktiles + 31) / 32) * sizeof(int32_t)) : 0;
+    L.off_knn_again = off;  off += mpc_align(bt * (int64_t)s->hq * ((s->wq + 31) / 32) * sizeof(int32_t));
     L.off_knn_far = off;    off += mpc_knn_uses_far_list(s) ? mpc_align(bt * (1 + (int64_t)L.G) * sizeof(int32_t)) : 0;
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;
@@ -222,8 +226,7 @@ extern "C" int64_t mpc_knn_state_floats(const mpc_shape *s) {
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     const int64_t bt = (int64_t)s->B * s->nb;
-    const int km = mpc_knn_margin(s);
-    return 3 * bt * s->hq * s->wq + bt * ((s->hq + 2 * km + 15) / 16) * ((s->wq + 2 * km + 15) / 16) * 5;
+    return 3 * bt * s->hq * s->wq + bt * mpc_knn_tiles(s) * 5;
 }
 
 extern "C" int64_t mpc_knn_fail_list_offset(const mpc_shape *s) {

@@ -76,6 +76,10 @@ struct mpc_ws_layout {
     int64_t off_knn_reach;   // float  [B*nb][tiles of the bucket grid]  backward search reach per 16x16 tile
     int64_t off_knn_fail;    // int32  [1 + B*nb*G]  queries handed from the strip kernel to the fallback kernel
     int64_t off_knn_retry;   // int32  [1 + B*nb*ceil(wq/2)*ceil(hq/128)]  strips the strip kernel searches again in quarters (staging overflow)
+    int64_t off_knn_farstrip; // int32 [1 + strips]  strips that hold far queries (k_knn_strip_more<FARQ>)
+    int64_t off_knn_ftlist;  // int32 [1 + B*nb*tiles]  (sample, bin, tile) work items of k_knn_bwd_far;  off_knn_ftbits: uint32 [B*nb][ceil(tiles/32)] the same as bits
+    int64_t off_knn_ftbits;
+    int64_t off_knn_again;   // uint32 [B*nb][hq][ceil(wq/32)]  queries the strip kernel's main launch hands to its second launch
     int64_t off_knn_far;     // int32  [B*nb][1 + G]  per (sample, bin): the queries the fallback kernel served, for k_knn_bwd_far
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8] bucket fill counters, marker; then [nbb] capacities and [nbb] first records of the backward buckets
@@ -115,6 +119,7 @@ int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float 
 int mpc_validate_shape(const mpc_shape *s);
 // KNN (knn.hip): margin of the bucket grid; is the points' counting sort the global-memory one; does the forward keep a far list
 int mpc_knn_margin(const mpc_shape *s);
+int mpc_knn_tiles(const mpc_shape *s);          // 16 x 16 cell tiles of the bucket grid per (sample, bin)
 bool mpc_knn_big_sort(const mpc_shape *s);
 bool mpc_knn_uses_far_list(const mpc_shape *s);
 

@@ -58,8 +58,8 @@ template <bool CACHED, int NPT>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
                                                      int *__restrict__ cell_start, int *__restrict__ sat,
                                                      float2 *__restrict__ spos, int *__restrict__ sidx, int S,
-                                                     float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail, int *__restrict__ retry,
-                                                     int *__restrict__ far, int *__restrict__ zero_ptr, int zero_words) {
+                                                     float *__restrict__ tile_dkmax, int ntiles, const KnnLists ls,
+                                                     int *__restrict__ zero_ptr, int zero_words) {
     extern __shared__ int s_cnt[];
     __shared__ int s_wave[16];
     __shared__ int s_low[16];
@@ -78,8 +78,13 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
     // atomicMax and its fallback lists are appended to (knn_strip.hip)
     if (part == 0) for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;
-    if (part == 0 && tid == 0 && far != nullptr) far[(size_t)bt * (p.G + 1)] = 0;
-    if (blockIdx.x == 0 && tid == 0) { fail[0] = 0; retry[0] = 0; }
+    // ... and the work lists of the forward start empty (knn_device.h: KnnLists)
+    if (part == 0 && ls.far != nullptr) {
+        if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
+        if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
+    }
+    if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) ls.again[(size_t)bt * ls.again_words + i] = 0u;
+    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; }
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
     const int rows_per = (p.hb + S - 1) / S;
     const int g_lo = min(part * rows_per, p.hb) * p.wb, g_hi = min((part + 1) * rows_per, p.hb) * p.wb, Gp = g_hi - g_lo;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 #ifdef KNN_BK_STAMP
     BK_STAMP(7);
     __syncthreads();
-    if (tid < 8) fail[1 + 100000 + 8 * blockIdx.x + tid] = tid == 0 ? (int)s_stp[0] : (int)(s_stp[tid] - s_stp[0]);      // [0]: absolute start (low 32 bits)
+    if (tid < 8) ls.fail[1 + 100000 + 8 * blockIdx.x + tid] = tid == 0 ? (int)s_stp[0] : (int)(s_stp[tid] - s_stp[0]);      // [0]: absolute start (low 32 bits)
 #endif
 }
 
@@ -332,13 +337,17 @@ __global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, con
 // grid B*nb, 1024 threads
 __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
                                                           int *__restrict__ cell_start,
-                                                          float *__restrict__ tile_dkmax, int ntiles, int *__restrict__ fail, int *__restrict__ retry,
-                                                          int *__restrict__ far, int *__restrict__ zero_ptr, int zero_words) {
+                                                          float *__restrict__ tile_dkmax, int ntiles, const KnnLists ls,
+                                                          int *__restrict__ zero_ptr, int zero_words) {
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, bt = blockIdx.x;
     for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;       // (see k_knn_bucket)
-    if (tid == 0 && far != nullptr) far[(size_t)bt * (p.G + 1)] = 0;
-    if (bt == 0 && tid == 0) { fail[0] = 0; retry[0] = 0; }
+    if (ls.far != nullptr) {
+        if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
+        if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
+    }
+    if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) ls.again[(size_t)bt * ls.again_words + i] = 0u;
+    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; }
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
     int *cur = cursor + (size_t)bt * p.Gb;
     int *cs = cell_start + (size_t)bt * (p.Gb + 1);
@@ -630,8 +639,8 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
                                                             int gx, int gy) {
     constexpr int NT = TS * TS, SUB = TS / 16;
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_rowbase[TS + 1];
-    __shared__ int s_rowg[TS];
+    __shared__ int s_rowbase[KNN_TROWS + 1];
+    __shared__ int s_rowg[KNN_TROWS];
     __shared__ float s_Rsub[SUB * SUB];
     const int tid = threadIdx.x;
     // 1-D grid, XCD-contiguous: the gx*gy tiles of one (sample, bin) run on one XCD, so the halo cells that
@@ -644,7 +653,9 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
     const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
-    // (tiles of the BUCKET grid: knn_tile_of)
+    int tcy0, tcy1, tcx0, tcx1;           // cells of the tile's points: a border tile owns the margin beside it (knn_tile_cells)
+    knn_tile_cells(by_, p.hq, p.m, tcy0, tcy1); knn_tile_cells(bx_, p.wq, p.m, tcx0, tcx1);
+    const int nrow = tcy1 - tcy0;
     // phase 1 (independent loads): reach of the 16x16 sub-tiles; per tile row the contiguous range of
     // the bucketed arrays, turned into a running offset by a wavefront scan
     if (tid < SUB * SUB) {
@@ -654,15 +665,11 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     }
     if (tid < 64) {
         int gs = 0, ge = 0;
-        const int yq = by_ * TS - KNN_TILE_OFF + tid;      // cell row of the tile (query numbering)
-        if (tid < TS && yq >= -p.m && yq < p.hq + p.m) {
-            const int xa = max(bx_ * TS - KNN_TILE_OFF, -p.m), xb = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m);
-            if (xa < xb) { gs = cs[knn_ci(p, yq, xa)]; ge = cs[knn_ci(p, yq, xb)]; }
-        }
+        if (tid < nrow) { gs = cs[knn_ci(p, tcy0 + tid, tcx0)]; ge = cs[knn_ci(p, tcy0 + tid, tcx1)]; }      // cell rows of the tile, margin included
         int run = ge - gs;                               // inclusive scan over the lanes
 #pragma unroll
-        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
-        if (tid < TS) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
+        for (int o2 = 1; o2 < KNN_TROWS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
+        if (tid < nrow) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
         if (tid == 0) s_rowbase[0] = 0;
     }
     __syncthreads();
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
     const int RQ = use_lds ? RQ_need : 0;
     const int RW = TS + 2 * RQ;
-    const int ry0 = by_ * TS - KNN_TILE_OFF - RQ, rx0 = bx_ * TS - KNN_TILE_OFF - RQ;      // (query-grid coordinates)
+    const int ry0 = by_ * TS - RQ, rx0 = bx_ * TS - RQ;
     // LDS: only the fast path (num_tref == 1, 'mean') stages anything: one float4 per query cell
     // {K-th distance, K-th index, dL/dLUT.y, dL/dLUT.x} (+ float2 of the flow_to_next gradient)
     float4 *lq4 = reinterpret_cast<float4 *>(s_dyn);
@@ -700,17 +707,16 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
         }
     }
     __syncthreads();
-    const int total = s_rowbase[TS];
+    const int total = s_rowbase[nrow];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const int *si_ = sidx + (size_t)bt * p.n;
     for (int pi = tid; pi < total; pi += NT) {
-        int lo = 0, hi = TS;
+        int lo = 0, hi = nrow;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
         const int g = s_rowg[lo] + (pi - s_rowbase[lo]);
         const float2 pt = sp_[g];
         const int i = si_[g];
-        if (SUB > 1) R = s_Rsub[(lo >> 4) * SUB + ((cell_of(pt.y, p.sp, p.wq, p.m) + KNN_TILE_OFF - bx_ * TS) >> 4)];
         // query cells within reach: |q - p| <= R per axis.  R already carries a 0.01 px + 1e-4 relative
         // margin, which dominates the rounding of these four expressions, so no extra cell is added.
         // (a reciprocal multiply instead of four divisions: its 1e-7 relative error is far inside that margin too)
@@ -923,8 +929,8 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     int st_slow = 0;
 #endif
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_rowbase[TS + 1];
-    __shared__ int s_rowg[TS];
+    __shared__ int s_rowbase[KNN_TROWS + 1];
+    __shared__ int s_rowg[KNN_TROWS];
     __shared__ float s_wr[1];
     __shared__ int s_tiew[4];
     const int tid = threadIdx.x;
@@ -936,7 +942,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
     const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
-    // (tiles of the BUCKET grid: knn_tile_of)
+    int tcy0, tcy1, tcx0, tcx1;           // cells of the tile's points: a border tile owns the margin beside it (knn_tile_cells)
+    knn_tile_cells(by_, p.hq, p.m, tcy0, tcy1); knn_tile_cells(bx_, p.wq, p.m, tcx0, tcx1);
+    const int nrow = tcy1 - tcy0;
     // ---- phase 1: reach of this tile = the largest linear K-th distance among the tiles whose queries can touch it
     //      (Chebyshev gap between this tile's cell area and their query centres); bucketed ranges of the tile rows --
     // Wavefront 0 alone.  Step A: the largest K-th distance of ANY class of ANY tile of the slice (coalesced reads).  A
@@ -952,22 +960,18 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     } else if (tid < 128) {
         const int ln = tid - 64;
         int gs = 0, ge = 0;
-        const int yq = by_ * TS - KNN_TILE_OFF + ln;       // cell row of the tile (query numbering)
-        if (ln < TS && yq >= -p.m && yq < p.hq + p.m) {
-            const int xa = max(bx_ * TS - KNN_TILE_OFF, -p.m), xb = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m);
-            if (xa < xb) { gs = cs[knn_ci(p, yq, xa)]; ge = cs[knn_ci(p, yq, xb)]; }
-        }
+        if (ln < nrow) { gs = cs[knn_ci(p, tcy0 + ln, tcx0)]; ge = cs[knn_ci(p, tcy0 + ln, tcx1)]; }      // cell rows of the tile, margin included
         int run = ge - gs;
 #pragma unroll
-        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (ln >= o2) run += v; }
-        if (ln < TS) { s_rowg[ln] = gs; s_rowbase[ln + 1] = run; }
+        for (int o2 = 1; o2 < KNN_TROWS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (ln >= o2) run += v; }
+        if (ln < nrow) { s_rowg[ln] = gs; s_rowbase[ln + 1] = run; }
         if (ln == 0) s_rowbase[0] = 0;
     }
     // ---- phase 2 (after the reach is known; staging a guessed halo before it, so that the loads of the two phases
     //      travel together, measured slower: too many tiles stage twice): the K-th distance, K-th index | tie flag and
     //      dL/dLUT of the tile's query cells and the halo the reach asks for ------------------------------------------
     float *ldk; int *lik; float2 *lg, *lgn;
-    int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS - KNN_TILE_OFF, rx0 = bx_ * TS - KNN_TILE_OFF;      // (query-grid coordinates)
+    int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS, rx0 = bx_ * TS;
     const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
         // The K-th INDEX (only read on the exact path, for a tie) stays in global memory then, which keeps the workgroup
         // at 19.5 KB -- eight per CU as before.  With the flow_to_next gradient (8 more bytes per cell) the pitch stays 32.
         RP = NEXT ? (RW <= 32 ? 32 : RW) : KNN_BW_PITCH;
-        ry0 = by_ * TS - KNN_TILE_OFF - RQ; rx0 = bx_ * TS - KNN_TILE_OFF - RQ;
+        ry0 = by_ * TS - RQ; rx0 = bx_ * TS - RQ;
         // separate arrays (the hot loop reads the K-th distance and the gradient only; neighbouring lanes then read
         // neighbouring 4- and 8-byte words): K-th distance, [K-th index,] dL/dLUT, [dL/dflow_next]
         const size_t ncell = (size_t)RW * RP + KNN_BW_WMAX;
@@ -1024,7 +1028,6 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     };
     if ((tid & 63) == 0) s_tiew[tid >> 6] = 0;
     __syncthreads();
-    if (s_rowbase[TS] == 0) return;          // (a tile of the margin ring that holds no point: workgroup-uniform)
     const float R = s_wr[0];
     const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo the reach asks for, in cells
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 #ifdef KNN_BW_STAMP
     const unsigned long long st1 = wall_clock64();
 #endif
-    const int total = s_rowbase[TS];
+    const int total = s_rowbase[nrow];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const int *si_ = sidx + (size_t)bt * p.n;
@@ -1045,7 +1048,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
         const int pi = base + tid;
         const bool act = pi < total;
         if (__ballot(act) == 0ull) continue;          // (a tile holds ~256 points: a second round is mostly one wavefront)
-        int lo = 0, hi = TS;
+        int lo = 0, hi = nrow;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
         const int g = act ? s_rowg[lo] + (pi - s_rowbase[lo]) : 0;
         const float2 pt = sp_[g];
@@ -1147,172 +1150,167 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 }
 
 // ------------------------------------------------------------------------------------------
-// backward of the FAR queries (the ones the forward's fallback kernel served: fewer than K points within the largest square
-// of the strip kernel -- queries inside a band the flow field emptied, whose K neighbours lie in a thin segment of a disc
-// tens of pixels away).  Counting them in the tile maxima would make every point of the tiles around such a band search a
+// backward of the FAR queries (no square of up to KNN_RCAP cells around them holds K points: queries inside a band the flow
+// field emptied, whose K neighbours lie in a thin segment of a disc tens of pixels away; served by k_knn_strip_more<FARQ> or
+// the fallback kernel).  Counting them in the tile maxima would make every point of the tiles around such a band search a
 // window of hundreds of query cells for the few dozen of them that hold it; k_knn_bwd_tile therefore leaves them out, and
-// here the search runs the other way round, as in the forward: one thread per far query walks the cell rows of the tile
-// that its disc (centre, K-th distance) touches, tests the bucketed points of the chord and adds dL/dLUT to the
-// accumulators of the members -- 64-bit fixed point in LDS (scaled by a power of two from the largest gradient of the list:
-// integer sums, any order, bitwise reproducible), then added to what the gather wrote for the point.
-// grid: as k_knn_bwd_tile (one workgroup per tile of the bucket grid and (sample, bin)); returns at once when the list of
-// the (sample, bin) is empty (the white-noise benchmark: ~1 query per slice)
+// here the search runs the other way round, as in the forward: the tile's bucketed points and cell offsets are staged in LDS,
+// one thread per far query of the (sample, bin) walks the cell rows of the tile that its disc (centre, K-th distance) touches,
+// tests the points of the chord and adds dL/dLUT to the accumulators of the members -- 64-bit fixed point in LDS (scaled by a
+// power of two from the largest gradient of the list: integer sums, any order, bitwise reproducible), then added to what the
+// gather wrote for the point.
+// Work items: the (sample, bin, tile) entries the forward put on the list (knn_far_mark_tiles: the tiles a far query's disc can
+// touch).  grid: a fixed number of workgroups (the list length is only known on the device; the lattice-like point sets of
+// the benchmark have a few hundred items per step)
 // ------------------------------------------------------------------------------------------
 #define KNN_FAR_CAP 512       // points of a tile per round of accumulators
+#define KNN_FAR_BLOCKS 2048
 template <bool L1, bool NEXT>
 __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const int *__restrict__ cell_start,
                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
-                                                     const float *__restrict__ knn_state, const int *__restrict__ far,
+                                                     const float *__restrict__ knn_state, const KnnLists ls,
                                                      float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
-                                                     float2 *__restrict__ gtraj_direct, int gx, int gy) {
-    constexpr int TS = 16;
-    __shared__ unsigned long long s_acc[KNN_FAR_CAP * (NEXT ? 4 : 2)];
-    __shared__ int s_rowbase[TS + 1];
-    __shared__ int s_rowg[TS];
+                                                     float2 *__restrict__ gtraj_direct) {
+    constexpr int NA = NEXT ? 4 : 2;
+    __shared__ unsigned long long s_acc[KNN_FAR_CAP * NA];
+    __shared__ float2 s_pos[KNN_FAR_CAP];
+    __shared__ unsigned short s_idx[KNN_FAR_CAP];
+    __shared__ int s_cs[KNN_TROWS][KNN_TROWS + 1];          // first point (numbered within the tile) of every cell of the tile
+    __shared__ int s_rowbase[KNN_TROWS + 1];
+    __shared__ int s_rowg[KNN_TROWS];
     __shared__ float s_wm[4];
     const int tid = threadIdx.x;
-    const int nblk = gx * gy * p.B * p.nb;
-    const int lblk = (int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3);
-    if (lblk >= nblk) return;
-    const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
-    const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
-    const int b = bt / p.nb, t = bt - b * p.nb;
-    const int *fl = far + (size_t)bt * (p.G + 1);
-    const int nfar = min(fl[0], p.G);
-    if (nfar <= 0) return;
+    const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m), nt = ntx * nty;
+    const int nwork = min(ls.ftlist[0], p.B * p.nb * nt);
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
-    const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
-    const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
-    const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
-    const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
-    const float *dks = knn_state + (size_t)bt * p.G;
-    const int *iks = reinterpret_cast<const int *>(knn_state) + BQ + (size_t)bt * p.G;
-    // pixel extent of the tile's cells; the outermost cells also hold what lies beyond the margin: open on that side
-    float ay0, ay1, ax0, ax1;
-    knn_tile_area(p, by_, bx_, ay0, ay1, ax0, ax1);
-    const int ty0 = max(by_ * TS - KNN_TILE_OFF, -p.m), tx0 = max(bx_ * TS - KNN_TILE_OFF, -p.m);      // first / last cell row and column of the tile (query numbering)
-    const int ty1 = min(by_ * TS - KNN_TILE_OFF + TS, p.hq + p.m) - 1, tx1 = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m) - 1;
-    if (ty0 == -p.m) ay0 = -INFINITY;
-    if (ty1 == p.hq + p.m - 1) ay1 = INFINITY;
-    if (tx0 == -p.m) ax0 = -INFINITY;
-    if (tx1 == p.wq + p.m - 1) ax1 = INFINITY;
-    {   // does the disc of any far query touch this tile?  (the lattice-like point sets of the benchmark have a handful of far
-        // queries per (sample, bin): nearly every workgroup ends here)
-        int any = 0;
-        for (int e = tid; e < nfar; e += 256) {
-            const int cell = fl[1 + e];
-            const int cy = cell / p.wq, cx = cell - cy * p.wq;
-            const float dk = dks[cell];
-            const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-            const float gy_ = fmaxf(0.f, fmaxf(qy - ay1, ay0 - qy)), gx_ = fmaxf(0.f, fmaxf(qx - ax1, ax0 - qx));
-            any |= ((L1 ? gy_ + gx_ : gy_ * gy_ + gx_ * gx_) <= dk) ? 1 : 0;
-        }
-        if (!__syncthreads_or(any)) return;
-    }
-    // bucketed ranges of the tile rows
-    if (tid < 64) {
-        int gs = 0, ge = 0;
-        const int yq = by_ * TS - KNN_TILE_OFF + tid;
-        if (tid < TS && yq >= -p.m && yq < p.hq + p.m) {
-            const int xa = max(bx_ * TS - KNN_TILE_OFF, -p.m), xb = min(bx_ * TS - KNN_TILE_OFF + TS, p.wq + p.m);
-            if (xa < xb) { gs = cs[knn_ci(p, yq, xa)]; ge = cs[knn_ci(p, yq, xb)]; }
-        }
-        int run = ge - gs;
-#pragma unroll
-        for (int o2 = 1; o2 < TS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
-        if (tid < TS) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
-        if (tid == 0) s_rowbase[0] = 0;
-    }
-    // largest gradient of the list -> the power of two that scales the fixed-point sums (values below 2^40, up to 2^20 of them)
-    float gm = 0.f;
-    for (int e = tid; e < nfar; e += 256) {
-        const int cell = fl[1 + e];
-        const float2 g = gl2[cell];
-        gm = fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y)));
-        if (has_next) { const float2 gn = gn2[cell]; gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
-    }
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o2, 64));
-    if ((tid & 63) == 0) s_wm[tid >> 6] = gm;
-    __syncthreads();
-    gm = fmaxf(fmaxf(s_wm[0], s_wm[1]), fmaxf(s_wm[2], s_wm[3]));
-    const int total = s_rowbase[TS];
-    if (total == 0 || !(gm > 0.f) || !(gm < INFINITY)) return;          // (no point to receive anything / nothing to add)
-    int ex;
-    (void)frexpf(gm, &ex);                                              // gm = f * 2^ex, f in [0.5, 1)
-    const double scale = ldexp(1.0, 40 - ex), inv_scale = ldexp(1.0, ex - 40);
     const float invK = 1.f / (float)p.K;
-    constexpr int NA = NEXT ? 4 : 2;
-    for (int c0 = 0; c0 < total; c0 += KNN_FAR_CAP) {
-        for (int i = tid; i < KNN_FAR_CAP * NA; i += 256) s_acc[i] = 0ull;
-        __syncthreads();
+    for (int w = (int)blockIdx.x; w < nwork; w += (int)gridDim.x) {
+        const int item = ls.ftlist[1 + w];
+        const int bt = item / nt, tile = item - bt * nt;
+        const int by_ = tile / ntx, bx_ = tile - by_ * ntx;
+        const int b = bt / p.nb, t = bt - b * p.nb;
+        const int *fl = ls.far + (size_t)bt * (p.G + 1);
+        const int nfar = min(fl[0], p.G);
+        const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+        const float2 *sp_ = spos + (size_t)bt * p.n;
+        const int *si_ = sidx + (size_t)bt * p.n;
+        const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
+        const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
+        const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
+        const float *dks = knn_state + (size_t)bt * p.G;
+        const int *iks = reinterpret_cast<const int *>(knn_state) + BQ + (size_t)bt * p.G;
+        // cells of the tile's points (a border tile owns the margin beside it) and their pixel extent; the outermost cells also
+        // hold what lies beyond the margin: open on that side
+        int ty0, ty1, tx0, tx1;
+        knn_tile_cells(by_, p.hq, p.m, ty0, ty1); knn_tile_cells(bx_, p.wq, p.m, tx0, tx1);
+        const int nrow = ty1 - ty0, ncol = tx1 - tx0;
+        float ay0 = (float)(ty0 * p.sp) - 0.5f, ay1 = (float)(ty1 * p.sp) - 0.5f, ax0 = (float)(tx0 * p.sp) - 0.5f, ax1 = (float)(tx1 * p.sp) - 0.5f;
+        if (ty0 == -p.m) ay0 = -INFINITY;
+        if (ty1 == p.hq + p.m) ay1 = INFINITY;
+        if (tx0 == -p.m) ax0 = -INFINITY;
+        if (tx1 == p.wq + p.m) ax1 = INFINITY;
+        // bucketed ranges of the tile rows; cell offsets of the tile
+        if (tid < 64) {
+            int gs = 0, ge = 0;
+            if (tid < nrow) { gs = cs[knn_ci(p, ty0 + tid, tx0)]; ge = cs[knn_ci(p, ty0 + tid, tx1)]; }
+            int run = ge - gs;
+#pragma unroll
+            for (int o2 = 1; o2 < KNN_TROWS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (tid >= o2) run += v; }
+            if (tid < nrow) { s_rowg[tid] = gs; s_rowbase[tid + 1] = run; }
+            if (tid == 0) s_rowbase[0] = 0;
+        }
+        // largest gradient of the list -> the power of two that scales the fixed-point sums (values below 2^40, up to 2^20 of them)
+        float gm = 0.f;
         for (int e = tid; e < nfar; e += 256) {
             const int cell = fl[1 + e];
-            const int cy = cell / p.wq, cx = cell - cy * p.wq;
-            const float dk = dks[cell];
-            const int ik = iks[cell] & KNN_IDX_MASK;
-            const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-            // does the disc of the query touch the tile's area at all?
-            const float gy_ = fmaxf(0.f, fmaxf(qy - ay1, ay0 - qy)), gx_ = fmaxf(0.f, fmaxf(qx - ax1, ax0 - qx));
-            if ((L1 ? gy_ + gx_ : gy_ * gy_ + gx_ * gx_) > dk) continue;
             const float2 g = gl2[cell];
-            const float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
-            const long long fy = __double2ll_rn((double)g.x * scale), fx = __double2ll_rn((double)g.y * scale);
-            const long long fny = __double2ll_rn((double)gn.x * scale), fnx = __double2ll_rn((double)gn.y * scale);
-            for (int yq = ty0; yq <= ty1; ++yq) {
-                // a point of cell row yq is at least dyc away along y (none for the open side of an outermost row); along x
-                // it then lies within wx of the query
-                float dyc = fmaxf((float)abs(yq - cy) - 0.5f, 0.f) * (float)p.sp;
-                const float w2 = L1 ? dk - dyc : dk - dyc * dyc;
-                if (w2 < 0.f) continue;
-                const int xr = (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1;
-                int xa = max(cx - xr, tx0), xb = min(cx + xr, tx1);
-                if (cx - xr <= -p.m) xa = tx0;                   // (the outermost column holds everything beyond it)
-                if (cx + xr >= p.wq + p.m - 1) xb = tx1;
-                if (xa > xb) continue;
-                const int rr = yq - (by_ * TS - KNN_TILE_OFF);
-                const int js = cs[knn_ci(p, yq, xa)], je = cs[knn_ci(p, yq, xb + 1)];
-                for (int j = js; j < je; ++j) {
-                    const float2 pj = sp_[j];
-                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                    if (d > dk || (d == dk && si_[j] > ik)) continue;
-                    const int li = s_rowbase[rr] + (j - s_rowg[rr]) - c0;
-                    if (li < 0 || li >= KNN_FAR_CAP) continue;
-                    atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fy);
-                    atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fx);
-                    if (NEXT && has_next) { atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fny); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fnx); }
+            gm = fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y)));
+            if (has_next) { const float2 gn = gn2[cell]; gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o2, 64));
+        if ((tid & 63) == 0) s_wm[tid >> 6] = gm;
+        __syncthreads();
+        gm = fmaxf(fmaxf(s_wm[0], s_wm[1]), fmaxf(s_wm[2], s_wm[3]));
+        const int total = s_rowbase[nrow];
+        const bool nothing = total == 0 || !(gm > 0.f) || !(gm < INFINITY);      // (no point to receive anything / nothing to add: uniform)
+        int ex = 0;
+        (void)frexpf(nothing ? 1.f : gm, &ex);                              // gm = f * 2^ex, f in [0.5, 1)
+        const double scale = ldexp(1.0, 40 - ex), inv_scale = ldexp(1.0, ex - 40);
+        for (int i = tid; i < nrow * (ncol + 1); i += 256) {
+            const int rr = i / (ncol + 1), cc = i - rr * (ncol + 1);
+            s_cs[rr][cc] = s_rowbase[rr] + cs[knn_ci(p, ty0 + rr, tx0 + cc)] - s_rowg[rr];
+        }
+        for (int c0 = 0; c0 < total && !nothing; c0 += KNN_FAR_CAP) {
+            for (int i = tid; i < KNN_FAR_CAP * NA; i += 256) s_acc[i] = 0ull;
+            for (int li = tid; li < min(KNN_FAR_CAP, total - c0); li += 256) {          // this round's points: position and index
+                const int pi = c0 + li;
+                int lo = 0, hi = nrow;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
+                const int g = s_rowg[lo] + (pi - s_rowbase[lo]);
+                s_pos[li] = sp_[g]; s_idx[li] = (unsigned short)si_[g];
+            }
+            __syncthreads();
+            for (int e = tid; e < nfar; e += 256) {
+                const int cell = fl[1 + e];
+                const int cy = cell / p.wq, cx = cell - cy * p.wq;
+                const float dk = dks[cell];
+                const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+                // does the disc of the query touch the tile's area at all?
+                const float gy_ = fmaxf(0.f, fmaxf(qy - ay1, ay0 - qy)), gx_ = fmaxf(0.f, fmaxf(qx - ax1, ax0 - qx));
+                if ((L1 ? gy_ + gx_ : gy_ * gy_ + gx_ * gx_) > dk) continue;
+                const int ik = iks[cell] & KNN_IDX_MASK;
+                const float2 g = gl2[cell];
+                const float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
+                const long long fy = __double2ll_rn((double)g.x * scale), fx = __double2ll_rn((double)g.y * scale);
+                const long long fny = __double2ll_rn((double)gn.x * scale), fnx = __double2ll_rn((double)gn.y * scale);
+                for (int rr = 0; rr < nrow; ++rr) {
+                    // a point of this cell row is at least dyc away along y; along x it then lies within wx of the query
+                    const float dyc = fmaxf((float)abs(ty0 + rr - cy) - 0.5f, 0.f) * (float)p.sp;
+                    const float w2 = L1 ? dk - dyc : dk - dyc * dyc;
+                    if (w2 < 0.f) continue;
+                    const int xr = (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1;
+                    int xa = max(cx - xr, tx0), xb = min(cx + xr, tx1 - 1);
+                    if (cx - xr <= -p.m) xa = tx0;                   // (the outermost column holds everything beyond it)
+                    if (cx + xr >= p.wq + p.m - 1) xb = tx1 - 1;
+                    if (xa > xb) continue;
+                    const int ja = max(s_cs[rr][xa - tx0] - c0, 0), jb = min(s_cs[rr][xb + 1 - tx0] - c0, KNN_FAR_CAP);
+                    for (int li = ja; li < jb; ++li) {
+                        const float2 pj = s_pos[li];
+                        const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                        if (d > dk || (d == dk && (int)s_idx[li] > ik)) continue;
+                        atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fy);
+                        atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fx);
+                        if (NEXT && has_next) { atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fny); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fnx); }
+                    }
                 }
             }
-        }
-        __syncthreads();
-        for (int li = tid; li < min(KNN_FAR_CAP, total - c0); li += 256) {
-            const long long ay = (long long)s_acc[li * NA + 0], ax = (long long)s_acc[li * NA + 1];
-            const long long any_ = NEXT ? (long long)s_acc[li * NA + 2] : 0ll, anx = NEXT ? (long long)s_acc[li * NA + 3] : 0ll;
-            if ((ay | ax | any_ | anx) == 0ll) continue;
-            const int pi = c0 + li;
-            int lo = 0, hi = TS;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
-            const int i = si_[s_rowg[lo] + (pi - s_rowbase[lo])];
-            const float vy = invK * (float)((double)ay * inv_scale), vx = invK * (float)((double)ax * inv_scale);
-            if (gtraj_direct != nullptr) {
-                float2 *dst = gtraj_direct + ((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i;
-                const float2 o = *dst;
-                *dst = make_float2(o.x - vy, o.y - vx);
-            } else {
-                float2 *dst = tmp_g + (size_t)bt * p.n + i;
-                const float2 o = *dst;
-                *dst = make_float2(o.x + vy, o.y + vx);
-                if (NEXT && gnext != nullptr) {
-                    float2 *da = tmp_a + (size_t)bt * p.n + i;
-                    const float2 oa = *da;
-                    *da = make_float2(oa.x + invK * (float)((double)any_ * inv_scale), oa.y + invK * (float)((double)anx * inv_scale));
+            __syncthreads();
+            for (int li = tid; li < min(KNN_FAR_CAP, total - c0); li += 256) {
+                const long long ay = (long long)s_acc[li * NA + 0], ax = (long long)s_acc[li * NA + 1];
+                const long long any_ = NEXT ? (long long)s_acc[li * NA + 2] : 0ll, anx = NEXT ? (long long)s_acc[li * NA + 3] : 0ll;
+                if ((ay | ax | any_ | anx) == 0ll) continue;
+                const int i = (int)s_idx[li];
+                const float vy = invK * (float)((double)ay * inv_scale), vx = invK * (float)((double)ax * inv_scale);
+                if (gtraj_direct != nullptr) {
+                    float2 *dst = gtraj_direct + ((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i;
+                    const float2 o = *dst;
+                    *dst = make_float2(o.x - vy, o.y - vx);
+                } else {
+                    float2 *dst = tmp_g + (size_t)bt * p.n + i;
+                    const float2 o = *dst;
+                    *dst = make_float2(o.x + vy, o.y + vx);
+                    if (NEXT && gnext != nullptr) {
+                        float2 *da = tmp_a + (size_t)bt * p.n + i;
+                        const float2 oa = *da;
+                        *da = make_float2(oa.x + invK * (float)((double)any_ * inv_scale), oa.y + invK * (float)((double)anx * inv_scale));
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+        __syncthreads();          // (the next item reuses the tables)
     }
 }
 
@@ -1393,6 +1391,7 @@ int mpc_knn_r_init(const mpc_shape *s) {
 
 // margin of the bucket grid (knn_device.h): the strip kernel never reaches the outermost ring
 int mpc_knn_margin(const mpc_shape *) { return KNN_MARGIN; }
+int mpc_knn_tiles(const mpc_shape *s) { return knn_tiles_x(s->wq, KNN_MARGIN) * knn_tiles_y(s->hq, KNN_MARGIN); }
 
 // true where the forward is the strip kernel + fallback (num_tref == 1: the shipped configurations)
 static bool knn_fwd_is_strip(const mpc_shape *s, const int32_t *idx_out) {
@@ -1422,6 +1421,22 @@ static bool knn_sort_plan(const mpc_shape *s, int *S_out, size_t *lds_out) {
     return (int64_t)hb * wb > MPC_KNN_LDS_SORT_CELLS || lds > 145 * 1024;
 }
 bool mpc_knn_big_sort(const mpc_shape *s) { int S; size_t l; return knn_sort_plan(s, &S, &l); }
+
+// the work lists of the forward in the workspace (knn_device.h: KnnLists)
+static KnnLists knn_lists(const mpc_shape *s, const mpc_ws_layout &L, void *ws) {
+    KnnLists ls;
+    ls.fail = (int *)((char *)ws + L.off_knn_fail);
+    ls.retry = (int *)((char *)ws + L.off_knn_retry);
+    ls.farstrip = (int *)((char *)ws + L.off_knn_farstrip);
+    const bool far = mpc_knn_uses_far_list(s);
+    ls.far = far ? (int *)((char *)ws + L.off_knn_far) : nullptr;
+    ls.ftlist = far ? (int *)((char *)ws + L.off_knn_ftlist) : nullptr;
+    ls.ftbits = far ? (unsigned *)((char *)ws + L.off_knn_ftbits) : nullptr;
+    ls.ftwords = (mpc_knn_tiles(s) + 31) / 32;
+    ls.again = (unsigned *)((char *)ws + L.off_knn_again);
+    ls.again_words = s->hq * ((s->wq + 31) / 32);
+    return ls;
+}
 
 static int set_max_lds(const void *fn, const char *who) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1455,9 +1470,7 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     float2 *spos = (float2 *)((char *)ws + L.off_spos);
     int *sidx = (int *)((char *)ws + L.off_sidx);
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
-    int *fail = (int *)((char *)ws + L.off_knn_fail);
-    int *retry = (int *)((char *)ws + L.off_knn_retry);
-    int *far = mpc_knn_uses_far_list(s) ? (int *)((char *)ws + L.off_knn_far) : nullptr;
+    const KnnLists ls = knn_lists(s, L, ws);
     const int ntiles = knn_tiles_x(s->wq, p.m) * knn_tiles_y(s->hq, p.m);
     int *zero_ptr = (int *)((char *)ws + L.off_fcount);
     const int zero_words = (zero_event_counters && L.strip_rows > 0) ? L.nfb + 2 * L.nbb + 8 : 0;
@@ -1484,12 +1497,12 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
         if (e) return e;
         const dim3 gp(mpc_cdiv(s->n, 256), s->B * s->nb), gc(mpc_cdiv(p.Gb, 4), s->B * s->nb);
         MPC_LAUNCH(k_knn_bucket_count, gp, dim3(256), 0, st, p, traj, cursor);
-        MPC_LAUNCH(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, fail, retry, far, zero_ptr, zero_words);
+        MPC_LAUNCH(k_knn_bucket_scan, dim3(s->B * s->nb), dim3(1024), 0, st, p, cursor, cell_start, tile_dkmax, ntiles, ls, zero_ptr, zero_words);
         MPC_LAUNCH(k_knn_bucket_scatter, gp, dim3(256), 0, st, p, traj, cursor, spos, sidx);
         MPC_LAUNCH(k_knn_bucket_order, gc, dim3(256), 0, st, p, cell_start, spos, sidx, traj);
     } else {
         sat_launch = S != 1;
-#define KB_LAUNCH(C_, N_) MPC_LAUNCH((k_knn_bucket<C_, N_>), dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, strip ? sat : nullptr, spos, sidx, S, tile_dkmax, ntiles, fail, retry, far, zero_ptr, zero_words)
+#define KB_LAUNCH(C_, N_) MPC_LAUNCH((k_knn_bucket<C_, N_>), dim3(s->B * s->nb * S), dim3(1024), sort_lds, st, p, traj, cell_start, strip ? sat : nullptr, spos, sidx, S, tile_dkmax, ntiles, ls, zero_ptr, zero_words)
         if (s->n <= 8 * 1024) KB_LAUNCH(true, 8);
         else if (s->n <= 16 * 1024) KB_LAUNCH(true, 16);
         else if (s->n <= 20 * 1024) KB_LAUNCH(true, 20);
@@ -1505,7 +1518,7 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
             MPC_LAUNCH(k_knn_sat, dim3(s->B * s->nb), dim3(1024), (size_t)((p.hb + 7) / 8) * (p.wb + 1) * sizeof(int), st, p, cell_start, sat);
             MPC_CHECK_LAUNCH();
         }
-        rc = mpc_knn_strip_launch(s, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, retry, far, r_init,
+        rc = mpc_knn_strip_launch(s, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, &ls, r_init,
                                   evc.events ? &evc : nullptr, st);
         if (!rc && done) *done = (zero_words > 0 ? 1 : 0) | (evc.events ? 2 : 0);
         return rc;
@@ -1642,10 +1655,10 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         MPC_CHECK_LAUNCH();
         if (mpc_knn_uses_far_list(s)) {
             // the queries the forward's fallback kernel served (left out of the gather above)
-            const int *far = (const int *)((char *)ws + L.off_knn_far);
+            const KnnLists ls = knn_lists(s, L, ws);
 #define KF_LAUNCH(L1_, NEXT_)                                                                                            \
-            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), gridb, dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
-                               knn_state, far, tmp_g, tmp_a, direct, gxb, gyb)
+            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), dim3(KNN_FAR_BLOCKS), dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
+                               knn_state, ls, tmp_g, tmp_a, direct)
             if (p.l1) { if (grad_flow_next) KF_LAUNCH(true, true); else KF_LAUNCH(true, false); }
             else { if (grad_flow_next) KF_LAUNCH(false, true); else KF_LAUNCH(false, false); }
 #undef KF_LAUNCH

@@ -40,13 +40,36 @@ struct KnnParams {
     int l1, iwd, want_next;
     float off;   // sp/2 - 0.5 : centre of cell 0 (focus.py:117)
 };
-#define KNN_RCAP 6                 // largest search radius (cells) of the strip kernel; beyond it a query goes to the fallback
-#define KNN_MARGIN 8              // > KNN_RCAP; a multiple of 8, so that 8 query rows x 2 columns of a strip lie in one 16 x 16 tile
+#define KNN_RCAP 6                 // largest search radius (cells) of the strip kernel's main launch
+#define KNN_RFAR 20                // ... of its launch for the FAR queries (no square up to KNN_RCAP cells holds enough points: the
+                                   // inside of a band the flow field emptied); beyond it a query goes to the fallback kernel
+#define KNN_MARGIN (KNN_RCAP + 1)
 // smallest count of points in the (2r + 1)^2 cell square of a query for which radius r is tried (K / (pi / 4) at K = 32: the
 // disc of the ring bound holds K points if they are spread evenly over the square; calibrated on smooth flow fields)
 __host__ __device__ static inline int knn_square_need(int K) { return (int)((float)K * 1.28f + 0.5f); }
 
+// count of points in the square for which a FAR query tries radius r: the K neighbours of a query inside an emptied band lie
+// in a segment of the disc, the square also holds what the disc cuts off (calibrated as above: 2.6 K misses 4 % of them)
+__host__ __device__ static inline int knn_square_need_far(int K) { return (int)((float)K * 2.65f + 0.5f); }
+
 int mpc_knn_margin(const mpc_shape *s);
+
+// Work lists of the KNN forward, all in the workspace, counters zeroed by the bucket kernels:
+//   fail     int [1 + B*nb*G]      queries for k_knn_fallback (bits 0..29 the query, bits 30..31 why)
+//   retry    int [1 + strips]      strips whose points overflowed the staging area: k_knn_strip_retry searches them in quarters
+//   farstrip int [1 + strips]      strips that hold far queries: k_knn_strip_far
+//   far      int [B*nb][1 + G]     per (sample, bin): the cells (cy * wq + cx) of the far queries that were served (K-th key
+//                                  saved, flagged KNN_FAR_FLAG), for k_knn_bwd_far; null where the backward is not the tile gather
+//   ftbits   u32 [B*nb][ftwords]   tiles whose points a far query's disc can touch; ftlist int [1 + B*nb*tiles]: the same as a
+//                                  list of (sample, bin) * tiles + tile: the work items of k_knn_bwd_far
+//   again    u32 [B*nb][hq][ceil(wq/32)]  queries the main launch of the strip kernel could not finish (fewer than K candidates
+//                                  below the ring bound after all, more slots than its registers hold): k_knn_strip_more<FARQ>
+//                                  searches them with one more ring, 128 slots and chord-shaped rows
+struct KnnLists {
+    int *fail, *retry, *farstrip, *far, *ftlist;
+    unsigned *ftbits, *again;
+    int ftwords, again_words;       // words per (sample, bin)
+};
 
 static KnnParams knn_params(const mpc_shape *s) {
     KnnParams p;
@@ -71,14 +94,19 @@ __device__ __forceinline__ int knn_ci(const KnnParams &p, int y, int x) { return
 __device__ __forceinline__ int knn_cell_index(const KnnParams &p, float py, float px) {
     return knn_ci(p, cell_of(py, p.sp, p.hq, p.m), cell_of(px, p.sp, p.wq, p.m));
 }
-// 16 x 16 cell tiles of the bucket grid (the backward's workgroups; the tile maxima of the K-th distance).  Tile t holds the
-// cells 16 t - 16 .. 16 t - 1 (query numbering): the tiles of the query grid are the same with and without the margin, and
-// the margin cells above / left of the image have a ring of tiles of their own (mostly empty: those workgroups return at once).
-#define KNN_TILE_OFF 16
-static_assert(KNN_MARGIN <= KNN_TILE_OFF, "the margin lies within one ring of tiles");
-__host__ __device__ static inline int knn_tile_of(int c) { return (c + KNN_TILE_OFF) >> 4; }
-__host__ __device__ static inline int knn_tiles_x(int wq, int m) { return knn_tile_of(wq + m - 1) + 1; }
-__host__ __device__ static inline int knn_tiles_y(int hq, int m) { return knn_tile_of(hq + m - 1) + 1; }
+// 16 x 16 cell tiles (the backward's workgroups; the tile maxima of the K-th distance): the tiles of the QUERY grid; the
+// tiles along the image border also own the margin cells beside them (up to KNN_TROWS cell rows / columns of points, still
+// 16 x 16 queries), so that the tile count -- and the work of the lattice-like point sets -- is that of the query grid.
+#define KNN_TROWS (16 + 2 * KNN_MARGIN)
+__host__ __device__ static inline int knn_tiles_x(int wq, int) { return (wq + 15) >> 4; }
+__host__ __device__ static inline int knn_tiles_y(int hq, int) { return (hq + 15) >> 4; }
+// tile of cell c (query numbering, may lie in the margin) along an axis of n query cells
+__host__ __device__ static inline int knn_tile_of(int c, int n) { return (c < 0 ? 0 : (c > n - 1 ? n - 1 : c)) >> 4; }
+// cells [c0, c1) of tile t along an axis of n query cells and margin m
+__host__ __device__ static inline void knn_tile_cells(int t, int n, int m, int &c0, int &c1) {
+    c0 = t == 0 ? -m : 16 * t;
+    c1 = 16 * t + 16 >= n ? n + m : 16 * t + 16;
+}
 // summed-area table of the cell counts: sat[(y + m) * (wb + 1) + (x + m)] = points in cells (y', x') with y' < y and x' < x
 __device__ __forceinline__ int knn_square_count(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r) {
     const int y0 = max(cy - r, -p.m) + p.m, y1 = min(cy + r, p.hq + p.m - 1) + p.m + 1;
@@ -528,31 +556,60 @@ __device__ __forceinline__ void knn_tile_max_add(float *__restrict__ tile_dkmax,
                                                  int bd, float dK) {
     if (tile_dkmax == nullptr) return;
     const int gx16 = knn_tiles_x(p.wq, p.m), gy16 = knn_tiles_y(p.hq, p.m);
-    int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + knn_tile_of(cy)) * gx16 + knn_tile_of(cx)) * KNN_NCLS;
+    int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (cy >> 4)) * gx16 + (cx >> 4)) * KNN_NCLS;
     const unsigned m = knn_query_classes(p, cy, cx, bd);
 #pragma unroll
     for (int c = 0; c < KNN_NCLS; ++c) if ((m >> c) & 1u) atomicMax(dst + c, __float_as_int(dK));
 }
+// A far query (cy, cx) with K-th distance dK has been served: its cell onto the far list of (sample, bin) bt is the caller's
+// business (one atomic per wavefront); here the tiles whose points its disc can touch go onto the work list of k_knn_bwd_far
+// (each tile once: the bit map).  Called by the lane that owns the query.
+__device__ __forceinline__ void knn_far_mark_tiles(const KnnParams &p, const KnnLists &ls, int bt, int cy, int cx, float dK) {
+    const float R = (p.l1 ? dK : sqrtf(dK)) * 1.0001f + 0.01f;
+    const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+    const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m);
+    const int ta = knn_tile_of(cell_of(qy - R, p.sp, p.hq, p.m), p.hq), tb = knn_tile_of(cell_of(qy + R, p.sp, p.hq, p.m), p.hq);
+    const int tc = knn_tile_of(cell_of(qx - R, p.sp, p.wq, p.m), p.wq), td = knn_tile_of(cell_of(qx + R, p.sp, p.wq, p.m), p.wq);
+    for (int ty = ta; ty <= tb; ++ty)
+        for (int tx = tc; tx <= td; ++tx) {
+            const int tile = ty * ntx + tx;
+            const unsigned bit = 1u << (tile & 31);
+            unsigned *w = ls.ftbits + (size_t)bt * ls.ftwords + (tile >> 5);
+            if ((*w & bit) != 0u) continue;                       // (set already: the usual case inside a band)
+            if ((atomicOr(w, bit) & bit) == 0u) ls.ftlist[1 + atomicAdd(&ls.ftlist[0], 1)] = bt * ntx * nty + tile;
+        }
+}
+// Is a query's K-th distance beyond what the backward's gather should carry in its tile maxima?  One ring more than the radius
+// of the mean density: the odd query the fallback kernel finishes with a slightly larger square stays in the gather (its
+// tile searches a window two cells wider), a query of an emptied band goes on the far list (k_knn_bwd_far).
+__device__ __forceinline__ bool knn_is_far_dk(const KnnParams &p, float dK, int r_init) {
+    const float lim = ((float)(r_init + 1) + 0.5f) * (float)p.sp;
+    return dK > (p.l1 ? lim : lim * lim);
+}
 // Search radius of a query from the summed-area table of the cell counts: the smallest r in [rmin, KNN_RCAP] whose square
 // of (2r + 1)^2 cells (clipped to the bucket grid) holds at least `need` points; KNN_RCAP + 1 if none does.
-__device__ __forceinline__ int knn_sat_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int rmin, int need) {
+__device__ __forceinline__ int knn_sat_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int rmin, int need, int rcap = KNN_RCAP) {
     int r = rmin;
-    while (r <= KNN_RCAP && knn_square_count(p, sat, cy, cx, r) < need) ++r;
+    while (r <= rcap && knn_square_count(p, sat, cy, cx, r) < need) ++r;
     return r;
+}
+// half width, in cells, of the part of cell row cy + j that can hold a point within the ring bound of radius r around a query
+// of cell (cy, cx): the cells cx - w .. cx + w (-1: none)
+__device__ __forceinline__ int knn_chord_cells(int r, int j, int sp, bool l1) {
+    const float lb = ((float)r + 0.5f) * (float)sp - KNN_SLACK;
+    const float dyc = fmaxf((float)j - 0.5f, 0.f) * (float)sp;
+    const float w2 = l1 ? lb - dyc : lb * lb - dyc * dyc;
+    if (!(w2 > 0.f)) return -1;
+    return (int)((l1 ? w2 : sqrtf(w2)) / (float)sp + 0.5f) + 1;          // (+1: rounding of the square root)
 }
 #endif
 
 // ---- strip kernel (knn_strip.hip): the fast path of the forward for num_tref == 1 ---------------------------
-// `fail` = int [1 + B*nb*G]: fail[0] counts the queries handed to the fallback kernel (zeroed, like tile_dkmax, by the
-// bucket kernels), fail[1..] lists them (bits 0..29 the query, bits 30..31 why).
-// `retry` = int [1 + strips]: strips whose points overflowed the staging area (k_knn_strip_retry searches them in quarters).
-// `far`  = int [B*nb][1 + G]: per (sample, bin) the number and the cells (cy * wq + cx) of the queries the fallback kernel
-// served, for k_knn_bwd_far (counters zeroed by the bucket kernels); null where the backward is not the tile gather.
 bool mpc_knn_strip_usable(const mpc_shape *s, int r_init);
 bool mpc_knn_uses_far_list(const mpc_shape *s);
 struct EvCountArgs;      // ev_count_device.h: event rows to count per backward bucket in spare workgroups of the strip kernel, or null
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const int *sat, const float2 *spos, const int *sidx,
-                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int *retry, int *far, int r_init,
+                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, const KnnLists *lists, int r_init,
                          const EvCountArgs *evc, hipStream_t st);
 bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc);
 
@@ -575,21 +632,23 @@ struct KnnReachJob {
 };
 
 #ifdef __HIPCC__
-// query cells of class c inside tile (sy, sx) of the bucket grid: false if there are none
+// query cells of class c inside tile (sy, sx): false if there are none
 __device__ __forceinline__ bool knn_tile_class_cells(const KnnParams &p, int sy, int sx, int c, int bd, int &cy0, int &cy1, int &cx0, int &cx1) {
-    cy0 = max(sy * 16 - KNN_TILE_OFF, 0); cy1 = min(sy * 16 + 16 - KNN_TILE_OFF, p.hq) - 1;
-    cx0 = max(sx * 16 - KNN_TILE_OFF, 0); cx1 = min(sx * 16 + 16 - KNN_TILE_OFF, p.wq) - 1;
+    cy0 = sy * 16; cy1 = min(sy * 16 + 16, p.hq) - 1;
+    cx0 = sx * 16; cx1 = min(sx * 16 + 16, p.wq) - 1;
     if (c == 1) cy1 = min(cy1, bd - 1);
     if (c == 2) cy0 = max(cy0, p.hq - bd);
     if (c == 3) cx1 = min(cx1, bd - 1);
     if (c == 4) cx0 = max(cx0, p.wq - bd);
     return cy0 <= cy1 && cx0 <= cx1;
 }
-// pixel extent of the cells of tile (ty, tx) of the bucket grid (its bucketed points lie inside, or -- clamped into the
+// pixel extent of the cells of tile (ty, tx), margin included (its bucketed points lie inside, or -- clamped into the
 // outermost ring -- farther out, which only makes them farther from every query)
 __device__ __forceinline__ void knn_tile_area(const KnnParams &p, int ty, int tx, float &ay0, float &ay1, float &ax0, float &ax1) {
-    ay0 = (float)(max(ty * 16 - KNN_TILE_OFF, -p.m) * p.sp) - 0.5f; ay1 = (float)(min(ty * 16 + 16 - KNN_TILE_OFF, p.hq + p.m) * p.sp) - 0.5f;
-    ax0 = (float)(max(tx * 16 - KNN_TILE_OFF, -p.m) * p.sp) - 0.5f; ax1 = (float)(min(tx * 16 + 16 - KNN_TILE_OFF, p.wq + p.m) * p.sp) - 0.5f;
+    int y0, y1, x0, x1;
+    knn_tile_cells(ty, p.hq, p.m, y0, y1); knn_tile_cells(tx, p.wq, p.m, x0, x1);
+    ay0 = (float)(y0 * p.sp) - 0.5f; ay1 = (float)(y1 * p.sp) - 0.5f;
+    ax0 = (float)(x0 * p.sp) - 0.5f; ax1 = (float)(x1 * p.sp) - 0.5f;
 }
 
 template <bool L1>

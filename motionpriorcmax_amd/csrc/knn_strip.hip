@@ -37,12 +37,11 @@
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
 #define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
-#define KS_TAIL (4 * KS_MAXCH + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
+#define KS_MAXCH_FAR 32             // ... of the launch for the far queries (128 slots)
+#define KS_TAIL(MAXCH_) (4 * (MAXCH_) + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
-#define KS_FB_WAVE_MAX (1 << 30)    // longest list served a wavefront per query; longer: a thread per query (measured: the per-lane
-                                    // gathers of the thread form cost 5-7 ns per query against ~2 of the wavefront form: not used)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
 #define KS_RETRY_BLOCKS 768         // workgroups of the retry kernel (3 per CU)
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
@@ -63,31 +62,42 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // One strip (workgroup-wide): the query rows [pr0, pr1) of strip `lblk`.  SPLIT = false: the whole strip (pr0 = 0, pr1 = TH); a
 // strip whose points do not fit the staging area (a place where the flow field packs the points) goes on the retry list and
 // is searched again by k_knn_strip_retry in quarters (SPLIT = true); what does not fit a quarter goes to the fallback list.
-template <int WS, bool L1, bool NEXT, bool IWD, bool SPLIT>
+// MODE 0: the main launch -- the queries whose square of up to KNN_RCAP cells holds enough points; a strip that holds others (FAR
+// queries) is noted on the farstrip list.  MODE 1: k_knn_strip_retry (SPLIT).  MODE 2: k_knn_strip_far -- the far queries of the
+// strips on that list alone, with radii up to KNN_RFAR, the region rows staged as wide as the widest CHORD that uses them (the
+// disc of the ring bound, not the square: above and below a horizontal band front the squares are a hundred cells wide);
+// served far queries go on the far list of their (sample, bin) for k_knn_bwd_far and stay out of the tile maxima.
+#define KS_NR_MAX (KS_NT / 2 + 2 * KNN_RFAR)
+template <int WS, bool L1, bool NEXT, bool IWD, int MODE>
 __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__restrict__ traj,
                                            const int *__restrict__ cell_start, const int *__restrict__ sat,
                                            const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                            float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                            float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                           int *__restrict__ fail, int *__restrict__ retry, int r_init, int cap, int gx, int gy,
-                                           int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, int *s_rq) {
+                                           const KnnLists &ls, int r_init, int cap, int gx, int gy,
+                                           int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq) {
+    constexpr bool SPLIT = MODE == 1, FARK = MODE == 2;
+    constexpr int MAXCH = FARK ? KS_MAXCH_FAR : KS_MAXCH;      // words of four slots per query
+    (void)SPLIT;
+    constexpr int RC = FARK ? KNN_RFAR : KNN_RCAP;
     constexpr int TH = KS_NT / WS;
-    constexpr int NR = TH + 2 * KNN_RCAP;               // region rows: the strip's query rows and the largest radius above and below
-    static_assert(NR <= KS_NT, "one thread per region row");
+    constexpr int NR = TH + 2 * RC;                     // region rows: the strip's query rows and the largest radius above and below
+    static_assert(NR <= KS_NT && NR <= KS_NR_MAX, "one thread per region row");
+    int *const fail = ls.fail;
     const int tid = threadIdx.x;
     const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
     const int sy = bxy / gx, sx = bxy - sy * gx;
     const int b = bt / p.nb, t = bt - b * p.nb;
     const int qx0 = sx * WS, qy0 = sy * TH;
     const int qx1 = min(qx0 + WS, p.wq) - 1, qy1 = min(qy0 + TH, p.hq) - 1;
-    const int ry_base = qy0 - KNN_RCAP;          // grid row of region row 0 (may lie outside the bucket grid: an empty row)
+    const int ry_base = qy0 - RC;                // grid row of region row 0 (may lie outside the bucket grid: an empty row)
     // ---- LDS carve-up ----------------------------------------------------------------------------
     int2 *s_row = reinterpret_cast<int2 *>(s_dyn);             // [NR] {first bucketed slot, points (-1: no such row)}
     int *s_rowstart = reinterpret_cast<int *>(s_row + NR);     // [NR + 1] first slot of every region row
     size_t o = ((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15;
-    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
-    float2 *lflow = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL) * 8;
-    float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL) * 8 : 0;
+    float2 *lpos = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL(MAXCH)) * 8;
+    float2 *lflow = reinterpret_cast<float2 *>(s_dyn + o); o += (size_t)(cap + KS_TAIL(MAXCH)) * 8;
+    float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL(MAXCH)) * 8 : 0;
     unsigned short *lidx = reinterpret_cast<unsigned short *>(s_dyn + o);
 
     const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
@@ -110,25 +120,66 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     const bool valid = cy <= qy1 && cx <= qx1;
     // Radius from the summed-area table (four loads per radius tried): the smallest r whose square holds `need` points.
     // Starts at the radius of the mean density; only a clearly denser place tries smaller ones.
-    int r = 0;
+    const int aw = (p.wq + 31) >> 5;
+    unsigned *const again_w = ls.again + (size_t)bt * ls.again_words + (size_t)min(cy, p.hq - 1) * aw + (min(cx, p.wq - 1) >> 5);
+    // (the launch for the far queries: only the queries the main launch marked in the `again` map -- far ones and those it
+    // could not finish -- look at the table at all)
+    const bool marked = FARK && valid && ((*again_w >> (cx & 31)) & 1u) != 0u;
+    int r = 0, nr = 0;                                  // radius and the points in its square
     bool served = false;
-    if (valid) {
+    if (FARK ? marked : valid) {
         const int need = knn_square_need(p.K);
         r = min(r_init, KNN_RCAP);
-        const int n0 = knn_square_count(p, sat_bt, cy, cx, r);
-        if (n0 >= need) {
-            if (2 * n0 >= 3 * need) while (r > 1 && knn_square_count(p, sat_bt, cy, cx, r - 1) >= need) --r;
-        } else r = knn_sat_radius(p, sat_bt, cy, cx, r + 1, need);
+        nr = knn_square_count(p, sat_bt, cy, cx, r);
+        if (nr >= need) {
+            if (2 * nr >= 3 * need) {
+                for (;;) {
+                    const int nm = r > 1 ? knn_square_count(p, sat_bt, cy, cx, r - 1) : 0;
+                    if (nm < need) break;
+                    --r; nr = nm;
+                }
+            }
+        } else {
+            for (++r; r <= KNN_RCAP; ++r) { nr = knn_square_count(p, sat_bt, cy, cx, r); if (nr >= need) break; }
+        }
         served = r <= KNN_RCAP;
     }
+    const bool isfar = (FARK ? marked : valid) && !served;      // no square up to KNN_RCAP holds enough points: k_knn_strip_more<FARQ>'s query
+    if (!FARK) {
+        // The count says how many points the SQUARE holds; the disc of the ring bound holds pi / 4 of them, give or take the
+        // scatter of the positions.  With fewer than need + need / 7 points in the square (47 for K = 32: the lattice has 49
+        // in its 7 x 7 square) one query in ten .. a hundred comes up short.  Where that is the rare lane (white-noise
+        // coefficients: 9 % of the lanes) the radius stands -- a wavefront pays for its widest lane, one more ring is 90 slots
+        // instead of 63 -- and the query that does come up short is searched again; where it is the rule (an expanding flow
+        // field: every square holds ~44) those lanes take one more ring right away.
+        const int need = knn_square_need(p.K);
+        const bool marginal = served && r < KNN_RCAP && nr < need + need / 7;
+        const int nm = __popcll(__ballot(marginal)), nv = __popcll(__ballot(served));
+        if (2 * nm >= nv && marginal) ++r;
+        if (isfar) atomicOr(again_w, 1u << (cx & 31));      // (for the launch that follows)
+    }
+    if (FARK) {
+        served = false;
+        if (isfar) {
+            r = knn_sat_radius(p, sat_bt, cy, cx, KNN_RCAP + 1, knn_square_need_far(p.K), KNN_RFAR);
+            served = r <= KNN_RFAR;                     // (else: the fallback kernel)
+        } else if (marked) {
+            r += 2; served = true;                      // the main launch could not finish it: two more rings (<= KNN_RFAR)
+        }
+    }
+    const bool mine = FARK ? marked : (valid && !isfar);
     {   // radius of the widest square of every query row (the WS lanes of a row are neighbours)
-        int rr = served ? r : 0;
+        int rr = (mine && served) ? r : 0;
 #pragma unroll
         for (int o2 = 1; o2 < WS; o2 <<= 1) rr = max(rr, __shfl_xor(rr, o2, 64));
-        if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = rr;
+        if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr;
     }
     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
-    __syncthreads();
+    // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
+    // k_knn_strip_more<FARQ> when this workgroup ends
+    bool anyfar = false;
+    if (MODE == 0) anyfar = __syncthreads_or(isfar ? 1 : 0) != 0;
+    else __syncthreads();
     // ---- column extent of every region row = the widest square (of the query rows [pr0, pr1) of the strip) that uses the
     //      row; slots of the region rows: an exclusive scan of the row lengths; a row of even length gets one dummy slot so
     //      that the row pitch is odd (consecutive rows then start in different LDS banks: with the 8 points per row of a
@@ -139,8 +190,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (tid < NR) {
             const int y = ry_base + tid;
             int R = 0;
-            const int c0 = max(tid - 2 * KNN_RCAP, pr0), c1 = min(tid, pr1 - 1);       // query rows within KNN_RCAP of this row
-            for (int c = c0; c <= c1; ++c) { const int rq = s_rq[c]; if (abs(c - (tid - KNN_RCAP)) <= rq) R = max(R, rq); }
+            const int c0 = max(tid - 2 * RC, pr0), c1 = min(tid, pr1 - 1);       // query rows within RC of this row
+            for (int c = c0; c <= c1; ++c) {
+                const int rq = (int)s_rq[c], j = abs(c - (tid - RC));
+                if (j > rq) continue;
+                // main launch: the square of the query; far queries: the chord of their disc at this row
+                R = max(R, FARK ? knn_chord_cells(rq, j, p.sp, L1) : rq);
+            }
             if (R > 0 && y >= -p.m && y < p.hq + p.m) {
                 const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
                 gs = cs[knn_ci(p, y, xl)];
@@ -163,15 +219,18 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         __syncthreads();
         return s_rowstart[NR];
     };
-    const bool inpass = valid && (cy - qy0) >= pr0 && (cy - qy0) < pr1;
+    const bool inpass = mine && (cy - qy0) >= pr0 && (cy - qy0) < pr1;
     const int total = region_rows(pr0, pr1);
     bool overflow = false;
     if (total > cap) {
-        if (!SPLIT) {                 // (workgroup-uniform) again in quarters: k_knn_strip_retry
-            if (tid == 0) retry[1 + atomicAdd(&retry[0], 1)] = lblk;
+        if (MODE == 0) {              // (workgroup-uniform) again in quarters: k_knn_strip_more
+            if (tid == 0) {
+                ls.retry[1 + atomicAdd(&ls.retry[0], 1)] = lblk;
+                if (anyfar) ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk;
+            }
             return;
         }
-        overflow = true;              // even a quarter of the strip does not fit: its queries go to the fallback list
+        overflow = true;              // even a quarter of the strip (or the far queries' region) does not fit: to the fallback list
     }
     {
         const bool act = inpass && served && !overflow;
@@ -220,7 +279,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
             // the tail behind the staged slots: far-away positions, zero flows (lanes whose range is shorter than the
             // wavefront's trip count read them, flagged off)
-            for (int i = total + tid; i < total + KS_TAIL; i += KS_NT) {
+            for (int i = total + tid; i < total + KS_TAIL(MAXCH); i += KS_NT) {
                 lpos[i] = make_float2(KS_FAR, KS_FAR);
                 lflow[i] = make_float2(0.f, 0.f);
                 if (NEXT) lnext[i] = make_float2(0.f, 0.f);
@@ -230,13 +289,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
 
         // ---- search --------------------------------------------------------------------------------------
         const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
-        bool failed = (inpass && !served) || (inpass && overflow);       // no radius up to KNN_RCAP holds enough points (why 0)
+        bool failed = inpass && (!served || overflow);       // far query beyond KNN_RFAR (why 0) / staging overflow (why 2)
         unsigned why = (inpass && served && overflow) ? 2u : 0u;      // diagnostics: top two bits of a list entry (0 few candidates, 1 too many slots, 2 staging overflow)
         int s = 0, nsl = 0;
         if (act) {
             s = s_rowstart[cy - r - ry_base];
             nsl = s_rowstart[cy + r - ry_base + 1] - s;
-            if (nsl > 4 * KS_MAXCH) { failed = true; why = 1u; nsl = 0; s = 0; }
+            if (nsl > 4 * MAXCH) { failed = true; why = 1u; nsl = 0; s = 0; }
         }
         // anything outside the square is at least lb away along one axis
         const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
@@ -257,9 +316,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
         const float2 *pp = lpos + s;
         // pass 1: nearness byte of every slot; groups of 8 slots whose loads are issued together
-        unsigned w[KS_MAXCH];
+        unsigned w[MAXCH];
 #pragma unroll
-        for (int g = 0; g < KS_MAXCH / 2; ++g) {
+        for (int g = 0; g < MAXCH / 2; ++g) {
             w[2 * g] = w[2 * g + 1] = 0u;
             if (8 * g < nmax) {
                 float2 pj[8];
@@ -299,7 +358,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 if (nmax > 4 * KS_BASECH + 16) {
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int c = KS_BASECH + 4; c < KS_MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                    for (int c = KS_BASECH + 4; c < MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
                 }
             }
             return acc;
@@ -330,16 +389,17 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         // plain sum) which the final division removes.  Dead lanes: beta 128 twice -- no slot anywhere.
         const bool do_next = NEXT && (t < p.nb - 1);
         float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
-        unsigned E[(KS_MAXCH + 7) / 8];
+        constexpr int NE = (MAXCH + 7) / 8;
+        unsigned E[NE];
 #pragma unroll
-        for (int e = 0; e < (KS_MAXCH + 7) / 8; ++e) E[e] = 0u;
+        for (int e = 0; e < NE; ++e) E[e] = 0u;
         const unsigned beta2 = (live && bstar < KS_NLEV) ? (unsigned)bstar + 1u : 128u;
         const unsigned c1 = (128u - (live ? (unsigned)bstar : 128u)) * 0x01010101u, c2 = (128u - beta2) * 0x01010101u;
         // The four flags of word j (of the eight words of a mask) go to bits j, 8 + j, 16 + j, 24 + j: slot 32 m + 4 j + u <->
         // bit j + 8 u of E[m].
         const float2 *pf = lflow + s, *pn = lnext + s;
 #pragma unroll
-        for (int g = 0; g < KS_MAXCH / 2; ++g) {
+        for (int g = 0; g < MAXCH / 2; ++g) {
             if (8 * g < nmax) {
                 float2 fj[8], gj[8];
 #pragma unroll
@@ -389,13 +449,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const bool light = live && !heavy;
             const int mmax = __builtin_amdgcn_readfirstlane(wave_max_i(light ? inbin : 0));
             unsigned long long em = ((unsigned long long)E[1] << 32) | E[0];
-            unsigned e2 = E[2];
+            unsigned long long e2 = ((unsigned long long)(NE > 3 ? E[NE - 1] : 0u) << 32) | E[2];      // slots 64 ..
 #pragma unroll
             for (int a = 0; a < KS_LMAX; ++a) {
                 dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0; kraw[a] = 0;
                 if (a < mmax) {
-                    int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffs(e2) - 1 : -1);      // a bit still in the mask ...
-                    if (em) em &= em - 1ull; else e2 &= e2 - 1u;
+                    int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffsll((long long)e2) - 1 : -1);      // a bit still in the mask ...
+                    if (em) em &= em - 1ull; else e2 &= e2 - 1ull;
                     kraw[a] = k;
                     k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
                     if (light && k >= 0) {
@@ -432,11 +492,11 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 const int h = __ffsll((long long)hm) - 1;
                 hm &= hm - 1ull;
                 const int hs = lane_i(s, h), hneed = lane_i(need, h);
-                const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h);
+                const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h), h3 = NE > 3 ? lane_u(E[NE - 1], h) : 0u;
                 const float hqy = lane_f(qy, h), hqx = lane_f(qx, h);
                 // this lane's two slots of the heavy query: lane and lane + 64
                 const int mybit = ((lane >> 2) & 7) + 8 * (lane & 3);            // bit of slot `lane` (and of slot 64 + lane) in its mask word
-                const bool b0 = (((lane < 32 ? h0 : h1) >> mybit) & 1u) != 0u, b1 = lane < 32 && ((h2 >> mybit) & 1u) != 0u;
+                const bool b0 = (((lane < 32 ? h0 : h1) >> mybit) & 1u) != 0u, b1 = (((lane < 32 ? h2 : h3) >> mybit) & 1u) != 0u;
                 float d0 = INFINITY, d1 = INFINITY;
                 int i0 = 0x7fffffff, i1 = 0x7fffffff, r0_ = 0, r1_ = 0;
                 if (b0) { const float2 pj = lpos[hs + lane]; d0 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i0 = (int)lidx[hs + lane]; }
@@ -450,11 +510,11 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                     r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
                     r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
                 }
-                unsigned k2 = h2;
-                while (k2 != 0u) {
-                    const int kb = __ffs(k2) - 1;
-                    k2 &= k2 - 1u;
-                    const int k = 4 * (kb & 7) + (kb >> 3);                          // slot - 64 of the bit
+                unsigned long long k2 = ((unsigned long long)h3 << 32) | h2;
+                while (k2 != 0ull) {
+                    const int kb = __ffsll((long long)k2) - 1;
+                    k2 &= k2 - 1ull;
+                    const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot - 64 of the bit
                     const float kd = lane_f(d1, k); const int ki = lane_i(i1, k);
                     r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
                     r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
@@ -510,7 +570,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
             }
             knn_state[q] = dK;
-            reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0);
+            reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0) | ((FARK && ls.far != nullptr && knn_is_far_dk(p, dK, r_init)) ? KNN_FAR_FLAG : 0);
 #ifdef KS_DEBUG_INBIN
             norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
             knn_state[2 * BQ + q] = norm;
@@ -519,7 +579,16 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
 #endif
         }
         {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
-            const bool push = inpass && !live;
+            // (main launch: a query with too few candidates below the ring bound or too many slots gets a second chance in
+            // k_knn_strip_more<FARQ> -- more rings, 128 slots, only such queries staged: its bit in the `again` map -- if the
+            // strip goes there anyway (far queries) or has more than two of them; the odd one: the fallback list)
+            const bool late = MODE == 0 && inpass && !live && why < 2u;
+            int nlate = 0;
+            if (MODE == 0) nlate = __syncthreads_count(late ? 1 : 0);
+            const bool to_more = MODE == 0 && (anyfar || nlate > 2);
+            if (late && to_more) atomicOr(again_w, 1u << (cx & 31));
+            if (to_more && tid == 0) ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk;
+            const bool push = inpass && !live && !(late && to_more);
             const unsigned long long pm = __ballot(push);
             if (pm != 0ull) {
                 const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
@@ -531,15 +600,14 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         }
         // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
         // backward): a wavefront covers 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
-        // (knn_tile_of: the tiles of the query grid start at multiples of 16).  Only wavefronts next to the image border hold
-        // anything but class 0 (knn_device.h).
-        {
+        // (the tiles of the query grid).  Only wavefronts next to the image border hold anything but class 0 (knn_device.h).
+        if (!FARK) {
             static_assert(WS == 2, "32 lanes = one tile");
             const int bd = knn_band_depth(r_init);
             const unsigned cls = live ? knn_query_classes(p, cy, cx, bd) : 0u;
             const bool plain = __ballot(cls > 1u) == 0ull;
             const int gx16 = knn_tiles_x(p.wq, p.m), gy16 = knn_tiles_y(p.hq, p.m);
-            int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + knn_tile_of(min(cy, p.hq - 1))) * gx16 + knn_tile_of(qx0)) * KNN_NCLS;
+            int *dst = reinterpret_cast<int *>(tile_dkmax) + (((size_t)bt * gy16 + (min(cy, p.hq - 1) >> 4)) * gx16 + (qx0 >> 4)) * KNN_NCLS;
             const bool writer = (tid & (16 * WS - 1)) == 0 && cy <= qy1;
 #pragma unroll
             for (int c = 0; c < KNN_NCLS; ++c) {
@@ -549,23 +617,41 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 for (int o2 = 8 * WS; o2 > 0; o2 >>= 1) m = fmaxf(m, __shfl_xor(m, o2, 64));
                 if (writer && m > 0.f) atomicMax(dst + c, __float_as_int(m));
             }
-        }
+        } else if (ls.far != nullptr) {
+            // a served query of the second launch with a K-th distance the gather should not carry: onto the far list of its
+            // (sample, bin) (one atomic per wavefront) and its tiles onto the work list of k_knn_bwd_far; the others into the
+            // tile maxima like any query
+            const bool isf = live && knn_is_far_dk(p, dK, r_init);
+            if (live && !isf) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+            const unsigned long long pm = __ballot(isf);
+            if (pm != 0ull) {
+                const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
+                int *fl = ls.far + (size_t)bt * (p.G + 1);
+                int base = 0;
+                if (lane == first) base = atomicAdd(&fl[0], __popcll(pm));
+                base = __shfl(base, first, 64);
+                if (isf) {
+                    fl[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = cy * p.wq + cx;
+                    knn_far_mark_tiles(p, ls, bt, cy, cx, dK);
+                }
+            }
+        } else if (live) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);      // (far query, general gather backward)
     }
 }
 
 // 1-D grid of gx * gy * B * nb workgroups (gx strips, gy row blocks) in XCD-contiguous order, 256 threads,
 // dynamic LDS sized by the launcher
 template <int WS, bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
+__global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
                                                      const int *__restrict__ cell_start, const int *__restrict__ sat,
                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                     int *__restrict__ fail, int *__restrict__ retry, int r_init, int cap, int gx, int gy,
+                                                     const KnnLists ls, int r_init, int cap, int gx, int gy,
                                                      const EvCountArgs evc, int n_evc, int evc_stride) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
-    __shared__ int s_rq[KS_NT / WS];                    // radius of the widest square of every query row of the strip (0: none)
+    __shared__ unsigned char s_rq[KS_NT / WS];          // radius of the widest square of every query row of the strip (0: none)
     // mpc_focus_fwd: some workgroups do not search -- they count the event rows per backward bucket for the event kernels
     // that follow (ev_count_device.h).  This kernel is bound by vector-instruction issue and leaves HBM idle, so the 67 MB of
     // C3's events are read beside it.  The counting workgroups come in groups of 8 (one per XCD: the search workgroups keep
@@ -584,28 +670,35 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip(const KnnParams p, const fl
     const int nblk = gx * gy * p.B * p.nb;
     const int lblk = (pblk & 7) * ((nblk + 7) >> 3) + (pblk >> 3);
     if (lblk >= nblk) return;
-    strip_body<WS, L1, NEXT, IWD, false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, retry,
-                                         r_init, cap, gx, gy, lblk, 0, KS_NT / WS, s_dyn, s_wsum, s_wmax, s_rq);
+    strip_body<WS, L1, NEXT, IWD, 0>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
+                                     r_init, cap, gx, gy, lblk, 0, KS_NT / WS, s_dyn, s_wsum, s_wmax, s_rq);
 }
 
-// The strips on the retry list, a quarter of the query rows per workgroup and round.  grid: a fixed number of workgroups (the
-// list length is only known on the device; nothing to do for the lattice-like point sets of the benchmark)
+// The strips on the retry list (a quarter of the query rows per workgroup and round), then the strips on the farstrip list (their
+// far queries and the queries the main launch could not finish).  grid: a fixed number of workgroups (the list lengths are only
+// known on the device; nothing to do for the lattice-like point sets of the benchmark: both lists empty or nearly)
 template <int WS, bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(KS_NT) void k_knn_strip_retry(const KnnParams p, const float *__restrict__ traj,
-                                                           const int *__restrict__ cell_start, const int *__restrict__ sat,
-                                                           const float2 *__restrict__ spos, const int *__restrict__ sidx,
-                                                           float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                                           float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                           int *__restrict__ fail, int *__restrict__ retry, int r_init, int cap, int gx, int gy) {
+__global__ __launch_bounds__(KS_NT) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
+                                                          const int *__restrict__ cell_start, const int *__restrict__ sat,
+                                                          const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                          float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                                          float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                                          const KnnLists ls, int r_init, int cap, int gx, int gy) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
-    __shared__ int s_rq[KS_NT / WS];
+    __shared__ unsigned char s_rq[KS_NT / WS];
     constexpr int TH = KS_NT / WS;
-    const int nwork = 4 * min(retry[0], gx * gy * p.B * p.nb);
-    for (int w = (int)blockIdx.x; w < nwork; w += (int)gridDim.x) {
-        const int lblk = retry[1 + (w >> 2)], quarter = w & 3;
-        strip_body<WS, L1, NEXT, IWD, true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, fail, retry,
-                                            r_init, cap, gx, gy, lblk, quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq);
+    const int nstrips = gx * gy * p.B * p.nb;
+    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], nstrips);
+    for (int w = (int)blockIdx.x; w < nretry; w += (int)gridDim.x) {
+        const int quarter = w & 3;
+        strip_body<WS, L1, NEXT, IWD, 1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
+                                         r_init, cap, gx, gy, ls.retry[1 + (w >> 2)], quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq);
+        __syncthreads();
+    }
+    for (int w = (int)blockIdx.x; w < nfar; w += (int)gridDim.x) {
+        strip_body<WS, L1, NEXT, IWD, 2>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
+                                         r_init, cap, gx, gy, ls.farstrip[1 + w], 0, TH, s_dyn, s_wsum, s_wmax, s_rq);
         __syncthreads();
     }
 }
@@ -626,27 +719,29 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip_retry(const KnnParams p, co
 // ------------------------------------------------------------------------------------------
 // first radius of a fallback search: the smallest square with 1.25 x the strip kernel's count (which it has tried), growing
 // by a quarter per step
-__device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx) {
+__device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r0) {
     const int need = knn_square_need(p.K) + (knn_square_need(p.K) >> 2);
     const int rmax = max(p.hb, p.wb);
-    int r = 2;
+    int r = max(r0, 2);
     while (r < rmax && knn_square_count(p, sat, cy, cx, r) < need) r += 1 + (r >> 2);
     return r;
 }
 
-// one entry on the far list of (sample, bin) bt; called by ONE lane
-__device__ __forceinline__ void far_list_add(const KnnParams &p, int *__restrict__ far, int bt, int cell) {
-    int *fl = far + (size_t)bt * (p.G + 1);
+// one served far query: onto the far list of its (sample, bin), its tiles onto the work list of k_knn_bwd_far; called by ONE lane
+__device__ __forceinline__ void far_list_add(const KnnParams &p, const KnnLists &ls, int bt, int cy, int cx, float dK) {
+    int *fl = ls.far + (size_t)bt * (p.G + 1);
     const int k = atomicAdd(&fl[0], 1);
-    fl[1 + k] = cell;
+    fl[1 + k] = cy * p.wq + cx;
+    knn_far_mark_tiles(p, ls, bt, cy, cx, dK);
 }
 
 template <bool L1>
 __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const int *__restrict__ cell_start,
                                    const int *__restrict__ sat, const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, int *__restrict__ far, int q, int r_init,
+                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, const KnnLists &ls, int q, int r_init,
                                    unsigned (*s_hist)[256]) {
+    int *const far = ls.far;
     const int lane = threadIdx.x & 63;
     const int bt = q / p.G, cell = q - bt * p.G;
     const int cy = cell / p.wq, cx = cell - cy * p.wq;
@@ -657,7 +752,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
     const int ylo = -p.m, yhi = p.hq + p.m - 1, xlo = -p.m, xhi = p.wq + p.m - 1;
-    int r = fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx);
+    int r = fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx, r_init);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS];
     float2 pq[KS_FB_SLOTS];
     bool serial = false;
@@ -717,8 +812,6 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         if (cnt >= p.K || whole) break;
         r += 1 + (r >> 2);
     }
-    const int flag_far = far != nullptr ? KNN_FAR_FLAG : 0;
-    if (far != nullptr && lane == 0) far_list_add(p, far, bt, cell);
     if (serial) {
         // more rows or candidates than the lanes hold (a very dense place, a very deep band): the generic thread-serial search
         if (lane == 0) {
@@ -727,8 +820,10 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
             c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
             float dK = 0.f;
-            knn_one_query<false, L1, 256, true>(p, c, b, t, cy, cx, r, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, flag_far);
-            if (far == nullptr) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+            knn_one_query<false, L1, 256, true>(p, c, b, t, cy, cx, r, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, 0);
+            const bool isf = far != nullptr && knn_is_far_dk(p, dK, r_init);
+            if (isf) { reinterpret_cast<int *>(knn_state)[(size_t)p.B * p.nb * p.G + q] |= KNN_FAR_FLAG; far_list_add(p, ls, bt, cy, cx, dK); }
+            else knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
         }
         return;
     }
@@ -784,10 +879,12 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
             float2 on; on.x = ny_ / (float)p.K; on.y = nx_ / (float)p.K;
             reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
         }
+        const bool isf = far != nullptr && knn_is_far_dk(p, dK, r_init);
         knn_state[q] = dK;
-        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0) | flag_far;
+        reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0) | (isf ? KNN_FAR_FLAG : 0);
         knn_state[2 * BQ + q] = norm;
-        if (far == nullptr) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+        if (isf) far_list_add(p, ls, bt, cy, cx, dK);
+        else knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
     }
 }
 
@@ -796,7 +893,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
                                                       const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                       float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                       float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                      const int *__restrict__ fail, int *__restrict__ far, int r_init, const EvCountArgs evc) {
+                                                      const KnnLists ls, int r_init, const EvCountArgs evc) {
+    const int *fail = ls.fail;
     __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
     // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B workgroups turn
     // the counts of their sample into first records (the event kernels follow on the stream)
@@ -806,52 +904,11 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
     }
     const int nq = p.B * p.nb * p.G;
     const int nfail = min(fail[0], nq);
-    if (nfail <= KS_FB_WAVE_MAX) {
-        const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-        for (int i = wv; i < nfail; i += nw) {
-            const int q = fail[1 + i] & 0x3fffffff;
-            if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, far, q, r_init, s_hist);
-            else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, far, q, r_init, s_hist);
-        }
-        return;
-    }
-    // a thread per query; the list is in the order the strip kernel's wavefronts appended to it: the 64 entries of a wavefront
-    // are mostly neighbouring queries of one strip
-    const int flag_far = far != nullptr ? KNN_FAR_FLAG : 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ((nfail + 63) & ~63); i += gridDim.x * 256) {
-        const bool on = i < nfail;
-        const int q = on ? (fail[1 + i] & 0x3fffffff) : 0;
-        const int bt = q / p.G, cell = q - bt * p.G;
-        const int cy = cell / p.wq, cx = cell - cy * p.wq;
-        const int b = bt / p.nb, t = bt - b * p.nb;
-        if (on) {
-            QueryCtx c;
-            c.cs = cell_start + (size_t)bt * (p.Gb + 1); c.spos = spos + (size_t)bt * p.n; c.sidx = sidx + (size_t)bt * p.n;
-            c.traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
-            c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
-            c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
-            const int r0 = fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx);
-            float dK = 0.f;
-            if (p.l1) knn_one_query<false, true, 256, true>(p, c, b, t, cy, cx, r0, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, flag_far);
-            else knn_one_query<false, false, 256, true>(p, c, b, t, cy, cx, r0, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, flag_far);
-            if (far == nullptr) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
-        }
-        if (far != nullptr) {
-            // far list of every (sample, bin) among the wavefront's queries: one atomic per distinct (sample, bin)
-            const int lane = threadIdx.x & 63;
-            unsigned long long todo = __ballot(on);
-            while (todo != 0ull) {
-                const int first = __ffsll((long long)todo) - 1;
-                const int bt0 = __shfl(bt, first, 64);
-                const unsigned long long same = __ballot(on && bt == bt0) & todo;
-                int base = 0;
-                int *fl = far + (size_t)bt0 * (p.G + 1);
-                if (lane == first) base = atomicAdd(&fl[0], __popcll(same));
-                base = __shfl(base, first, 64);
-                if (on && bt == bt0) fl[1 + base + __popcll(same & ((1ull << lane) - 1ull))] = cell;
-                todo &= ~same;
-            }
-        }
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    for (int i = wv; i < nfail; i += nw) {
+        const int q = fail[1 + i] & 0x3fffffff;
+        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist);
+        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist);
     }
 }
 
@@ -859,21 +916,26 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
 // launcher (called by mpc_knn_lut_fwd once the points are bucketed; `fail[0]`, the far-list counters and tile_dkmax zeroed by
 // the bucket kernel)
 // ------------------------------------------------------------------------------------------
-static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out, size_t *lds_out) {
-    const int TH = KS_NT / WS, NR = TH + 2 * KNN_RCAP;
-    if (NR > KS_NT || r_init > KNN_RCAP) return false;
+// staging capacity (slots) of a strip and the dynamic LDS of the main launch / of the launch for the far queries (more region
+// rows, more dummy slots behind the staged ones)
+static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out, size_t *lds_out, size_t *lds_far_out = nullptr) {
+    const int TH = KS_NT / WS;
+    if (TH + 2 * KNN_RFAR > KS_NT || r_init > KNN_RCAP) return false;
     const double dens = (double)s->n / ((double)s->hq * s->wq);
     const double row_pts = dens * (WS + 2 * r_init);                       // points per region row of an inner strip
     // slots of an inner query: its rows, one dummy slot per even row; must leave room for denser places
     if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * KS_MAXCH) return false;
     const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
-    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 64;
+    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 48;
     cap = (cap + 15) / 16 * 16;
     const bool next = (s->flags & MPC_F_WANT_NEXT) != 0;
-    const size_t lds = (((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + KS_TAIL) * 8 * (next ? 3 : 2) +
-                       (size_t)cap * 2 + 16;
-    if (lds > 64 * 1024) return false;
+    auto lds_of = [&](int NR, int tail) {
+        return (((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + tail) * 8 * (next ? 3 : 2) + (size_t)cap * 2 + 16;
+    };
+    const size_t lds = lds_of(TH + 2 * KNN_RCAP, KS_TAIL(KS_MAXCH)), lds_far = lds_of(TH + 2 * KNN_RFAR, KS_TAIL(KS_MAXCH_FAR));
+    if (lds_far > 64 * 1024) return false;
     *cap_out = cap; *lds_out = lds;
+    if (lds_far_out) *lds_far_out = lds_far;
     return true;
 }
 
@@ -892,11 +954,12 @@ bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc) {
 }
 
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const int *sat, const float2 *spos, const int *sidx,
-                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, int *fail, int *retry, int *far, int r_init,
+                         float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, const KnnLists *lists, int r_init,
                          const EvCountArgs *evc, hipStream_t st) {
     const KnnParams p = knn_params(s);
-    int cap = 0; size_t lds = 0;
-    if (!strip_geometry(s, r_init, 2, &cap, &lds)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
+    const KnnLists ls = *lists;
+    int cap = 0; size_t lds = 0, lds_far = 0;
+    if (!strip_geometry(s, r_init, 2, &cap, &lds, &lds_far)) { mpc_set_error("mpc_knn_strip_launch: shape not served by the strip kernel"); return MPC_E_UNSUPPORTED; }
     constexpr int WS = 2, TH = KS_NT / WS;
     const int gx = mpc_cdiv(s->wq, WS), gy = mpc_cdiv(s->hq, TH);
     EvCountArgs ec{};
@@ -906,13 +969,14 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_
     int evc_stride = n_evc > 0 ? (int)(total / (n_evc >> 3) / 8 * 8) : 8;       // a group of 8 counting workgroups every `stride` workgroups
     if (evc_stride < 8) evc_stride = 8;
     const dim3 grid((unsigned)total);
-    // (the retry kernel: nothing to do unless a strip overflowed its staging area -- 256 workgroups that read one word)
+    // (the follow-up launch: nothing to do unless a strip overflowed its staging area / holds far queries -- workgroups that
+    // read two words)
 #define KS_LAUNCH(L1_, NEXT_, IWD_)                                                                                       \
     do {                                                                                                                  \
         MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, sat, spos, sidx, \
-                           flow_lut, flow_next, knn_state, tile_dkmax, fail, retry, r_init, cap, gx, gy, ec, n_evc, evc_stride); \
-        MPC_LAUNCH((k_knn_strip_retry<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS), dim3(KS_NT), lds, st, p, traj, cell_start, sat, spos, sidx, \
-                           flow_lut, flow_next, knn_state, tile_dkmax, fail, retry, r_init, cap, gx, gy);                 \
+                           flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy, ec, n_evc, evc_stride);   \
+        MPC_LAUNCH((k_knn_strip_more<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS), dim3(KS_NT), lds_far, st, p, traj, cell_start, sat, spos, sidx, \
+                           flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy);                          \
     } while (0)
     switch ((p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0)) {
     case 0: KS_LAUNCH(false, false, false); break;
@@ -927,7 +991,7 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_
 #undef KS_LAUNCH
     MPC_CHECK_LAUNCH();
     MPC_LAUNCH(k_knn_fallback, dim3(KS_FB_BLOCKS), dim3(256), 0, st, p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next,
-                       knn_state, tile_dkmax, fail, far, r_init, ec);
+                       knn_state, tile_dkmax, ls, r_init, ec);
     MPC_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Which queries does the strip kernel hand to the fallback, and why?  python tools/fail_probe.py [family] [B]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from motionpriorcmax_amd import LossFactory, ops, _lib as C  # noqa: E402
+from motionpriorcmax_amd.utils import synth  # noqa: E402
+
+fam = sys.argv[1] if len(sys.argv) > 1 else 'translate40'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+dev = torch.device('cuda', 0)
+wl = bench.WORKLOADS['C3']
+traj, _ = synth.synth_trajectories(B, 3, wl['nb'], (bench.H, bench.W), bench.PATCH, fam, seed=11)
+L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+shape = ops.make_shape(L._cfg, B, 0, 0, traj.shape[2])
+ws = ops.alloc_workspace(shape, dev)
+ops.knn_lut_fwd(L._cfg, shape, traj.to(dev), ws)
+torch.cuda.synchronize()
+off = C.lib().mpc_knn_fail_list_offset(ctypes.byref(shape))
+n = int(ws[off:off + 4].view(torch.int32).item())
+ent = ws[off + 4:off + 4 + 4 * n].view(torch.int32).cpu().numpy().astype(np.uint32)
+G = shape.hq * shape.wq
+q = ent & 0x3fffffff
+why = ent >> 30
+bt = q // G
+cell = q % G
+cy, cx = cell // shape.wq, cell % shape.wq
+print(f'{fam}: {n} of {B * shape.nb * G} queries on the list ({100.0 * n / (B * shape.nb * G):.3f} %)')
+print('why (0 few candidates / beyond the far radius, 1 too many slots, 2 staging overflow):', np.bincount(why, minlength=4))
+print('by bin:', np.bincount(bt % shape.nb, minlength=shape.nb))
+for w in range(3):
+    m = why == w
+    if m.sum():
+        print(f' why {w}: rows min/max {cy[m].min()}..{cy[m].max()}  cols {cx[m].min()}..{cx[m].max()};  row histogram (16-row bands):',
+              np.bincount(cy[m] // 16, minlength=8), ' col histogram (16-col bands):', np.bincount(cx[m] // 16, minlength=10))
