@@ -115,6 +115,10 @@ int64_t mpc_knn_state_floats(const mpc_shape *s);
  * fast path holds, 2 more keys at the K-th distance level than it ranks, 3 staging overflow).  Read it after
  * mpc_knn_lut_fwd (tests assert that the fast path serves nearly all queries of the benchmark shapes). */
 int64_t mpc_knn_fail_list_offset(const mpc_shape *s);
+/* Diagnostics: byte offsets of the other work lists of the KNN forward inside the workspace: out[0] strips searched again in
+ * quarters, [1] strips with far queries or queries to search again, [2] / [3] the maps of such queries (bit per query; those
+ * that need more rings), [4] far lists per (sample, bin), [5] tiles for the far queries' backward; -1: no such list. */
+int mpc_knn_list_offsets(const mpc_shape *s, int64_t *out);
 
 /* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants,
  * focus.py:157-163).  grad_flow_next may be NULL.  grad_traj [B][T+nb][n][2] is overwritten. */

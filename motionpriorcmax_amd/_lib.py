@@ -27,7 +27,7 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
-           'mpc_knn_fail_list_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
+           'mpc_knn_fail_list_offset', 'mpc_knn_list_offsets', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
            'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
            'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add']
@@ -83,6 +83,7 @@ def lib():
     L.mpc_workspace_bytes.restype = i64
     L.mpc_workspace_bytes.argtypes = [sp]
     L.mpc_knn_fail_list_offset.argtypes = [sp]
+    L.mpc_knn_list_offsets.argtypes = [sp, ctypes.POINTER(ctypes.c_int64)]
     L.mpc_knn_state_floats.argtypes = [sp]
     L.mpc_knn_lut_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
     L.mpc_knn_lut_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]

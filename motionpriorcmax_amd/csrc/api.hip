@@ -143,7 +143,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_knn_farstrip = off; off += mpc_align((1 + bt * (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128)) * sizeof(int32_t));
     L.off_knn_ftlist = off; off += mpc_knn_uses_far_list(s) ? mpc_align((1 + bt * ktiles) * sizeof(int32_t)) : 0;
     L.off_knn_ftbits = off; off += mpc_knn_uses_far_list(s) ? mpc_align(bt * ((ktiles + 31) / 32) * sizeof(int32_t)) : 0;
-    L.off_knn_again = off;  off += mpc_align(bt * (int64_t)s->hq * ((s->wq + 31) / 32) * sizeof(int32_t));
+    L.off_knn_chord = off;  off += mpc_align(1024);
+    L.off_knn_again = off;  off += mpc_align(2 * bt * (int64_t)s->hq * ((s->wq + 31) / 32) * sizeof(int32_t));      // (`again` and `grow`)
     L.off_knn_far = off;    off += mpc_knn_uses_far_list(s) ? mpc_align(bt * (1 + (int64_t)L.G) * sizeof(int32_t)) : 0;
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;
@@ -234,6 +235,20 @@ extern "C" int64_t mpc_knn_fail_list_offset(const mpc_shape *s) {
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     return mpc_layout(s).off_knn_fail;
+}
+
+// Diagnostics (tools/fail_probe.py): byte offsets, inside the workspace, of the work lists of the KNN forward --
+// out[0] retry, [1] farstrip, [2] again map, [3] grow map, [4] far lists, [5] far tile list; -1 where a list does not exist.
+extern "C" int mpc_knn_list_offsets(const mpc_shape *s, int64_t *out) {
+    if (!s || !out) { mpc_set_error("mpc_knn_list_offsets: null argument"); return MPC_E_NULL; }
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const mpc_ws_layout L = mpc_layout(s);
+    const int64_t bt = (int64_t)(s->B > 0 ? s->B : 1) * s->nb;
+    out[0] = L.off_knn_retry; out[1] = L.off_knn_farstrip; out[2] = L.off_knn_again;
+    out[3] = L.off_knn_again + bt * (int64_t)s->hq * ((s->wq + 31) / 32) * 4;
+    out[4] = mpc_knn_uses_far_list(s) ? L.off_knn_far : -1; out[5] = mpc_knn_uses_far_list(s) ? L.off_knn_ftlist : -1;
+    return 0;
 }
 
 extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {

@@ -79,7 +79,8 @@ struct mpc_ws_layout {
     int64_t off_knn_farstrip; // int32 [1 + strips]  strips that hold far queries (k_knn_strip_more<FARQ>)
     int64_t off_knn_ftlist;  // int32 [1 + B*nb*tiles]  (sample, bin, tile) work items of k_knn_bwd_far;  off_knn_ftbits: uint32 [B*nb][ceil(tiles/32)] the same as bits
     int64_t off_knn_ftbits;
-    int64_t off_knn_again;   // uint32 [B*nb][hq][ceil(wq/32)]  queries the strip kernel's main launch hands to its second launch
+    int64_t off_knn_chord;   // uint8 [21][21]  chord table of the strip kernels (knn_device.h: knn_chord_cells)
+    int64_t off_knn_again;   // uint32 [2][B*nb][hq][ceil(wq/32)]  queries the strip kernel's main launch hands to its second launch; those that need more rings
     int64_t off_knn_far;     // int32  [B*nb][1 + G]  per (sample, bin): the queries the fallback kernel served, for k_knn_bwd_far
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8] bucket fill counters, marker; then [nbb] capacities and [nbb] first records of the backward buckets

@@ -83,8 +83,10 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
         if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
     }
-    if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) ls.again[(size_t)bt * ls.again_words + i] = 0u;
+    if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
     if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; }
+    if (blockIdx.x == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))      // (the chord table of the strip kernels' row tables)
+        ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
     const int rows_per = (p.hb + S - 1) / S;
     const int g_lo = min(part * rows_per, p.hb) * p.wb, g_hi = min((part + 1) * rows_per, p.hb) * p.wb, Gp = g_hi - g_lo;
@@ -346,8 +348,10 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
         if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
         if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
     }
-    if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) ls.again[(size_t)bt * ls.again_words + i] = 0u;
+    if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
     if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; }
+    if (bt == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))
+        ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
     int *cur = cursor + (size_t)bt * p.Gb;
     int *cs = cell_start + (size_t)bt * (p.Gb + 1);
@@ -1435,6 +1439,8 @@ static KnnLists knn_lists(const mpc_shape *s, const mpc_ws_layout &L, void *ws) 
     ls.ftwords = (mpc_knn_tiles(s) + 31) / 32;
     ls.again = (unsigned *)((char *)ws + L.off_knn_again);
     ls.again_words = s->hq * ((s->wq + 31) / 32);
+    ls.chord = (unsigned char *)ws + L.off_knn_chord;
+    ls.grow = ls.again + (size_t)(s->B > 0 ? s->B : 1) * s->nb * ls.again_words;
     return ls;
 }
 

@@ -65,9 +65,12 @@ int mpc_knn_margin(const mpc_shape *s);
 //   again    u32 [B*nb][hq][ceil(wq/32)]  queries the main launch of the strip kernel could not finish (fewer than K candidates
 //                                  below the ring bound after all, more slots than its registers hold): k_knn_strip_more<FARQ>
 //                                  searches them with one more ring, 128 slots and chord-shaped rows
+//   grow     u32, same shape: of those, the ones that need more RINGS (too few candidates below the bound; far queries)
+//   chord    u8 [KNN_RFAR + 1][KNN_RFAR + 1]  chord[r][j] = knn_chord_cells(r, j): written by the bucket kernels, read by the strip kernels
 struct KnnLists {
     int *fail, *retry, *farstrip, *far, *ftlist;
-    unsigned *ftbits, *again;
+    unsigned *ftbits, *again, *grow;
+    unsigned char *chord;
     int ftwords, again_words;       // words per (sample, bin)
 };
 
@@ -593,14 +596,24 @@ __device__ __forceinline__ int knn_sat_radius(const KnnParams &p, const int *__r
     while (r <= rcap && knn_square_count(p, sat, cy, cx, r) < need) ++r;
     return r;
 }
-// half width, in cells, of the part of cell row cy + j that can hold a point within the ring bound of radius r around a query
-// of cell (cy, cx): the cells cx - w .. cx + w (-1: none)
+// half width, in cells, of the part of cell row cy + j (0 <= j <= r) that can hold a point below the ring bound of radius r
+// around a query of cell (cy, cx): the cells cx - w .. cx + w.  A point of cell column cx + w (w >= 1) is at least (w - 0.5) sp
+// away along x and one of row cy + j at least (j - 0.5) sp along y: the column counts only while that corner distance is below
+// the bound -- the comparison the search itself makes (`d < upper`), on a distance no point of the cell can undercut.
 __device__ __forceinline__ int knn_chord_cells(int r, int j, int sp, bool l1) {
     const float lb = ((float)r + 0.5f) * (float)sp - KNN_SLACK;
+    const float upper = l1 ? lb : lb * lb;
     const float dyc = fmaxf((float)j - 0.5f, 0.f) * (float)sp;
-    const float w2 = l1 ? lb - dyc : lb * lb - dyc * dyc;
-    if (!(w2 > 0.f)) return -1;
-    return (int)((l1 ? w2 : sqrtf(w2)) / (float)sp + 0.5f) + 1;          // (+1: rounding of the square root)
+    int w = r;
+    while (w >= 1) {
+        const float dxc = ((float)w - 0.5f) * (float)sp;
+        // (the corner itself is not in the cell -- cells are half open -- and rounding of the points' own distances is far
+        // below the 0.01 px of KNN_SLACK; one ulp of margin here keeps the cell on a tie)
+        const float dc = l1 ? dxc + dyc : dxc * dxc + dyc * dyc;
+        if (dc * 0.999999f < upper) break;
+        --w;
+    }
+    return w;
 }
 #endif
 

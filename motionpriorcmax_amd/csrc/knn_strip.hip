@@ -116,15 +116,15 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         const int gb = (p.hq - 1) >> 4;
         if (gb >= 2) grp = (grp == 1) ? gb : ((grp == gb) ? 1 : grp);
     }
-    const int cy = qy0 + grp * 16 + (tid % (16 * WS)) / WS, cx = qx0 + tid % WS;
+    int cy = qy0 + grp * 16 + (tid % (16 * WS)) / WS, cx = qx0 + tid % WS;
     const bool valid = cy <= qy1 && cx <= qx1;
     // Radius from the summed-area table (four loads per radius tried): the smallest r whose square holds `need` points.
     // Starts at the radius of the mean density; only a clearly denser place tries smaller ones.
     const int aw = (p.wq + 31) >> 5;
-    unsigned *const again_w = ls.again + (size_t)bt * ls.again_words + (size_t)min(cy, p.hq - 1) * aw + (min(cx, p.wq - 1) >> 5);
+    const int aoff = bt * ls.again_words + min(cy, p.hq - 1) * aw + (min(cx, p.wq - 1) >> 5);      // this query's word of the `again` / `grow` maps
     // (the launch for the far queries: only the queries the main launch marked in the `again` map -- far ones and those it
     // could not finish -- look at the table at all)
-    const bool marked = FARK && valid && ((*again_w >> (cx & 31)) & 1u) != 0u;
+    const bool marked = FARK && valid && ((ls.again[aoff] >> (cx & 31)) & 1u) != 0u;
     int r = 0, nr = 0;                                  // radius and the points in its square
     bool served = false;
     if (FARK ? marked : valid) {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         }
         served = r <= KNN_RCAP;
     }
-    const bool isfar = (FARK ? marked : valid) && !served;      // no square up to KNN_RCAP holds enough points: k_knn_strip_more<FARQ>'s query
+    bool isfar = (FARK ? marked : valid) && !served;      // no square up to KNN_RCAP holds enough points: k_knn_strip_more<FARQ>'s query
     if (!FARK) {
         // The count says how many points the SQUARE holds; the disc of the ring bound holds pi / 4 of them, give or take the
         // scatter of the positions.  With fewer than need + need / 7 points in the square (47 for K = 32: the lattice has 49
@@ -153,10 +153,11 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         // instead of 63 -- and the query that does come up short is searched again; where it is the rule (an expanding flow
         // field: every square holds ~44) those lanes take one more ring right away.
         const int need = knn_square_need(p.K);
+        // (a square with barely `need` points comes up short every other time: one more ring whatever the neighbours do)
         const bool marginal = served && r < KNN_RCAP && nr < need + need / 7;
         const int nm = __popcll(__ballot(marginal)), nv = __popcll(__ballot(served));
-        if (2 * nm >= nv && marginal) ++r;
-        if (isfar) atomicOr(again_w, 1u << (cx & 31));      // (for the launch that follows)
+        if (marginal && (4 * nm >= nv || nr < need + 2)) ++r;
+        if (isfar) atomicOr(ls.again + aoff, 1u << (cx & 31));      // (for the launch that follows)
     }
     if (FARK) {
         served = false;
@@ -164,22 +165,49 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             r = knn_sat_radius(p, sat_bt, cy, cx, KNN_RCAP + 1, knn_square_need_far(p.K), KNN_RFAR);
             served = r <= KNN_RFAR;                     // (else: the fallback kernel)
         } else if (marked) {
-            r += 2; served = true;                      // the main launch could not finish it: two more rings (<= KNN_RFAR)
+            // the main launch could not finish it: too few candidates below the ring bound -- two more rings (<= KNN_RFAR) -- or
+            // more slots than its registers hold -- the same radius with this launch's 128 slots
+            if (((ls.grow[aoff] >> (cx & 31)) & 1u) != 0u) r += 2;
+            served = true;
         }
     }
-    const bool mine = FARK ? marked : (valid && !isfar);
+    bool mine = FARK ? marked : (valid && !isfar);
     {   // radius of the widest square of every query row (the WS lanes of a row are neighbours)
         int rr = (mine && served) ? r : 0;
 #pragma unroll
         for (int o2 = 1; o2 < WS; o2 <<= 1) rr = max(rr, __shfl_xor(rr, o2, 64));
         if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr;
     }
-    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
+    // chord of the disc of radius r at row offset j, for the row tables below (knn_device.h)
+    __shared__ unsigned char s_chord[(RC + 1) * (RC + 1)];
+    for (int i = tid; i < (RC + 1) * (RC + 1); i += KS_NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
     // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
     // k_knn_strip_more<FARQ> when this workgroup ends
     bool anyfar = false;
     if (MODE == 0) anyfar = __syncthreads_or(isfar ? 1 : 0) != 0;
     else __syncthreads();
+    if (FARK) {
+        // The marked queries of the strip -- a few dozen of its 256 -- move into the first lanes: one wavefront searches them
+        // instead of four that each carry a handful (the row tables above are per query ROW: they do not care).
+        int *s_list = reinterpret_cast<int *>(lpos);            // (the staging area is not in use yet)
+        const int lane = tid & 63, wv = tid >> 6;
+        const unsigned long long mm = __ballot(mine);
+        if (lane == 0) s_wsum[wv] = __popcll(mm);
+        __syncthreads();
+        int base = 0, nmine = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < KS_NT / 64; ++w2) { const int c = s_wsum[w2]; if (w2 < wv) base += c; nmine += c; }
+        if (mine) s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (cy - qy0) | ((cx - qx0) << 8) | (r << 12) | (served ? 1 << 20 : 0) | (isfar ? 1 << 21 : 0);
+        __syncthreads();
+        mine = tid < nmine;
+        served = false; isfar = false; r = 0;
+        if (mine) {
+            const int e = s_list[tid];
+            cy = qy0 + (e & 0xff); cx = qx0 + ((e >> 8) & 0xf); r = (e >> 12) & 0xff; served = ((e >> 20) & 1) != 0; isfar = ((e >> 21) & 1) != 0;
+        }
+        __syncthreads();                                         // (before the staging area is written)
+    }
+    const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
     // ---- column extent of every region row = the widest square (of the query rows [pr0, pr1) of the strip) that uses the
     //      row; slots of the region rows: an exclusive scan of the row lengths; a row of even length gets one dummy slot so
     //      that the row pitch is odd (consecutive rows then start in different LDS banks: with the 8 points per row of a
@@ -194,8 +222,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             for (int c = c0; c <= c1; ++c) {
                 const int rq = (int)s_rq[c], j = abs(c - (tid - RC));
                 if (j > rq) continue;
-                // main launch: the square of the query; far queries: the chord of their disc at this row
-                R = max(R, FARK ? knn_chord_cells(rq, j, p.sp, L1) : rq);
+                // the chord of the query's disc at this row (the corner cells of the square hold nothing below the ring bound)
+                R = max(R, (int)s_chord[rq * (RC + 1) + j]);
             }
             if (R > 0 && y >= -p.m && y < p.hq + p.m) {
                 const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
@@ -586,7 +614,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             int nlate = 0;
             if (MODE == 0) nlate = __syncthreads_count(late ? 1 : 0);
             const bool to_more = MODE == 0 && (anyfar || nlate > 2);
-            if (late && to_more) atomicOr(again_w, 1u << (cx & 31));
+            if (late && to_more) {
+                atomicOr(ls.again + aoff, 1u << (cx & 31));
+                if (why == 0u) atomicOr(ls.grow + aoff, 1u << (cx & 31));
+            }
             if (to_more && tid == 0) ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk;
             const bool push = inpass && !live && !(late && to_more);
             const unsigned long long pm = __ballot(push);
@@ -717,14 +748,23 @@ __global__ __launch_bounds__(KS_NT) void k_knn_strip_more(const KnnParams p, con
 // KNN_FAR_FLAG and stays out of the tile maxima: k_knn_bwd_far computes its gradient (knn.hip).
 // grid: KS_FB_BLOCKS workgroups (the list length is only known on the device), 256 threads
 // ------------------------------------------------------------------------------------------
-// first radius of a fallback search: the smallest square with 1.25 x the strip kernel's count (which it has tried), growing
-// by a quarter per step
+// first radius of a fallback search from the summed-area table: up to KNN_RCAP the smallest square with 1.25 x the strip
+// kernel's count (which it has tried); beyond it the far queries' rule, found by doubling and bisection (a band 20 rings deep
+// costs 8 probes of four loads, not 20)
 __device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r0) {
-    const int need = knn_square_need(p.K) + (knn_square_need(p.K) >> 2);
+    const int need = knn_square_need(p.K) + (knn_square_need(p.K) >> 2), need_far = knn_square_need_far(p.K);
     const int rmax = max(p.hb, p.wb);
     int r = max(r0, 2);
-    while (r < rmax && knn_square_count(p, sat, cy, cx, r) < need) r += 1 + (r >> 2);
-    return r;
+    while (r <= KNN_RCAP && knn_square_count(p, sat, cy, cx, r) < need) ++r;
+    if (r <= KNN_RCAP) return r;
+    int lo = KNN_RCAP, hi = KNN_RCAP + 2;
+    while (hi < rmax && knn_square_count(p, sat, cy, cx, hi) < need_far) { lo = hi; hi += max(2, hi >> 1); }
+    hi = min(hi, rmax);
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (knn_square_count(p, sat, cy, cx, mid) >= need_far) hi = mid; else lo = mid;
+    }
+    return hi;
 }
 
 // one served far query: onto the far list of its (sample, bin), its tiles onto the work list of k_knn_bwd_far; called by ONE lane
@@ -740,9 +780,9 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
                                    const int *__restrict__ sat, const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                    float *__restrict__ knn_state, float *__restrict__ tile_dkmax, const KnnLists &ls, int q, int r_init,
-                                   unsigned (*s_hist)[256]) {
+                                   unsigned (*s_hist)[256], float4 (*s_comp)[256]) {
     int *const far = ls.far;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
     const int bt = q / p.G, cell = q - bt * p.G;
     const int cy = cell / p.wq, cx = cell - cy * p.wq;
     const int b = bt / p.nb, t = bt - b * p.nb;
@@ -761,56 +801,103 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         const int y0 = max(cy - r, ylo), y1 = min(cy + r, yhi), x0 = max(cx - r, xlo), x1 = min(cx + r, xhi);
         const bool whole = (y0 == ylo && x0 == xlo && y1 == yhi && x1 == xhi);
         const int nrows = y1 - y0 + 1;
-        if (nrows > 64) { serial = true; break; }
         const float lb = ((float)r + 0.5f) * (float)p.sp - KNN_SLACK;
         const float upper = whole ? INFINITY : (L1 ? lb : lb * lb);
-        // lane l < nrows: the bucketed range of row y0 + l -- only the cells that can hold a point below the ring bound;
-        // exclusive scan over the lanes -> flat candidate numbering
-        int js = 0, ln = 0;
-        if (lane < nrows) {
+        // bucketed range of cell row y -- only the cells that can hold a point below the ring bound
+        auto row_range = [&](int y, int &js, int &ln) {
             int xa = x0, xb = x1;
             if (!whole) {
-                const float dyc = fmaxf((float)abs(y0 + lane - cy) - 0.5f, 0.f) * (float)p.sp;
+                const float dyc = fmaxf((float)abs(y - cy) - 0.5f, 0.f) * (float)p.sp;
                 const float w2 = L1 ? upper - dyc : upper - dyc * dyc;
                 const int xr = w2 > 0.f ? (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1 : -1;
                 xa = max(xa, cx - xr); xb = min(xb, cx + xr);
             }
-            if (xa <= xb) { js = cs[knn_ci(p, y0 + lane, xa)]; ln = cs[knn_ci(p, y0 + lane, xb + 1)] - js; }
-        }
+            js = 0; ln = 0;
+            if (xa <= xb) { js = cs[knn_ci(p, y, xa)]; ln = cs[knn_ci(p, y, xb + 1)] - js; }
+        };
+        // lane l < nrows: the range of row y0 + l; exclusive scan over the lanes -> flat candidate numbering
+        int js = 0, ln = 0;
+        if (lane < min(nrows, 64)) row_range(y0 + lane, js, ln);
         int incl = ln;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if (lane >= o2) incl += v; }
         const int N = __shfl(incl, 63, 64);
-        if (N > 64 * KS_FB_SLOTS) { serial = true; break; }
-        ns = (N + 63) >> 6;
-        const int excl = incl - ln;
         int cnt = 0;
+        if (nrows <= 64 && N <= 64 * KS_FB_SLOTS) {
+            ns = (N + 63) >> 6;
+            const int excl = incl - ln;
 #pragma unroll
-        for (int m = 0; m < KS_FB_SLOTS; ++m) {
-            const int k = lane + 64 * m;                    // flat candidate number of this lane's m-th slot
-            dd[m] = INFINITY; ii[m] = 0x7fffffff; pq[m] = make_float2(0.f, 0.f);
-            if (m >= ns) continue;
-            // row of candidate k: the last lane whose exclusive offset is <= k (offsets are non-decreasing)
-            int lo = 0, hi = 64;
+            for (int m = 0; m < KS_FB_SLOTS; ++m) {
+                const int k = lane + 64 * m;                    // flat candidate number of this lane's m-th slot
+                dd[m] = INFINITY; ii[m] = 0x7fffffff; pq[m] = make_float2(0.f, 0.f);
+                if (m >= ns) continue;
+                // row of candidate k: the last lane whose exclusive offset is <= k (offsets are non-decreasing)
+                int lo = 0, hi = 64;
 #pragma unroll
-            for (int st = 0; st < 6; ++st) {
-                const int mid = (lo + hi) >> 1;
-                const int ev = __shfl(excl, mid, 64);
-                if (ev <= k) lo = mid; else hi = mid;
+                for (int st = 0; st < 6; ++st) {
+                    const int mid = (lo + hi) >> 1;
+                    const int ev = __shfl(excl, mid, 64);
+                    if (ev <= k) lo = mid; else hi = mid;
+                }
+                const int rjs = __shfl(js, lo, 64), rex = __shfl(excl, lo, 64);
+                if (k < N) {
+                    const int g = rjs + (k - rex);
+                    const float2 pj = sp_[g];
+                    const int id = si_[g];                          // (with the position: one round trip, not two)
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                    if (d < upper) { dd[m] = d; ii[m] = id; pq[m] = pj; ++cnt; }
+                }
             }
-            const int rjs = __shfl(js, lo, 64), rex = __shfl(excl, lo, 64);
-            if (k < N) {
-                const int g = rjs + (k - rex);
-                const float2 pj = sp_[g];
-                const int id = si_[g];                          // (with the position: one round trip, not two)
-                const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                if (d < upper) { dd[m] = d; ii[m] = id; pq[m] = pj; ++cnt; }
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
+        } else {
+            // more rows than lanes (a band deeper than 30 rings) or more candidates than the lanes' slots (the outermost ring of
+            // the margin in reach: everything that left the image lies there, nearly all of it beyond the ring bound): rows in
+            // rounds of 64, candidates in rounds of 64, those BELOW the bound compacted into LDS -- up to 256 of them
+            for (int rb = 0; rb < nrows; rb += 64) {
+                if (rb > 0) { js = 0; ln = 0; if (rb + lane < nrows) row_range(y0 + rb + lane, js, ln); }
+                int inc2 = ln;
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(inc2, o2, 64); if (lane >= o2) inc2 += v; }
+                const int Nr = __shfl(inc2, 63, 64), exc2 = inc2 - ln;
+                for (int k0 = 0; k0 < Nr; k0 += 64) {
+                    const int k = k0 + lane;
+                    int lo = 0, hi = 64;
+#pragma unroll
+                    for (int st = 0; st < 6; ++st) {
+                        const int mid = (lo + hi) >> 1;
+                        const int ev = __shfl(exc2, mid, 64);
+                        if (ev <= k) lo = mid; else hi = mid;
+                    }
+                    const int rjs = __shfl(js, lo, 64), rex = __shfl(exc2, lo, 64);
+                    bool keep = false;
+                    float d = 0.f; int id = 0; float2 pj = make_float2(0.f, 0.f);
+                    if (k < Nr) {
+                        const int g = rjs + (k - rex);
+                        pj = sp_[g]; id = si_[g];
+                        d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                        keep = d < upper;
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    const int slot = cnt + __popcll(km & ((1ull << lane) - 1ull));
+                    if (keep && slot < 64 * KS_FB_SLOTS) s_comp[wvi][slot] = make_float4(d, __int_as_float(id), pj.x, pj.y);
+                    cnt += __popcll(km);
+                }
+            }
+            if (cnt > 64 * KS_FB_SLOTS) { serial = true; break; }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (the other lanes' LDS writes, before the reads below)
+            ns = (cnt + 63) >> 6;
+#pragma unroll
+            for (int m = 0; m < KS_FB_SLOTS; ++m) {
+                dd[m] = INFINITY; ii[m] = 0x7fffffff; pq[m] = make_float2(0.f, 0.f);
+                if (lane + 64 * m < cnt) {
+                    const float4 e = s_comp[wvi][lane + 64 * m];
+                    dd[m] = e.x; ii[m] = __float_as_int(e.y); pq[m] = make_float2(e.z, e.w);
+                }
             }
         }
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) cnt += __shfl_xor(cnt, o2, 64);
         if (cnt >= p.K || whole) break;
-        r += 1 + (r >> 2);
+        r += 1 + (r >> 3);
     }
     if (serial) {
         // more rows or candidates than the lanes hold (a very dense place, a very deep band): the generic thread-serial search
@@ -896,6 +983,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
                                                       const KnnLists ls, int r_init, const EvCountArgs evc) {
     const int *fail = ls.fail;
     __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
+    __shared__ float4 s_comp[4][64 * KS_FB_SLOTS];  // per wavefront: the candidates below the ring bound, compacted (fallback_one_query)
     // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B workgroups turn
     // the counts of their sample into first records (the event kernels follow on the stream)
     if (evc.events != nullptr && (int)blockIdx.x < evc.B) {
@@ -907,8 +995,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     for (int i = wv; i < nfail; i += nw) {
         const int q = fail[1 + i] & 0x3fffffff;
-        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist);
-        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist);
+        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist, s_comp);
+        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist, s_comp);
     }
 }
 
@@ -926,7 +1014,7 @@ static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out,
     // slots of an inner query: its rows, one dummy slot per even row; must leave room for denser places
     if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * KS_MAXCH) return false;
     const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
-    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 48;
+    int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 32;
     cap = (cap + 15) / 16 * 16;
     const bool next = (s->flags & MPC_F_WANT_NEXT) != 0;
     auto lds_of = [&](int NR, int tail) {

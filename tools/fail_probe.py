@@ -40,3 +40,17 @@ for w in range(3):
     if m.sum():
         print(f' why {w}: rows min/max {cy[m].min()}..{cy[m].max()}  cols {cx[m].min()}..{cx[m].max()};  row histogram (16-row bands):',
               np.bincount(cy[m] // 16, minlength=8), ' col histogram (16-col bands):', np.bincount(cx[m] // 16, minlength=10))
+
+offs = (ctypes.c_int64 * 6)()
+C.lib().mpc_knn_list_offsets(ctypes.byref(shape), offs)
+i32 = lambda o, n=1: ws[o:o + 4 * n].view(torch.int32).cpu().numpy()
+nstrips = B * shape.nb * ((shape.wq + 1) // 2) * ((shape.hq + 127) // 128)
+aw = B * shape.nb * shape.hq * ((shape.wq + 31) // 32)
+ag = ws[offs[2]:offs[2] + 4 * aw].view(torch.int32).cpu().numpy().view(np.uint32)
+gr = ws[offs[3]:offs[3] + 4 * aw].view(torch.int32).cpu().numpy().view(np.uint32)
+pop = lambda a: int(np.unpackbits(a.view(np.uint8)).sum())
+print(f'strips {nstrips}: searched again in quarters {int(i32(offs[0])[0])}, on the second launch\'s list {int(i32(offs[1])[0])};  '
+      f'queries marked for the second launch {pop(ag)} ({100.0 * pop(ag) / (B * shape.nb * G):.3f} %), of them needing more rings {pop(gr)}')
+if offs[4] >= 0:
+    fl = ws[offs[4]:offs[4] + 4 * B * shape.nb * (G + 1)].view(torch.int32).cpu().numpy().reshape(B * shape.nb, G + 1)
+    print(f'far lists: {int(fl[:, 0].sum())} queries ({100.0 * fl[:, 0].sum() / (B * shape.nb * G):.3f} %); work items (tiles) of the far backward: {int(i32(offs[5])[0])}')
