@@ -586,7 +586,7 @@ __device__ __forceinline__ void knn_far_mark_tiles(const KnnParams &p, const Knn
 // of the mean density: the odd query the fallback kernel finishes with a slightly larger square stays in the gather (its
 // tile searches a window two cells wider), a query of an emptied band goes on the far list (k_knn_bwd_far).
 __device__ __forceinline__ bool knn_is_far_dk(const KnnParams &p, float dK, int r_init) {
-    const float lim = ((float)(r_init + 1) + 0.5f) * (float)p.sp;
+    const float lim = ((float)(r_init + 2) + 0.5f) * (float)p.sp;
     return dK > (p.l1 ? lim : lim * lim);
 }
 // Search radius of a query from the summed-area table of the cell counts: the smallest r in [rmin, KNN_RCAP] whose square

@@ -33,6 +33,12 @@
 #include <stdlib.h>
 
 #define KS_NT 256
+#ifndef KS_MORE_MIN
+#define KS_MORE_MIN 16               // a strip goes to the second launch for its unfinished queries if it has more than this many (or far queries)
+#endif
+#ifndef KS_MAIN_CHORD
+#define KS_MAIN_CHORD 1            // main launch: region rows as wide as the widest chord (1) or square (0) that uses them
+#endif
 #define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
 #define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
@@ -44,6 +50,7 @@
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
 #define KS_RETRY_BLOCKS 768         // workgroups of the retry kernel (3 per CU)
+static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
 
 // value of lane `l` (wave-uniform l): v_readlane, no LDS round trip
@@ -130,9 +137,18 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     if (FARK ? marked : valid) {
         const int need = knn_square_need(p.K);
         r = min(r_init, KNN_RCAP);
+#ifdef KS_AB_NOSAT
+        nr = 1000;
+#else
         nr = knn_square_count(p, sat_bt, cy, cx, r);
+#endif
         if (nr >= need) {
-            if (2 * nr >= 3 * need) {
+#ifndef KS_AB_NOSAT
+            if (2 * nr >= 3 * need)
+#else
+            if (false)
+#endif
+            {
                 for (;;) {
                     const int nm = r > 1 ? knn_square_count(p, sat_bt, cy, cx, r - 1) : 0;
                     if (nm < need) break;
@@ -180,7 +196,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     }
     // chord of the disc of radius r at row offset j, for the row tables below (knn_device.h)
     __shared__ unsigned char s_chord[(RC + 1) * (RC + 1)];
-    for (int i = tid; i < (RC + 1) * (RC + 1); i += KS_NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
+    if (FARK) for (int i = tid; i < (RC + 1) * (RC + 1); i += KS_NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
     // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
     // k_knn_strip_more<FARQ> when this workgroup ends
     bool anyfar = false;
@@ -223,7 +239,16 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 const int rq = (int)s_rq[c], j = abs(c - (tid - RC));
                 if (j > rq) continue;
                 // the chord of the query's disc at this row (the corner cells of the square hold nothing below the ring bound)
-                R = max(R, (int)s_chord[rq * (RC + 1) + j]);
+                // the chord of the query's disc at this row (the corner cells of the square hold nothing below the ring bound).
+                // Far queries: from the table.  Main launch (r <= 6): only the outermost row of a square (and the one before it
+                // from r = 5) is narrower -- (2w - 1)^2 + (2j - 1)^2 < (2r + 1)^2 in half cells, whatever the cell size: the
+                // widths packed four bits per radius; the L1 ball is the diamond w <= r - j + 1
+                int wc;
+                if (FARK) wc = (int)s_chord[rq * (RC + 1) + j];
+                else if (!KS_MAIN_CHORD) wc = rq;
+                else if (L1) wc = min(rq, rq - j + 1);
+                else wc = j == rq ? (int)((0x3332210u >> (4 * rq)) & 15u) : (j == rq - 1 ? (int)((0x5443210u >> (4 * rq)) & 15u) : rq);
+                R = max(R, wc);
             }
             if (R > 0 && y >= -p.m && y < p.hq + p.m) {
                 const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
@@ -612,8 +637,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             // strip goes there anyway (far queries) or has more than two of them; the odd one: the fallback list)
             const bool late = MODE == 0 && inpass && !live && why < 2u;
             int nlate = 0;
+#ifndef KS_AB_NOCOUNT
             if (MODE == 0) nlate = __syncthreads_count(late ? 1 : 0);
-            const bool to_more = MODE == 0 && (anyfar || nlate > 2);
+#endif
+            const bool to_more = MODE == 0 && (anyfar || nlate > KS_MORE_MIN);
             if (late && to_more) {
                 atomicOr(ls.again + aoff, 1u << (cx & 31));
                 if (why == 0u) atomicOr(ls.grow + aoff, 1u << (cx & 31));

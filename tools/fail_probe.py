@@ -17,7 +17,10 @@ fam = sys.argv[1] if len(sys.argv) > 1 else 'translate40'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 dev = torch.device('cuda', 0)
 wl = bench.WORKLOADS['C3']
-traj, _ = synth.synth_trajectories(B, 3, wl['nb'], (bench.H, bench.W), bench.PATCH, fam, seed=11)
+if fam == 'white':
+    _, _, traj, _ = bench.synth_inputs(dict(wl, B=B), seed=1)
+else:
+    traj, _ = synth.synth_trajectories(B, 3, wl['nb'], (bench.H, bench.W), bench.PATCH, fam, seed=11)
 L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
 shape = ops.make_shape(L._cfg, B, 0, 0, traj.shape[2])
 ws = ops.alloc_workspace(shape, dev)
