@@ -164,14 +164,20 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
             // at C3 (14 x 2 images): 16 strips of 30 rows (448 workgroups = 1.75 rounds) 23.6 us, 18 of 27 (1.97 rounds) 22.3,
             // 36 of 14 (two per CU, 1.97 rounds) 19.9, 54 of 9: 20.8 with k_ev_bin + 1.7; at B = 1 thin strips are the parallelism
             // there is (C4: 16 strips 15.3 us, 32: 10.6).  MPC_EV_STRIPS=<n> forces a count (tuning).
-            static const int ncu = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            // (per device: a process may drive GPUs with different CU counts; -1 = not asked yet)
+            static std::atomic<int> ncu_of[64];
+            static std::atomic<bool> ncu_init{false};
+            if (!ncu_init.exchange(true)) for (auto &v : ncu_of) v.store(0);
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+            int ncu = ncu_of[dev & 63].load();
+            if (ncu <= 0) {
+                if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
                     (void)hipGetLastError();
-                    n = 256;
+                    ncu = 256;
                 }
-                return n;
-            }();
+                ncu_of[dev & 63].store(ncu);
+            }
             static const int forced = getenv("MPC_EV_STRIPS") ? atoi(getenv("MPC_EV_STRIPS")) : 0;
             const int n0 = L.n_strips;
             auto cost_of = [&](int n) {

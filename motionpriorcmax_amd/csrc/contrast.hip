@@ -828,7 +828,11 @@ __global__ __launch_bounds__(256) void k_pool2_fwd(const float *__restrict__ in,
 __global__ __launch_bounds__(256) void k_pool2_bwd_add(const float *__restrict__ small, const float *__restrict__ coef_small,
                                                        float *__restrict__ big, const float *__restrict__ coef_big, int nimg, int H, int W) {
     const int H2 = H >> 1, W2 = W >> 1;
-    const float r = 0.25f * (coef_small[0] / coef_big[0]);
+    // (a level whose objective is flat -- an empty or constant image -- has coefficient 0 or inf: it passes nothing on, and
+    // a finer level without a coefficient of its own receives nothing: no inf / NaN into the gradient)
+    const float cs_ = coef_small[0], cb_ = coef_big[0];
+    const float ratio = cs_ / cb_;
+    const float r = (cb_ != 0.f && ratio == ratio && fabsf(ratio) < INFINITY) ? 0.25f * ratio : 0.f;
     const size_t n = (size_t)nimg * H * W;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int x = (int)(i % W), y = (int)((i / W) % H);

@@ -49,7 +49,7 @@
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
-#define KS_RETRY_BLOCKS 768         // workgroups of the retry kernel (3 per CU)
+#define KS_RETRY_BLOCKS 1024        // workgroups of the second launch (4 per CU)
 static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
 
@@ -178,7 +178,15 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     if (FARK) {
         served = false;
         if (isfar) {
-            r = knn_sat_radius(p, sat_bt, cy, cx, KNN_RCAP + 1, knn_square_need_far(p.K), KNN_RFAR);
+            // smallest radius in (KNN_RCAP, KNN_RFAR] whose square holds the far queries' count: bisection (the count grows with
+            // the radius), four probes instead of up to fourteen -- each a dependent round trip
+            const int need_far = knn_square_need_far(p.K);
+            int lo = KNN_RCAP, hi = KNN_RFAR + 1;       // (lo: too few; hi: enough, or nothing within KNN_RFAR)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (knn_square_count(p, sat_bt, cy, cx, mid) >= need_far) hi = mid; else lo = mid;
+            }
+            r = hi;
             served = r <= KNN_RFAR;                     // (else: the fallback kernel)
         } else if (marked) {
             // the main launch could not finish it: too few candidates below the ring bound -- two more rings (<= KNN_RFAR) -- or
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnPara
 // far queries and the queries the main launch could not finish).  grid: a fixed number of workgroups (the list lengths are only
 // known on the device; nothing to do for the lattice-like point sets of the benchmark: both lists empty or nearly)
 template <int WS, bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(KS_NT) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
+__global__ __launch_bounds__(KS_NT, 4) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
                                                           const int *__restrict__ cell_start, const int *__restrict__ sat,
                                                           const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                           float *__restrict__ flow_lut, float *__restrict__ flow_next,

@@ -330,13 +330,15 @@ class _Plan:
 _PLANS = {}
 
 
-def _plan(cfg, B, M, Mp, n, need_grad, has_offs):
-    key = (cfg, B, M, Mp, n, need_grad, has_offs)
+def _plan(cfg, B, M, Mp, n, need_grad, has_offs, dev):
+    # (per device: the workspace layout follows the CU count of the device the step runs on, api.hip: mpc_layout)
+    key = (cfg, B, M, Mp, n, need_grad, has_offs, dev.index)
     p = _PLANS.get(key)
     if p is None:
         if len(_PLANS) > 256:
             _PLANS.clear()
-        p = _PLANS[key] = _Plan(cfg, B, M, Mp, n, need_grad, has_offs)
+        with torch.cuda.device(dev):
+            p = _PLANS[key] = _Plan(cfg, B, M, Mp, n, need_grad, has_offs)
     return p
 
 
@@ -447,7 +449,7 @@ class FocusCalcFn(torch.autograd.Function):
 
         if STAGE_TIMER is None and FUSED_CALLS:
             # one C-ABI call for the whole forward (mpc_focus_fwd issues the same launches); per-shape host state is cached
-            p = _plan(cfg, B, M, Mp, n, need_grad, event_offsets is not None)
+            p = _plan(cfg, B, M, Mp, n, need_grad, event_offsets is not None, dev)
             offs = _check_offsets(event_offsets, cfg, p.shape, dev)
             ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
             buf = torch.empty(p.buf_floats, dtype=torch.float32, device=dev)
@@ -574,6 +576,9 @@ class PyramidFocusFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         traj, ev, tr, flow_lut, state, g_field = saved[:6]
         scals, gimgs = saved[6:6 + L], list(saved[6 + L:6 + 2 * L])
+        # (the coarser levels are ADDED into the finer adjoint images below: on copies, so that a second backward of a retained
+        # graph starts from the saved images again)
+        gimgs = [gi.clone() for gi in gimgs[:-1]] + gimgs[-1:]
         dev = traj.device
         g = _f32c(g_loss.reshape(1))
         # the coarser levels' adjoint images into the finer ones, each in units of its own level's 1 / val^2 coefficient
@@ -604,9 +609,14 @@ class StaticFocusPlan:
     caller hands over a different tensor than last time)."""
 
     def __init__(self, cfg, B, M, Mp, n, dev, need_grad, traj, ev, tr, offs):
-        p = self.plan = _plan(cfg, B, M, Mp, n, need_grad, offs is not None)
+        p = self.plan = _plan(cfg, B, M, Mp, n, need_grad, offs is not None, dev)
         self.dev = dev
-        self.offs = _check_offsets(offs, cfg, p.shape, dev)
+        # the offsets table of bucket-ordered events is an INPUT like the events: ingest hands over a fresh tensor with every
+        # batch, so the plan owns a buffer of its own and the table is copied in every step (a few KB)
+        self.offs = None
+        if offs is not None:
+            self.offs = torch.empty_like(_check_offsets(offs, cfg, p.shape, dev))
+            self.offs.copy_(offs)
         self.traj, self.ev, self.tr = torch.empty_like(traj), torch.empty_like(ev), torch.empty_like(tr)
         self.ev_src, self.ev_version = None, -1
         self.ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
@@ -649,7 +659,7 @@ class StaticFocusCalcFn(torch.autograd.Function):
     def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, event_offsets, plans: dict):
         B, M, Mp, n, dev, traj, ev, tr = _calc_inputs(trajectories, events, t_ref, cfg, num_pos)
         need_grad = trajectories.requires_grad
-        key = (B, M, Mp, n, need_grad, dev.index, None if event_offsets is None else event_offsets.data_ptr())
+        key = (B, M, Mp, n, need_grad, dev.index, event_offsets is not None)      # shape only: every input is copied in
         sp = plans.get(key)
         if sp is None:
             if len(plans) >= 8:              # every shape holds its buffers: keep the set small
@@ -660,6 +670,8 @@ class StaticFocusCalcFn(torch.autograd.Function):
             sp.ev.copy_(ev)                 # a new batch (or one modified in place): copied once
             sp.ev_src, sp.ev_version = weakref.ref(events), events._version
         sp.tr.copy_(tr)
+        if event_offsets is not None:
+            sp.offs.copy_(_check_offsets(event_offsets, cfg, sp.plan.shape, dev))
         sp.generation += 1
         ctx.sp, ctx.gen = sp, sp.generation
         ctx.set_materialize_grads(False)

@@ -111,3 +111,27 @@ def test_static_shapes_refuses_a_stale_backward_and_handles_new_shapes_and_no_gr
         l4, _, m4 = Ls.calc(traj.to(dev), td, batch)
         l4e, _, m4e = Le.calc(traj.to(dev), td, batch)
     assert torch.equal(l4, l4e) and torch.equal(m4['iwes'], m4e['iwes'])
+
+
+def test_static_shapes_replays_with_fresh_ordered_batches():
+    """static_shapes=True with the library's own bucket-ordered ingest: every batch brings a NEW event tensor and a NEW offsets
+    table of the same shape.  The plan is keyed on the shape only and copies the table in like the events: one plan, replayed,
+    bit-identical to eager for both batches (the plans used to be keyed on the table's address: a capture per step)."""
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(8)
+    _, ev2, _, _, _ = _c2(9)
+    Le = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+    Ls = LossFactory.get_loss_calculator('FOCUS', dict(bench.loss_config(wl), static_shapes=True))
+    td = times.to(dev)
+    batches = [Le.order_events({'events': e.to(dev), 'num_pos_events': num_pos}) for e in (ev, ev2, ev, ev2)]
+    assert batches[0]['event_offsets'].data_ptr() != batches[1]['event_offsets'].data_ptr()
+    for it, b in enumerate(batches):
+        te = (traj + 0.1 * it).to(dev).requires_grad_(True)
+        ts = (traj + 0.1 * it).to(dev).requires_grad_(True)
+        le, _, me = Le.calc(te, td, b); le.backward()
+        ls, _, ms = Ls.calc(ts, td, b); ls.backward()
+        assert torch.equal(ls.detach(), le.detach()), it
+        assert torch.equal(ms['iwes'], me['iwes']) and torch.equal(ts.grad, te.grad), it
+    assert len(Ls._static_plans) == 1
