@@ -118,8 +118,8 @@ __device__ __forceinline__ float blurT_w(int q, int y, int n, float ka, float kc
 //                u = sign / 2x;  blurred output and objective of the own pixels
 //   row y - 3  : gB = Sobel^T u  (hx = ux[c-1] - ux[c+1] per row, vy = uy(y-4) - uy(y-2) per column)
 //   row y - 4  : adjoint of the blur (border weights fold the reflect ring back) -> grad image of the own pixels
-// Same association of the sums as the tiled kernel below (which stays for reference / the variance objective's twin).
-// The tiled kernel spent 190 vector instructions per pixel on LDS traffic and index arithmetic; this one ~70 per lane-row.
+// (Round 1's LDS-tiled kernel spent 190 vector instructions per pixel on LDS traffic and index arithmetic; this one ~70 per
+// lane-row.  It was removed in round 4: profiles/README.md has its numbers.)
 // grid (ceil(W/56), ceil(H/MPC_CT_H), nimg), 64 threads
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lane_left(float v) {      // value of lane - 1 (0 for lane 0)
@@ -238,139 +238,6 @@ __global__ __launch_bounds__(64) void k_contrast_march(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// fused forward + adjoint image (gradient magnitude): raw -> blurred, partial sums, Blur^T Sobel^T u.
-// One pass over the raw image (tile + 4-px halo in LDS) instead of two kernels that each stream the
-// whole batch of images through HBM.  Three LDS planes are recycled:
-//   A: raw -> blurred -> gB      B: horizontal blur -> ux      C: uy
-// Tile = 32 rows x 56 columns, so that tile + halo is exactly 64 columns: thread (tx, ty) of the
-// 64 x 4 workgroup owns local column tx and rows ty, ty+4, ...; a wavefront is one row, column tests
-// are hoisted out of the row loops, and there is no integer division in the kernel.
-// grid (ceil(W/56), ceil(H/32), nimg), 256 threads
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_contrast_fused(const float *__restrict__ raw,
-                                                        float *__restrict__ blur,
-                                                        float *__restrict__ gimg,
-                                                        double *__restrict__ part, int H, int W,
-                                                        int norm_l2) {
-    constexpr int TH = MPC_CT_H, TW = MPC_CF_TW, LH = TH + 8, LW = TW + 8, LP = LW + 1;
-    static_assert(LW == 64, "one local column per lane");
-    __shared__ float sA[LH][LP];
-    __shared__ float sB[LH][LP];
-    __shared__ float sC[LH][LP];
-    __shared__ double s_red[4];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;      // local column, first local row
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const size_t img_off = (size_t)blockIdx.z * H * W;
-    const float *src = raw + img_off;
-    float ka, kc;
-    blur_taps(ka, kc);
-    // local (r, c) <-> image (ty0 - 4 + r, tx0 - 4 + c)
-    const int x = tx0 - 4 + c;
-    const bool xin = x >= 0 && x < W;
-    const int xr = (x >= -1 && x <= W) ? reflect1(x, W) : -1;
-    {   // P0: stage raw (reflect ring at coordinates -1 and H / W); all loads first
-        float v[LH / 4];
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) {
-            const int y = ty0 - 4 + rl + 4 * i;
-            v[i] = (xr >= 0 && y >= -1 && y <= H) ? src[(size_t)reflect1(y, H) * W + xr] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) sA[rl + 4 * i][c] = v[i];
-    }
-    __syncthreads();
-    const bool c1 = c >= 1 && c <= LW - 2, c2 = c >= 2 && c <= LW - 3, c3 = c >= 3 && c <= LW - 4;
-    // P1: horizontal blur, columns 1 .. LW-2
-    if (c1)
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) { const int r = rl + 4 * i; sB[r][c] = ka * sA[r][c - 1] + kc * sA[r][c] + ka * sA[r][c + 1]; }
-    __syncthreads();
-    // P2: vertical blur, rows 1 .. LH-2; zero outside the image (Sobel pads with zeros)
-    if (c1)
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) {
-            const int r = rl + 4 * i, y = ty0 - 4 + r;
-            if (r >= 1 && r <= LH - 2)
-                sA[r][c] = (xin && y >= 0 && y < H) ? ka * sB[r - 1][c] + kc * sB[r][c] + ka * sB[r + 1][c] : 0.f;
-        }
-    __syncthreads();
-    // P3: Sobel on rows/cols 2 .. L-3: u = d|grad|/d(dx,dy); own pixels: blurred output + objective
-    double acc = 0.0;
-    const bool own_col = c >= 4 && c < 4 + TW;
-    if (c2)
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) {
-            const int r = rl + 4 * i, y = ty0 - 4 + r;
-            if (r < 2 || r > LH - 3) continue;
-            float ux = 0.f, uy = 0.f;
-            if (xin && y >= 0 && y < H) {
-                const float tl = sA[r - 1][c - 1], tc = sA[r - 1][c], tr = sA[r - 1][c + 1];
-                const float ml = sA[r][c - 1], mr = sA[r][c + 1];
-                const float bl_ = sA[r + 1][c - 1], bc = sA[r + 1][c], br = sA[r + 1][c + 1];
-                const float dx = (tr - tl) + 2.f * (mr - ml) + (br - bl_);
-                const float dy = (bl_ - tl) + 2.f * (bc - tc) + (br - tr);
-                if (norm_l2) {
-                    ux = 2.f * dx;
-                    uy = 2.f * dy;
-                } else {
-                    ux = (dx > 0.f) ? 1.f : ((dx < 0.f) ? -1.f : 0.f);
-                    uy = (dy > 0.f) ? 1.f : ((dy < 0.f) ? -1.f : 0.f);
-                }
-                if (own_col && r >= 4 && r < 4 + TH) {
-                    blur[img_off + (size_t)y * W + x] = sA[r][c];
-                    acc += norm_l2 ? (double)(dx * dx + dy * dy) : (double)(fabsf(dx) + fabsf(dy));
-                }
-            }
-            sB[r][c] = ux;
-            sC[r][c] = uy;
-        }
-    __syncthreads();
-    // P4: gB on rows/cols 3 .. L-4; zero outside the image
-    if (c3)
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) {
-            const int r = rl + 4 * i, y = ty0 - 4 + r;
-            if (r < 3 || r > LH - 4) continue;
-            float g = 0.f;
-            if (xin && y >= 0 && y < H) {
-                const float gx = (sB[r + 1][c - 1] - sB[r + 1][c + 1]) + 2.f * (sB[r][c - 1] - sB[r][c + 1]) +
-                                 (sB[r - 1][c - 1] - sB[r - 1][c + 1]);
-                const float gy = (sC[r - 1][c + 1] - sC[r + 1][c + 1]) + 2.f * (sC[r - 1][c] - sC[r + 1][c]) +
-                                 (sC[r - 1][c - 1] - sC[r + 1][c - 1]);
-                g = gx + gy;
-            }
-            sA[r][c] = g;
-        }
-    __syncthreads();
-    // P5: adjoint of the blur for own pixels (column weights hoisted out of the row loop)
-    if (own_col && x < W) {
-        float wx[3];
-#pragma unroll
-        for (int d = -1; d <= 1; ++d) wx[d + 1] = (x + d >= 0 && x + d < W) ? blurT_w(x + d, x, W, ka, kc) : 0.f;
-#pragma unroll
-        for (int i = 0; i < TH / 4; ++i) {
-            const int r = 4 + rl + 4 * i, y = ty0 - 4 + r;
-            if (y >= H) break;
-            float a = 0.f;
-#pragma unroll
-            for (int d = -1; d <= 1; ++d) {
-                const int qy = y + d;
-                if (qy < 0 || qy >= H) continue;
-                const float wy = blurT_w(qy, y, H, ka, kc);
-                a += wy * (wx[0] * sA[r + d][c - 1] + wx[1] * sA[r + d][c] + wx[2] * sA[r + d][c + 1]);
-            }
-            gimg[img_off + (size_t)y * W + x] = a;
-        }
-    }
-    const double r0 = block_sum_d<256>(acc, s_red);
-    if (threadIdx.x == 0) {
-        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        part[2 * bid] = r0;
-        part[2 * bid + 1] = 0.0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // backward (variance objective): blurred -> Blur^T (x - mean_img)   (unscaled)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_image_means(const double *__restrict__ part,
@@ -422,105 +289,6 @@ __global__ __launch_bounds__(256) void k_contrast_bwd_var(const float *__restric
             }
             gimg[img_off + (size_t)y * W + x] = acc;
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// smoothness of a flow field stored [nimg][hq][wq][C] (C even: (y,x) pairs): forward partial sums +
-// gradient.  One workgroup = 16 x 60 cells of one channel PAIR (float2 loads); tile + 2-cell halo is
-// exactly 64 columns, one per lane (same mapping as k_contrast_fused: no index division).
-// grid (ceil(wq/60), ceil(hq/16), nimg*C/2), 256 threads
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lut_smooth(const float *__restrict__ field,
-                                                    float *__restrict__ gfield,
-                                                    double *__restrict__ part, int hq, int wq, int C,
-                                                    float gscale /* smooth_weight/(2*count) */) {
-    constexpr int TH = MPC_SM_H, TW = MPC_SM_W, LH = TH + 4, LW = TW + 4, LP = LW + 1;
-    static_assert(LW == 64, "one local column per lane");
-    __shared__ float2 s_f[LH][LP];
-    __shared__ float2 s_vx[LH][LP];
-    __shared__ float2 s_vy[LH][LP];
-    __shared__ double s_red[2][4];
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int C2 = C >> 1;
-    const int img = blockIdx.z / C2, cp = blockIdx.z - img * C2;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const size_t base = (size_t)img * hq * wq * C2 + cp;        // in float2 units
-    const float2 *f2 = reinterpret_cast<const float2 *>(field);
-    const float eps2 = 1e-3f * 1e-3f;   // charbonnier epsilon ** 2 (loss.py:46,55)
-    // local (r, c) <-> cell (y0 - 2 + r, x0 - 2 + c)
-    const int x = x0 - 2 + c;
-    const bool xin = x >= 0 && x < wq;
-    {
-        float2 v[LH / 4];
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) {
-            const int y = y0 - 2 + rl + 4 * i;
-            v[i] = (xin && y >= 0 && y < hq) ? f2[base + ((size_t)y * wq + x) * C2] : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) s_f[rl + 4 * i][c] = v[i];
-    }
-    __syncthreads();
-    double a0 = 0.0, a1 = 0.0;
-    const bool own_col = c >= 2 && c < 2 + TW;
-    if (c >= 1 && c <= LW - 2)
-#pragma unroll
-        for (int i = 0; i < LH / 4; ++i) {
-            const int r = rl + 4 * i, y = y0 - 2 + r;
-            if (r < 1 || r > LH - 2) continue;
-            float2 vx = make_float2(0.f, 0.f), vy = make_float2(0.f, 0.f);
-            if (xin && y >= 0 && y < hq) {
-                const float2 tl = s_f[r - 1][c - 1], tc = s_f[r - 1][c], tr = s_f[r - 1][c + 1];
-                const float2 ml = s_f[r][c - 1], mr = s_f[r][c + 1];
-                const float2 bl_ = s_f[r + 1][c - 1], bc = s_f[r + 1][c], br = s_f[r + 1][c + 1];
-                const bool own = own_col && r >= 2 && r < 2 + TH;
-#define MPC_SM_CH(ch)                                                                       \
-                {                                                                           \
-                    const float dx = (tr.ch - tl.ch) + 2.f * (mr.ch - ml.ch) + (br.ch - bl_.ch); \
-                    const float dy = (bl_.ch - tl.ch) + 2.f * (bc.ch - tc.ch) + (br.ch - tr.ch); \
-                    /* hardware sqrt and reciprocal (1 ulp each) instead of the correctly rounded sequences:  \
-                       the charbonnier terms and their derivatives dx / sqrt(dx^2 + eps^2) move by ~1e-7      \
-                       relative, far inside the 1e-5 tolerance, and this kernel is VALU bound */            \
-                    const float sx = __builtin_amdgcn_sqrtf(dx * dx + eps2), sy = __builtin_amdgcn_sqrtf(dy * dy + eps2); \
-                    vx.ch = dx * __builtin_amdgcn_rcpf(sx);                                  \
-                    vy.ch = dy * __builtin_amdgcn_rcpf(sy);                                  \
-                    if (own) { a0 += (double)sx; a1 += (double)sy; }                         \
-                }
-                MPC_SM_CH(x)
-                MPC_SM_CH(y)
-#undef MPC_SM_CH
-            }
-            s_vx[r][c] = vx;
-            s_vy[r][c] = vy;
-        }
-    __syncthreads();
-    if (gfield != nullptr && own_col && x < wq) {
-        float2 *g2 = reinterpret_cast<float2 *>(gfield);
-#pragma unroll
-        for (int i = 0; i < TH / 4; ++i) {
-            const int r = 2 + rl + 4 * i, y = y0 - 2 + r;
-            if (y >= hq) break;
-            float2 o;
-#define MPC_SM_G(ch)                                                                                 \
-            o.ch = gscale * (((s_vx[r + 1][c - 1].ch - s_vx[r + 1][c + 1].ch) +                       \
-                              2.f * (s_vx[r][c - 1].ch - s_vx[r][c + 1].ch) +                          \
-                              (s_vx[r - 1][c - 1].ch - s_vx[r - 1][c + 1].ch)) +                        \
-                             ((s_vy[r - 1][c + 1].ch - s_vy[r + 1][c + 1].ch) +                        \
-                              2.f * (s_vy[r - 1][c].ch - s_vy[r + 1][c].ch) +                          \
-                              (s_vy[r - 1][c - 1].ch - s_vy[r + 1][c - 1].ch)));
-            MPC_SM_G(x)
-            MPC_SM_G(y)
-#undef MPC_SM_G
-            g2[base + ((size_t)y * wq + x) * C2] = o;
-        }
-    }
-    const double r0 = block_sum_d<256>(a0, s_red[0]);
-    const double r1 = block_sum_d<256>(a1, s_red[1]);
-    if (threadIdx.x == 0) {
-        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        part[2 * bid] = r0;
-        part[2 * bid + 1] = r1;
     }
 }
 
@@ -615,7 +383,7 @@ __global__ void k_scale(const float *__restrict__ x, const float *__restrict__ a
 // ------------------------------------------------------------------------------------------
 // smoothness, MARCHING form (as k_contrast_march: lane = column, rows walked with rolling register windows, DPP lane
 // shifts, no LDS, no barrier): one wavefront owns 60 cell columns (+ 2 halo each side) and MPC_SM_H rows (+ 2) of one
-// channel pair.  Same sums, in the same association, as k_lut_smooth above.
+// channel pair.  Same sums, in the same association, as round 1's LDS-tiled kernel had (removed in round 4).
 // grid (ceil(wq/60), ceil(hq/MPC_SM_H), nimg*C/2), 64 threads
 // ------------------------------------------------------------------------------------------
 // TH rows per band: MPC_SM_H (16), or half of it for small fields (smooth_band_rows below)
@@ -665,7 +433,7 @@ __global__ __launch_bounds__(64) void k_lut_smooth_march(const float *__restrict
             const float dxx = hd2.x + 2.f * hd1.x + hd0.x, dxy = hd2.y + 2.f * hd1.y + hd0.y;
             const float dyx = lane_left(vd.x) + 2.f * vd.x + lane_right(vd.x), dyy = lane_left(vd.y) + 2.f * vd.y + lane_right(vd.y);
             if (xin && ys >= 0 && ys < hq) {
-                // hardware sqrt and reciprocal (1 ulp each), as in k_lut_smooth
+                // hardware sqrt and reciprocal (1 ulp each)
                 const float sxx = __builtin_amdgcn_sqrtf(dxx * dxx + eps2), syx = __builtin_amdgcn_sqrtf(dyx * dyx + eps2);
                 const float sxy = __builtin_amdgcn_sqrtf(dxy * dxy + eps2), syy = __builtin_amdgcn_sqrtf(dyy * dyy + eps2);
                 vx.x = dxx * __builtin_amdgcn_rcpf(sxx); vy1.x = dyx * __builtin_amdgcn_rcpf(syx);
@@ -713,12 +481,7 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     const int l2 = (s->flags & MPC_F_NORM_L2) ? 1 : 0;
     if (grad_iwe && !variance) {
         const dim3 gridf(mpc_cdiv(s->W, MPC_CF_TW), mpc_cdiv(s->H, MPC_CT_H), L.nimg);
-        static const bool tiled = getenv("MPC_CONTRAST_TILED") && atoi(getenv("MPC_CONTRAST_TILED")) != 0;    // (tuning: the LDS-tiled kernel)
-        if (tiled) {
-            const int e = mpc_zero_async(cpart, (size_t)L.n_cblocks * 2 * sizeof(double), st);
-            if (e) return e;
-            MPC_LAUNCH(k_contrast_fused, gridf, dim3(256), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, l2);
-        } else if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {
+        if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {        } else if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {
             // few images: bands of 16 rows, twice the wavefronts (the partial-sum array is sized for them)
             const dim3 gridh(gridf.x, mpc_cdiv(s->H, MPC_CT_H / 2), L.nimg);
             if (l2) MPC_LAUNCH((k_contrast_march<true, MPC_CT_H / 2>), gridh, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);
@@ -760,8 +523,7 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
     if (rc) return rc;
     const mpc_ws_layout L = mpc_layout(s);
     MPC_CHECK_ARG(nimg > 0 && C > 0 && (C % 2) == 0, MPC_E_SHAPE, "field must have an even number of channels");
-    static const bool tiled = getenv("MPC_SMOOTH_TILED") && atoi(getenv("MPC_SMOOTH_TILED")) != 0;      // (tuning: the LDS-tiled kernel)
-    const int band = tiled ? MPC_SM_H : smooth_band_rows(s, nimg, C);
+    const int band = smooth_band_rows(s, nimg, C);
     const dim3 grid(mpc_cdiv(s->wq, MPC_SM_W), mpc_cdiv(s->hq, band), nimg * (C / 2));
     const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
     MPC_CHECK_ARG(nblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
@@ -769,8 +531,7 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
     double *spart = (double *)((char *)ws + L.off_spart);
     const double count = (double)nimg * C * s->hq * s->wq;
     const float gscale = (float)((double)smooth_weight / (2.0 * count));
-    if (tiled) MPC_LAUNCH(k_lut_smooth, grid, dim3(256), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
-    else if (band == MPC_SM_H) MPC_LAUNCH(k_lut_smooth_march<MPC_SM_H>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
+    if (band == MPC_SM_H) MPC_LAUNCH(k_lut_smooth_march<MPC_SM_H>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
     else MPC_LAUNCH(k_lut_smooth_march<MPC_SM_H / 2>, grid, dim3(64), 0, st, field, grad_field, spart, s->hq, s->wq, C, gscale);
     MPC_CHECK_LAUNCH();
     return 0;
@@ -786,8 +547,7 @@ extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smo
     int64_t nsblk = 0;
     double count = 1.0;
     if (smooth_nimg > 0) {
-        static const bool tiled = getenv("MPC_SMOOTH_TILED") && atoi(getenv("MPC_SMOOTH_TILED")) != 0;
-        const int band = tiled ? MPC_SM_H : smooth_band_rows(s, smooth_nimg, smooth_C);
+        const int band = smooth_band_rows(s, smooth_nimg, smooth_C);
         nsblk = (int64_t)mpc_cdiv(s->wq, MPC_SM_W) * mpc_cdiv(s->hq, band) * smooth_nimg * (smooth_C / 2);
         MPC_CHECK_ARG(nsblk <= L.n_sblocks_max, MPC_E_SHAPE, "field larger than the LUT of this shape");
         count = (double)smooth_nimg * smooth_C * s->hq * s->wq;
