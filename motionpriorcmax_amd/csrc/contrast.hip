@@ -481,7 +481,7 @@ extern "C" int mpc_contrast_fwd(const mpc_shape *s, const float *iwe_raw, float 
     const int l2 = (s->flags & MPC_F_NORM_L2) ? 1 : 0;
     if (grad_iwe && !variance) {
         const dim3 gridf(mpc_cdiv(s->W, MPC_CF_TW), mpc_cdiv(s->H, MPC_CT_H), L.nimg);
-        if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {        } else if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {
+        if ((int64_t)gridf.x * gridf.y * gridf.z < 1536) {
             // few images: bands of 16 rows, twice the wavefronts (the partial-sum array is sized for them)
             const dim3 gridh(gridf.x, mpc_cdiv(s->H, MPC_CT_H / 2), L.nimg);
             if (l2) MPC_LAUNCH((k_contrast_march<true, MPC_CT_H / 2>), gridh, dim3(64), 0, st, iwe_raw, iwe_blur, grad_iwe, cpart, s->H, s->W, L.n_cblocks);

@@ -92,6 +92,12 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     static_assert(NR <= KS_NT && NR <= KS_NR_MAX, "one thread per region row");
     int *const fail = ls.fail;
     const int tid = threadIdx.x;
+    if (MODE == 0) {
+        // (main launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
+        // the first bucketed slots of the rows go later (s_row); this early barrier costs nothing: every wavefront is here at once
+        if (tid < NR) reinterpret_cast<int2 *>(s_dyn)[tid].x = 0;
+        __syncthreads();
+    }
     const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
     const int sy = bxy / gx, sx = bxy - sy * gx;
     const int b = bt / p.nb, t = bt - b * p.nb;
@@ -134,8 +140,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     const bool marked = FARK && valid && ((ls.again[aoff] >> (cx & 31)) & 1u) != 0u;
     int r = 0, nr = 0;                                  // radius and the points in its square
     bool served = false;
+    const int need_q = knn_square_need(p.K);
     if (FARK ? marked : valid) {
-        const int need = knn_square_need(p.K);
+        const int need = need_q;
         r = min(r_init, KNN_RCAP);
 #ifdef KS_AB_NOSAT
         nr = 1000;
@@ -168,7 +175,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         // coefficients: 9 % of the lanes) the radius stands -- a wavefront pays for its widest lane, one more ring is 90 slots
         // instead of 63 -- and the query that does come up short is searched again; where it is the rule (an expanding flow
         // field: every square holds ~44) those lanes take one more ring right away.
-        const int need = knn_square_need(p.K);
+        const int need = need_q;
         // (a square with barely `need` points comes up short every other time: one more ring whatever the neighbours do)
         const bool marginal = served && r < KNN_RCAP && nr < need + need / 7;
         const int nm = __popcll(__ballot(marginal)), nv = __popcll(__ballot(served));
@@ -200,7 +207,25 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         int rr = (mine && served) ? r : 0;
 #pragma unroll
         for (int o2 = 1; o2 < WS; o2 <<= 1) rr = max(rr, __shfl_xor(rr, o2, 64));
-        if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr;
+        if (MODE != 0) { if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr; }
+        else if ((tid % WS) == 0 && rr > 0) {
+            // main launch: every query row pushes the width of its disc's chord onto the region rows it uses -- 2 r + 1 LDS
+            // atomics per row of queries instead of every region row looking at 13 query rows (the loop of the other launches)
+            int2 *s_w = reinterpret_cast<int2 *>(s_dyn);
+            const int rc = cy - qy0 + RC;                   // region row of this query row
+            for (int j = -rr; j <= rr; ++j) {
+                const int aj = abs(j);
+                int wc;
+                // the chord of the query's disc at row offset j (the corner cells of the square hold nothing below the ring
+                // bound): only the outermost row of a square (and the one before it from r = 5) is narrower --
+                // (2w - 1)^2 + (2j - 1)^2 < (2r + 1)^2 in half cells, whatever the cell size: the widths packed four bits per
+                // radius; the L1 ball is the diamond w <= r - j + 1
+                if (!KS_MAIN_CHORD) wc = rr;
+                else if (L1) wc = min(rr, rr - aj + 1);
+                else wc = aj == rr ? (int)((0x3332210u >> (4 * rr)) & 15u) : (aj == rr - 1 ? (int)((0x5443210u >> (4 * rr)) & 15u) : rr);
+                atomicMax(&s_w[rc + j].x, wc);
+            }
+        }
     }
     // chord of the disc of radius r at row offset j, for the row tables below (knn_device.h)
     __shared__ unsigned char s_chord[(RC + 1) * (RC + 1)];
@@ -242,21 +267,16 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (tid < NR) {
             const int y = ry_base + tid;
             int R = 0;
-            const int c0 = max(tid - 2 * RC, pr0), c1 = min(tid, pr1 - 1);       // query rows within RC of this row
-            for (int c = c0; c <= c1; ++c) {
-                const int rq = (int)s_rq[c], j = abs(c - (tid - RC));
-                if (j > rq) continue;
-                // the chord of the query's disc at this row (the corner cells of the square hold nothing below the ring bound)
-                // the chord of the query's disc at this row (the corner cells of the square hold nothing below the ring bound).
-                // Far queries: from the table.  Main launch (r <= 6): only the outermost row of a square (and the one before it
-                // from r = 5) is narrower -- (2w - 1)^2 + (2j - 1)^2 < (2r + 1)^2 in half cells, whatever the cell size: the
-                // widths packed four bits per radius; the L1 ball is the diamond w <= r - j + 1
-                int wc;
-                if (FARK) wc = (int)s_chord[rq * (RC + 1) + j];
-                else if (!KS_MAIN_CHORD) wc = rq;
-                else if (L1) wc = min(rq, rq - j + 1);
-                else wc = j == rq ? (int)((0x3332210u >> (4 * rq)) & 15u) : (j == rq - 1 ? (int)((0x5443210u >> (4 * rq)) & 15u) : rq);
-                R = max(R, wc);
+            if (MODE == 0) R = s_row[tid].x;                // (collected with atomics above)
+            else {
+                const int c0 = max(tid - 2 * RC, pr0), c1 = min(tid, pr1 - 1);       // query rows within RC of this row
+                for (int c = c0; c <= c1; ++c) {
+                    const int rq = (int)s_rq[c], j = abs(c - (tid - RC));
+                    if (j > rq) continue;
+                    // the chord of the query's disc at this row: far queries from the table, the quarters of an overflowed strip
+                    // the square
+                    R = max(R, FARK ? (int)s_chord[rq * (RC + 1) + j] : rq);
+                }
             }
             if (R > 0 && y >= -p.m && y < p.hq + p.m) {
                 const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
