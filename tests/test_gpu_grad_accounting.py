@@ -92,14 +92,16 @@ def test_every_gradient_mismatch_is_explained_by_a_near_zero_response(shape, B, 
     print(f'explained cells {100 * frac_explained:.2f} %, mismatching cells {100 * frac_mismatch:.3f} % of {n_cells}')
 
 
-def test_end_to_end_gradient_mismatches_are_explained():
+@pytest.mark.parametrize('shape,B,M,nb,K', [((192, 256), 2, 60000, 5, 8), ((480, 640), 1, 100000, 15, 32)])
+def test_end_to_end_gradient_mismatches_are_explained(shape, B, M, nb, K):
     """The same accounting for d loss / d trajectories through the KNN LUT (dsec.yaml switches, smoothness on): a
-    trajectory point may differ from the oracle only if an explained LUT cell lies within the reach of its neighbourhood."""
+    trajectory point may differ from the oracle only if an explained LUT cell lies within the reach of its neighbourhood.
+    Second case: the DSEC sensor with K = 32 and 15 bins (one sample; the oracle's brute-force KNN takes a minute or two)."""
     from motionpriorcmax_amd import LossFactory, ops
     from oracle import focus_oracle as O
-    shape, B, M, nb, sp, K = (192, 256), 2, 60000, 5, 4, 8
+    sp = 4
     H, W = shape
-    cfg = dict(_cfg(shape, nb, 'l1'), smooth_weight=0.003)
+    cfg = dict(_cfg(shape, nb, 'l1'), smooth_weight=0.003, num_knn=K)
     ev, num_pos = O.synth_events(B, M, shape, nb, seed=5, pad_frac=0.02)
     g = torch.Generator().manual_seed(5)
     coeff = torch.randn(B, 1, 2, H, W, generator=g) * 3.0
@@ -135,7 +137,7 @@ def test_end_to_end_gradient_mismatches_are_explained():
         hq, wq = H // sp, W // sp
         cell = torch.zeros(B, nb, hq, wq)
         cell[bi[hit], it[hit], iy[hit], ix[hit]] = 1.0
-        # a LUT cell averages K = 8 points around it (~2 cells away at one point per cell; 6 is generous)
+        # a LUT cell averages K points around it (~2 cells away at K = 8, ~3.3 at K = 32, one point per cell; 6 is generous)
         near = F.max_pool2d(cell, 13, stride=1, padding=6) > 0        # [B, nb, hq, wq]
         # trajectory point -> its cell at the bin's time (row 1 + t of the tensor)
         pos = traj[:, 1:]                                              # [B, nb, n, 2]
