@@ -293,18 +293,50 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 template <class F>
 __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, int *__restrict__ S, int *s_part) {
     const int W1 = p.wb + 1, ngrp = (p.hb + 7) >> 3, nthr = blockDim.x;
-    for (int it = threadIdx.x; it < ngrp * W1; it += nthr) {
+    // every (column, group of 8 rows) item keeps its 8 row prefixes in registers between the two phases; all 16 loads of an
+    // item are in flight together (from global memory a dependent chain of them was the whole 18 us of the kernel at B = 1)
+    constexpr int ITEMS = 4;                           // items per thread held in registers (more: a second round re-reads)
+    int pre[ITEMS][8];
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        const int it = threadIdx.x + u * nthr;
+        const int g = it / W1, x = it - g * W1;
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int y = g * 8 + k;
+            const bool on = it < ngrp * W1 && y < p.hb;
+            const int a = on ? rowstart(y, x) : 0, z = on ? rowstart(y, 0) : 0;
+            pre[u][k] = a - z;
+            sum += pre[u][k];
+        }
+        if (it < ngrp * W1) s_part[it] = sum;
+    }
+    for (int it = threadIdx.x + ITEMS * nthr; it < ngrp * W1; it += nthr) {        // (grids beyond ITEMS x threads items)
         const int g = it / W1, x = it - g * W1;
         int sum = 0;
         for (int y = g * 8; y < min(g * 8 + 8, p.hb); ++y) sum += rowstart(y, x) - rowstart(y, 0);
         s_part[it] = sum;
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < ngrp * W1; it += nthr) {
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+        const int it = threadIdx.x + u * nthr;
+        if (it >= ngrp * W1) continue;
         const int g = it / W1, x = it - g * W1;
         int acc = 0;
         for (int gg = 0; gg < g; ++gg) acc += s_part[gg * W1 + x];
         if (g == 0) S[x] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int y = g * 8 + k;
+            if (y < p.hb) { acc += pre[u][k]; S[(size_t)(y + 1) * W1 + x] = acc; }
+        }
+    }
+    for (int it = threadIdx.x + ITEMS * nthr; it < ngrp * W1; it += nthr) {
+        const int g = it / W1, x = it - g * W1;
+        int acc = 0;
+        for (int gg = 0; gg < g; ++gg) acc += s_part[gg * W1 + x];
         for (int y = g * 8; y < min(g * 8 + 8, p.hb); ++y) {
             acc += rowstart(y, x) - rowstart(y, 0);
             S[(size_t)(y + 1) * W1 + x] = acc;

@@ -92,8 +92,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     static_assert(NR <= KS_NT && NR <= KS_NR_MAX, "one thread per region row");
     int *const fail = ls.fail;
     const int tid = threadIdx.x;
-    if (MODE == 0) {
-        // (main launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
+    if (MODE != 1) {
+        // (main and second launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
         // the first bucketed slots of the rows go later (s_row); this early barrier costs nothing: every wavefront is here at once
         if (tid < NR) reinterpret_cast<int2 *>(s_dyn)[tid].x = 0;
         __syncthreads();
@@ -135,13 +135,15 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     // Starts at the radius of the mean density; only a clearly denser place tries smaller ones.
     const int aw = (p.wq + 31) >> 5;
     const int aoff = bt * ls.again_words + min(cy, p.hq - 1) * aw + (min(cx, p.wq - 1) >> 5);      // this query's word of the `again` / `grow` maps
-    // (the launch for the far queries: only the queries the main launch marked in the `again` map -- far ones and those it
-    // could not finish -- look at the table at all)
-    const bool marked = FARK && valid && ((ls.again[aoff] >> (cx & 31)) & 1u) != 0u;
+    // (the second launch: only the queries the main launch marked look at the table at all -- `grow` alone: a far query, no
+    // square up to KNN_RCAP holds enough points; `again`: one it could not finish, with `grow` if for too few candidates)
+    const bool bit_again = FARK && valid && ((ls.again[aoff] >> (cx & 31)) & 1u) != 0u;
+    const bool bit_grow = FARK && valid && ((ls.grow[aoff] >> (cx & 31)) & 1u) != 0u;
+    const bool marked = bit_again || bit_grow, farq = bit_grow && !bit_again;
     int r = 0, nr = 0;                                  // radius and the points in its square
     bool served = false;
     const int need_q = knn_square_need(p.K);
-    if (FARK ? marked : valid) {
+    if (FARK ? bit_again : valid) {
         const int need = need_q;
         r = min(r_init, KNN_RCAP);
 #ifdef KS_AB_NOSAT
@@ -167,7 +169,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         }
         served = r <= KNN_RCAP;
     }
-    bool isfar = (FARK ? marked : valid) && !served;      // no square up to KNN_RCAP holds enough points: k_knn_strip_more<FARQ>'s query
+    bool isfar = FARK ? farq : (valid && !served);      // no square up to KNN_RCAP holds enough points: the second launch's query
     if (!FARK) {
         // The count says how many points the SQUARE holds; the disc of the ring bound holds pi / 4 of them, give or take the
         // scatter of the positions.  With fewer than need + need / 7 points in the square (47 for K = 32: the lattice has 49
@@ -180,7 +182,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         const bool marginal = served && r < KNN_RCAP && nr < need + need / 7;
         const int nm = __popcll(__ballot(marginal)), nv = __popcll(__ballot(served));
         if (marginal && (4 * nm >= nv || nr < need + 2)) ++r;
-        if (isfar) atomicOr(ls.again + aoff, 1u << (cx & 31));      // (for the launch that follows)
+        if (isfar) atomicOr(ls.grow + aoff, 1u << (cx & 31));       // (for the launch that follows: `grow` without `again` = far)
     }
     if (FARK) {
         served = false;
@@ -195,10 +197,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
             r = hi;
             served = r <= KNN_RFAR;                     // (else: the fallback kernel)
-        } else if (marked) {
+        } else if (bit_again) {
             // the main launch could not finish it: too few candidates below the ring bound -- two more rings (<= KNN_RFAR) -- or
             // more slots than its registers hold -- the same radius with this launch's 128 slots
-            if (((ls.grow[aoff] >> (cx & 31)) & 1u) != 0u) r += 2;
+            if (bit_grow) r += 2;
             served = true;
         }
     }
@@ -207,7 +209,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         int rr = (mine && served) ? r : 0;
 #pragma unroll
         for (int o2 = 1; o2 < WS; o2 <<= 1) rr = max(rr, __shfl_xor(rr, o2, 64));
-        if (MODE != 0) { if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr; }
+        if (MODE == 1) { if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr; }
+        else if (MODE == 2) { }                          // (pushed per query after the compaction below)
         else if ((tid % WS) == 0 && rr > 0) {
             // main launch: every query row pushes the width of its disc's chord onto the region rows it uses -- 2 r + 1 LDS
             // atomics per row of queries instead of every region row looking at 13 query rows (the loop of the other launches)
@@ -254,7 +257,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const int e = s_list[tid];
             cy = qy0 + (e & 0xff); cx = qx0 + ((e >> 8) & 0xf); r = (e >> 12) & 0xff; served = ((e >> 20) & 1) != 0; isfar = ((e >> 21) & 1) != 0;
         }
-        __syncthreads();                                         // (before the staging area is written)
+        // every query pushes the chords of its disc onto the region rows it uses (as the main launch does per query row)
+        if (mine && served) {
+            int2 *s_w = reinterpret_cast<int2 *>(s_dyn);
+            const int rc = cy - qy0 + RC;
+            for (int j = -r; j <= r; ++j) atomicMax(&s_w[rc + j].x, (int)s_chord[r * (RC + 1) + abs(j)]);
+        }
+        __syncthreads();                                         // (before the row tables are read and the staging area is written)
     }
     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
     // ---- column extent of every region row = the widest square (of the query rows [pr0, pr1) of the strip) that uses the
@@ -267,7 +276,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (tid < NR) {
             const int y = ry_base + tid;
             int R = 0;
-            if (MODE == 0) R = s_row[tid].x;                // (collected with atomics above)
+            if (MODE != 1) R = s_row[tid].x;                // (collected with atomics above)
             else {
                 const int c0 = max(tid - 2 * RC, pr0), c1 = min(tid, pr1 - 1);       // query rows within RC of this row
                 for (int c = c0; c <= c1; ++c) {

@@ -52,8 +52,10 @@ aw = B * shape.nb * shape.hq * ((shape.wq + 31) // 32)
 ag = ws[offs[2]:offs[2] + 4 * aw].view(torch.int32).cpu().numpy().view(np.uint32)
 gr = ws[offs[3]:offs[3] + 4 * aw].view(torch.int32).cpu().numpy().view(np.uint32)
 pop = lambda a: int(np.unpackbits(a.view(np.uint8)).sum())
+far_b = gr & ~ag
 print(f'strips {nstrips}: searched again in quarters {int(i32(offs[0])[0])}, on the second launch\'s list {int(i32(offs[1])[0])};  '
-      f'queries marked for the second launch {pop(ag)} ({100.0 * pop(ag) / (B * shape.nb * G):.3f} %), of them needing more rings {pop(gr)}')
+      f'queries marked for the second launch: far {pop(far_b)} ({100.0 * pop(far_b) / (B * shape.nb * G):.3f} %), unfinished {pop(ag)} '
+      f'({100.0 * pop(ag) / (B * shape.nb * G):.3f} %; {pop(ag & gr)} of them for more rings)')
 if offs[4] >= 0:
     fl = ws[offs[4]:offs[4] + 4 * B * shape.nb * (G + 1)].view(torch.int32).cpu().numpy().reshape(B * shape.nb, G + 1)
     print(f'far lists: {int(fl[:, 0].sum())} queries ({100.0 * fl[:, 0].sum() / (B * shape.nb * G):.3f} %); work items (tiles) of the far backward: {int(i32(offs[5])[0])}')
