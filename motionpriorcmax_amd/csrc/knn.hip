@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 // touch).  grid: a fixed number of workgroups (the list length is only known on the device; the lattice-like point sets of
 // the benchmark have a few hundred items per step)
 // ------------------------------------------------------------------------------------------
-#define KNN_FAR_CAP 512       // points of a tile per round of accumulators
+#define KNN_FAR_CAP 640       // points of a tile per round of accumulators (a border tile with its margin cells: 24 x 24)
 #define KNN_FAR_BLOCKS 2048
 template <bool L1, bool NEXT>
 __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const int *__restrict__ cell_start,
@@ -1257,12 +1257,19 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
             if (tid == 0) s_rowbase[0] = 0;
         }
         // largest gradient of the list -> the power of two that scales the fixed-point sums (values below 2^40, up to 2^20 of them)
+        // (list entries four at a time: their dependent loads -- entry, then what it points at -- travel together)
         float gm = 0.f;
-        for (int e = tid; e < nfar; e += 256) {
-            const int cell = fl[1 + e];
-            const float2 g = gl2[cell];
-            gm = fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y)));
-            if (has_next) { const float2 gn = gn2[cell]; gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
+        for (int e0 = 0; e0 < nfar; e0 += 4 * 256) {
+            int cellv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * 256 + tid; cellv[u] = e < nfar ? fl[1 + e] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (cellv[u] < 0) continue;
+                const float2 g = gl2[cellv[u]];
+                gm = fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y)));
+                if (has_next) { const float2 gn = gn2[cellv[u]]; gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
+            }
         }
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o2, 64));
@@ -1288,10 +1295,18 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
                 s_pos[li] = sp_[g]; s_idx[li] = (unsigned short)si_[g];
             }
             __syncthreads();
-            for (int e = tid; e < nfar; e += 256) {
-                const int cell = fl[1 + e];
+            for (int e0 = 0; e0 < nfar; e0 += 4 * 256) {
+              int cellv[4]; float dkv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { const int e = e0 + u * 256 + tid; cellv[u] = e < nfar ? fl[1 + e] : -1; }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) dkv[u] = cellv[u] >= 0 ? dks[cellv[u]] : -1.f;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int cell = cellv[u];
+                if (cell < 0) continue;
                 const int cy = cell / p.wq, cx = cell - cy * p.wq;
-                const float dk = dks[cell];
+                const float dk = dkv[u];
                 const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
                 // does the disc of the query touch the tile's area at all?
                 const float gy_ = fmaxf(0.f, fmaxf(qy - ay1, ay0 - qy)), gx_ = fmaxf(0.f, fmaxf(qx - ax1, ax0 - qx));
@@ -1301,26 +1316,40 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
                 const float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
                 const long long fy = __double2ll_rn((double)g.x * scale), fx = __double2ll_rn((double)g.y * scale);
                 const long long fny = __double2ll_rn((double)gn.x * scale), fnx = __double2ll_rn((double)gn.y * scale);
+#ifdef KF_AB_NOROWS
+                for (int rr = 0; rr < 0; ++rr) {
+#else
                 for (int rr = 0; rr < nrow; ++rr) {
+#endif
                     // a point of this cell row is at least dyc away along y; along x it then lies within wx of the query
                     const float dyc = fmaxf((float)abs(ty0 + rr - cy) - 0.5f, 0.f) * (float)p.sp;
                     const float w2 = L1 ? dk - dyc : dk - dyc * dyc;
                     if (w2 < 0.f) continue;
-                    const int xr = (int)((L1 ? w2 : sqrtf(w2)) / (float)p.sp + 0.5f) + 1;
+                    // cells cx - xr .. cx + xr: (|x - cx| - 0.5) sp < wx, i.e. |x - cx| <= floor(wx / sp + 0.5) (one ulp of slack in wx)
+                    const int xr = (int)((L1 ? w2 : sqrtf(w2) * 1.000001f) / (float)p.sp + 0.5f);
                     int xa = max(cx - xr, tx0), xb = min(cx + xr, tx1 - 1);
                     if (cx - xr <= -p.m) xa = tx0;                   // (the outermost column holds everything beyond it)
                     if (cx + xr >= p.wq + p.m - 1) xb = tx1 - 1;
                     if (xa > xb) continue;
                     const int ja = max(s_cs[rr][xa - tx0] - c0, 0), jb = min(s_cs[rr][xb + 1 - tx0] - c0, KNN_FAR_CAP);
+#ifdef KF_AB_NOPTS
+                    for (int li = ja; li < min(jb, ja); ++li) {
+#else
                     for (int li = ja; li < jb; ++li) {
+#endif
                         const float2 pj = s_pos[li];
                         const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                         if (d > dk || (d == dk && (int)s_idx[li] > ik)) continue;
+#ifndef KF_AB_NOATOM
                         atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fy);
                         atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fx);
+#else
+                        if (fy == 12345 && fx == 54321) s_acc[li * NA] = 1ull;
+#endif
                         if (NEXT && has_next) { atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fny); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fnx); }
                     }
                 }
+              }
             }
             __syncthreads();
             for (int li = tid; li < min(KNN_FAR_CAP, total - c0); li += 256) {

@@ -690,7 +690,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 int base = 0;
                 if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
                 base = __shfl(base, first, 64);
-                if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | (why << 30));
+                // (entry: the query, why in bits 30..31 and -- where the query ids leave room: fewer than 2^24 queries -- the radius
+                // that was tried in bits 24..29, so that the fallback kernel need not read it off the summed-area table again)
+                const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24) && served) ? (unsigned)min(r, 63) << 24 : 0u;
+                if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | hint | (why << 30));
             }
         }
         // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
@@ -843,7 +846,7 @@ template <bool L1>
 __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const int *__restrict__ cell_start,
                                    const int *__restrict__ sat, const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, const KnnLists &ls, int q, int r_init,
+                                   float *__restrict__ knn_state, float *__restrict__ tile_dkmax, const KnnLists &ls, int q, int r_init, int r_start,
                                    unsigned (*s_hist)[256], float4 (*s_comp)[256]) {
     int *const far = ls.far;
     const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
@@ -856,7 +859,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
     const int ylo = -p.m, yhi = p.hq + p.m - 1, xlo = -p.m, xhi = p.wq + p.m - 1;
-    int r = fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx, r_init);
+    int r = r_start > 0 ? r_start : fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx, r_init);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS];
     float2 pq[KS_FB_SLOTS];
     bool serial = false;
@@ -1058,9 +1061,14 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
     const int nfail = min(fail[0], nq);
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     for (int i = wv; i < nfail; i += nw) {
-        const int q = fail[1 + i] & 0x3fffffff;
-        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist, s_comp);
-        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, s_hist, s_comp);
+        const unsigned ent = (unsigned)fail[1 + i];
+        const bool hinted = (size_t)nq < (1u << 24);
+        const int q = (int)(ent & (hinted ? 0x00ffffffu : 0x3fffffffu));
+        // radius to start from: the one the strip kernel tried (one more ring if it held too few candidates), else from the table
+        const int why = (int)(ent >> 30), rh = hinted ? (int)((ent >> 24) & 63u) : 0;
+        const int r_start = rh > 0 ? rh + (why == 0 ? 1 : 0) : 0;
+        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_hist, s_comp);
+        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_hist, s_comp);
     }
 }
 

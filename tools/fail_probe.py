@@ -30,7 +30,7 @@ off = C.lib().mpc_knn_fail_list_offset(ctypes.byref(shape))
 n = int(ws[off:off + 4].view(torch.int32).item())
 ent = ws[off + 4:off + 4 + 4 * n].view(torch.int32).cpu().numpy().astype(np.uint32)
 G = shape.hq * shape.wq
-q = ent & 0x3fffffff
+q = ent & (0x00ffffff if B * shape.nb * G < (1 << 24) else 0x3fffffff)
 why = ent >> 30
 bt = q // G
 cell = q % G
