@@ -140,7 +140,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_knn_reach = off;  off += mpc_align(bt * ktiles * sizeof(float));
     L.off_knn_fail = off;   off += mpc_align((1 + bt * (int64_t)L.G) * sizeof(int32_t));
     L.off_knn_retry = off;  off += mpc_align((1 + bt * (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128)) * sizeof(int32_t));
-    L.off_knn_farstrip = off; off += mpc_align((1 + bt * (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128)) * sizeof(int32_t));
+    const int64_t fitems = (int64_t)mpc_cdiv(s->wq, 2) * mpc_cdiv(s->hq, 128);       // (knn_device.h: KNN_FAR_WS x KNN_FAR_TH blocks of queries)
+    L.off_knn_farstrip = off; off += mpc_align((1 + bt * fitems) * sizeof(int32_t));
     L.off_knn_ftlist = off; off += mpc_knn_uses_far_list(s) ? mpc_align((1 + bt * ktiles) * sizeof(int32_t)) : 0;
     L.off_knn_ftbits = off; off += mpc_knn_uses_far_list(s) ? mpc_align(bt * ((ktiles + 31) / 32) * sizeof(int32_t)) : 0;
     L.off_knn_chord = off;  off += mpc_align(1024);

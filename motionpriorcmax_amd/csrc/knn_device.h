@@ -73,6 +73,15 @@ struct KnnLists {
     unsigned char *chord;
     int ftwords, again_words;       // words per (sample, bin)
 };
+// Blocks of queries of the second launch of the strip kernel: the main launch's strips, 2 columns x 128 rows.  The far queries of
+// a band along the top or bottom border are a few rows of EVERY strip, so wider, shorter blocks were tried: 4 x 64 halves the
+// workgroups of such a band and 8 x 32 quarters them, but every region row is 2 / 6 cells wider and two / three times as many
+// queries need more than the 128 slots and end up in the fallback kernel (C3, 40 px translation: 1.08 ms with 2 x 128, 1.15 with
+// 4 x 64, 1.21 with 8 x 32).
+#define KNN_FAR_WS 2
+#define KNN_FAR_TH 128
+__host__ __device__ static inline int knn_far_items_x(int wq) { return (wq + KNN_FAR_WS - 1) / KNN_FAR_WS; }
+__host__ __device__ static inline int knn_far_items_y(int hq) { return (hq + KNN_FAR_TH - 1) / KNN_FAR_TH; }
 
 static KnnParams knn_params(const mpc_shape *s) {
     KnnParams p;

@@ -50,6 +50,7 @@
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
 #define KS_RETRY_BLOCKS 1024        // workgroups of the second launch (4 per CU)
+static_assert(KNN_FAR_WS * KNN_FAR_TH == KS_NT, "a block of queries of the second launch = one workgroup");
 static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
 
@@ -96,6 +97,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         // (main and second launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
         // the first bucketed slots of the rows go later (s_row); this early barrier costs nothing: every wavefront is here at once
         if (tid < NR) reinterpret_cast<int2 *>(s_dyn)[tid].x = 0;
+        if (tid == 0) s_rq[0] = 0;                    // (main launch: "this strip holds far queries", set below; it has no other use for s_rq)
         __syncthreads();
     }
     const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
@@ -182,7 +184,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         const bool marginal = served && r < KNN_RCAP && nr < need + need / 7;
         const int nm = __popcll(__ballot(marginal)), nv = __popcll(__ballot(served));
         if (marginal && (4 * nm >= nv || nr < need + 2)) ++r;
-        if (isfar) atomicOr(ls.grow + aoff, 1u << (cx & 31));       // (for the launch that follows: `grow` without `again` = far)
+        // (for the launch that follows: `grow` without `again` = far; the strip goes onto its work list when this workgroup ends)
+        if (isfar) { atomicOr(ls.grow + aoff, 1u << (cx & 31)); s_rq[0] = 1; }
     }
     if (FARK) {
         served = false;
@@ -235,9 +238,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     if (FARK) for (int i = tid; i < (RC + 1) * (RC + 1); i += KS_NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
     // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
     // k_knn_strip_more<FARQ> when this workgroup ends
-    bool anyfar = false;
-    if (MODE == 0) anyfar = __syncthreads_or(isfar ? 1 : 0) != 0;
-    else __syncthreads();
+    __syncthreads();
+    const bool anyfar = MODE == 0 && s_rq[0] != 0;
     if (FARK) {
         // The marked queries of the strip -- a few dozen of its 256 -- move into the first lanes: one wavefront searches them
         // instead of four that each carry a handful (the row tables above are per query ROW: they do not care).
@@ -671,13 +673,14 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
             // (main launch: a query with too few candidates below the ring bound or too many slots gets a second chance in
             // k_knn_strip_more<FARQ> -- more rings, 128 slots, only such queries staged: its bit in the `again` map -- if the
-            // strip goes there anyway (far queries) or has more than two of them; the odd one: the fallback list)
+            // strip has more than KS_MORE_MIN of them or far queries; the odd one: the fallback list)
             const bool late = MODE == 0 && inpass && !live && why < 2u;
             int nlate = 0;
 #ifndef KS_AB_NOCOUNT
             if (MODE == 0) nlate = __syncthreads_count(late ? 1 : 0);
 #endif
-            const bool to_more = MODE == 0 && (anyfar || nlate > KS_MORE_MIN);
+            // ... or the strip goes there anyway for its far queries
+            const bool to_more = MODE == 0 && (nlate > KS_MORE_MIN || anyfar);
             if (late && to_more) {
                 atomicOr(ls.again + aoff, 1u << (cx & 31));
                 if (why == 0u) atomicOr(ls.grow + aoff, 1u << (cx & 31));
@@ -700,7 +703,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         // backward): a wavefront covers 64 / WS consecutive rows of one tile column, i.e. 64 / (16 WS) tiles of 16 WS lanes each
         // (the tiles of the query grid).  Only wavefronts next to the image border hold anything but class 0 (knn_device.h).
         if (!FARK) {
-            static_assert(WS == 2, "32 lanes = one tile");
+            static_assert(FARK || WS == 2, "32 lanes = one tile");
             const int bd = knn_band_depth(r_init);
             const unsigned cls = live ? knn_query_classes(p, cy, cx, bd) : 0u;
             const bool plain = __ballot(cls > 1u) == 0ull;
@@ -787,7 +790,8 @@ __global__ __launch_bounds__(KS_NT, 4) void k_knn_strip_more(const KnnParams p, 
     __shared__ unsigned char s_rq[KS_NT / WS];
     constexpr int TH = KS_NT / WS;
     const int nstrips = gx * gy * p.B * p.nb;
-    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], nstrips);
+    const int gxf = knn_far_items_x(p.wq), gyf = knn_far_items_y(p.hq);
+    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
     for (int w = (int)blockIdx.x; w < nretry; w += (int)gridDim.x) {
         const int quarter = w & 3;
         strip_body<WS, L1, NEXT, IWD, 1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
@@ -795,8 +799,8 @@ __global__ __launch_bounds__(KS_NT, 4) void k_knn_strip_more(const KnnParams p, 
         __syncthreads();
     }
     for (int w = (int)blockIdx.x; w < nfar; w += (int)gridDim.x) {
-        strip_body<WS, L1, NEXT, IWD, 2>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                                         r_init, cap, gx, gy, ls.farstrip[1 + w], 0, TH, s_dyn, s_wsum, s_wmax, s_rq);
+        strip_body<KNN_FAR_WS, L1, NEXT, IWD, 2>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
+                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq);
         __syncthreads();
     }
 }

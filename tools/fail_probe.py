@@ -53,7 +53,7 @@ ag = ws[offs[2]:offs[2] + 4 * aw].view(torch.int32).cpu().numpy().view(np.uint32
 gr = ws[offs[3]:offs[3] + 4 * aw].view(torch.int32).cpu().numpy().view(np.uint32)
 pop = lambda a: int(np.unpackbits(a.view(np.uint8)).sum())
 far_b = gr & ~ag
-print(f'strips {nstrips}: searched again in quarters {int(i32(offs[0])[0])}, on the second launch\'s list {int(i32(offs[1])[0])};  '
+print(f"second-launch blocks (2 x 128 queries) listed: {int(i32(offs[1])[0])} of {B * shape.nb * ((shape.wq + 1) // 2) * ((shape.hq + 127) // 128)}"); print(f'strips {nstrips}: searched again in quarters {int(i32(offs[0])[0])}, on the second launch\'s list {int(i32(offs[1])[0])};  '
       f'queries marked for the second launch: far {pop(far_b)} ({100.0 * pop(far_b) / (B * shape.nb * G):.3f} %), unfinished {pop(ag)} '
       f'({100.0 * pop(ag) / (B * shape.nb * G):.3f} %; {pop(ag & gr)} of them for more rings)')
 if offs[4] >= 0:
