@@ -293,7 +293,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
                 gs = cs[knn_ci(p, y, xl)];
                 len = cs[knn_ci(p, y, xh + 1)] - gs;
-                padded = len + ((len & 1) ? 0 : 1);
+                // (an EMPTY row takes no slot at all: a far query's square is mostly empty rows -- 28 of the 33 at radius 16 --
+                // and a dummy slot for each used to eat a quarter of its 128 slots)
+                padded = len == 0 ? 0 : len + ((len & 1) ? 0 : 1);
             }
         }
         int incl = padded;
@@ -344,7 +346,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 for (int u = 0; u < KS_SB; ++u) {
                     const int it = base + u * KS_NT + tid, rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1), k = it - rr * pitch;
                     const int2 row = s_row[rr];                                     // {first bucketed slot, points}
-                    in[u] = it < items && row.y >= 0 && k < (row.y | 1);            // (an even row has one dummy slot: odd pitch)
+                    in[u] = it < items && row.y > 0 && k < (row.y | 1);             // (an even row has one dummy slot: odd pitch; an empty row none)
                     real[u] = in[u] && k < row.y;
                     slot[u] = s_rowstart[rr] + k;
                     pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
