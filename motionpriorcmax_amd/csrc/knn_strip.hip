@@ -43,13 +43,19 @@
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
 #define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
-#define KS_MAXCH_FAR 32             // ... of the launch for the far queries (128 slots)
+#ifndef KS_MAXCH_FAR
+#define KS_MAXCH_FAR 64             // ... of the launch for the far queries (256 slots: a band along the left or right border -- every region row as wide as the
+                                   // widest chord -- needs ~160)
+#endif
 #define KS_TAIL(MAXCH_) (4 * (MAXCH_) + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
-#define KS_RETRY_BLOCKS 1024        // workgroups of the second launch (4 per CU)
+#ifndef KS_MORE_OCC
+#define KS_MORE_OCC 3               // workgroups per CU of the second launch (its register budget)
+#endif
+#define KS_RETRY_BLOCKS (256 * KS_MORE_OCC)   // workgroups of the second launch
 static_assert(KNN_FAR_WS * KNN_FAR_TH == KS_NT, "a block of queries of the second launch = one workgroup");
 static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
@@ -85,6 +91,14 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                                            const KnnLists &ls, int r_init, int cap, int gx, int gy,
                                            int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq) {
     constexpr bool SPLIT = MODE == 1, FARK = MODE == 2;
+#ifdef KS_STAMP2
+    // diagnostics build (tools/more_stamp_probe.py): phase stamps of thread 0 of a second-launch work item, 10 ns units, far inside the fallback list
+    unsigned long long stp_[8]; int nstp_ = 0;
+#define KS_STP() do { if (FARK && nstp_ < 8) { __builtin_amdgcn_s_waitcnt(0); stp_[nstp_++] = wall_clock64(); } } while (0)
+#else
+#define KS_STP() do { } while (0)
+#endif
+    KS_STP();
     constexpr int MAXCH = FARK ? KS_MAXCH_FAR : KS_MAXCH;      // words of four slots per query
     (void)SPLIT;
     constexpr int RC = FARK ? KNN_RFAR : KNN_RCAP;
@@ -145,7 +159,11 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     int r = 0, nr = 0;                                  // radius and the points in its square
     bool served = false;
     const int need_q = knn_square_need(p.K);
-    if (FARK ? bit_again : valid) {
+    // (second launch: the radius the main launch worked out for a far query / tried for one it could not finish, left in the
+    // query's K-th distance slot of knn_state -- whichever kernel serves the query overwrites it.  Reading the table again here
+    // was a chain of four to five dependent round trips in front of everything else a work item does: 12 of its 29 us.)
+    if (FARK && marked) r = reinterpret_cast<const int *>(knn_state)[(size_t)bt * p.G + (size_t)cy * p.wq + cx];
+    if (!FARK && valid) {
         const int need = need_q;
         r = min(r_init, KNN_RCAP);
 #ifdef KS_AB_NOSAT
@@ -185,25 +203,32 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         const int nm = __popcll(__ballot(marginal)), nv = __popcll(__ballot(served));
         if (marginal && (4 * nm >= nv || nr < need + 2)) ++r;
         // (for the launch that follows: `grow` without `again` = far; the strip goes onto its work list when this workgroup ends)
-        if (isfar) { atomicOr(ls.grow + aoff, 1u << (cx & 31)); s_rq[0] = 1; }
-    }
-    if (FARK) {
-        served = false;
-        if (isfar) {
-            // smallest radius in (KNN_RCAP, KNN_RFAR] whose square holds the far queries' count: bisection (the count grows with
-            // the radius), four probes instead of up to fourteen -- each a dependent round trip
+        // (MODE 0 only: the quarters of an overflowed strip run beside the second launch's far pass -- which may have served the
+        // query and written its K-th distance by now -- and the main launch marked the strip's far queries before it gave up)
+        if (MODE == 0 && isfar) {
+            // smallest radius in (KNN_RCAP, KNN_RFAR] whose square holds the far queries' count, for the second launch: bisection
+            // (the count grows with the radius), four probes instead of up to fourteen -- here, where five other workgroups of
+            // the CU cover the round trips (KNN_RFAR + 1: nothing within KNN_RFAR, the fallback kernel)
+            // (a LOWER BOUND of the candidates below the ring bound -- the points of the cells inside a cross of rectangles
+            // inscribed in the disc, five rectangle counts -- instead of this estimate was measured: no fewer queries on the
+            // fallback list, larger radii, queries in dense places beyond the 256 slots: not kept)
             const int need_far = knn_square_need_far(p.K);
-            int lo = KNN_RCAP, hi = KNN_RFAR + 1;       // (lo: too few; hi: enough, or nothing within KNN_RFAR)
+            int lo = KNN_RCAP, hi = KNN_RFAR + 1;       // (lo: too few; hi: enough)
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
                 if (knn_square_count(p, sat_bt, cy, cx, mid) >= need_far) hi = mid; else lo = mid;
             }
-            r = hi;
-            served = r <= KNN_RFAR;                     // (else: the fallback kernel)
-        } else if (bit_again) {
-            // the main launch could not finish it: too few candidates below the ring bound -- two more rings (<= KNN_RFAR) -- or
-            // more slots than its registers hold -- the same radius with this launch's 128 slots
-            if (bit_grow) r += 2;
+            reinterpret_cast<int *>(knn_state)[(size_t)bt * p.G + (size_t)cy * p.wq + cx] = hi;
+            atomicOr(ls.grow + aoff, 1u << (cx & 31)); s_rq[0] = 1;
+        }
+    }
+    if (FARK) {
+        served = false;
+        if (isfar) served = r <= KNN_RFAR;              // (else: the fallback kernel)
+        else if (bit_again) {
+            // the main launch could not finish it: too few candidates below the ring bound -- two more rings -- or more slots
+            // than its registers hold -- the same radius with this launch's 256 slots
+            if (bit_grow) r = min(r + 2, KNN_RFAR);
             served = true;
         }
     }
@@ -239,6 +264,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
     // k_knn_strip_more<FARQ> when this workgroup ends
     __syncthreads();
+    KS_STP();        // 1: marks read, radius from the table
     const bool anyfar = MODE == 0 && s_rq[0] != 0;
     if (FARK) {
         // The marked queries of the strip -- a few dozen of its 256 -- move into the first lanes: one wavefront searches them
@@ -266,6 +292,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             for (int j = -r; j <= r; ++j) atomicMax(&s_w[rc + j].x, (int)s_chord[r * (RC + 1) + abs(j)]);
         }
         __syncthreads();                                         // (before the row tables are read and the staging area is written)
+        KS_STP();    // 2: compaction, chords pushed
     }
     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
     // ---- column extent of every region row = the widest square (of the query rows [pr0, pr1) of the strip) that uses the
@@ -315,6 +342,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     };
     const bool inpass = mine && (cy - qy0) >= pr0 && (cy - qy0) < pr1;
     const int total = region_rows(pr0, pr1);
+    KS_STP();        // 3: row table
     bool overflow = false;
     if (total > cap) {
         if (MODE == 0) {              // (workgroup-uniform) again in quarters: k_knn_strip_more
@@ -336,7 +364,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const bool has_next = NEXT && (t < p.nb - 1);
             // item -> (row, slot of the row) with a reciprocal multiply: (it + 0.5) / pitch is at least 0.5 / pitch away from
             // an integer, far more than the rounding of the product (it < 2^14)
-            const int items = NR * pitch;
+            // (second launch: item = staged slot, its row by a search over the first slots of the rows -- the rows of a far
+            // query's region are up to 42 cells wide and nearly all of them empty: on the (row, slot of the row) grid of the
+            // main launch a workgroup walked 7 000 items for 300 points, nine rounds of dependent loads)
+            const int items = FARK ? total : NR * pitch;
             const float inv_pitch = __builtin_amdgcn_rcpf((float)pitch);        // (1 ulp: the margin below is 0.5 / pitch)
             for (int base = 0; base < items; base += KS_NT * KS_SB) {
                 int slot[KS_SB], id[KS_SB];
@@ -344,11 +375,20 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 float2 pj[KS_SB], f0[KS_SB], f1[KS_SB];
 #pragma unroll
                 for (int u = 0; u < KS_SB; ++u) {
-                    const int it = base + u * KS_NT + tid, rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1), k = it - rr * pitch;
+                    const int it = base + u * KS_NT + tid;
+                    int rr, k;
+                    if (FARK) {
+                        // the last row whose first slot is <= it (an empty row shares its first slot with the row behind it)
+                        int lo = 0, hi = NR;
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowstart[mid] <= it) lo = mid; else hi = mid; }
+                        rr = lo; k = it - s_rowstart[lo];
+                    } else {
+                        rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1); k = it - rr * pitch;
+                    }
                     const int2 row = s_row[rr];                                     // {first bucketed slot, points}
                     in[u] = it < items && row.y > 0 && k < (row.y | 1);             // (an even row has one dummy slot: odd pitch; an empty row none)
                     real[u] = in[u] && k < row.y;
-                    slot[u] = s_rowstart[rr] + k;
+                    slot[u] = FARK ? it : s_rowstart[rr] + k;
                     pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
                     if (real[u]) { pj[u] = sp_[row.x + k]; id[u] = si_[row.x + k]; }
                 }
@@ -380,6 +420,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
         }
         __syncthreads();
+        KS_STP();    // 4: staged
 
         // ---- search --------------------------------------------------------------------------------------
         const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
@@ -451,8 +492,21 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 for (int c = KS_BASECH; c < KS_BASECH + 4; ++c) acc += __popc((w[c] + C) & 0x80808080u);
                 if (nmax > 4 * KS_BASECH + 16) {
                     asm volatile("" ::: "memory");
+                    constexpr int T2 = MAXCH < 32 ? MAXCH : 32;
 #pragma unroll
-                    for (int c = KS_BASECH + 4; c < MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                    for (int c = KS_BASECH + 4; c < T2; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                    // (the second launch: up to 256 slots, in two more steps)
+                    if (MAXCH > 32 && nmax > 128) {
+                        asm volatile("" ::: "memory");
+                        constexpr int T3 = MAXCH < 48 ? MAXCH : 48;
+#pragma unroll
+                        for (int c = 32; c < T3; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                        if (MAXCH > 48 && nmax > 192) {
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int c = 48; c < MAXCH; ++c) acc += __popc((w[c] + C) & 0x80808080u);
+                        }
+                    }
                 }
             }
             return acc;
@@ -542,14 +596,19 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             float dd[KS_LMAX]; int ii[KS_LMAX], jj[KS_LMAX], kraw[KS_LMAX];
             const bool light = live && !heavy;
             const int mmax = __builtin_amdgcn_readfirstlane(wave_max_i(light ? inbin : 0));
+            // the masks of the K-th level, 64 slots each (NM of them: two on the main launch)
             unsigned long long em = ((unsigned long long)E[1] << 32) | E[0];
-            unsigned long long e2 = ((unsigned long long)(NE > 3 ? E[NE - 1] : 0u) << 32) | E[2];      // slots 64 ..
+            unsigned long long e2 = ((unsigned long long)(NE > 3 ? E[3] : 0u) << 32) | E[2];      // slots 64 ..
+            unsigned long long e3 = 0ull, e4 = 0ull;                                               // slots 128 .., 192 .. (second launch)
+            if (NE > 4) e3 = ((unsigned long long)(NE > 5 ? E[NE > 5 ? 5 : 0] : 0u) << 32) | E[NE > 4 ? 4 : 0];
+            if (NE > 6) e4 = ((unsigned long long)(NE > 7 ? E[NE > 7 ? 7 : 0] : 0u) << 32) | E[NE > 6 ? 6 : 0];
 #pragma unroll
             for (int a = 0; a < KS_LMAX; ++a) {
                 dd[a] = INFINITY; ii[a] = 0x7fffffff; jj[a] = 0; kraw[a] = 0;
                 if (a < mmax) {
                     int k = em ? __ffsll((long long)em) - 1 : (e2 ? 64 + __ffsll((long long)e2) - 1 : -1);      // a bit still in the mask ...
-                    if (em) em &= em - 1ull; else e2 &= e2 - 1ull;
+                    if (NE > 4 && !em && !e2) k = e3 ? 128 + __ffsll((long long)e3) - 1 : (e4 ? 192 + __ffsll((long long)e4) - 1 : -1);
+                    if (em) em &= em - 1ull; else if (e2 || NE <= 4) e2 &= e2 - 1ull; else if (e3) e3 &= e3 - 1ull; else e4 &= e4 - 1ull;
                     kraw[a] = k;
                     k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
                     if (light && k >= 0) {
@@ -586,47 +645,43 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 const int h = __ffsll((long long)hm) - 1;
                 hm &= hm - 1ull;
                 const int hs = lane_i(s, h), hneed = lane_i(need, h);
-                const unsigned h0 = lane_u(E[0], h), h1 = lane_u(E[1], h), h2 = lane_u(E[2], h), h3 = NE > 3 ? lane_u(E[NE - 1], h) : 0u;
+                constexpr int NM = (NE + 1) / 2;                  // chunks of 64 slots (two on the main launch, four on the second)
+                unsigned hw[2 * NM];
+#pragma unroll
+                for (int e = 0; e < 2 * NM; ++e) hw[e] = e < NE ? lane_u(E[e < NE ? e : 0], h) : 0u;
                 const float hqy = lane_f(qy, h), hqx = lane_f(qx, h);
-                // this lane's two slots of the heavy query: lane and lane + 64
-                const int mybit = ((lane >> 2) & 7) + 8 * (lane & 3);            // bit of slot `lane` (and of slot 64 + lane) in its mask word
-                const bool b0 = (((lane < 32 ? h0 : h1) >> mybit) & 1u) != 0u, b1 = (((lane < 32 ? h2 : h3) >> mybit) & 1u) != 0u;
-                float d0 = INFINITY, d1 = INFINITY;
-                int i0 = 0x7fffffff, i1 = 0x7fffffff, r0_ = 0, r1_ = 0;
-                if (b0) { const float2 pj = lpos[hs + lane]; d0 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i0 = (int)lidx[hs + lane]; }
-                if (b1) { const float2 pj = lpos[hs + 64 + lane]; d1 = pair_dist(hqy, hqx, pj.x, pj.y, L1); i1 = (int)lidx[hs + 64 + lane]; }
-                unsigned long long km = ((unsigned long long)h1 << 32) | h0;
-                while (km != 0ull) {
-                    const int kb = __ffsll((long long)km) - 1;
-                    km &= km - 1ull;
-                    const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot of the bit
-                    const float kd = lane_f(d0, k); const int ki = lane_i(i0, k);
-                    r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
-                    r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
+                // this lane's slots of the heavy query: lane, lane + 64, ...
+                const int mybit = ((lane >> 2) & 7) + 8 * (lane & 3);            // bit of slot `lane` (and of slot 64 c + lane) in its mask word
+                bool bb[NM]; float dc[NM]; int ic[NM], rc[NM];
+#pragma unroll
+                for (int c = 0; c < NM; ++c) {
+                    bb[c] = (((lane < 32 ? hw[2 * c] : hw[2 * c + 1]) >> mybit) & 1u) != 0u;
+                    dc[c] = INFINITY; ic[c] = 0x7fffffff; rc[c] = 0;
+                    if (bb[c]) { const float2 pj = lpos[hs + 64 * c + lane]; dc[c] = pair_dist(hqy, hqx, pj.x, pj.y, L1); ic[c] = (int)lidx[hs + 64 * c + lane]; }
                 }
-                unsigned long long k2 = ((unsigned long long)h3 << 32) | h2;
-                while (k2 != 0ull) {
-                    const int kb = __ffsll((long long)k2) - 1;
-                    k2 &= k2 - 1ull;
-                    const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot - 64 of the bit
-                    const float kd = lane_f(d1, k); const int ki = lane_i(i1, k);
-                    r0_ += ((kd < d0) | ((kd == d0) & (ki < i0))) ? 1 : 0;
-                    r1_ += ((kd < d1) | ((kd == d1) & (ki < i1))) ? 1 : 0;
+#pragma unroll
+                for (int c2 = 0; c2 < NM; ++c2) {
+                    unsigned long long km = ((unsigned long long)hw[2 * c2 + 1] << 32) | hw[2 * c2];
+                    while (km != 0ull) {
+                        const int kb = __ffsll((long long)km) - 1;
+                        km &= km - 1ull;
+                        const int k = (kb & ~31) + 4 * (kb & 7) + ((kb & 31) >> 3);      // slot - 64 c2 of the bit
+                        const float kd = lane_f(dc[c2], k); const int ki = lane_i(ic[c2], k);
+#pragma unroll
+                        for (int c = 0; c < NM; ++c) rc[c] += ((kd < dc[c]) | ((kd == dc[c]) & (ki < ic[c]))) ? 1 : 0;
+                    }
                 }
                 float cy_ = 0.f, cx_ = 0.f, cw_ = 0.f, cny = 0.f, cnx = 0.f, cdk = 0.f;
                 int cik = -1;
                 const bool hnext = NEXT && (t < p.nb - 1);
-                if (b0 && r0_ < hneed) {
-                    const float2 f = lflow[hs + lane];
-                    if (IWD) { const float wgt = 1.f / (d0 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
-                    if (hnext) { const float2 g2 = lnext[hs + lane]; cny += g2.x; cnx += g2.y; }
-                    if (r0_ == hneed - 1) { cdk = d0; cik = i0; }
-                }
-                if (b1 && r1_ < hneed) {
-                    const float2 f = lflow[hs + 64 + lane];
-                    if (IWD) { const float wgt = 1.f / (d1 + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
-                    if (hnext) { const float2 g2 = lnext[hs + 64 + lane]; cny += g2.x; cnx += g2.y; }
-                    if (r1_ == hneed - 1) { cdk = d1; cik = i1; }
+#pragma unroll
+                for (int c = 0; c < NM; ++c) {
+                    if (bb[c] && rc[c] < hneed) {
+                        const float2 f = lflow[hs + 64 * c + lane];
+                        if (IWD) { const float wgt = 1.f / (dc[c] + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
+                        if (hnext) { const float2 g2 = lnext[hs + 64 * c + lane]; cny += g2.x; cnx += g2.y; }
+                        if (rc[c] == hneed - 1) { cdk = dc[c]; cik = ic[c]; }
+                    }
                 }
 #pragma unroll
                 for (int o2 = 32; o2 > 0; o2 >>= 1) {
@@ -635,7 +690,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                     if (NEXT) { cny += __shfl_xor(cny, o2, 64); cnx += __shfl_xor(cnx, o2, 64); }
                     cdk = fmaxf(cdk, __shfl_xor(cdk, o2, 64)); cik = max(cik, __shfl_xor(cik, o2, 64));
                 }
-                const bool htie = __ballot((b0 && d0 == cdk && i0 > cik) || (b1 && d1 == cdk && i1 > cik)) != 0ull;
+                bool mytie = false;
+#pragma unroll
+                for (int c = 0; c < NM; ++c) mytie = mytie || (bb[c] && dc[c] == cdk && ic[c] > cik);
+                const bool htie = __ballot(mytie) != 0ull;
                 if (lane == h) {
                     if (IWD) { sy_ += cy_; sx_ += cx_; sw_ += cw_; }
                     else { sy_ = fmaf(128.f, cy_, sy_); sx_ = fmaf(128.f, cx_, sx_); }
@@ -684,6 +742,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             // ... or the strip goes there anyway for its far queries
             const bool to_more = MODE == 0 && (nlate > KS_MORE_MIN || anyfar);
             if (late && to_more) {
+                reinterpret_cast<int *>(knn_state)[q] = r;          // (the radius that was tried, for the second launch)
                 atomicOr(ls.again + aoff, 1u << (cx & 31));
                 if (why == 0u) atomicOr(ls.grow + aoff, 1u << (cx & 31));
             }
@@ -739,6 +798,19 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 }
             }
         } else if (live) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);      // (far query, general gather backward)
+#ifdef KS_STAMP2
+        if (FARK) {
+            __syncthreads();
+            KS_STP();    // 5: searched, lists written
+            const int nmk = __syncthreads_count(mine ? 1 : 0);
+            if (tid == 0) {
+                int *dst = ls.fail + 1 + 200000 + 8 * (int)blockIdx.x;         // (the LAST item of a workgroup stays)
+                dst[0] = (int)(stp_[0] & 0x7fffffffull);
+                for (int k = 1; k < 6; ++k) dst[k] = (int)(stp_[k] - stp_[0]);
+                dst[6] = total; dst[7] = nmk;
+            }
+        }
+#endif
     }
 }
 
@@ -781,7 +853,7 @@ __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnPara
 // far queries and the queries the main launch could not finish).  grid: a fixed number of workgroups (the list lengths are only
 // known on the device; nothing to do for the lattice-like point sets of the benchmark: both lists empty or nearly)
 template <int WS, bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(KS_NT, 4) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
+__global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
                                                           const int *__restrict__ cell_start, const int *__restrict__ sat,
                                                           const float2 *__restrict__ spos, const int *__restrict__ sidx,
                                                           float *__restrict__ flow_lut, float *__restrict__ flow_next,
