@@ -576,12 +576,41 @@ __device__ __forceinline__ void knn_tile_max_add(float *__restrict__ tile_dkmax,
 // A far query (cy, cx) with K-th distance dK has been served: its cell onto the far list of (sample, bin) bt is the caller's
 // business (one atomic per wavefront); here the tiles whose points its disc can touch go onto the work list of k_knn_bwd_far
 // (each tile once: the bit map).  Called by the lane that owns the query.
-__device__ __forceinline__ void knn_far_mark_tiles(const KnnParams &p, const KnnLists &ls, int bt, int cy, int cx, float dK) {
+// the tiles (ta..tb) x (tc..td) whose points the disc of a far query can touch
+__device__ __forceinline__ void knn_far_tile_range(const KnnParams &p, int cy, int cx, float dK, int &ta, int &tb, int &tc, int &td) {
     const float R = (p.l1 ? dK : sqrtf(dK)) * 1.0001f + 0.01f;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+    ta = knn_tile_of(cell_of(qy - R, p.sp, p.hq, p.m), p.hq); tb = knn_tile_of(cell_of(qy + R, p.sp, p.hq, p.m), p.hq);
+    tc = knn_tile_of(cell_of(qx - R, p.sp, p.wq, p.m), p.wq); td = knn_tile_of(cell_of(qx + R, p.sp, p.wq, p.m), p.wq);
+}
+// The same for the far queries of a whole WORKGROUP (all of one (sample, bin)): every lane that owns one ORs its tiles into a
+// bit map in LDS (s_ft: KNN_FT_LDS_WORDS words, zeroed by the caller before a barrier); knn_far_flush_tiles, after a barrier,
+// lets one thread per word add what is new to the global map and the work list -- one load and at most one atomic per word of
+// the workgroup instead of a chain of a load and an atomic per tile of every query.
+#define KNN_FT_LDS_WORDS 64
+__device__ __forceinline__ void knn_far_mark_tiles_lds(const KnnParams &p, unsigned *s_ft, int cy, int cx, float dK) {
+    int ta, tb, tc, td;
+    knn_far_tile_range(p, cy, cx, dK, ta, tb, tc, td);
+    const int ntx = knn_tiles_x(p.wq, p.m);
+    for (int ty = ta; ty <= tb; ++ty)
+        for (int tx = tc; tx <= td; ++tx) { const int tile = ty * ntx + tx; atomicOr(&s_ft[tile >> 5], 1u << (tile & 31)); }
+}
+__device__ __forceinline__ void knn_far_flush_tiles(const KnnParams &p, const KnnLists &ls, int bt, const unsigned *s_ft, int word) {
+    const unsigned need = s_ft[word];
+    if (need == 0u) return;
+    unsigned *w = ls.ftbits + (size_t)bt * ls.ftwords + word;
+    unsigned fresh = need & ~*w;
+    if (fresh == 0u) return;                                  // (set already: the usual case inside a band)
+    fresh &= ~atomicOr(w, fresh);
+    if (fresh == 0u) return;
     const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m);
-    const int ta = knn_tile_of(cell_of(qy - R, p.sp, p.hq, p.m), p.hq), tb = knn_tile_of(cell_of(qy + R, p.sp, p.hq, p.m), p.hq);
-    const int tc = knn_tile_of(cell_of(qx - R, p.sp, p.wq, p.m), p.wq), td = knn_tile_of(cell_of(qx + R, p.sp, p.wq, p.m), p.wq);
+    int k = atomicAdd(&ls.ftlist[0], __popc(fresh));
+    while (fresh) { const int bit = __ffs(fresh) - 1; fresh &= fresh - 1u; ls.ftlist[1 + k++] = bt * ntx * nty + 32 * word + bit; }
+}
+__device__ __forceinline__ void knn_far_mark_tiles(const KnnParams &p, const KnnLists &ls, int bt, int cy, int cx, float dK) {
+    int ta, tb, tc, td;
+    knn_far_tile_range(p, cy, cx, dK, ta, tb, tc, td);
+    const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m);
     for (int ty = ta; ty <= tb; ++ty)
         for (int tx = tc; tx <= td; ++tx) {
             const int tile = ty * ntx + tx;

@@ -153,6 +153,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     const int aoff = bt * ls.again_words + min(cy, p.hq - 1) * aw + (min(cx, p.wq - 1) >> 5);      // this query's word of the `again` / `grow` maps
     // (the second launch: only the queries the main launch marked look at the table at all -- `grow` alone: a far query, no
     // square up to KNN_RCAP holds enough points; `again`: one it could not finish, with `grow` if for too few candidates)
+    // (the radius hint of a marked query -- below -- is requested with the two words, for every query: one round trip, not two)
+    int r_hint = 0;
+    if (FARK && valid) r_hint = reinterpret_cast<const int *>(knn_state)[(size_t)bt * p.G + (size_t)cy * p.wq + cx];
     const bool bit_again = FARK && valid && ((ls.again[aoff] >> (cx & 31)) & 1u) != 0u;
     const bool bit_grow = FARK && valid && ((ls.grow[aoff] >> (cx & 31)) & 1u) != 0u;
     const bool marked = bit_again || bit_grow, farq = bit_grow && !bit_again;
@@ -162,7 +165,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     // (second launch: the radius the main launch worked out for a far query / tried for one it could not finish, left in the
     // query's K-th distance slot of knn_state -- whichever kernel serves the query overwrites it.  Reading the table again here
     // was a chain of four to five dependent round trips in front of everything else a work item does: 12 of its 29 us.)
-    if (FARK && marked) r = reinterpret_cast<const int *>(knn_state)[(size_t)bt * p.G + (size_t)cy * p.wq + cx];
+    if (FARK && marked) r = r_hint;
     if (!FARK && valid) {
         const int need = need_q;
         r = min(r_init, KNN_RCAP);
@@ -260,6 +263,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     }
     // chord of the disc of radius r at row offset j, for the row tables below (knn_device.h)
     __shared__ unsigned char s_chord[(RC + 1) * (RC + 1)];
+    __shared__ unsigned s_ft[FARK ? KNN_FT_LDS_WORDS : 1];          // second launch: tiles the served far queries' discs touch (knn_far_mark_tiles_lds)
+    if (FARK && tid < KNN_FT_LDS_WORDS) s_ft[tid] = 0u;
     if (FARK) for (int i = tid; i < (RC + 1) * (RC + 1); i += KS_NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
     // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
     // k_knn_strip_more<FARQ> when this workgroup ends
@@ -794,8 +799,15 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 base = __shfl(base, first, 64);
                 if (isf) {
                     fl[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = cy * p.wq + cx;
-                    knn_far_mark_tiles(p, ls, bt, cy, cx, dK);
+                    // its tiles onto the work list of k_knn_bwd_far: through the workgroup's bit map in LDS where the (sample,
+                    // bin)'s tiles fit it (a per-query chain of a load and an atomic per tile was a third of a work item's time)
+                    if (ls.ftwords <= KNN_FT_LDS_WORDS) knn_far_mark_tiles_lds(p, s_ft, cy, cx, dK);
+                    else knn_far_mark_tiles(p, ls, bt, cy, cx, dK);
                 }
+            }
+            if (ls.ftwords <= KNN_FT_LDS_WORDS) {           // (workgroup-uniform)
+                __syncthreads();
+                if (tid < ls.ftwords) { knn_far_flush_tiles(p, ls, bt, s_ft, tid); s_ft[tid] = 0u; }
             }
         } else if (live) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);      // (far query, general gather backward)
 #ifdef KS_STAMP2
