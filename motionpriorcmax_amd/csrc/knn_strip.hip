@@ -924,12 +924,25 @@ __device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__
     return hi;
 }
 
-// one served far query: onto the far list of its (sample, bin), its tiles onto the work list of k_knn_bwd_far; called by ONE lane
-__device__ __forceinline__ void far_list_add(const KnnParams &p, const KnnLists &ls, int bt, int cy, int cx, float dK) {
-    int *fl = ls.far + (size_t)bt * (p.G + 1);
-    const int k = atomicAdd(&fl[0], 1);
-    fl[1 + k] = cy * p.wq + cx;
-    knn_far_mark_tiles(p, ls, bt, cy, cx, dK);
+// one served far query: onto the far list of its (sample, bin), its tiles onto the work list of k_knn_bwd_far.  Called by ALL
+// lanes of the wavefront that served it: lane 0 appends the query, every lane takes one of the tiles its disc can touch (their
+// loads and atomics travel together -- one lane walking them was a chain of two round trips per tile behind every query)
+__device__ __forceinline__ void far_list_add(const KnnParams &p, const KnnLists &ls, int bt, int cy, int cx, float dK, int lane) {
+    if (lane == 0) {
+        int *fl = ls.far + (size_t)bt * (p.G + 1);
+        const int k = atomicAdd(&fl[0], 1);
+        fl[1 + k] = cy * p.wq + cx;
+    }
+    int ta, tb, tc, td;
+    knn_far_tile_range(p, cy, cx, dK, ta, tb, tc, td);
+    const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m), nx = td - tc + 1, cnt = (tb - ta + 1) * nx;
+    for (int i = lane; i < cnt; i += 64) {
+        const int ty = ta + i / nx, tx = tc + i % nx, tile = ty * ntx + tx;
+        const unsigned bit = 1u << (tile & 31);
+        unsigned *w = ls.ftbits + (size_t)bt * ls.ftwords + (tile >> 5);
+        if ((*w & bit) != 0u) continue;                       // (set already: the usual case inside a band)
+        if ((atomicOr(w, bit) & bit) == 0u) ls.ftlist[1 + atomicAdd(&ls.ftlist[0], 1)] = bt * ntx * nty + tile;
+    }
 }
 
 template <bool L1>
@@ -1058,17 +1071,20 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     }
     if (serial) {
         // more rows or candidates than the lanes hold (a very dense place, a very deep band): the generic thread-serial search
+        float dK = 0.f;
         if (lane == 0) {
             QueryCtx c;
             c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
             c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
             c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
-            float dK = 0.f;
             knn_one_query<false, L1, 256, true>(p, c, b, t, cy, cx, r, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, 0);
-            const bool isf = far != nullptr && knn_is_far_dk(p, dK, r_init);
-            if (isf) { reinterpret_cast<int *>(knn_state)[(size_t)p.B * p.nb * p.G + q] |= KNN_FAR_FLAG; far_list_add(p, ls, bt, cy, cx, dK); }
-            else knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
         }
+        dK = __shfl(dK, 0, 64);
+        const bool isf = far != nullptr && knn_is_far_dk(p, dK, r_init);
+        if (isf) {
+            if (lane == 0) reinterpret_cast<int *>(knn_state)[(size_t)p.B * p.nb * p.G + q] |= KNN_FAR_FLAG;
+            far_list_add(p, ls, bt, cy, cx, dK, lane);
+        } else if (lane == 0) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
         return;
     }
     // the K-th smallest key (distance bits, index) by a bitwise search from the top: distances are non-negative floats
@@ -1127,9 +1143,9 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         knn_state[q] = dK;
         reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0) | (isf ? KNN_FAR_FLAG : 0);
         knn_state[2 * BQ + q] = norm;
-        if (isf) far_list_add(p, ls, bt, cy, cx, dK);
-        else knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
+        if (!isf) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
     }
+    if (far != nullptr && knn_is_far_dk(p, dK, r_init)) far_list_add(p, ls, bt, cy, cx, dK, lane);      // (dK is wave-uniform)
 }
 
 __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const float *__restrict__ traj,
