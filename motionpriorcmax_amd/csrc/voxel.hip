@@ -4,7 +4,9 @@
 // entries.  Same machinery as the IWE (events.hip): one binning pass appends 16-byte records to
 // per-(sample, channel, row-strip) buckets, one workgroup per bucket accumulates its strip in LDS as
 // Q33.30 fixed point (ds_add_u64) and writes it with plain stores; overflowing buckets spill to a
-// list applied with global atomics.
+// list that the workgroups of the buckets concerned read beside their own records.  With mean_std / max
+// normalisation the strips are accumulated twice -- statistics first, then written normalised -- so the
+// grid is written once and never read back (k_vox_accum).
 //
 // Arithmetic follows the reference op for op: x0 = int(x) (truncation), tap weight
 // value * (1-|xl-x|) * (1-|yl-y|) * (1-|tl-t_norm|) (left to right; value = 2p-1 is +-1, so its sign
@@ -12,13 +14,18 @@
 #include "common.h"
 
 #define VOX_FIX_SHIFT 30
+#ifndef VOX_STRIP_KB
+#define VOX_STRIP_KB 75       // LDS budget of a strip: two workgroups per CU, whose zero / accumulate / write phases overlap (150 KB, one per CU:
+                              // 0.283 ms against 0.265 at the DSEC batch shape; 50 KB: the binning pass pays for the extra buckets)
+#endif
 #define VOX_PER_THREAD 2
 
 struct VoxLayout {
     int SR, NS, NBk, cap;
     int *gcount;          // [NBk + 8]   (NBk+0: spill count)
     float4 *rec, *ovf;
-    double *part;         // [B][nblk][4]
+    double *part;         // [B][nblk][4]   partial statistics of k_vox_stats (quantile clipping: the entries change after the strips)
+    double *spart;        // [NBk][4]       partial statistics of the strips (k_vox_accum<1>)
     float *stat;          // [B][4]  mean, 1/std (or 1/max), flag
     int nstat_blocks;
 };
@@ -124,16 +131,27 @@ __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const Vo
         }
 }
 
-// grid NBk, 1024 threads, dynamic LDS = SR * W * 8
-__global__ __launch_bounds__(1024) void k_vox_accum(const VoxLayout L, float *__restrict__ grid, int H, int W) {
+// grid NBk, 1024 threads, dynamic LDS = SR * W * 8.  One strip of one channel image accumulated in LDS (64-bit fixed point:
+// integer sums, any order, bitwise reproducible) from its bucket of records and -- rare: a bucket beyond its capacity -- from
+// the records of the spill list that name it.
+//   MODE 0: the strip written as it is (no normalisation, or quantile clipping follows)
+//   MODE 1: nothing written -- the strip's share of the per-sample statistics of the non-zero entries (count, sum, sum of
+//           squares, largest magnitude) to spart[g]
+//   MODE 2: the strip written NORMALISED with the sample's (mean, 1 / std) or 1 / max from k_vox_finalize
+// mean_std / max normalisation = MODE 1, k_vox_finalize, MODE 2: the records (90 MB at the DSEC batch shape) are read twice and
+// the grid (258 MB) is written once; the three passes over the grid this replaces (write, statistics, read-modify-write) moved
+// 1.2 GB.
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_vox_accum(const VoxLayout L, float *__restrict__ grid, int H, int W, int C, int norm) {
     extern __shared__ unsigned long long s_acc[];
+    __shared__ double s_red[4][16];
     const int tid = threadIdx.x;
     const int g = blockIdx.x, img = g / L.NS, strip = g - img * L.NS;
     const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
     const int npix = (row1 - row0) * W;
     for (int i = tid; i < npix; i += 1024) s_acc[i] = 0ull;
     __syncthreads();
-    const int n = min(L.gcount[g], L.cap);
+    const int n = min(L.gcount[g], L.cap), nsp = L.gcount[L.NBk];
     const float4 *rec = L.rec + (size_t)g * L.cap;
     for (int r = tid; r < n; r += 1024) {
         const float4 e = rec[r];
@@ -141,19 +159,47 @@ __global__ __launch_bounds__(1024) void k_vox_accum(const VoxLayout L, float *__
             atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)vox_to_fixed(v));
         });
     }
-    __syncthreads();
-    float *dst = grid + ((size_t)img * H + row0) * W;
-    for (int i = tid; i < npix; i += 1024) dst[i] = vox_from_fixed((long long)s_acc[i]);
-}
-
-__global__ __launch_bounds__(256) void k_vox_overflow(const VoxLayout L, float *__restrict__ grid, int H, int W) {
-    const int n = L.gcount[L.NBk];
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    for (int r = tid; r < nsp; r += 1024) {              // (the spill list: empty unless the events pile up in a few strips)
         const float4 e = L.ovf[r];
-        const int g = __float_as_int(e.w), img = g / L.NS, strip = g - img * L.NS;
-        const int row0 = strip * L.SR, row1 = min(row0 + L.SR, H);
-        float *dst = grid + (size_t)img * H * W;
-        vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) { atomicAdd(dst + (size_t)yy * W + xx, v); });
+        if (__float_as_int(e.w) != g) continue;
+        vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) {
+            atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)vox_to_fixed(v));
+        });
+    }
+    __syncthreads();
+    if (MODE == 1) {
+        // per-thread partials in fp32 (a thread sees ~20 entries), everything above them in fp64
+        int cnt = 0;
+        float sum = 0.f, sq = 0.f, mx = 0.f;
+        for (int i = tid; i < npix; i += 1024) {
+            const float v = vox_from_fixed((long long)s_acc[i]);
+            if (v != 0.f) { ++cnt; sum += v; sq = fmaf(v, v, sq); mx = fmaxf(mx, fabsf(v)); }
+        }
+        const double r0 = block_sum_d<1024>((double)cnt, s_red[0]);
+        const double r1 = block_sum_d<1024>((double)sum, s_red[1]);
+        const double r2 = block_sum_d<1024>((double)sq, s_red[2]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        if ((tid & 63) == 0) s_red[3][tid >> 6] = (double)mx;
+        __syncthreads();
+        if (tid == 0) {
+            double m = 0.0;
+            for (int w = 0; w < 16; ++w) m = fmax(m, s_red[3][w]);
+            double *p = L.spart + (size_t)g * 4;
+            p[0] = r0; p[1] = r1; p[2] = r2; p[3] = m;
+        }
+        return;
+    }
+    float sub = 0.f, mul = 1.f;
+    if (MODE == 2) { const int b = img / C; sub = L.stat[b * 4 + 0]; mul = L.stat[b * 4 + 1]; }
+    float *dst = grid + ((size_t)img * H + row0) * W;
+    for (int i = tid; i < npix; i += 1024) {
+        float v = vox_from_fixed((long long)s_acc[i]);
+        if (MODE == 2) {                                 // (k_vox_norm's arithmetic)
+            if (norm == 1) { if (v != 0.f) v = (v - sub) * mul; }
+            else v = v * mul;
+        }
+        dst[i] = v;
     }
 }
 
@@ -183,6 +229,7 @@ __global__ __launch_bounds__(256) void k_vox_stats(const float *__restrict__ gri
 }
 
 // one workgroup per sample: mean / std of the non-zero entries (unbiased std, torch.std) or max
+// (part: nblk partials per sample -- those of the strips, or of k_vox_stats)
 __global__ __launch_bounds__(256) void k_vox_finalize(const double *__restrict__ part, float *__restrict__ stat, int nblk, int norm) {
     __shared__ double s_red[4][4];
     const int b = blockIdx.x;
@@ -341,12 +388,13 @@ static int vox_validate(const mpc_vox_shape *s) {
     return 0;
 }
 
-struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_part, off_stat, off_qhist, off_qstate, total; unsigned *qhist, *qstate; };
+struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_part, off_spart, off_stat, off_qhist, off_qstate, total; unsigned *qhist, *qstate; };
 
 static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     VoxHostLayout h;
     VoxLayout &L = h.L;
-    L.SR = (int)((150 * 1024) / ((int64_t)s->W * 8));
+    L.SR = (int)(((int64_t)VOX_STRIP_KB * 1024) / ((int64_t)s->W * 8));
+    if (L.SR < 1) L.SR = (int)((150 * 1024) / ((int64_t)s->W * 8));
     if (L.SR > s->H) L.SR = s->H;
     L.NS = mpc_cdiv(s->H, L.SR);
     L.SR = mpc_cdiv(s->H, L.NS);
@@ -361,6 +409,7 @@ static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     h.off_rec = off;   off += mpc_align((int64_t)L.NBk * L.cap * 16);
     h.off_ovf = off;   off += mpc_align((int64_t)4 * s->B * s->N * 16 + 16);
     h.off_part = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * L.nstat_blocks * 4 * 8);
+    h.off_spart = off; off += mpc_align((int64_t)(L.NBk > 0 ? L.NBk : 1) * 4 * 8);
     h.off_stat = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 4 * 4);
     h.off_qhist = off; off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * VOX_QBINS * 4);
     h.off_qstate = off; off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 8 * 4);
@@ -370,6 +419,7 @@ static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     L.rec = (float4 *)(w + h.off_rec);
     L.ovf = (float4 *)(w + h.off_ovf);
     L.part = (double *)(w + h.off_part);
+    L.spart = (double *)(w + h.off_spart);
     L.stat = (float *)(w + h.off_stat);
     h.qhist = (unsigned *)(w + h.off_qhist);
     h.qstate = (unsigned *)(w + h.off_qstate);
@@ -394,7 +444,9 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
     hipStream_t st = (hipStream_t)stream;
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_vox_accum, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        hipError_t e = hipFuncSetAttribute((const void *)k_vox_accum<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_vox_accum<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_vox_accum<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
         attr_once.mark();
     }
@@ -406,12 +458,19 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
                            *s, L, reinterpret_cast<const float4 *>(xytp), counts);
         MPC_CHECK_LAUNCH();
     }
-    MPC_LAUNCH(k_vox_accum, dim3(L.NBk), dim3(1024), (size_t)L.SR * s->W * 8, st, L, grid, s->H, s->W);
-    MPC_CHECK_LAUNCH();
-    MPC_LAUNCH(k_vox_overflow, dim3(64), dim3(256), 0, st, L, grid, s->H, s->W);
+    const size_t strip_lds = (size_t)L.SR * s->W * 8;
+    const int64_t per_sample = (int64_t)s->C * s->H * s->W;
+    if (s->norm != 0 && !(s->quantile > 0.f)) {
+        // statistics from the strips in LDS, then the strips again, written normalised: the grid is written once and never read
+        MPC_LAUNCH(k_vox_accum<1>, dim3(L.NBk), dim3(1024), strip_lds, st, L, grid, s->H, s->W, s->C, s->norm);
+        MPC_LAUNCH(k_vox_finalize, dim3(s->B), dim3(256), 0, st, L.spart, L.stat, s->C * L.NS, s->norm);
+        MPC_LAUNCH(k_vox_accum<2>, dim3(L.NBk), dim3(1024), strip_lds, st, L, grid, s->H, s->W, s->C, s->norm);
+        MPC_CHECK_LAUNCH();
+        return 0;
+    }
+    MPC_LAUNCH(k_vox_accum<0>, dim3(L.NBk), dim3(1024), strip_lds, st, L, grid, s->H, s->W, s->C, s->norm);
     MPC_CHECK_LAUNCH();
     if (s->quantile > 0.f) {
-        const int64_t per_sample = (int64_t)s->C * s->H * s->W;
         // torch.quantile(x, 1 - q) gets 1 - q computed in double and rounds it to fp32: the caller passes that value
         const float qf = s->keep > 0.f ? s->keep : (float)(1.0 - (double)s->quantile);
         const int e1 = mpc_zero_async(h.qhist, (size_t)s->B * VOX_QBINS * 4, st);
@@ -426,7 +485,6 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
         MPC_CHECK_LAUNCH();
     }
     if (s->norm != 0) {
-        const int64_t per_sample = (int64_t)s->C * s->H * s->W;
         MPC_LAUNCH(k_vox_stats, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.part, per_sample);
         MPC_LAUNCH(k_vox_finalize, dim3(s->B), dim3(256), 0, st, L.part, L.stat, L.nstat_blocks, s->norm);
         MPC_LAUNCH(k_vox_norm, dim3(L.nstat_blocks, s->B), dim3(256), 0, st, grid, L.stat, per_sample, s->norm);
