@@ -28,26 +28,56 @@ __device__ __forceinline__ int classify(float x, float y, float p, int H, int W)
     return p == 1.f ? 1 : (p == 0.f ? 2 : 0);
 }
 
+// the four consecutive events of a thread: one 16-byte load per array (two for the timestamps) where the sample's first event is
+// 16-byte aligned (vec: N a multiple of 4 and aligned base pointers) and all four exist, else element by element
+struct IngQuad { float x[4], y[4], p[4]; long long t[4]; };
+__device__ __forceinline__ IngQuad ing_load4(const float *__restrict__ x, const float *__restrict__ y, const long long *__restrict__ t,
+                                             const float *__restrict__ p, size_t base, int i0, int n, int vec) {
+    IngQuad q;
+    if (vec && i0 + 3 < n) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + base + i0), yv = *reinterpret_cast<const float4 *>(y + base + i0);
+        const float4 pv = *reinterpret_cast<const float4 *>(p + base + i0);
+        const longlong2 t0 = *reinterpret_cast<const longlong2 *>(t + base + i0), t1 = *reinterpret_cast<const longlong2 *>(t + base + i0 + 2);
+        q.x[0] = xv.x; q.x[1] = xv.y; q.x[2] = xv.z; q.x[3] = xv.w;
+        q.y[0] = yv.x; q.y[1] = yv.y; q.y[2] = yv.z; q.y[3] = yv.w;
+        q.p[0] = pv.x; q.p[1] = pv.y; q.p[2] = pv.z; q.p[3] = pv.w;
+        q.t[0] = t0.x; q.t[1] = t0.y; q.t[2] = t1.x; q.t[3] = t1.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = i0 + k < n;
+            q.x[k] = on ? x[base + i0 + k] : -1.f; q.y[k] = on ? y[base + i0 + k] : -1.f; q.p[k] = on ? p[base + i0 + k] : -1.f;
+            q.t[k] = on ? t[base + i0 + k] : 0;
+        }
+    }
+    return q;
+}
+
 // grid (nchunks, B), 256 threads
 __global__ __launch_bounds__(256) void k_ingest_count(const mpc_ingest_shape s, const IngLayout L,
                                                       const float *__restrict__ x, const float *__restrict__ y,
                                                       const long long *__restrict__ t, const float *__restrict__ p,
-                                                      const int *__restrict__ counts) {
+                                                      const int *__restrict__ counts, int *__restrict__ out_max, int vec) {
     __shared__ int s_c[2][4];
     __shared__ long long s_t[2][4];
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    // (the batch maxima that k_ingest_scan raises with atomicMax start at 0: set here, a launch earlier, instead of by a memset)
+    if (b == 0 && chunk == 0 && tid < 2) out_max[tid] = 0;
     const int n = min(counts[b], s.N);
     const size_t base = (size_t)b * s.N;
     int cp = 0, cn = 0;
     long long tmin = 0x7fffffffffffffffLL, tmax = -0x7fffffffffffffffLL - 1;
+    const int i0 = chunk * ING_CHUNK + tid * 4;
+    if (i0 < n) {
+        const IngQuad q = ing_load4(x, y, t, p, base, i0, n, vec);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = chunk * ING_CHUNK + tid * 4 + k;
-        if (i < n) {
-            const int c = classify(x[base + i], y[base + i], p[base + i], s.H, s.W);
-            cp += c == 1; cn += c == 2;
-            const long long tv = t[base + i];       // extrema over ALL events of the window (loader.py:152)
-            tmin = tv < tmin ? tv : tmin; tmax = tv > tmax ? tv : tmax;
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) {
+                const int c = classify(q.x[k], q.y[k], q.p[k], s.H, s.W);
+                cp += c == 1; cn += c == 2;
+                const long long tv = q.t[k];            // extrema over ALL events of the window (loader.py:152)
+                tmin = tv < tmin ? tv : tmin; tmax = tv > tmax ? tv : tmax;
+            }
         }
     }
 #pragma unroll
@@ -131,24 +161,36 @@ __device__ __forceinline__ int bin_index(double tn, int nb) {
     return i - 1 < 0 ? 0 : i - 1;
 }
 
-// grid (nchunks, B), 256 threads.  Thread t owns 4 consecutive events, so ranks follow the input order.
+// grid (nchunks, B), 256 threads.  Thread t owns 4 consecutive events, so ranks follow the input order.  The rows of a
+// workgroup are two contiguous runs of the output (its positives, its negatives): they are put together in LDS and written as
+// runs of 8-byte words (a lane writing its own 24-byte row was six scattered 4-byte stores per event).  The padding rows of
+// the sample (loader.py:360-364: zero rows, valid = 0) are zeroed here too, a share per workgroup -- not by a memset of the
+// whole tensor in front of the kernel.
 __global__ __launch_bounds__(256) void k_ingest_scatter(const mpc_ingest_shape s, const IngLayout L,
                                                         const float *__restrict__ x, const float *__restrict__ y,
                                                         const long long *__restrict__ t, const float *__restrict__ p,
                                                         const int *__restrict__ counts, int max_pos, int max_neg,
-                                                        float *__restrict__ events, float *__restrict__ xytp) {
+                                                        float *__restrict__ events, float *__restrict__ xytp, int vec) {
     __shared__ int s_w[2][4];
+    __shared__ float2 s_rows[ING_CHUNK * 3];          // positives from the front, the negatives behind them
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int n = min(counts[b], s.N);
     const size_t base = (size_t)b * s.N;
     const long long tmin = L.tminmax[b * 2], tmax = L.tminmax[b * 2 + 1];
     const double span = (double)(tmax - tmin);
+    const int M = max_pos + max_neg;
+    const int i0 = chunk * ING_CHUNK + tid * 4;
+    IngQuad q;
     int cls[4], lp = 0, ln = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = chunk * ING_CHUNK + tid * 4 + k;
-        cls[k] = (i < n) ? classify(x[base + i], y[base + i], p[base + i], s.H, s.W) : 0;
-        lp += cls[k] == 1; ln += cls[k] == 2;
+    for (int k = 0; k < 4; ++k) cls[k] = 0;
+    if (i0 < n) {
+        q = ing_load4(x, y, t, p, base, i0, n, vec);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            cls[k] = (i0 + k < n) ? classify(q.x[k], q.y[k], q.p[k], s.H, s.W) : 0;
+            lp += cls[k] == 1; ln += cls[k] == 2;
+        }
     }
     // exclusive scan of (lp, ln) over the workgroup
     int ip = lp, in_ = ln;
@@ -159,28 +201,48 @@ __global__ __launch_bounds__(256) void k_ingest_scatter(const mpc_ingest_shape s
     }
     if ((tid & 63) == 63) { s_w[0][tid >> 6] = ip; s_w[1][tid >> 6] = in_; }
     __syncthreads();
-    int wp = 0, wn = 0;
-    for (int w = 0; w < (tid >> 6); ++w) { wp += s_w[0][w]; wn += s_w[1][w]; }
-    const size_t co = ((size_t)b * L.nchunks + chunk) * 2;
-    int rp = L.chunk_off[co] + wp + ip - lp;
-    int rn = L.chunk_off[co + 1] + wn + in_ - ln;
-    const int M = max_pos + max_neg;
+    int wp = 0, wn = 0, np_wg = 0, nn_wg = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = chunk * ING_CHUNK + tid * 4 + k;
-        if (i >= n) continue;
-        const long long tv = t[base + i];
-        if (xytp != nullptr) {
-            // loader.py:135-138: t = (t - t[0]).astype(float32); t = t / t[-1]   (t increasing)
-            const float tf = (float)(tv - tmin) / (float)(tmax - tmin);
-            reinterpret_cast<float4 *>(xytp)[base + i] = make_float4(x[base + i], y[base + i], tf, p[base + i]);
+    for (int w = 0; w < 4; ++w) {
+        if (w < (tid >> 6)) { wp += s_w[0][w]; wn += s_w[1][w]; }
+        np_wg += s_w[0][w]; nn_wg += s_w[1][w];
+    }
+    int rp = wp + ip - lp, rn = np_wg + wn + in_ - ln;          // LDS rows of this thread's first positive / negative
+    if (i0 < n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k >= n) continue;
+            const long long tv = q.t[k];
+            if (xytp != nullptr) {
+                // loader.py:135-138: t = (t - t[0]).astype(float32); t = t / t[-1]   (t increasing)
+                const float tf = (float)(tv - tmin) / (float)(tmax - tmin);
+                reinterpret_cast<float4 *>(xytp)[base + i0 + k] = make_float4(q.x[k], q.y[k], tf, q.p[k]);
+            }
+            if (cls[k] == 0) continue;
+            const double tn = (double)(tv - tmin) / span;                       // loader.py:152 (float64)
+            const int row = cls[k] == 1 ? rp++ : rn++;
+            s_rows[3 * row + 0] = make_float2(q.y[k], q.x[k]);
+            s_rows[3 * row + 1] = make_float2((float)tn, q.p[k]);
+            s_rows[3 * row + 2] = make_float2((float)bin_index(tn, s.nb), 1.f);
         }
-        if (cls[k] == 0) continue;
-        const double tn = (double)(tv - tmin) / span;                       // loader.py:152 (float64)
-        const int row = cls[k] == 1 ? rp++ : max_pos + rn++;
-        float *e = events + ((size_t)b * M + row) * 6;
-        e[0] = y[base + i]; e[1] = x[base + i]; e[2] = (float)tn; e[3] = p[base + i];
-        e[4] = (float)bin_index(tn, s.nb); e[5] = 1.f;
+    }
+    __syncthreads();
+    const size_t co = ((size_t)b * L.nchunks + chunk) * 2;
+    float2 *dstp = reinterpret_cast<float2 *>(events + ((size_t)b * M + L.chunk_off[co]) * 6);
+    float2 *dstn = reinterpret_cast<float2 *>(events + ((size_t)b * M + max_pos + L.chunk_off[co + 1]) * 6);
+    for (int j = tid; j < 3 * np_wg; j += 256) dstp[j] = s_rows[j];
+    for (int j = tid; j < 3 * nn_wg; j += 256) dstn[j] = s_rows[3 * np_wg + j];
+    // this workgroup's share of the sample's padding rows
+    const int tp = L.totals[b * 2], tn_ = L.totals[b * 2 + 1];
+    const int pad_p = 3 * (max_pos - tp), pad_n = 3 * (max_neg - tn_), pad = pad_p + pad_n;
+    if (pad > 0) {
+        const int per = (pad + (int)gridDim.x - 1) / (int)gridDim.x;
+        float2 *zp = reinterpret_cast<float2 *>(events + ((size_t)b * M + tp) * 6);
+        float2 *zn = reinterpret_cast<float2 *>(events + ((size_t)b * M + max_pos + tn_) * 6);
+        const int j1 = min((chunk + 1) * per, pad);
+        for (int j = chunk * per + tid; j < j1; j += 256) {
+            if (j < pad_p) zp[j] = make_float2(0.f, 0.f); else zn[j - pad_p] = make_float2(0.f, 0.f);
+        }
     }
 }
 
@@ -273,6 +335,11 @@ static int ing_validate(const mpc_ingest_shape *s) {
     return 0;
 }
 
+// 16-byte loads of four consecutive events: every sample's first event aligned
+static int ing_vec(const mpc_ingest_shape *s, const void *x, const void *y, const void *t, const void *p) {
+    return (s->N % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)t | (uintptr_t)p) & 15) == 0 ? 1 : 0;
+}
+
 struct IngHost { IngLayout L; int64_t total; };
 
 static IngHost ing_layout(const mpc_ingest_shape *s, void *ws) {
@@ -304,12 +371,10 @@ extern "C" int mpc_ingest_count(const mpc_ingest_shape *s, const float *x, const
     int rc = ing_validate(s);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int e = mpc_zero_async(out_max, 2 * sizeof(int32_t), st);
-    if (e) return e;
-    if (s->B == 0) return 0;
+    if (s->B == 0) return mpc_zero_async(out_max, 2 * sizeof(int32_t), st);
     const IngLayout L = ing_layout(s, ws).L;
     MPC_LAUNCH(k_ingest_count, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
-                       reinterpret_cast<const long long *>(t_us), p, counts);
+                       reinterpret_cast<const long long *>(t_us), p, counts, out_max, ing_vec(s, x, y, t_us, p));
     MPC_LAUNCH(k_ingest_scan, dim3(s->B), dim3(256), 0, st, L, out_max);
     MPC_CHECK_LAUNCH();
     return 0;
@@ -325,14 +390,10 @@ extern "C" int mpc_ingest_scatter(const mpc_ingest_shape *s, const float *x, con
     if (s->B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t M = (int64_t)max_pos + max_neg;
-    if (M > 0) {
-        const int e = mpc_zero_async(events, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows
-        if (e) return e;
-    }
-    if (s->N == 0) return 0;
+    if (s->N == 0) return M > 0 ? mpc_zero_async(events, (size_t)s->B * M * 6 * sizeof(float), st) : 0;     // padding rows only
     const IngLayout L = ing_layout(s, ws).L;
     MPC_LAUNCH(k_ingest_scatter, dim3(L.nchunks, s->B), dim3(256), 0, st, *s, L, x, y,
-                       reinterpret_cast<const long long *>(t_us), p, counts, max_pos, max_neg, events, xytp);
+                       reinterpret_cast<const long long *>(t_us), p, counts, max_pos, max_neg, events, xytp, ing_vec(s, x, y, t_us, p));
     MPC_CHECK_LAUNCH();
     return 0;
 }
