@@ -50,15 +50,15 @@ def loss_config(wl):
                 polarity_aware_batching=True, interpolation_scheme='mean', smooth_type=wl['smooth_type'])
 
 
-def synth_inputs(wl, seed, B=None):
-    """Seeded synthetic batch: events [B,M,6] + trajectories [B,1+nb,n,2] on CPU."""
+def synth_inputs(wl, seed, B=None, trefs=(0.41,)):
+    """Seeded synthetic batch: events [B,M,6] + trajectories [B,len(trefs)+nb,n,2] on CPU."""
     from motionpriorcmax_amd import utils
     from motionpriorcmax_amd.utils.synth import synth_events, bin_mid_times
     B = wl['B'] if B is None else B
     nb, k = wl['nb'], wl['k']
     ev, num_pos = synth_events(B, wl['M'], (H, W), nb, seed=seed, pad_frac=0.02, time_sorted=True)
     g = torch.Generator().manual_seed(seed + 7)
-    times = torch.cat((torch.tensor([0.41]), bin_mid_times(nb)))
+    times = torch.cat((torch.tensor(list(trefs)), bin_mid_times(nb)))
     mask = utils.get_optical_flow_tile_mask((H, W), PATCH)
     if wl['k'] == 10:
         # Bezier control points N(0, 2^2) per tile, (x, y) channel order (bezier.py / polynomial.py:60-61)
@@ -760,6 +760,36 @@ def main():
                     'worst_vs_white': max(r['vs_first'] for r in rows)}
             except Exception as e:
                 also['realistic_inputs'] = {'error': repr(e)[:300]}
+        # configurations outside the shipped yaml files (served by the general KNN kernels, not the strip kernels): timed once
+        try:
+            from motionpriorcmax_amd import LossFactory as _LF
+            nd = {}
+            for tag, over, trefs in (('iwd', {'interpolation_scheme': 'iwd'}, (0.41,)), ('dist_l1', {'dist_norm': 'l1'}, (0.41,)),
+                                     ('num_tref_2', {'num_tref': 2, 'scale_iwe_by_dt': False, 'polarity_aware_batching': False}, (0.41, 0.77))):
+                evn, npn, trn, tmn = synth_inputs(wl, seed=1, trefs=trefs)
+                Ln = _LF.get_loss_calculator('FOCUS', dict(loss_config(wl), **over))
+                evd_, tmd_ = evn.to(dev), tmn.to(dev)
+                trd_ = trn.to(dev).requires_grad_(True)
+                bn = {'events': evd_, 'num_pos_events': npn}
+
+                def _st():
+                    l_, _, _ = Ln.calc(trd_, tmd_, bn)
+                    l_.backward()
+                    trd_.grad = None
+                for _ in range(4):
+                    _st()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    _st()
+                torch.cuda.synchronize()
+                nd[tag] = {'ms_per_step': round(1e2 * (time.perf_counter() - t0), 4)}
+                del Ln, trd_, evd_
+            nd['note'] = ('same workload and inputs as the headline with one loss setting changed; iwd: strip forward, point-gather backward '
+                          '(k_knn_bwd_points); num_tref = 2: tile kernel k_knn_query forward and k_knn_bwd_points backward')
+            also['non_default_configs'] = nd
+        except Exception as e:
+            also['non_default_configs'] = {'error': repr(e)[:200]}
         # next row 8f-2: voxel-grid builder on the same window shape (network input; not part of `value`)
         try:
             from motionpriorcmax_amd.utils import voxel_grids

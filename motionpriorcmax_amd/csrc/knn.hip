@@ -1450,7 +1450,9 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine_direct(const KnnParams 
 // border classes of the tile maxima.
 int mpc_knn_r_init(const mpc_shape *s) {
     const double dens = (double)s->n / ((double)s->hq * s->wq);
-    int r_init = (int)ceil(sqrt((double)s->K / 3.14159265 / (dens > 0 ? dens : 1.0)) - 0.5);
+    // (the ball of K points at the mean density: a disc, pi r^2; with the L1 norm a diamond, 2 r^2)
+    const double ball = (s->flags & MPC_F_DIST_L1) ? 2.0 : 3.14159265;
+    int r_init = (int)ceil(sqrt((double)s->K / ball / (dens > 0 ? dens : 1.0)) - 0.5);
     return r_init < 1 ? 1 : r_init;
 }
 

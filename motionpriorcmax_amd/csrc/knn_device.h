@@ -46,11 +46,12 @@ struct KnnParams {
 #define KNN_MARGIN (KNN_RCAP + 1)
 // smallest count of points in the (2r + 1)^2 cell square of a query for which radius r is tried (K / (pi / 4) at K = 32: the
 // disc of the ring bound holds K points if they are spread evenly over the square; calibrated on smooth flow fields)
-__host__ __device__ static inline int knn_square_need(int K) { return (int)((float)K * 1.28f + 0.5f); }
+// (L1: the ball of the ring bound is a diamond, half of the square)
+__host__ __device__ static inline int knn_square_need(int K, int l1 = 0) { return (int)((float)K * (l1 ? 2.05f : 1.28f) + 0.5f); }
 
 // count of points in the square for which a FAR query tries radius r: the K neighbours of a query inside an emptied band lie
 // in a segment of the disc, the square also holds what the disc cuts off (calibrated as above: 2.6 K misses 4 % of them)
-__host__ __device__ static inline int knn_square_need_far(int K) { return (int)((float)K * 2.65f + 0.5f); }
+__host__ __device__ static inline int knn_square_need_far(int K, int l1 = 0) { return (int)((float)K * (l1 ? 4.2f : 2.65f) + 0.5f); }
 
 int mpc_knn_margin(const mpc_shape *s);
 

@@ -49,7 +49,9 @@
 #endif
 #define KS_TAIL(MAXCH_) (4 * (MAXCH_) + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
+#ifndef KS_SB
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
+#endif
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
 #ifndef KS_MORE_OCC
@@ -161,7 +163,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     const bool marked = bit_again || bit_grow, farq = bit_grow && !bit_again;
     int r = 0, nr = 0;                                  // radius and the points in its square
     bool served = false;
-    const int need_q = knn_square_need(p.K);
+    const int need_q = knn_square_need(p.K, p.l1);
     // (second launch: the radius the main launch worked out for a far query / tried for one it could not finish, left in the
     // query's K-th distance slot of knn_state -- whichever kernel serves the query overwrites it.  Reading the table again here
     // was a chain of four to five dependent round trips in front of everything else a work item does: 12 of its 29 us.)
@@ -215,7 +217,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             // (a LOWER BOUND of the candidates below the ring bound -- the points of the cells inside a cross of rectangles
             // inscribed in the disc, five rectangle counts -- instead of this estimate was measured: no fewer queries on the
             // fallback list, larger radii, queries in dense places beyond the 256 slots: not kept)
-            const int need_far = knn_square_need_far(p.K);
+            const int need_far = knn_square_need_far(p.K, p.l1);
             int lo = KNN_RCAP, hi = KNN_RFAR + 1;       // (lo: too few; hi: enough)
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -909,7 +911,7 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const Knn
 // kernel's count (which it has tried); beyond it the far queries' rule, found by doubling and bisection (a band 20 rings deep
 // costs 8 probes of four loads, not 20)
 __device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r0) {
-    const int need = knn_square_need(p.K) + (knn_square_need(p.K) >> 2), need_far = knn_square_need_far(p.K);
+    const int need = knn_square_need(p.K, p.l1) + (knn_square_need(p.K, p.l1) >> 2), need_far = knn_square_need_far(p.K, p.l1);
     const int rmax = max(p.hb, p.wb);
     int r = max(r0, 2);
     while (r <= KNN_RCAP && knn_square_count(p, sat, cy, cx, r) < need) ++r;
