@@ -124,3 +124,44 @@ def test_full_step_on_smooth_flow_matches_oracle_event_path():
     sm = Lo.smooth_loss(lut.cpu(), None)
     ref = float(f + sm)
     assert abs(float(outs[0][0]) - ref) <= 1e-5 * abs(ref), (float(outs[0][0]), ref)
+
+
+@pytest.mark.parametrize('family', ['unet', 'translate40'])
+def test_knn_lut_l1_norm_at_dsec_density(family):
+    """dist_norm = 'l1' at the DSEC density: the ball of the ring bound is a diamond (half the square), so the search radius is
+    4 cells and the general tile kernel serves the forward (knn_device.h: knn_square_need, knn.hip: mpc_knn_r_init): LUT and
+    gradient of sampled slices against a brute-force L1 K-nearest search (focus.py:133-134)."""
+    from motionpriorcmax_amd import LossFactory, ops
+    from motionpriorcmax_amd.utils import synth
+    from oracle import focus_oracle as O
+    dev = _dev()
+    B = 1
+    traj, _ = synth.synth_trajectories(B, 3, NB, (H, W), PATCH, family, seed=31)
+    L = LossFactory.get_loss_calculator('FOCUS', dict(
+        image_shape=(H, W), num_tref=1, num_bins=NB, num_knn=K, smooth_weight=0.003, lut_superpixel_size=SP,
+        focus_loss_norm='l1', dist_norm='l1', scale_iwe_by_dt=True, mask_image_border=True, polarity_aware_batching=True,
+        interpolation_scheme='mean', smooth_type='on_flow_to_tref'))
+    td = traj.to(dev).requires_grad_(True)
+    lut, _ = ops.KnnLutFn.apply(td, L._cfg)
+    g = torch.Generator().manual_seed(6)
+    wgt = torch.randn(lut.shape, generator=g).to(dev)
+    (lut * wgt).sum().backward()
+    grid, _, _ = O.lut_grid_points((H, W), SP)
+    q = grid.to(dev)
+    tb = traj.to(dev).requires_grad_(True)
+    tot = 0.
+    for t in (0, NB - 1):
+        pts = tb[0, 1 + t].detach()
+        idx = []
+        for c in range(0, q.shape[0], 2048):
+            d = (q[c:c + 2048, None, :] - pts[None, :, :]).abs().sum(-1)
+            idx.append(torch.sort(d, dim=1, stable=True).indices[:, :K])
+        idx = torch.cat(idx)
+        ref = (tb[0, 0] - tb[0, 1 + t])[idx].mean(1)
+        got = lut[0, t].reshape(-1, 2)
+        assert torch.allclose(got, ref.detach(), atol=1e-4, rtol=1e-5), (family, t, float((got - ref).abs().max()))
+        tot = tot + (ref * wgt[0, t].reshape(-1, 2)).sum()
+    tot.backward()
+    for t in (0, NB - 1):
+        a, r = td.grad[0, 1 + t], tb.grad[0, 1 + t]
+        assert float((a - r).norm()) <= 1e-5 * float(r.norm()) + 1e-7, (family, t, float((a - r).norm() / r.norm()))
