@@ -1200,7 +1200,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 // the benchmark have a few hundred items per step)
 // ------------------------------------------------------------------------------------------
 #define KNN_FAR_CAP 640       // points of a tile per round of accumulators (a border tile with its margin cells: 24 x 24)
+#ifndef KNN_FAR_BLOCKS
 #define KNN_FAR_BLOCKS 2048
+#endif
 template <bool L1, bool NEXT>
 __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const int *__restrict__ cell_start,
                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,

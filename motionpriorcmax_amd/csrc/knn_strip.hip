@@ -44,8 +44,8 @@
 #define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
 #ifndef KS_MAXCH_FAR
-#define KS_MAXCH_FAR 64             // ... of the launch for the far queries (256 slots: a band along the left or right border -- every region row as wide as the
-                                   // widest chord -- needs ~160)
+#define KS_MAXCH_FAR 48             // ... of the launch for the far queries (192 slots: a band along the left or right border -- every region row
+                                   // as wide as the widest chord -- needs ~160; 256 slots at three workgroups per CU measured slower, see KS_MORE_OCC)
 #endif
 #define KS_TAIL(MAXCH_) (4 * (MAXCH_) + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
@@ -55,7 +55,9 @@
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
 #ifndef KS_MORE_OCC
-#define KS_MORE_OCC 3               // workgroups per CU of the second launch (its register budget)
+#define KS_MORE_OCC 4               // workgroups per CU of the second launch = its register budget (128; 13 registers spill).  The launch is bound
+                                   // by the latency of its work items: C3, 40 px translation / 48 px contraction band: 4 per CU with 192 slots
+                                   // 161 / 308 us, 3 per CU with 192 slots 179 / 351, with 256 slots 190 / 368, 2 per CU 258 / -
 #endif
 #define KS_RETRY_BLOCKS (256 * KS_MORE_OCC)   // workgroups of the second launch
 static_assert(KNN_FAR_WS * KNN_FAR_TH == KS_NT, "a block of queries of the second launch = one workgroup");
@@ -232,7 +234,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (isfar) served = r <= KNN_RFAR;              // (else: the fallback kernel)
         else if (bit_again) {
             // the main launch could not finish it: too few candidates below the ring bound -- two more rings -- or more slots
-            // than its registers hold -- the same radius with this launch's 256 slots
+            // than its registers hold -- the same radius with this launch's 192 slots
             if (bit_grow) r = min(r + 2, KNN_RFAR);
             served = true;
         }
@@ -502,7 +504,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                     constexpr int T2 = MAXCH < 32 ? MAXCH : 32;
 #pragma unroll
                     for (int c = KS_BASECH + 4; c < T2; ++c) acc += __popc((w[c] + C) & 0x80808080u);
-                    // (the second launch: up to 256 slots, in two more steps)
+                    // (the second launch: up to 192 or 256 slots, in two more steps)
                     if (MAXCH > 32 && nmax > 128) {
                         asm volatile("" ::: "memory");
                         constexpr int T3 = MAXCH < 48 ? MAXCH : 48;
