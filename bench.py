@@ -372,6 +372,8 @@ def main():
     ap.add_argument('--no-realistic', action='store_true', help='skip the realistic-input variants reported in also.realistic_inputs')
     ap.add_argument('--no-hip-graph', action='store_true', help='skip the HIP-graph replay timing reported beside the eager one')
     ap.add_argument('--also', default='C2,C4,C4b6', help='extra workloads reported in the "also" field (N=1 only)')
+    ap.add_argument('--no-nondefault', action='store_true', help='skip the timing of the non-default loss settings (profiling runs: '
+                    'their kernels share names with the headline\'s)')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -725,7 +727,7 @@ def main():
             # (sized by the main workload) otherwise frees/reallocates inside the child's timed steps
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--steps', str(args.steps),
-                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--no-realistic', '--also', '', '--events-layout', args.events_layout]
+                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--no-realistic', '--no-nondefault', '--also', '', '--events-layout', args.events_layout]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 dj = json.loads(r.stdout.strip().splitlines()[-1])
@@ -762,6 +764,8 @@ def main():
                 also['realistic_inputs'] = {'error': repr(e)[:300]}
         # configurations outside the shipped yaml files (served by the general KNN kernels, not the strip kernels): timed once
         try:
+            if args.no_nondefault:
+                raise RuntimeError('skipped (--no-nondefault)')
             from motionpriorcmax_amd import LossFactory as _LF
             nd = {}
             for tag, over, trefs in (('iwd', {'interpolation_scheme': 'iwd'}, (0.41,)), ('dist_l1', {'dist_norm': 'l1'}, (0.41,)),
