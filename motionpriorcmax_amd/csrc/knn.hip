@@ -1200,6 +1200,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 // the benchmark have a few hundred items per step)
 // ------------------------------------------------------------------------------------------
 #define KNN_FAR_CAP 640       // points of a tile per round of accumulators (a border tile with its margin cells: 24 x 24)
+#ifndef KNN_FAR_QB
+#define KNN_FAR_QB 512        // far queries tested against the tile per batch (two per thread); those that touch it: a list in LDS
+#endif
 #ifndef KNN_FAR_BLOCKS
 #define KNN_FAR_BLOCKS 2048
 #endif
@@ -1218,6 +1221,10 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
     __shared__ int s_rowbase[KNN_TROWS + 1];
     __shared__ int s_rowg[KNN_TROWS];
     __shared__ float s_wm[4];
+    __shared__ int s_nq;                                   // far queries of the current batch that touch the tile: {cell, K-th index},
+    __shared__ int2 s_qc[KNN_FAR_QB];                      // K-th distance, gradient(s) in fixed point
+    __shared__ float s_qd[KNN_FAR_QB];
+    __shared__ longlong2 s_qg[KNN_FAR_QB * (NA / 2)];
     const int tid = threadIdx.x;
     const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m), nt = ntx * nty;
     const int nwork = min(ls.ftlist[0], p.B * p.nb * nt);
@@ -1297,14 +1304,20 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
                 s_pos[li] = sp_[g]; s_idx[li] = (unsigned short)si_[g];
             }
             __syncthreads();
-            for (int e0 = 0; e0 < nfar; e0 += 4 * 256) {
-              int cellv[4]; float dkv[4];
+            // The far queries of the (sample, bin) in batches of KNN_FAR_QB: first every thread tests two of them against the tile's
+            // area and puts the ones that touch it on a list in LDS (centre, K-th key, gradient in fixed point); then the list is
+            // worked off as (query, cell row of the tile) units spread evenly over the threads -- a thread per QUERY walked all
+            // rows of the tile for the few queries that touch it while most lanes had none: the walk was the kernel's time.
+            for (int e0 = 0; e0 < nfar; e0 += KNN_FAR_QB) {
+              int cellv[KNN_FAR_QB / 256]; float dkv[KNN_FAR_QB / 256];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) { const int e = e0 + u * 256 + tid; cellv[u] = e < nfar ? fl[1 + e] : -1; }
+              for (int u = 0; u < KNN_FAR_QB / 256; ++u) { const int e = e0 + u * 256 + tid; cellv[u] = e < nfar ? fl[1 + e] : -1; }
 #pragma unroll
-              for (int u = 0; u < 4; ++u) dkv[u] = cellv[u] >= 0 ? dks[cellv[u]] : -1.f;
+              for (int u = 0; u < KNN_FAR_QB / 256; ++u) dkv[u] = cellv[u] >= 0 ? dks[cellv[u]] : -1.f;
+              if (tid == 0) s_nq = 0;
+              __syncthreads();
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
+              for (int u = 0; u < KNN_FAR_QB / 256; ++u) {
                 const int cell = cellv[u];
                 if (cell < 0) continue;
                 const int cy = cell / p.wq, cx = cell - cy * p.wq;
@@ -1316,42 +1329,48 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
                 const int ik = iks[cell] & KNN_IDX_MASK;
                 const float2 g = gl2[cell];
                 const float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
-                const long long fy = __double2ll_rn((double)g.x * scale), fx = __double2ll_rn((double)g.y * scale);
-                const long long fny = __double2ll_rn((double)gn.x * scale), fnx = __double2ll_rn((double)gn.y * scale);
-#ifdef KF_AB_NOROWS
-                for (int rr = 0; rr < 0; ++rr) {
-#else
-                for (int rr = 0; rr < nrow; ++rr) {
-#endif
-                    // a point of this cell row is at least dyc away along y; along x it then lies within wx of the query
-                    const float dyc = fmaxf((float)abs(ty0 + rr - cy) - 0.5f, 0.f) * (float)p.sp;
-                    const float w2 = L1 ? dk - dyc : dk - dyc * dyc;
-                    if (w2 < 0.f) continue;
-                    // cells cx - xr .. cx + xr: (|x - cx| - 0.5) sp < wx, i.e. |x - cx| <= floor(wx / sp + 0.5) (one ulp of slack in wx)
-                    const int xr = (int)((L1 ? w2 : sqrtf(w2) * 1.000001f) / (float)p.sp + 0.5f);
-                    int xa = max(cx - xr, tx0), xb = min(cx + xr, tx1 - 1);
-                    if (cx - xr <= -p.m) xa = tx0;                   // (the outermost column holds everything beyond it)
-                    if (cx + xr >= p.wq + p.m - 1) xb = tx1 - 1;
-                    if (xa > xb) continue;
-                    const int ja = max(s_cs[rr][xa - tx0] - c0, 0), jb = min(s_cs[rr][xb + 1 - tx0] - c0, KNN_FAR_CAP);
-#ifdef KF_AB_NOPTS
-                    for (int li = ja; li < min(jb, ja); ++li) {
-#else
-                    for (int li = ja; li < jb; ++li) {
-#endif
-                        const float2 pj = s_pos[li];
-                        const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                        if (d > dk || (d == dk && (int)s_idx[li] > ik)) continue;
-#ifndef KF_AB_NOATOM
-                        atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fy);
-                        atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fx);
-#else
-                        if (fy == 12345 && fx == 54321) s_acc[li * NA] = 1ull;
-#endif
-                        if (NEXT && has_next) { atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fny); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fnx); }
+                const int k = atomicAdd(&s_nq, 1);
+                s_qc[k] = make_int2(cell, ik);
+                s_qd[k] = dk;
+                s_qg[k * (NA / 2) + 0] = make_longlong2(__double2ll_rn((double)g.x * scale), __double2ll_rn((double)g.y * scale));
+                if (NEXT) s_qg[k * (NA / 2) + 1] = make_longlong2(__double2ll_rn((double)gn.x * scale), __double2ll_rn((double)gn.y * scale));
+              }
+              __syncthreads();
+              const int units = s_nq * nrow;
+              const float inv_nrow = 1.f / (float)nrow;
+              for (int un = tid; un < units; un += 256) {
+                const int qi = min((int)(((float)un + 0.5f) * inv_nrow), s_nq - 1), rr = un - qi * nrow;      // (un < 2^16: the margin 0.5 / nrow dwarfs the rounding)
+                const int2 qc = s_qc[qi];
+                const int cell = qc.x, ik = qc.y;
+                const int cy = cell / p.wq, cx = cell - cy * p.wq;
+                const float dk = s_qd[qi];
+                const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
+                // a point of this cell row is at least dyc away along y; along x it then lies within wx of the query
+                const float dyc = fmaxf((float)abs(ty0 + rr - cy) - 0.5f, 0.f) * (float)p.sp;
+                const float w2 = L1 ? dk - dyc : dk - dyc * dyc;
+                if (w2 < 0.f) continue;
+                // cells cx - xr .. cx + xr: (|x - cx| - 0.5) sp < wx, i.e. |x - cx| <= floor(wx / sp + 0.5) (one ulp of slack in wx)
+                const int xr = (int)((L1 ? w2 : sqrtf(w2) * 1.000001f) / (float)p.sp + 0.5f);
+                int xa = max(cx - xr, tx0), xb = min(cx + xr, tx1 - 1);
+                if (cx - xr <= -p.m) xa = tx0;                   // (the outermost column holds everything beyond it)
+                if (cx + xr >= p.wq + p.m - 1) xb = tx1 - 1;
+                if (xa > xb) continue;
+                const int ja = max(s_cs[rr][xa - tx0] - c0, 0), jb = min(s_cs[rr][xb + 1 - tx0] - c0, KNN_FAR_CAP);
+                if (ja >= jb) continue;
+                const longlong2 fg = s_qg[qi * (NA / 2) + 0];
+                for (int li = ja; li < jb; ++li) {
+                    const float2 pj = s_pos[li];
+                    const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
+                    if (d > dk || (d == dk && (int)s_idx[li] > ik)) continue;
+                    atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fg.x);
+                    atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fg.y);
+                    if (NEXT && has_next) {
+                        const longlong2 fn = s_qg[qi * (NA / 2) + 1];
+                        atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fn.x); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fn.y);
                     }
                 }
               }
+              __syncthreads();          // (the list is rewritten by the next batch)
             }
             __syncthreads();
             for (int li = tid; li < min(KNN_FAR_CAP, total - c0); li += 256) {
