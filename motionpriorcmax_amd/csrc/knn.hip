@@ -1201,10 +1201,11 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 // ------------------------------------------------------------------------------------------
 #define KNN_FAR_CAP 640       // points of a tile per round of accumulators (a border tile with its margin cells: 24 x 24)
 #ifndef KNN_FAR_QB
-#define KNN_FAR_QB 512        // far queries tested against the tile per batch (two per thread); those that touch it: a list in LDS
+#define KNN_FAR_QB 256        // far queries tested against the tile per batch (one per thread); those that touch it: a list in LDS
+                              // (512 / 1024 per batch: 244 / 273 us against 237 at a 48 px contraction band)
 #endif
 #ifndef KNN_FAR_BLOCKS
-#define KNN_FAR_BLOCKS 2048
+#define KNN_FAR_BLOCKS 4096     // (2048: 237 us against 218 at a 48 px contraction band)
 #endif
 template <bool L1, bool NEXT>
 __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const int *__restrict__ cell_start,
