@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
     }
     if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; }
+    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; }
     if (blockIdx.x == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))      // (the chord table of the strip kernels' row tables)
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
         if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
     }
     if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
-    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; }
+    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; }
     if (bt == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;

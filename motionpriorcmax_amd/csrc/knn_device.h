@@ -74,6 +74,10 @@ struct KnnLists {
     unsigned char *chord;
     int ftwords, again_words;       // words per (sample, bin)
 };
+// number of queries the main launch marked for the second one (behind the chord table, in the same 1 KB of the workspace)
+#ifdef __HIPCC__
+__device__ __forceinline__ int *knn_marked_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 512); }
+#endif
 // Blocks of queries of the second launch of the strip kernel: the main launch's strips, 2 columns x 128 rows.  The far queries of
 // a band along the top or bottom border are a few rows of EVERY strip, so wider, shorter blocks were tried: 4 x 64 halves the
 // workgroups of such a band and 8 x 32 quarters them, but every region row is 2 / 6 cells wider and two / three times as many

@@ -54,6 +54,9 @@
 #endif
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
+#ifndef KS_FORWARD_MAX
+#define KS_FORWARD_MAX 1024         // the second launch hands its queries on to the fallback kernel when the main launch marked at most this many
+#endif
 #ifndef KS_MORE_OCC
 #define KS_MORE_OCC 4               // workgroups per CU of the second launch = its register budget (128; 13 registers spill).  The launch is bound
                                    // by the latency of its work items: C3, 40 px translation / 48 px contraction band: 4 per CU with 192 slots
@@ -93,7 +96,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                                            float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                            float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                            const KnnLists &ls, int r_init, int cap, int gx, int gy,
-                                           int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq) {
+                                           int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq,
+                                           bool forward = false) {
     constexpr bool SPLIT = MODE == 1, FARK = MODE == 2;
 #ifdef KS_STAMP2
     // diagnostics build (tools/more_stamp_probe.py): phase stamps of thread 0 of a second-launch work item, 10 ns units, far inside the fallback list
@@ -294,6 +298,22 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const int e = s_list[tid];
             cy = qy0 + (e & 0xff); cx = qx0 + ((e >> 8) & 0xf); r = (e >> 12) & 0xff; served = ((e >> 20) & 1) != 0; isfar = ((e >> 21) & 1) != 0;
         }
+        if (forward) {
+            // (workgroup-uniform) the whole launch has only a few marked queries: a work item here is a chain of ~25 us whatever
+            // its size, a round of the fallback kernel ~14 us for up to 4 096 queries -- they go onto its list, with the radius
+            // worked out so far as the hint (why = 1: start exactly there)
+            const unsigned long long pm = __ballot(mine);
+            if (pm != 0ull) {
+                const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
+                int base = 0;
+                if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
+                base = __shfl(base, first, 64);
+                const size_t qid = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
+                const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24)) ? (unsigned)min(max(r, 1), 63) << 24 : 0u;
+                if (mine) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)qid | hint | (1u << 30));
+            }
+            return;
+        }
         // every query pushes the chords of its disc onto the region rows it uses (as the main launch does per query row)
         if (mine && served) {
             int2 *s_w = reinterpret_cast<int2 *>(s_dyn);
@@ -355,9 +375,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     bool overflow = false;
     if (total > cap) {
         if (MODE == 0) {              // (workgroup-uniform) again in quarters: k_knn_strip_more
+            const int nfq = anyfar ? __syncthreads_count(isfar ? 1 : 0) : 0;
             if (tid == 0) {
                 ls.retry[1 + atomicAdd(&ls.retry[0], 1)] = lblk;
-                if (anyfar) ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk;
+                if (anyfar) { ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk; atomicAdd(knn_marked_count(ls), nfq); }
             }
             return;
         }
@@ -755,7 +776,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 atomicOr(ls.again + aoff, 1u << (cx & 31));
                 if (why == 0u) atomicOr(ls.grow + aoff, 1u << (cx & 31));
             }
-            if (to_more && tid == 0) ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk;
+            // (and the number of queries marked for it: with only a handful in the whole launch it hands them on to the fallback kernel)
+            const int nfq = (MODE == 0 && anyfar) ? __syncthreads_count(isfar ? 1 : 0) : 0;
+            if (to_more && tid == 0) { ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk; atomicAdd(knn_marked_count(ls), nlate + nfq); }
             const bool push = inpass && !live && !(late && to_more);
             const unsigned long long pm = __ballot(push);
             if (pm != 0ull) {
@@ -888,9 +911,12 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const Knn
                                          r_init, cap, gx, gy, ls.retry[1 + (w >> 2)], quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq);
         __syncthreads();
     }
+    // (only a few marked queries in the whole launch -- a B = 1 step with a dozen of them in three strips paid a full work item's
+    // 25 us for them: they are handed on to the fallback kernel, whose round takes them beside what it has anyway)
+    const bool forward = *knn_marked_count(ls) <= KS_FORWARD_MAX;
     for (int w = (int)blockIdx.x; w < nfar; w += (int)gridDim.x) {
         strip_body<KNN_FAR_WS, L1, NEXT, IWD, 2>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq);
+                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq, forward);
         __syncthreads();
     }
 }
