@@ -50,3 +50,7 @@ tx = [torch.from_numpy(np.stack([r[k] for r in raws])).to(dev) for k in range(4)
 cnti = torch.full((Bv,), Nv, dtype=torch.int32)
 t, ks = timed(lambda: ingest_events(tx[0], tx[1], tx[2], tx[3], cnti, (H, W), wl['nb']))
 print(f'ingest         {1e3 * t:.4f} ms  ' + ' '.join(f'{k}={v}' for k, v in ks.items()))
+from motionpriorcmax_amd import LossFactory  # noqa: E402
+L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+t, ks = timed(lambda: ingest_events(tx[0], tx[1], tx[2], tx[3], cnti, (H, W), wl['nb'], order_for=L))
+print(f'ingest ordered {1e3 * t:.4f} ms  ' + ' '.join(f'{k}={v}' for k, v in ks.items()))
