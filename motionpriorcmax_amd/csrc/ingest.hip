@@ -264,7 +264,7 @@ __device__ __forceinline__ int ing_key(const mpc_ingest_shape &s, const IngKey &
 __global__ __launch_bounds__(256) void k_ingest_keycount(const mpc_ingest_shape s, const IngLayout L, const IngKey k,
                                                          const float *__restrict__ x, const float *__restrict__ y,
                                                          const long long *__restrict__ t, const float *__restrict__ p,
-                                                         const int *__restrict__ counts, int *__restrict__ kcounts) {
+                                                         const int *__restrict__ counts, int *__restrict__ kcounts, int vec) {
     extern __shared__ int s_k[];
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int n = min(counts[b], s.N);
@@ -273,14 +273,17 @@ __global__ __launch_bounds__(256) void k_ingest_keycount(const mpc_ingest_shape 
     const double span = (double)(tmax - tmin);
     for (int i = tid; i < 2 * (k.NK + 1); i += 256) s_k[i] = 0;
     __syncthreads();
+    const int i0 = chunk * ING_CHUNK + tid * 4;
+    if (i0 < n) {
+        const IngQuad q = ing_load4(x, y, t, p, base, i0, n, vec);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = chunk * ING_CHUNK + tid * 4 + u;
-        if (i >= n) continue;
-        const int c = classify(x[base + i], y[base + i], p[base + i], s.H, s.W);
-        if (c == 0) continue;
-        const double tn = (double)(t[base + i] - tmin) / span;
-        atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, y[base + i], tn)], 1);
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u >= n) continue;
+            const int c = classify(q.x[u], q.y[u], q.p[u], s.H, s.W);
+            if (c == 0) continue;
+            const double tn = (double)(q.t[u] - tmin) / span;
+            atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, q.y[u], tn)], 1);
+        }
     }
     __syncthreads();
     for (int i = tid; i < 2 * (k.NK + 1); i += 256) {
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void k_ingest_scatter_ordered(const mpc_ingest
                                                                 const long long *__restrict__ t, const float *__restrict__ p,
                                                                 const int *__restrict__ counts, int M,
                                                                 const int *__restrict__ kcounts, const int *__restrict__ offsets,
-                                                                float *__restrict__ events, float *__restrict__ xytp) {
+                                                                float *__restrict__ events, float *__restrict__ xytp, int vec) {
     extern __shared__ int s_k[];
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int n = min(counts[b], s.N);
@@ -309,22 +312,39 @@ __global__ __launch_bounds__(256) void k_ingest_scatter_ordered(const mpc_ingest
         s_k[i] = offsets[o] + kcounts[o * L.nchunks + chunk];
     }
     __syncthreads();
+    const int i0 = chunk * ING_CHUNK + tid * 4;
+    if (i0 < n) {
+        const IngQuad q = ing_load4(x, y, t, p, base, i0, n, vec);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = chunk * ING_CHUNK + tid * 4 + u;
-        if (i >= n) continue;
-        const long long tv = t[base + i];
-        if (xytp != nullptr) {
-            const float tf = (float)(tv - tmin) / (float)(tmax - tmin);
-            reinterpret_cast<float4 *>(xytp)[base + i] = make_float4(x[base + i], y[base + i], tf, p[base + i]);
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i >= n) continue;
+            const long long tv = q.t[u];
+            if (xytp != nullptr) {
+                const float tf = (float)(tv - tmin) / (float)(tmax - tmin);
+                reinterpret_cast<float4 *>(xytp)[base + i] = make_float4(q.x[u], q.y[u], tf, q.p[u]);
+            }
+            const int c = classify(q.x[u], q.y[u], q.p[u], s.H, s.W);
+            if (c == 0) continue;
+            const double tn = (double)(tv - tmin) / span;
+            const int row = atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, q.y[u], tn)], 1);
+            float2 *e = reinterpret_cast<float2 *>(events + ((size_t)b * M + row) * 6);      // (24-byte rows: 8-byte aligned)
+            e[0] = make_float2(q.y[u], q.x[u]); e[1] = make_float2((float)tn, q.p[u]);
+            e[2] = make_float2((float)bin_index(tn, s.nb), 1.f);
         }
-        const int c = classify(x[base + i], y[base + i], p[base + i], s.H, s.W);
-        if (c == 0) continue;
-        const double tn = (double)(tv - tmin) / span;
-        const int row = atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, y[base + i], tn)], 1);
-        float *e = events + ((size_t)b * M + row) * 6;
-        e[0] = y[base + i]; e[1] = x[base + i]; e[2] = (float)tn; e[3] = p[base + i];
-        e[4] = (float)bin_index(tn, s.nb); e[5] = 1.f;
+    }
+    // this workgroup's share of the sample's padding rows (they stay last in their block; no memset of the tensor)
+    const int Mp = offsets[(size_t)(b * 2 + 1) * (k.NK + 1)];          // first row of the negative block = max_pos
+    const int tp = L.totals[b * 2], tn_ = L.totals[b * 2 + 1];
+    const int pad_p = 3 * (Mp - tp), pad_n = 3 * (M - Mp - tn_), pad = pad_p + pad_n;
+    if (pad > 0) {
+        const int per = (pad + (int)gridDim.x - 1) / (int)gridDim.x;
+        float2 *zp = reinterpret_cast<float2 *>(events + ((size_t)b * M + tp) * 6);
+        float2 *zn = reinterpret_cast<float2 *>(events + ((size_t)b * M + Mp + tn_) * 6);
+        const int j1 = min((chunk + 1) * per, pad);
+        for (int j = chunk * per + tid; j < j1; j += 256) {
+            if (j < pad_p) zp[j] = make_float2(0.f, 0.f); else zn[j - pad_p] = make_float2(0.f, 0.f);
+        }
     }
 }
 
@@ -434,8 +454,8 @@ extern "C" int mpc_ingest_scatter_ordered(const mpc_ingest_shape *s, const mpc_s
     hipStream_t st = (hipStream_t)stream;
     const int64_t M = (int64_t)max_pos + max_neg;
     const IngKey k{LL.n_cstrips, LL.cstrip_rows, loss->nb * LL.n_cstrips, loss->sp, loss->hq};
-    if (M > 0) {
-        const int e = mpc_zero_async(events, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows
+    if (M > 0 && s->N == 0) {
+        const int e = mpc_zero_async(events, (size_t)s->B * M * 6 * sizeof(float), st);     // padding rows only (else: the scatter kernel zeroes them)
         if (e) return e;
     }
     const IngLayout L = ing_layout(s, ws).L;
@@ -443,11 +463,11 @@ extern "C" int mpc_ingest_scatter_ordered(const mpc_ingest_shape *s, const mpc_s
     int *totals = kcounts + (size_t)2 * s->B * (k.NK + 1) * L.nchunks;
     const size_t lds = (size_t)2 * (k.NK + 1) * sizeof(int);
     if (s->N == 0) return mpc_zero_async(offsets, (size_t)s->B * 2 * (k.NK + 1) * sizeof(int32_t), st);
-    MPC_LAUNCH(k_ingest_keycount, dim3(L.nchunks, s->B), dim3(256), lds, st, *s, L, k, x, y, reinterpret_cast<const long long *>(t_us), p, counts, kcounts);
+    MPC_LAUNCH(k_ingest_keycount, dim3(L.nchunks, s->B), dim3(256), lds, st, *s, L, k, x, y, reinterpret_cast<const long long *>(t_us), p, counts, kcounts, ing_vec(s, x, y, t_us, p));
     MPC_CHECK_LAUNCH();
     if ((rc = mpc_evo_scans(loss, k.NCS, k.CSR, kcounts, totals, offsets, L.nchunks, st))) return rc;
     MPC_LAUNCH(k_ingest_scatter_ordered, dim3(L.nchunks, s->B), dim3(256), lds, st, *s, L, k, x, y, reinterpret_cast<const long long *>(t_us), p,
-               counts, (int)M, kcounts, (const int *)offsets, events, xytp);
+               counts, (int)M, kcounts, (const int *)offsets, events, xytp, ing_vec(s, x, y, t_us, p));
     MPC_CHECK_LAUNCH();
     return 0;
 }

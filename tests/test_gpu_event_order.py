@@ -156,10 +156,18 @@ def test_offsets_are_checked():
     bad['event_offsets'] = ordered['event_offsets'].to(torch.int64)
     with pytest.raises(ValueError, match='event_offsets'):
         L.calc(traj.to(dev), times.to(dev), bad)
-    # a table that does not belong to the tensor (wild values): wrong gradient, but no fault and a finite result
-    wild = dict(ordered); wild['event_offsets'] = torch.randint(-10**6, 10**6, ordered['event_offsets'].shape, dtype=torch.int32, device=dev)
+    # a table that does not belong to the tensor (wild values): wrong results, but no fault.  (Seeded: one table in twenty makes
+    # the forward drop every event -- an infinite loss, which is what the reference returns for an empty image too; the unseeded
+    # draw of rounds 2-3 made this test fail at that rate.)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    wild = dict(ordered); wild['event_offsets'] = torch.randint(-10**6, 10**6, ordered['event_offsets'].shape, dtype=torch.int32, device=dev, generator=gen)
     l, g, _ = _step(L, traj.to(dev), times.to(dev), wild)
     assert torch.isfinite(g).all()
+    for seed in (193, 250):                      # two of the tables that empty the image: the call still returns
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        wild['event_offsets'] = torch.randint(-10**6, 10**6, ordered['event_offsets'].shape, dtype=torch.int32, device=dev, generator=gen)
+        l, g, _ = _step(L, traj.to(dev), times.to(dev), wild)
+        assert g.shape == traj.shape
     # num_tref > 1 has no bucketed layout
     L2 = LossFactory.get_loss_calculator('FOCUS', _cfg(shape, nb, num_tref=3, scale_iwe_by_dt=False, polarity_aware_batching=False))
     with pytest.raises(ValueError, match='bucketed'):
