@@ -4,7 +4,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out
 R=${R:-r04}
-python bench.py > $O/${R}_bench_C3.json 2> $O/${R}_bench_err.log; tail -c 400 $O/${R}_bench_C3.json
 for wl in C3 C2 C4; do
   tools/sq_profile.sh ${R}_$wl bench.py --workload $wl --also "" --no-cpu-baseline --no-hip-graph --no-realistic --no-nondefault --steps 10 > /dev/null 2>&1
   python3 tools/sq_to_json.py $O/${R}_${wl}_sq.csv $O/${R}_${wl}_kstats.csv $O/${R}_sq_$wl.json > /dev/null
@@ -18,3 +17,10 @@ for wl in C3 C2 C4; do
   rm -rf $O/pf_$wl $O/pw_$wl
 done
 rm -rf $O/cal_f $O/cal_w
+# the bench line LAST, with this run's summaries in profiles/ of the box's copy of the tree: its roofline block quotes them (kernel
+# stats, SQ counters of the library that is loaded, PMC traffic)
+for wl in C3 C2 C4; do
+  cp $O/${R}_${wl}_kstats.csv profiles/${R}_rocprofv3_kernel_stats_${wl}.csv; cp $O/${R}_${wl}_sq.csv profiles/${R}_sq_${wl}.csv
+  cp $O/${R}_sq_${wl}.json profiles/${R}_sq_${wl}.json; cp $O/traffic_${wl}.json profiles/traffic_${wl}.json
+done
+python bench.py > $O/${R}_bench_C3.json 2> $O/${R}_bench_err.log; tail -c 400 $O/${R}_bench_C3.json
