@@ -25,9 +25,9 @@
 //     slots at the K-th level are noted in a bit mask and ranked afterwards by exact (distance, index).
 // A query the fast path cannot serve (no square up to KNN_RCAP cells holds enough points: the inside of an emptied band;
 // fewer than K candidates below the ring bound after all; more slots than the registers hold; a strip whose points overflow
-// the staging area even in quarters) is appended to a list and searched by k_knn_fallback -- one wavefront per query while
-// the list is short, one thread per query when it is long: the result is the exact K-nearest set for any input, ties to
-// the lowest index.
+// the staging area even in quarters) is marked for the second launch (k_knn_strip_more: radii up to KNN_RFAR, chord-shaped
+// regions, 192 slots) or appended to a list and searched by k_knn_fallback, one wavefront per query: the result is the exact
+// K-nearest set for any input, ties to the lowest index.
 #include "knn_device.h"
 #include "ev_count_device.h"
 #include <stdlib.h>
@@ -922,15 +922,12 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const Knn
 }
 
 // ------------------------------------------------------------------------------------------
-// The queries the strip kernel could not serve.  Two forms, chosen by the length of the list:
-//   * short list (white-noise flows: one query in ten thousand, scattered): ONE WAVEFRONT per query -- a thread per query
-//     would spend ~100 us in dependent global loads.  The lanes take the rows of the query's search region, then its
-//     candidates (up to 64 * KS_FB_SLOTS of them), and the K-th key is found by a bitwise search with ballots;
-//   * long list (a flow field that emptied a band along an image border: every query of the band, up to a fifth of all):
-//     ONE THREAD per query, 64 neighbouring queries per wavefront, the generic two-scan search of knn_device.h on the global
-//     arrays -- 17 x fewer instructions per query than a wavefront each, and the lanes of a wavefront walk similar regions.
-// Both start from a radius read off the summed-area table and look only at the cells of each row that can hold a point
-// below the ring bound (a band query's neighbours lie in a thin segment of a large disc).
+// The queries the strip kernel could not serve: ONE WAVEFRONT per query -- a thread per query spends ~100 us in dependent global
+// loads (measured in round 4: 5-7 ns per query against ~3.5).  The lanes take the rows of the query's search region, then its
+// candidates (up to 64 * KS_FB_SLOTS of them; more: rows and candidates in rounds of 64, those below the ring bound compacted in
+// LDS), and the K-th key is found by a bitwise search with ballots.  The search starts from the radius the strip kernel tried (hint in
+// the list entry) or from one read off the summed-area table, and looks only at the cells of each row that can hold a point below
+// the ring bound (a band query's neighbours lie in a thin segment of a large disc).
 // With `far` (the backward is the tile gather) every query served here goes on the far list of its (sample, bin), is flagged
 // KNN_FAR_FLAG and stays out of the tile maxima: k_knn_bwd_far computes its gradient (knn.hip).
 // grid: KS_FB_BLOCKS workgroups (the list length is only known on the device), 256 threads
