@@ -794,6 +794,44 @@ def main():
             also['non_default_configs'] = nd
         except Exception as e:
             also['non_default_configs'] = {'error': repr(e)[:200]}
+        # UNPINNED extension: the per-event continuous-time basis warp (no LUT, no KNN) on the headline's events and coefficients
+        try:
+            if args.no_nondefault:
+                raise RuntimeError('skipped (--no-nondefault)')
+            from motionpriorcmax_amd import LossFactory as _LF2
+            kb = wl['k'] if wl['k'] <= 5 else 3
+            evp, npp, _, tmp_ = synth_inputs(wl, seed=1)
+            gpe = torch.Generator().manual_seed(8)
+            cgrid = (torch.randn(wl['B'], 1, 2 * kb, H, W, generator=gpe) * (3.0 if kb == 1 else 1.0)).to(dev).requires_grad_(True)
+            Lp = _LF2.get_loss_calculator('FOCUS', loss_config(wl))
+            bp = Lp.order_events({'events': evp.to(dev), 'num_pos_events': npp})      # (bucket-ordered rows: the backward without global atomics)
+
+            def _pe():
+                l_, _, _ = Lp.calc_per_event_basis(cgrid, 0.41, bp, kb)
+                l_.backward()
+                cgrid.grad = None
+            for _ in range(4):
+                _pe()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                _pe()
+            torch.cuda.synchronize()
+            tpe = (time.perf_counter() - t0) / 10
+            nvalid = float(evp[..., 5].sum())
+            with ops.KernelTimer() as ktp:
+                for _ in range(5):
+                    _pe()
+            kus = sum(v['total_us'] for v in ktp.summary().values()) / 5
+            also['per_event_basis'] = {'ms_per_step': round(1e3 * tpe, 4), 'value': round(nvalid / tpe / 1e6, 1), 'unit': 'Mevents/s',
+                                       'library_kernels_us_per_step': round(kus, 1),
+                                       'note': 'UNPINNED extension (no reference code): every event warped with the motion basis at its own '
+                                               'timestamp and the coefficients of its tile, no flow LUT and no KNN (mpc_pe_warp, the vote / blur / '
+                                               'objective kernels, mpc_pe_grad_ordered on bucket-ordered rows); the rest of the step is torch: the '
+                                               'tile coefficients sliced out of the dense [B,1,2k,H,W] grid and its backward, the smoothness field'}
+            del Lp, cgrid, bp
+        except Exception as e:
+            also['per_event_basis'] = {'error': repr(e)[:200]}
         # next row 8f-2: voxel-grid builder on the same window shape (network input; not part of `value`)
         try:
             from motionpriorcmax_amd.utils import voxel_grids

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 103
+#define MPC_VERSION 104
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -168,6 +168,33 @@ int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C, floa
  * add_term: same shape as the LUT or NULL (used to fold in the smoothness gradient of
  * mpc_lut_smooth).  grad_out: device scalar or NULL (= 1).  Must follow mpc_event_splat_fwd on the
  * same workspace (the LDS-tiled path reuses the records that call left there).                 */
+/* ---- UNPINNED EXTENSION (no reference code: the reference gathers a binned flow LUT, focus.py:182-195): gradient of the
+ * objective with respect to the warped position of every event, i.e. autograd of create_iwe (event_image_converter.py:333-391)
+ * through `warped = differences + events[..., :2]` (focus.py:191), for rows whose (y, x) columns hold positions that are warped
+ * already (s->flags must carry MPC_F_NO_WARP; num_tref == 1).  grad_pos[b][i][:] = grad_out * scal[GCOEF] * w * bilinear
+ * gradient of grad_iwe at the row's position, 0 for rows of weight 0.  Follows mpc_event_splat_fwd / mpc_contrast_fwd /
+ * mpc_finalize of the same rows.  Used by FocusLoss.calc_per_event_basis (per-event continuous-time basis warp).          */
+int mpc_event_pos_grad(const mpc_shape *s, const float *events, const float *t_ref, const float *grad_iwe,
+                       const float *scal, const float *grad_out, float *grad_pos, void *stream);
+/* Same extension, fused: mpc_pe_warp writes the rows with the per-event continuous-time basis warp applied --
+ *   rows_out[b][i] = (y + sum_j coef[cell][0][j] phi[b][i][j], x + sum_j coef[cell][1][j] phi[b][i][j], t, p, cell, valid),
+ * cell = the LUT cell of the event's own position (focus.py:186-187), coef_rows [B*hq*wq][2][k] the tile coefficients
+ * (trajectories.py:15-52), phi [B][M][k] = basis_j(t_ref) - basis_j(t_event) (basis.py:18-31), or phi = NULL: the polynomial basis
+ * t^(j+1) (basis.py:26-27) worked out in the kernels from t_ref[0] and the rows' time column, k <= 8 -- for mpc_event_splat_fwd with
+ * MPC_F_NO_WARP; mpc_pe_grad is its backward: grad_coef_rows (zeroed here) += phi * d objective / d warped position, with float
+ * atomics (the gradient of this extension is not bitwise reproducible).                                                    */
+int mpc_pe_warp(const mpc_shape *s, const float *events, const float *coef_rows, const float *phi, int32_t k,
+                const float *t_ref, float *rows_out, void *stream);
+int mpc_pe_grad(const mpc_shape *s, const float *rows, const float *phi, int32_t k, const float *t_ref, const float *grad_iwe,
+                const float *scal, const float *grad_out, float *grad_coef_rows, void *stream);
+/* mpc_pe_grad for bucket-ordered events (mpc_event_bucket_order / mpc_ingest_scatter_ordered and their `offsets` table): no
+ * global atomics -- every LUT strip of a sample accumulates in LDS fixed point (bitwise reproducible) and is written once.
+ * `split` workgroups share the row ranges of a strip and write partial results: grad_coef_rows is [split][B*hq*wq][2][k], to be
+ * summed over its first axis.  MPC_E_UNSUPPORTED if a strip's [cell][2][k] accumulators exceed the LDS (then: mpc_pe_grad).  */
+int mpc_pe_grad_ordered(const mpc_shape *s, const float *rows, const int32_t *offsets, const float *phi, int32_t k,
+                        const float *t_ref, const float *grad_iwe, const float *scal, const float *grad_out,
+                        float *grad_coef_rows, int32_t split, void *stream);
+
 int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *flow_lut,
                         const float *t_ref, const float *grad_iwe, const float *scal,
                         const float *grad_out, float *grad_flow_lut, const float *add_term,

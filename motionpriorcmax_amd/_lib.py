@@ -30,7 +30,7 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_fail_list_offset', 'mpc_knn_list_offsets', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
            'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
-           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add']
+           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add', 'mpc_event_pos_grad', 'mpc_pe_warp', 'mpc_pe_grad', 'mpc_pe_grad_ordered']
 
 
 class Shape(ctypes.Structure):
@@ -92,6 +92,10 @@ def lib():
     L.mpc_lut_smooth.argtypes = [sp, vp, i32, i32, f32, vp, vp, vp]
     L.mpc_finalize.argtypes = [sp, i32, i32, f32, vp, vp, vp]
     L.mpc_event_splat_bwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_event_pos_grad.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
+    L.mpc_pe_warp.argtypes = [sp, vp, vp, vp, ctypes.c_int32, vp, vp, vp]
+    L.mpc_pe_grad.argtypes = [sp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
+    L.mpc_pe_grad_ordered.argtypes = [sp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
     L.mpc_scale.argtypes = [vp, vp, vp, i64, vp]
     fb = ctypes.POINTER(FocusBuffers)
     L.mpc_focus_fwd.argtypes = [sp, fb, vp, vp]
@@ -127,8 +131,8 @@ def lib():
     L.mpc_pool2_bwd_add.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.mpc_profile_start.argtypes = []
     L.mpc_profile_stop.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(f32), i32]
-    if L.mpc_version() != 103:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (103)')
+    if L.mpc_version() != 104:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (104)')
     _lib = L
     return L
 

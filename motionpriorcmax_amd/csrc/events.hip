@@ -168,6 +168,38 @@ __global__ __launch_bounds__(256) void k_splat_bwd_atomic(const mpc_shape s,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// UNPINNED EXTENSION (default off, `FocusLoss.calc_per_event_basis`): gradient of the objective with respect to the WARPED
+// POSITION of every event -- what autograd computes for `warped = differences + events[..., :2]` (focus.py:191) through
+// create_iwe (event_image_converter.py:333-391).  The rows carry positions that are warped already (MPC_F_NO_WARP): a per-event
+// continuous-time warp (the motion basis evaluated at the event's own timestamp, no flow LUT and no KNN -- BASELINE.json's
+// north_star; the reference has none, focus.py:182-195 gathers a binned LUT) is formed by the caller in plain torch, whose
+// autograd carries grad_pos on to the coefficient grid.  One thread per event row, no atomics.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_event_pos_grad(const mpc_shape s, const float *__restrict__ events,
+                                                        const float *__restrict__ t_ref, const float *__restrict__ gimg,
+                                                        const float *__restrict__ scal, const float *__restrict__ grad_out,
+                                                        float2 *__restrict__ gpos) {
+    const EvParams p = make_params(s);
+    const float coef = scal[MPC_SCAL_GCOEF] * (grad_out ? grad_out[0] : 1.f);
+    const float tref = (p.flags & MPC_F_SCALE_BY_DT) ? t_ref[0] : 0.f;
+    const size_t total = (size_t)p.B * p.M;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < total; row += (size_t)gridDim.x * 256) {
+        const int b = (int)(row / p.M), i = (int)(row - (size_t)b * p.M);
+        float e[6];
+        load_event(events, row, e);
+        const int pol = (p.P == 2 && i >= p.Mp) ? 1 : 0;
+        Warped o;
+        float2 g = make_float2(0.f, 0.f);
+        if (warp_event_with(p, e, make_float2(0.f, 0.f), tref, o)) {
+            float gy, gx;
+            event_pos_grad(p, o, gimg + ((size_t)b * p.P + pol) * p.H * p.W, gy, gx);
+            g = make_float2(coef * gy, coef * gx);
+        }
+        gpos[row] = g;
+    }
+}
+
 // ==========================================================================================
 // v1: LDS-tiled path (num_tref == 1)
 //
@@ -811,6 +843,255 @@ int mpc_event_splat_bwd_job(const mpc_shape *s, const float *events, const int32
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     MPC_LAUNCH(k_splat_bwd_atomic, dim3(grid), dim3(256), 0, st, *s, events, flow_lut, t_ref,
                        grad_iwe, scal, grad_out, grad_flow_lut);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---- UNPINNED EXTENSION, fused form (FocusLoss.calc_per_event_basis): the per-event continuous-time basis warp itself and the
+// chain from the position gradient back to the tile coefficients, one pass over the events each.
+//   k_pe_warp : rows_out[b][i] = (y + sum_k c[cell][0][k] phi[b][i][k], x + sum_k c[cell][1][k] phi[b][i][k], t, p, cell, valid)
+//               cell = LUT cell of the event's own position (focus.py:186-187), kept in column 4 (its bits) for the backward --
+//               with MPC_F_NO_WARP nothing else reads that column; coef [B*hq*wq][2][k], phi [B][M][k] (basis_k(t_ref) - basis_k(t))
+//   k_pe_grad : grad_coef[cell][d][k] += phi[b][i][k] * d objective / d warped position_d  (float atomics: the gradient of this
+//               extension is not bitwise reproducible; the forward is)
+// phi[j] = basis_j(t_ref) - basis_j(t), j < k, from the tensor, or -- phi == nullptr: the polynomial basis t^(j+1) (basis.py:26-27) --
+// worked out here (one multiply per order instead of 4 k bytes of traffic per event and kernel)
+template <int KB>
+__device__ __forceinline__ void pe_phi(const float *__restrict__ phi, size_t row, int k, float t, float tref, float *out /* [KB or k <= 8] */) {
+    const int kk = KB > 0 ? KB : k;
+    if (phi != nullptr) { for (int j = 0; j < kk; ++j) out[j] = phi[row * k + j]; return; }
+    float a = tref, c = t;
+    for (int j = 0; j < kk; ++j) { out[j] = a - c; a *= tref; c *= t; }
+}
+#define PE_KMAX 8          // orders held in registers (more: the generic instantiation reads phi / recomputes per use)
+
+template <int KB>
+__global__ __launch_bounds__(256) void k_pe_warp(const mpc_shape s, const float *__restrict__ events, const float *__restrict__ coef,
+                                                 const float *__restrict__ phi, int k, const float *__restrict__ t_ref,
+                                                 float *__restrict__ rows_out) {
+    const EvParams p = make_params(s);
+    const float tref = t_ref ? t_ref[0] : 0.f;
+    const size_t total = (size_t)p.B * p.M;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < total; row += (size_t)gridDim.x * 256) {
+        const int b = (int)(row / p.M);
+        float e[6];
+        load_event(events, row, e);
+        const int iy = min(max((int)floorf(mpc_div_sp(e[0], p.sp)), 0), p.hq - 1), ix = min(max((int)floorf(mpc_div_sp(e[1], p.sp)), 0), p.wq - 1);
+        const int cell = (b * p.hq + iy) * p.wq + ix;
+        const float *c = coef + (size_t)cell * 2 * k;
+        float fy = 0.f, fx = 0.f;
+        float ph[KB > 0 ? KB : PE_KMAX];
+        pe_phi<KB>(phi, row, min(k, PE_KMAX), e[2], tref, ph);
+        if (KB > 0) {
+#pragma unroll
+            for (int j = 0; j < KB; ++j) { fy += c[j] * ph[j]; fx += c[KB + j] * ph[j]; }
+        } else {
+            for (int j = 0; j < k; ++j) { const float f = j < PE_KMAX ? ph[j] : phi[row * k + j]; fy += c[j] * f; fx += c[k + j] * f; }
+        }
+        float2 *o = reinterpret_cast<float2 *>(rows_out + row * 6);
+        o[0] = make_float2(e[0] + fy, e[1] + fx);
+        o[1] = make_float2(e[2], e[3]);
+        o[2] = make_float2(__int_as_float(cell), e[5]);
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256) void k_pe_grad(const mpc_shape s, const float *__restrict__ rows, const float *__restrict__ phi, int k,
+                                                 const float *__restrict__ t_ref, const float *__restrict__ gimg,
+                                                 const float *__restrict__ scal, const float *__restrict__ grad_out,
+                                                 float *__restrict__ gcoef) {
+    const EvParams p = make_params(s);
+    const float coef = scal[MPC_SCAL_GCOEF] * (grad_out ? grad_out[0] : 1.f);
+    const float tref = t_ref[0];
+    const size_t total = (size_t)p.B * p.M;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < total; row += (size_t)gridDim.x * 256) {
+        const int b = (int)(row / p.M), i = (int)(row - (size_t)b * p.M);
+        float e[6];
+        load_event(rows, row, e);
+        const int pol = (p.P == 2 && i >= p.Mp) ? 1 : 0;
+        Warped o;
+        if (!warp_event_with(p, e, make_float2(0.f, 0.f), tref, o)) continue;
+        float gy, gx;
+        event_pos_grad(p, o, gimg + ((size_t)b * p.P + pol) * p.H * p.W, gy, gx);
+        gy *= coef; gx *= coef;
+        if (gy == 0.f && gx == 0.f) continue;
+        const int cell = __float_as_int(e[4]);
+        float *g = gcoef + (size_t)cell * 2 * k;
+        const int kk = KB > 0 ? KB : k;
+        float ph[KB > 0 ? KB : PE_KMAX];
+        pe_phi<KB>(phi, row, min(k, PE_KMAX), e[2], tref, ph);
+        for (int j = 0; j < kk; ++j) { const float f = j < PE_KMAX ? ph[j] : phi[row * k + j]; atomicAdd(g + j, f * gy); atomicAdd(g + kk + j, f * gx); }
+    }
+}
+
+//   k_pe_accum: the same gradient WITHOUT global atomics, for bucket-ordered events (mpc_event_bucket_order / ingest: the rows of a
+//               (sample, polarity, bin, LUT strip) are contiguous, `offsets`): one workgroup per (sample, LUT strip) walks the
+//               2 * nb row ranges of its strip, gathers the adjoint-image taps of every row and adds phi * gradient to the strip's
+//               [cell][2][k] accumulators in LDS -- 64-bit fixed point like k_lut_accum: integer sums, bitwise reproducible -- and
+//               writes every cell of the strip once (global float atomics ran at ~20 G/s on this chip: 0.83 ms for the 17 M of a C3 step)
+#define PE_NT 1024
+#define PE_NIF 4
+template <int KB>
+__global__ __launch_bounds__(PE_NT) void k_pe_accum(const mpc_shape s, int CSR, int NCS, int SPLIT, const int *__restrict__ offsets,
+                                                    const float *__restrict__ rows, const float *__restrict__ phi, int k,
+                                                    const float *__restrict__ t_ref, const float *__restrict__ gimg,
+                                                    const float *__restrict__ scal, const float *__restrict__ grad_out,
+                                                    float *__restrict__ gcoef) {
+    extern __shared__ unsigned long long s_pacc[];
+    __shared__ int s_r0[2 * 64 + 1], s_pre[2 * 64 + 1];          // first row / running count of the 2 * nb ranges (nb <= 64)
+    const EvParams p = make_params(s);
+    const int tid = threadIdx.x, kk = KB > 0 ? KB : k;
+    // (SPLIT workgroups per (sample, strip), each with every SPLIT-th of the strip's row ranges and a partial output of its own:
+    // B * NCS workgroups -- 98 at the DSEC batch -- left most of the CUs idle)
+    const int part = blockIdx.x % SPLIT, bs = blockIdx.x / SPLIT;
+    const int b = bs / NCS, cst = bs - b * NCS;
+    const int crow0 = cst * CSR, crow1 = min(crow0 + CSR, p.hq), ncell = (crow1 - crow0) * p.wq;
+    const int cell0 = (b * p.hq + crow0) * p.wq;
+    const int NK = p.nb * NCS, nrange = 2 * p.nb;
+    for (int i = tid; i < ncell * 2 * kk; i += PE_NT) s_pacc[i] = 0ull;
+    if (tid == 0) {
+        int run = 0;
+        for (int j = 0; j < nrange; ++j) {
+            const int pol = j / p.nb, it = j - pol * p.nb;
+            const int *o = offsets + (size_t)(b * 2 + pol) * (NK + 1) + it * NCS + cst;
+            // (a table that does not belong to the tensor: clamp into the sample, never read outside it)
+            const int r0 = min(max(o[0], 0), p.M), r1 = (j % SPLIT == part) ? min(max(o[1], r0), p.M) : r0;
+            s_r0[j] = r0; s_pre[j] = run; run += r1 - r0;
+        }
+        s_pre[nrange] = run;
+    }
+    __syncthreads();
+    const int n = s_pre[nrange];
+    const float tref = t_ref[0];
+    for (int q0 = tid; q0 < n; q0 += PE_NIF * PE_NT) {
+        float e[PE_NIF][6];
+        size_t grow[PE_NIF];
+        bool on[PE_NIF];
+        int pol[PE_NIF];
+#pragma unroll
+        for (int u = 0; u < PE_NIF; ++u) {
+            const int q = q0 + u * PE_NT;
+            on[u] = q < n;
+            int j = 0;
+            if (on[u]) { int lo = 0, hi = nrange; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_pre[mid] <= q) lo = mid; else hi = mid; } j = lo; }
+            const int row = on[u] ? s_r0[j] + (q - s_pre[j]) : 0;
+            pol[u] = (p.P == 2) ? (row >= p.Mp ? 1 : 0) : 0;
+            grow[u] = (size_t)b * p.M + row;
+            load_event(rows, grow[u], e[u]);
+        }
+        float gy[PE_NIF], gx[PE_NIF];
+#pragma unroll
+        for (int u = 0; u < PE_NIF; ++u) {
+            Warped o;
+            gy[u] = gx[u] = 0.f;
+            if (on[u] && warp_event_with(p, e[u], make_float2(0.f, 0.f), tref, o))
+                event_pos_grad(p, o, gimg + ((size_t)b * p.P + pol[u]) * p.H * p.W, gy[u], gx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < PE_NIF; ++u) {
+            const int lc = __float_as_int(e[u][4]) - cell0;
+            if (!on[u] || lc < 0 || lc >= ncell || (gy[u] == 0.f && gx[u] == 0.f)) continue;
+            float ph[KB > 0 ? KB : PE_KMAX];
+            pe_phi<KB>(phi, grow[u], min(k, PE_KMAX), e[u][2], tref, ph);
+            unsigned long long *a = s_pacc + (size_t)lc * 2 * kk;
+            for (int j = 0; j < kk; ++j) {
+                const float f = j < PE_KMAX ? ph[j] : phi[grow[u] * k + j];
+                atomicAdd(a + j, (unsigned long long)ev_to_fixed(f * gy[u]));
+                atomicAdd(a + kk + j, (unsigned long long)ev_to_fixed(f * gx[u]));
+            }
+        }
+    }
+    __syncthreads();
+    const float coef = scal[MPC_SCAL_GCOEF] * (grad_out ? grad_out[0] : 1.f);
+    float *dst = gcoef + ((size_t)part * p.B * p.hq * p.wq + cell0) * 2 * kk;
+    for (int i = tid; i < ncell * 2 * kk; i += PE_NT) dst[i] = coef * ev_from_fixed((long long)s_pacc[i]);
+}
+
+extern "C" int mpc_pe_warp(const mpc_shape *s, const float *events, const float *coef_rows, const float *phi, int32_t k,
+                           const float *t_ref, float *rows_out, void *stream) {
+    MPC_CHECK_ARG(s && coef_rows && (phi || t_ref) && rows_out && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG(k >= 1 && k <= 64 && (phi || k <= PE_KMAX), MPC_E_SHAPE, "1 <= num_basis <= 64 (<= 8 for the built-in polynomial basis)");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const int64_t total = (int64_t)s->B * s->M;
+    if (total == 0) return 0;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 1) MPC_LAUNCH(k_pe_warp<1>, dim3(grid), dim3(256), 0, st, *s, events, coef_rows, phi, k, t_ref, rows_out);
+    else if (k == 3) MPC_LAUNCH(k_pe_warp<3>, dim3(grid), dim3(256), 0, st, *s, events, coef_rows, phi, k, t_ref, rows_out);
+    else MPC_LAUNCH(k_pe_warp<0>, dim3(grid), dim3(256), 0, st, *s, events, coef_rows, phi, k, t_ref, rows_out);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_pe_grad(const mpc_shape *s, const float *rows, const float *phi, int32_t k, const float *t_ref, const float *grad_iwe,
+                           const float *scal, const float *grad_out, float *grad_coef_rows, void *stream) {
+    MPC_CHECK_ARG(s && (phi || t_ref) && grad_iwe && scal && grad_coef_rows && (rows || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) && s->T == 1, MPC_E_UNSUPPORTED, "mpc_pe_grad takes the rows of mpc_pe_warp (MPC_F_NO_WARP), num_tref == 1");
+    MPC_CHECK_ARG(t_ref, MPC_E_NULL, "t_ref is null");
+    MPC_CHECK_ARG(k >= 1 && k <= 64 && (phi || k <= PE_KMAX), MPC_E_SHAPE, "1 <= num_basis <= 64 (<= 8 for the built-in polynomial basis)");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int e0 = mpc_zero_async(grad_coef_rows, (size_t)s->B * s->hq * s->wq * 2 * k * sizeof(float), st);
+    if (e0) return e0;
+    const int64_t total = (int64_t)s->B * s->M;
+    if (total == 0) return 0;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (k == 1) MPC_LAUNCH(k_pe_grad<1>, dim3(grid), dim3(256), 0, st, *s, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
+    else if (k == 3) MPC_LAUNCH(k_pe_grad<3>, dim3(grid), dim3(256), 0, st, *s, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
+    else MPC_LAUNCH(k_pe_grad<0>, dim3(grid), dim3(256), 0, st, *s, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_pe_grad_ordered(const mpc_shape *s, const float *rows, const int32_t *offsets, const float *phi, int32_t k,
+                                   const float *t_ref, const float *grad_iwe, const float *scal, const float *grad_out,
+                                   float *grad_coef_rows, int32_t split, void *stream) {
+    MPC_CHECK_ARG(s && offsets && (phi || t_ref) && grad_iwe && scal && grad_coef_rows && (rows || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) && s->T == 1, MPC_E_UNSUPPORTED, "mpc_pe_grad_ordered takes the rows of mpc_pe_warp (MPC_F_NO_WARP), num_tref == 1");
+    MPC_CHECK_ARG(t_ref, MPC_E_NULL, "t_ref is null");
+    MPC_CHECK_ARG(k >= 1 && k <= 64 && (phi || k <= PE_KMAX) && s->nb <= 64, MPC_E_SHAPE, "1 <= num_basis <= 64 (<= 8 built-in polynomial), num_bins <= 64");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    if (s->B == 0) return 0;
+    const mpc_ws_layout L = mpc_layout(s);
+    MPC_CHECK_ARG(L.n_cstrips > 0, MPC_E_UNSUPPORTED, "no bucketed event layout for this shape");
+    const size_t lds = (size_t)L.cstrip_rows * s->wq * 2 * k * 8;
+    MPC_CHECK_ARG(lds <= 150 * 1024, MPC_E_UNSUPPORTED, "a LUT strip's accumulators do not fit the LDS (use mpc_pe_grad)");
+    hipStream_t st = (hipStream_t)stream;
+    static mpc_device_once attr_once;
+    if (attr_once.need()) {
+        // (these kernels have 1 KB of static LDS of their own: the cap of set_max_lds_ev would pass the CU's 160 KB)
+        const void *fns[3] = {(const void *)k_pe_accum<1>, (const void *)k_pe_accum<3>, (const void *)k_pe_accum<0>};
+        for (const void *fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+            if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
+        }
+        attr_once.mark();
+    }
+    MPC_CHECK_ARG(split >= 1 && split <= 16, MPC_E_SHAPE, "1 <= split <= 16");
+    const dim3 grid(s->B * L.n_cstrips * split);
+    if (k == 1) MPC_LAUNCH(k_pe_accum<1>, grid, dim3(PE_NT), lds, st, *s, L.cstrip_rows, L.n_cstrips, split, offsets, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
+    else if (k == 3) MPC_LAUNCH(k_pe_accum<3>, grid, dim3(PE_NT), lds, st, *s, L.cstrip_rows, L.n_cstrips, split, offsets, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
+    else MPC_LAUNCH(k_pe_accum<0>, grid, dim3(PE_NT), lds, st, *s, L.cstrip_rows, L.n_cstrips, split, offsets, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
+    MPC_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mpc_event_pos_grad(const mpc_shape *s, const float *events, const float *t_ref, const float *grad_iwe,
+                                  const float *scal, const float *grad_out, float *grad_pos, void *stream) {
+    MPC_CHECK_ARG(s && grad_iwe && scal && grad_pos && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
+    MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) && s->T == 1, MPC_E_UNSUPPORTED, "mpc_event_pos_grad takes rows with warped positions (MPC_F_NO_WARP), num_tref == 1");
+    MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    const int64_t total = (int64_t)s->B * s->M;
+    if (total == 0) return 0;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    MPC_LAUNCH(k_event_pos_grad, dim3(grid), dim3(256), 0, (hipStream_t)stream, *s, events, t_ref, grad_iwe, scal, grad_out,
+               reinterpret_cast<float2 *>(grad_pos));
     MPC_CHECK_LAUNCH();
     return 0;
 }

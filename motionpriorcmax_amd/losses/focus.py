@@ -107,6 +107,74 @@ class FocusLoss(base.TrajectoryLossBase):
         out['events'], out['event_offsets'] = ev, offs
         return out
 
+    def calc_per_event_basis(self, coeff_grid, t_ref, batch, num_basis, basis_type='polynomial', basis_network=None, tile_size=None,
+                             fused=True):
+        """UNPINNED EXTENSION -- no reference code exists for it (the reference warps through a binned, KNN-inverted flow LUT,
+        focus.py:115-195); BASELINE.json's north_star names it: the per-event continuous-time warp.
+
+        Every event is warped with the motion basis evaluated at ITS OWN timestamp and the coefficients of the tile it lies in:
+            warped = (y, x) + sum_k c_k[tile(y, x)] * (basis_k(t_ref) - basis_k(t_event))
+        i.e. trajectory_at(t_ref) - trajectory_at(t_event) of the trajectory that STARTS at the event's tile (utils/trajectories.py,
+        utils/basis.py) -- no time bins, no nearest-neighbour look-up table; then the reference's weights, bilinear vote, blur and
+        objective (focus.py:197-230, event_image_converter.py:333-391, loss.py:4-27) on the HIP kernels.  The smoothness term is
+        the reference's Charbonnier term on the same flow sampled at the num_bins bin mid-times.
+
+        coeff_grid [B, 1, 2k, H, W] (first k channels y, next k x: the network's dense output, trajectory_net.py:142-161),
+        t_ref scalar tensor / float in [0, 1], batch as for `calc`.  Returns the triple of `calc`.  Differentiable w.r.t. coeff_grid
+        (not w.r.t. the weights of a 'learned' basis: the basis values enter as constants).  With a bucket-ordered batch
+        (`order_events` / `ingest_events(order_for=...)`: `event_offsets`) the backward accumulates per LUT strip in LDS fixed point
+        and is bitwise reproducible; without the table it uses global float atomics (slow: ~20 G atomics/s, and not
+        reproducible).  fused=False: the same in plain torch around the vote / objective kernels (cross-check)."""
+        from ..utils import basis_values
+        if self.num_tref != 1:
+            raise ValueError('calc_per_event_basis needs num_tref == 1')
+        events = batch['events']
+        num_pos_events = batch['num_pos_events'] if 'num_pos_events' in batch else -1
+        assert not self.polarity_aware_batching or num_pos_events > -1
+        dev = events.device
+        h, w = self._cfg.image_shape
+        sp = self.lut_superpixel_size
+        tile = sp if tile_size is None else int(tile_size)
+        if tile != sp:
+            raise ValueError('the coefficient tiles must be the look-up-table cells (tile_size == lut_superpixel_size)')
+        hq, wq = self._cfg.lut_grid
+        B, M = events.shape[0], events.shape[1]
+        G = hq * wq
+        # the coefficients at the tile centres (get_optical_flow_tile_mask + coeffs_grid_to_list, trajectories.py:3-52: offset
+        # tile // 2, row-major -- as a strided view, whose backward is a strided copy), scales summed as compute_basis does
+        cs = coeff_grid[:, :, :, tile // 2::tile, tile // 2::tile].sum(1)                          # [B, 2k, hq, wq]
+        if cs.shape[1] != 2 * num_basis or tuple(cs.shape[2:]) != (hq, wq):
+            raise ValueError(f'coeff_grid {tuple(coeff_grid.shape)} does not give [B, {2 * num_basis}, {hq}, {wq}] tile coefficients')
+        c = cs.reshape(B, 2, num_basis, hq, wq)
+        c_rows = c.permute(0, 3, 4, 1, 2).reshape(B * G, 2 * num_basis)                            # one row per tile: (y: k, x: k)
+        t_ref = torch.as_tensor(t_ref, dtype=torch.float32, device=dev).reshape(1)
+        phi = None           # (fused + polynomial basis of up to 8 orders: worked out inside the kernels)
+        if not (fused and basis_type == 'polynomial' and num_basis <= 8):
+            with torch.no_grad():
+                phi = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(events[..., 2], num_basis, basis_type, basis_network)
+        if fused:
+            offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events / ingest (optional)
+            focus, iwes = ops.PerEventBasisFocusFn.apply(c_rows, events, phi, t_ref, self._cfg, int(num_pos_events), offsets)
+        else:
+            # the same in plain torch around the vote / objective kernels (cross-check of the fused kernels)
+            with torch.no_grad():
+                iy = torch.div(events[..., 0], sp, rounding_mode='floor').long().clamp_(0, hq - 1)      # focus.py:186-187
+                ix = torch.div(events[..., 1], sp, rounding_mode='floor').long().clamp_(0, wq - 1)
+                idx = (torch.arange(B, device=dev).view(-1, 1) * G + iy * wq + ix).reshape(-1)
+            ce = ops.GatherRowsFn.apply(c_rows, idx).view(B, M, 2, num_basis)
+            warped = events[..., :2] + (ce * phi[:, :, None, :]).sum(-1)                              # [B, M, 2]  (y, x)
+            focus, iwes = ops.PrewarpedFocusFn.apply(warped, events, t_ref, self._cfg, int(num_pos_events))
+        smooth = torch.zeros((), device=dev)
+        if self.smooth_weight > 0:
+            from ..utils.synth import bin_mid_times
+            tm = bin_mid_times(self.num_bins).to(dev)
+            phim = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(tm, num_basis, basis_type, basis_network)   # [nb, k]
+            field = torch.einsum('bdkhw,tk->bthwd', c, phim)                                       # [B, nb, hq, wq, 2]
+            smooth = ops.LutSmoothFn.apply(field.reshape(B * self.num_bins, hq, wq, 2).contiguous(), self._cfg, float(self.smooth_weight))
+        loss = focus + smooth
+        iwes = iwes.reshape(B, 1, 2, h, w) if self.polarity_aware_batching else iwes.reshape(B, 1, h, w)
+        return loss, {'focus_loss': focus.detach(), 'smoothness_loss': smooth.detach()}, {'iwes': iwes.detach()}
+
     def calc(self, trajectories, times, batch):
         """Reference focus.py:66-113.
 

@@ -733,6 +733,129 @@ class EventFocusFn(torch.autograd.Function):
         return g_lut, None, None, None, None
 
 
+class PerEventBasisFocusFn(torch.autograd.Function):
+    """UNPINNED extension (FocusLoss.calc_per_event_basis), fused form: tile coefficients coef_rows [B*hq*wq, 2k] (differentiable),
+    events [B, M, 6], phi [B, M, k] = basis(t_ref) - basis(t_event) -> (focus_loss, iwes_blurred).
+    Forward: mpc_pe_warp -> mpc_event_splat_fwd (MPC_F_NO_WARP) -> mpc_contrast_fwd -> mpc_finalize; backward: mpc_pe_grad."""
+
+    @staticmethod
+    def forward(ctx, coef_rows, events, phi, t_ref, cfg: PathConfig, num_pos: int, offsets=None):
+        _require_gpu(coef_rows, 'coef_rows')
+        B, M, Mp = _check_events(events, cfg, num_pos)
+        dev = coef_rows.device
+        cr = _f32c(coef_rows.detach())
+        ev = _f32c(events.detach())
+        ph = _f32c(phi.detach()) if phi is not None else None       # None: the polynomial basis, worked out in the kernels
+        k = int(ph.shape[-1]) if ph is not None else int(coef_rows.shape[1]) // 2
+        tr = _f32c(t_ref.detach().to(dev))
+        need_grad = coef_rows.requires_grad
+        shape = make_shape(cfg, B, M, Mp, 0, K=0, extra_flags=C.F_NO_WARP | C.F_NO_BWD_RECORDS)
+        if tuple(cr.shape) != (B * shape.hq * shape.wq, 2 * k) or (ph is not None and tuple(ph.shape) != (B, M, k)) or (ph is None and k > 8):
+            raise ValueError(f'coef_rows {tuple(cr.shape)} / phi do not match [B*hq*wq, 2k] / [B, M, k] (k <= 8 without phi)')
+        ws = alloc_workspace(shape, dev)
+        rows = torch.empty_like(ev)
+        with _stage('mpc_pe_warp', dev):
+            C.check(C.lib().mpc_pe_warp(ctypes.byref(shape), _ptr(ev), _ptr(cr), _ptr(ph), k, _ptr(tr), _ptr(rows), _stream(dev)), 'mpc_pe_warp')
+        raw = event_splat_fwd(shape, rows, None, tr, ws)
+        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+        scal = finalize(shape, 0, 0, 0.0, ws, dev)
+        ctx.shape, ctx.k, ctx.n = shape, k, cr.shape[0]
+        # bucket-ordered events: the backward accumulates per LUT strip in LDS (no global atomics) where a strip's accumulators fit
+        offs = _check_offsets(offsets, cfg, shape, dev) if offsets is not None else None
+        if offs is not None:
+            ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+            if ncs <= 0 or -(-shape.hq // ncs) * shape.wq * 2 * k * 8 > 150 * 1024 or cfg.num_bins > 64:
+                offs = None
+        ctx.offs = offs
+        ctx.set_materialize_grads(False)
+        ctx.has_phi = ph is not None
+        ctx.save_for_backward(rows, ph if ph is not None else tr, tr, gimg, scal)
+        ctx.mark_non_differentiable(blur)
+        return scal[C.SCAL_FOCUS].clone(), blur
+
+    @staticmethod
+    def backward(ctx, g_focus, g_blur):
+        rows, ph, tr, gimg, scal = ctx.saved_tensors
+        if not ctx.has_phi:
+            ph = None
+        if g_focus is None:
+            return None, None, None, None, None, None, None
+        go = _f32c(g_focus.reshape(1))
+        if ctx.offs is not None:
+            # (a few workgroups per (sample, LUT strip), each with a share of the strip's row ranges and a partial result)
+            split = max(1, min(16, 512 // max(1, ctx.shape.B * int(C.lib().mpc_event_lut_strips(ctypes.byref(ctx.shape))))))
+            gp = torch.empty((split, ctx.n, 2 * ctx.k), dtype=torch.float32, device=rows.device)
+            with _stage('mpc_pe_grad_ordered', rows.device):
+                C.check(C.lib().mpc_pe_grad_ordered(ctypes.byref(ctx.shape), _ptr(rows), _ptr(ctx.offs), _ptr(ph), ctx.k, _ptr(tr), _ptr(gimg),
+                                                    _ptr(scal), _ptr(go), _ptr(gp), split, _stream(rows.device)), 'mpc_pe_grad_ordered')
+            return (gp.sum(0) if split > 1 else gp[0]), None, None, None, None, None, None
+        g = torch.empty((ctx.n, 2 * ctx.k), dtype=torch.float32, device=rows.device)
+        with _stage('mpc_pe_grad', rows.device):
+            C.check(C.lib().mpc_pe_grad(ctypes.byref(ctx.shape), _ptr(rows), _ptr(ph), ctx.k, _ptr(tr), _ptr(gimg), _ptr(scal),
+                                        _ptr(go), _ptr(g), _stream(rows.device)), 'mpc_pe_grad')
+        return g, None, None, None, None, None, None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """rows[idx] whose backward is index_add_ (float atomics) -- torch's own advanced-indexing backward sorts the indices
+    (index_put_ with accumulate): tens of milliseconds for the 2.8 M events of a DSEC batch.  UNPINNED extension
+    (FocusLoss.calc_per_event_basis); the gradient it returns is not bitwise reproducible."""
+
+    @staticmethod
+    def forward(ctx, rows, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = rows.shape[0]
+        return rows.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return torch.zeros((ctx.n, g.shape[1]), dtype=g.dtype, device=g.device).index_add_(0, idx, g.contiguous()), None
+
+
+def event_pos_grad(shape, rows, t_ref, gimg, scal, grad_out):
+    """UNPINNED extension: d objective / d warped position per event row -> [B, M, 2] (mpc_event_pos_grad)."""
+    B, M = rows.shape[0], rows.shape[1]
+    g = torch.empty((B, M, 2), dtype=torch.float32, device=rows.device)
+    with _stage('mpc_event_pos_grad', rows.device):
+        C.check(C.lib().mpc_event_pos_grad(ctypes.byref(shape), _ptr(rows), _ptr(t_ref), _ptr(gimg), _ptr(scal), _ptr(grad_out),
+                                           _ptr(g), _stream(rows.device)), 'mpc_event_pos_grad')
+    return g
+
+
+class PrewarpedFocusFn(torch.autograd.Function):
+    """UNPINNED extension (FocusLoss.calc_per_event_basis): A7-A9 on events whose positions are warped already.
+    warped_pos [B, M, 2] (y, x; the differentiable input), events [B, M, 6] (columns 2.. = t, p, bin, valid as the loader
+    writes them) -> (focus_loss, iwes_blurred).  Forward: the LDS-tiled vote of mpc_event_splat_fwd with MPC_F_NO_WARP;
+    backward: mpc_event_pos_grad (one thread per row, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, warped_pos, events, t_ref, cfg: PathConfig, num_pos: int):
+        _require_gpu(warped_pos, 'warped_pos')
+        B, M, Mp = _check_events(events, cfg, num_pos)
+        dev = warped_pos.device
+        rows = torch.cat((_f32c(warped_pos.detach()), _f32c(events.detach())[..., 2:]), dim=-1).contiguous()
+        tr = _f32c(t_ref.detach().to(dev))
+        need_grad = warped_pos.requires_grad
+        shape = make_shape(cfg, B, M, Mp, 0, K=0, extra_flags=C.F_NO_WARP | C.F_NO_BWD_RECORDS)
+        ws = alloc_workspace(shape, dev)
+        raw = event_splat_fwd(shape, rows, None, tr, ws)
+        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+        scal = finalize(shape, 0, 0, 0.0, ws, dev)
+        ctx.shape = shape
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(rows, tr, gimg, scal)
+        ctx.mark_non_differentiable(blur)
+        return scal[C.SCAL_FOCUS].clone(), blur
+
+    @staticmethod
+    def backward(ctx, g_focus, g_blur):
+        rows, tr, gimg, scal = ctx.saved_tensors
+        if g_focus is None:
+            return None, None, None, None, None
+        return event_pos_grad(ctx.shape, rows, tr, gimg, scal, _f32c(g_focus.reshape(1))), None, None, None, None
+
+
 class KnnLutFn(torch.autograd.Function):
     """A5: trajectories -> (flow_lut, flow_next or empty)."""
 

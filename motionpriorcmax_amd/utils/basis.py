@@ -26,6 +26,21 @@ def compute_basis(coeffs, times, num_basis, basis_type, basis_network=None):
     return torch.sum(torch.stack([ty, tx], dim=-1), dim=1)
 
 
+def basis_values(times, num_basis, basis_type, basis_network=None):
+    """The basis functions of `compute_basis` at arbitrary times: times [...] -> [..., k] (same formulas, same dtype as `times`).
+    Used by the per-event continuous-time warp (FocusLoss.calc_per_event_basis: UNPINNED extension), which evaluates the basis at
+    every event's own timestamp instead of at the num_bins bin mid-times."""
+    if basis_type == "dct":
+        k_idx = torch.arange(1, num_basis + 1, device=times.device)
+        return np.sqrt(2.0) * torch.cos(np.pi / 2.0 * ((2 * times[..., None] + 1) * k_idx))
+    if basis_type == "learned":
+        return basis_network(times[..., None])
+    if basis_type == "polynomial":
+        k_idx = torch.arange(1, num_basis + 1, device=times.device)
+        return times[..., None] ** k_idx
+    raise ValueError(basis_type)
+
+
 def bernstein_basis(times, degree):
     """[n_t] -> [n_t, degree]: C(d,i) (1-t)^(d-i) t^i for i = 1..d (P0 == 0), float64 then fp32."""
     t = np.asarray(times, dtype=np.float64).reshape(-1)

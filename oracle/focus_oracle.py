@@ -408,6 +408,42 @@ class FocusLossOracle:
         f = f.reshape(-1, f.shape[3], f.shape[4], f.shape[5])
         return self.smooth_weight * smoothness(f)
 
+    def calc_per_event_basis(self, coeff_grid, t_ref, batch, num_basis, basis_type='polynomial'):
+        """PARITY UNPINNED: the DEFINITION of the per-event continuous-time basis warp of
+        motionpriorcmax_amd.FocusLoss.calc_per_event_basis, written from the reference's building blocks -- the reference
+        itself has no such path (focus.py:182-195 gathers a binned KNN look-up table), so there is nothing to pin it to.
+            warped = (y, x) + sum_k c_k[tile(y, x)] * (basis_k(t_ref) - basis_k(t_event))
+        with the tile coefficients of trajectories.py:15-52 and the basis of basis.py:18-31 (the flow to t_ref of the trajectory
+        that starts at the event's tile), then focus.py:197-230 / loss.py unchanged; smoothness (loss.py:29-56) on the same
+        flow at the bin mid-times."""
+        events = batch['events']
+        num_pos = batch['num_pos_events'] if 'num_pos_events' in batch else -1
+        h, w = self.image_shape
+        mask = tile_mask((h, w), self.sp)
+        if coeff_grid.dim() == 4:
+            coeff_grid = coeff_grid[:, None]
+        coeffs, _ = coeff_grid_to_list(coeff_grid, mask, num_basis)              # [b,s,2,n,k]
+        hq, wq = -(-h // self.sp), -(-w // self.sp)
+        b, m, _ = events.shape
+        c = coeffs.sum(1).reshape(b, 2, hq, wq, num_basis)
+        t_ref = torch.as_tensor(t_ref, dtype=torch.float32).reshape(1)
+        ib = torch.arange(b)[:, None].expand(b, m)
+        iy = torch.div(events[..., 0], self.sp, rounding_mode='floor').to(torch.int64).clamp(0, hq - 1)
+        ix = torch.div(events[..., 1], self.sp, rounding_mode='floor').to(torch.int64).clamp(0, wq - 1)
+        phi = basis_matrix(t_ref, num_basis, basis_type)[None] - \
+            basis_matrix(events[..., 2].reshape(-1), num_basis, basis_type).reshape(b, m, num_basis)        # [b,m,k]
+        flow = (c[ib, :, iy, ix] * phi[:, :, None, :]).sum(-1)                  # [b,m,2]
+        warped = (events[..., :2] + flow)[:, None]                               # [b,T=1,m,2]
+        iwes, raw = make_iwes(events, warped, t_ref, self.image_shape, self.scale_iwe_by_dt,
+                              self.mask_image_border, self.polarity_aware_batching, num_pos)
+        focus = 1 / contrast_value(iwes, self.loss_type, self.focus_loss_norm)
+        smooth = torch.tensor(0.)
+        if self.smooth_weight > 0:
+            phim = basis_matrix(t_ref, num_basis, basis_type) - basis_matrix(bin_mid_times(self.num_bins), num_basis, basis_type)
+            field = torch.einsum('bdhwk,tk->btdhw', c, phim).reshape(-1, 2, hq, wq)
+            smooth = self.smooth_weight * smoothness(field)
+        return focus + smooth, {'focus_loss': focus.detach(), 'smoothness_loss': smooth.detach()}, {'iwes': iwes.detach()}
+
     def calc(self, trajectories, times, batch):
         """focus.py:66-113.  Returns (loss, log_metadata, misc_metadata)."""
         events = batch['events']
