@@ -142,7 +142,8 @@ class FocusLoss(base.TrajectoryLossBase):
         G = hq * wq
         # the coefficients at the tile centres (get_optical_flow_tile_mask + coeffs_grid_to_list, trajectories.py:3-52: offset
         # tile // 2, row-major -- as a strided view, whose backward is a strided copy), scales summed as compute_basis does
-        cs = coeff_grid[:, :, :, tile // 2::tile, tile // 2::tile].sum(1)                          # [B, 2k, hq, wq]
+        cs = coeff_grid[:, :, :, tile // 2::tile, tile // 2::tile]
+        cs = cs[:, 0] if cs.shape[1] == 1 else cs.sum(1)                                           # [B, 2k, hq, wq]
         if cs.shape[1] != 2 * num_basis or tuple(cs.shape[2:]) != (hq, wq):
             raise ValueError(f'coeff_grid {tuple(coeff_grid.shape)} does not give [B, {2 * num_basis}, {hq}, {wq}] tile coefficients')
         c = cs.reshape(B, 2, num_basis, hq, wq)
