@@ -121,3 +121,35 @@ def test_hand_derived_contrast_gradient_matches_autograd(norm):
     v2, gr = O.contrast_grad_image(raw.detach(), norm)
     assert abs(v2.item() - val.item()) < 1e-6 * val.item()
     np.testing.assert_allclose(gr.numpy(), raw.grad.numpy(), atol=2e-7, rtol=1e-4)
+
+
+def test_per_event_basis_definition_is_consistent_with_the_lut_path():
+    """PARITY UNPINNED (no reference code for the per-event continuous-time basis warp): the oracle's definition reduces to the
+    reference's pinned LUT event path where the two must agree -- zero coefficients = a zero LUT; a coefficient grid that is
+    constant in space with a constant-in-time basis difference... i.e. events all at ONE timestamp and a spatially constant grid =
+    the LUT holding that constant flow in every cell."""
+    import torch
+    from oracle import focus_oracle as O
+    H, W, sp, nb, k = 64, 96, 4, 5, 3
+    cfg = dict(image_shape=(H, W), num_tref=1, num_bins=nb, num_knn=4, smooth_weight=0.0, lut_superpixel_size=sp, focus_loss_norm='l1',
+               dist_norm='l2', scale_iwe_by_dt=True, mask_image_border=True, polarity_aware_batching=True, interpolation_scheme='mean',
+               smooth_type='on_flow_to_tref')
+    L = O.FocusLossOracle(**cfg)
+    ev, npos = O.synth_events(2, 3000, (H, W), nb, seed=1)
+    batch = {'events': ev, 'num_pos_events': npos}
+    tref = torch.tensor([0.41])
+    l0, _, m0 = L.calc_per_event_basis(torch.zeros(2, 1, 2 * k, H, W), 0.41, batch, k)
+    f0, iw0, _ = L.event_path(ev, torch.zeros(2, nb, H // sp, W // sp, 1, 2), tref, npos)
+    assert abs(float(l0) - float(f0)) <= 1e-6 * abs(float(f0)) and torch.allclose(m0['iwes'].reshape(iw0.shape), iw0)
+    # one timestamp, spatially constant coefficients: flow = sum_k c_k (tref^k - t^k) for every event = a constant LUT
+    ev1 = ev.clone(); ev1[..., 2] = 0.8
+    c = torch.tensor([1.5, -0.7, 0.3, -2.0, 0.9, 0.4])                      # (y: k, x: k)
+    grid = c.view(1, 1, 2 * k, 1, 1).expand(2, 1, 2 * k, H, W).contiguous()
+    kk = torch.arange(1, k + 1, dtype=torch.float32)
+    phi = 0.41 ** kk - 0.8 ** kk
+    flow = torch.stack(((c[:k] * phi).sum(), (c[k:] * phi).sum()))
+    lut = flow.view(1, 1, 1, 1, 1, 2).expand(2, nb, H // sp, W // sp, 1, 2).contiguous()
+    l1, _, m1 = L.calc_per_event_basis(grid, 0.41, {'events': ev1, 'num_pos_events': npos}, k)
+    f1, iw1, _ = L.event_path(ev1, lut, tref, npos)
+    assert abs(float(l1) - float(f1)) <= 1e-5 * abs(float(f1))
+    assert (m1['iwes'].reshape(iw1.shape) - iw1).abs().max() <= 1e-4 * iw1.abs().max()
