@@ -855,16 +855,16 @@ int mpc_event_splat_bwd_job(const mpc_shape *s, const float *events, const int32
 //               with MPC_F_NO_WARP nothing else reads that column; coef [B*hq*wq][2][k], phi [B][M][k] (basis_k(t_ref) - basis_k(t))
 //   k_pe_grad : grad_coef[cell][d][k] += phi[b][i][k] * d objective / d warped position_d  (float atomics: the gradient of this
 //               extension is not bitwise reproducible; the forward is)
+#define PE_KMAX 8          // orders held in registers (beyond: the generic instantiation reads phi per use)
 // phi[j] = basis_j(t_ref) - basis_j(t), j < k, from the tensor, or -- phi == nullptr: the polynomial basis t^(j+1) (basis.py:26-27) --
 // worked out here (one multiply per order instead of 4 k bytes of traffic per event and kernel)
 template <int KB>
-__device__ __forceinline__ void pe_phi(const float *__restrict__ phi, size_t row, int k, float t, float tref, float *out /* [KB or k <= 8] */) {
-    const int kk = KB > 0 ? KB : k;
+__device__ __forceinline__ void pe_phi(const float *__restrict__ phi, size_t row, int k, float t, float tref, float *out /* [KB or min(k, 8)] */) {
+    const int kk = KB > 0 ? KB : min(k, PE_KMAX);       // (k: the row stride of phi; the first PE_KMAX orders go to registers)
     if (phi != nullptr) { for (int j = 0; j < kk; ++j) out[j] = phi[row * k + j]; return; }
     float a = tref, c = t;
     for (int j = 0; j < kk; ++j) { out[j] = a - c; a *= tref; c *= t; }
 }
-#define PE_KMAX 8          // orders held in registers (more: the generic instantiation reads phi / recomputes per use)
 
 template <int KB>
 __global__ __launch_bounds__(256) void k_pe_warp(const mpc_shape s, const float *__restrict__ events, const float *__restrict__ coef,
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void k_pe_warp(const mpc_shape s, const float 
         const float *c = coef + (size_t)cell * 2 * k;
         float fy = 0.f, fx = 0.f;
         float ph[KB > 0 ? KB : PE_KMAX];
-        pe_phi<KB>(phi, row, min(k, PE_KMAX), e[2], tref, ph);
+        pe_phi<KB>(phi, row, k, e[2], tref, ph);
         if (KB > 0) {
 #pragma unroll
             for (int j = 0; j < KB; ++j) { fy += c[j] * ph[j]; fx += c[KB + j] * ph[j]; }
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void k_pe_grad(const mpc_shape s, const float 
         float *g = gcoef + (size_t)cell * 2 * k;
         const int kk = KB > 0 ? KB : k;
         float ph[KB > 0 ? KB : PE_KMAX];
-        pe_phi<KB>(phi, row, min(k, PE_KMAX), e[2], tref, ph);
+        pe_phi<KB>(phi, row, k, e[2], tref, ph);
         for (int j = 0; j < kk; ++j) { const float f = j < PE_KMAX ? ph[j] : phi[row * k + j]; atomicAdd(g + j, f * gy); atomicAdd(g + kk + j, f * gx); }
     }
 }
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(PE_NT) void k_pe_accum(const mpc_shape s, int CSR, 
             const int lc = __float_as_int(e[u][4]) - cell0;
             if (!on[u] || lc < 0 || lc >= ncell || (gy[u] == 0.f && gx[u] == 0.f)) continue;
             float ph[KB > 0 ? KB : PE_KMAX];
-            pe_phi<KB>(phi, grow[u], min(k, PE_KMAX), e[u][2], tref, ph);
+            pe_phi<KB>(phi, grow[u], k, e[u][2], tref, ph);
             unsigned long long *a = s_pacc + (size_t)lc * 2 * kk;
             for (int j = 0; j < kk; ++j) {
                 const float f = j < PE_KMAX ? ph[j] : phi[grow[u] * k + j];

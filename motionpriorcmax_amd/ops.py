@@ -754,8 +754,9 @@ class PerEventBasisFocusFn(torch.autograd.Function):
             raise ValueError(f'coef_rows {tuple(cr.shape)} / phi do not match [B*hq*wq, 2k] / [B, M, k] (k <= 8 without phi)')
         ws = alloc_workspace(shape, dev)
         rows = torch.empty_like(ev)
-        with _stage('mpc_pe_warp', dev):
-            C.check(C.lib().mpc_pe_warp(ctypes.byref(shape), _ptr(ev), _ptr(cr), _ptr(ph), k, _ptr(tr), _ptr(rows), _stream(dev)), 'mpc_pe_warp')
+        if B * M > 0:                 # (an empty tensor has no pointer to hand over)
+            with _stage('mpc_pe_warp', dev):
+                C.check(C.lib().mpc_pe_warp(ctypes.byref(shape), _ptr(ev), _ptr(cr), _ptr(ph), k, _ptr(tr), _ptr(rows), _stream(dev)), 'mpc_pe_warp')
         raw = event_splat_fwd(shape, rows, None, tr, ws)
         blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
         scal = finalize(shape, 0, 0, 0.0, ws, dev)

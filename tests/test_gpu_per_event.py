@@ -25,6 +25,7 @@ def _cfg(shape, nb, **over):
 @pytest.mark.parametrize('over,basis,k', [
     ({}, 'polynomial', 3), ({'polarity_aware_batching': False, 'scale_iwe_by_dt': False}, 'polynomial', 1),
     ({'focus_loss_norm': 'l2', 'smooth_weight': 0.0}, 'dct', 2), ({'mask_image_border': False}, 'polynomial', 5),
+    ({'smooth_weight': 0.0}, 'polynomial', 9),        # more orders than the kernels keep in registers: phi from torch, strided reads
 ])
 @pytest.mark.parametrize('fused', [True, False, 'ordered'])
 def test_per_event_basis_against_its_definition(over, basis, k, fused):
@@ -92,3 +93,12 @@ def test_per_event_basis_is_reproducible_and_zero_coefficients_are_the_identity_
         l.backward()
         outs.append((l.detach().clone(), cg.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # ... and the forward does not care about the row order inside a polarity block: same loss, bit for bit
+    cg = c.clone().requires_grad_(True)
+    lp, _, _ = L.calc_per_event_basis(cg, 0.3, batch, k)
+    assert torch.equal(lp.detach(), outs[0][0])
+    for kk, basis in ((9, 'polynomial'), (8, 'dct')):
+        c9 = (torch.randn(B, 1, 2 * kk, *shape, generator=g) * 0.5).to(dev)
+        la, _, _ = L.calc_per_event_basis(c9, 0.3, batch, kk, basis)
+        lb, _, _ = L.calc_per_event_basis(c9, 0.3, ob, kk, basis)
+        assert torch.equal(la, lb), (kk, basis, float(la), float(lb))
