@@ -142,12 +142,9 @@ class FocusLoss(base.TrajectoryLossBase):
         G = hq * wq
         # the coefficients at the tile centres (get_optical_flow_tile_mask + coeffs_grid_to_list, trajectories.py:3-52: offset
         # tile // 2, row-major -- as a strided view, whose backward is a strided copy), scales summed as compute_basis does
-        cs = coeff_grid[:, :, :, tile // 2::tile, tile // 2::tile]
-        cs = cs[:, 0] if cs.shape[1] == 1 else cs.sum(1)                                           # [B, 2k, hq, wq]
-        if cs.shape[1] != 2 * num_basis or tuple(cs.shape[2:]) != (hq, wq):
-            raise ValueError(f'coeff_grid {tuple(coeff_grid.shape)} does not give [B, {2 * num_basis}, {hq}, {wq}] tile coefficients')
-        c = cs.reshape(B, 2, num_basis, hq, wq)
-        c_rows = c.permute(0, 3, 4, 1, 2).reshape(B * G, 2 * num_basis)                            # one row per tile: (y: k, x: k)
+        if coeff_grid.dim() != 5 or coeff_grid.shape[2] != 2 * num_basis or -(-coeff_grid.shape[3] // tile) != hq or -(-coeff_grid.shape[4] // tile) != wq:
+            raise ValueError(f'coeff_grid {tuple(coeff_grid.shape)} is not [B, scales, {2 * num_basis}, H, W] of this image shape')
+        c_rows = ops.TileCoeffRowsFn.apply(coeff_grid, tile)                                       # [B*G, 2k]: per tile (y: k, x: k)
         t_ref = torch.as_tensor(t_ref, dtype=torch.float32, device=dev).reshape(1)
         phi = None           # (fused + polynomial basis of up to 8 orders: worked out inside the kernels)
         if not (fused and basis_type == 'polynomial' and num_basis <= 8):
@@ -169,9 +166,10 @@ class FocusLoss(base.TrajectoryLossBase):
         if self.smooth_weight > 0:
             from ..utils.synth import bin_mid_times
             tm = bin_mid_times(self.num_bins).to(dev)
-            phim = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(tm, num_basis, basis_type, basis_network)   # [nb, k]
-            field = torch.einsum('bdkhw,tk->bthwd', c, phim)                                       # [B, nb, hq, wq, 2]
-            smooth = ops.LutSmoothFn.apply(field.reshape(B * self.num_bins, hq, wq, 2).contiguous(), self._cfg, float(self.smooth_weight))
+            with torch.no_grad():
+                phim = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(tm, num_basis, basis_type, basis_network)   # [nb, k]
+            field = ops.BasisFieldFn.apply(c_rows, phim, B, hq, wq)                                # [B*nb, hq, wq, 2]
+            smooth = ops.LutSmoothFn.apply(field, self._cfg, float(self.smooth_weight))
         loss = focus + smooth
         iwes = iwes.reshape(B, 1, 2, h, w) if self.polarity_aware_batching else iwes.reshape(B, 1, h, w)
         return loss, {'focus_loss': focus.detach(), 'smoothness_loss': smooth.detach()}, {'iwes': iwes.detach()}

@@ -797,6 +797,50 @@ class PerEventBasisFocusFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
+class TileCoeffRowsFn(torch.autograd.Function):
+    """coeff_grid [B, S, 2k, H, W] -> the coefficients at the tile centres (offset tile // 2, row-major: trajectories.py:3-52),
+    scales summed, one row per tile: [B*hq*wq, 2k].  One autograd node with a strided copy each way instead of the half dozen
+    view / sum / permute nodes of the plain-torch spelling (the per-event step is bound by the host)."""
+
+    @staticmethod
+    def forward(ctx, coeff_grid, tile):
+        ctx.shape_in, ctx.tile = tuple(coeff_grid.shape), int(tile)
+        cs = coeff_grid[:, :, :, tile // 2::tile, tile // 2::tile]
+        cs = cs[:, 0] if cs.shape[1] == 1 else cs.sum(1)                      # [B, 2k, hq, wq]
+        B, c2, hq, wq = cs.shape
+        return cs.permute(0, 2, 3, 1).reshape(B * hq * wq, c2)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, c2, H, W = ctx.shape_in
+        t = ctx.tile
+        out = torch.zeros(ctx.shape_in, dtype=g.dtype, device=g.device)
+        view = out[:, :, :, t // 2::t, t // 2::t]
+        view.copy_(g.view(B, view.shape[3], view.shape[4], c2).permute(0, 3, 1, 2)[:, None].expand_as(view))
+        return out, None
+
+
+class BasisFieldFn(torch.autograd.Function):
+    """c_rows [B*G, 2k] (per tile: y orders, x orders), phim [nb, k] -> flow field at nb times [B*nb, hq, wq, 2] (the layout
+    of LutSmoothFn): field[b, t, cell, d] = sum_j c[b, cell, d, j] phim[t, j].  One node, a small GEMM and a copy each way."""
+
+    @staticmethod
+    def forward(ctx, c_rows, phim, B, hq, wq):
+        k = phim.shape[1]
+        ctx.save_for_backward(phim)
+        ctx.dims = (B, hq, wq, k)
+        f = c_rows.reshape(B * hq * wq * 2, k) @ phim.t()                     # [B*G*2, nb]
+        return f.view(B, hq * wq, 2, phim.shape[0]).permute(0, 3, 1, 2).reshape(B * phim.shape[0], hq, wq, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (phim,) = ctx.saved_tensors
+        B, hq, wq, k = ctx.dims
+        nb = phim.shape[0]
+        gf = g.reshape(B, nb, hq * wq, 2).permute(0, 2, 3, 1).reshape(B * hq * wq * 2, nb)
+        return (gf @ phim).view(B * hq * wq, 2 * k), None, None, None, None
+
+
 class GatherRowsFn(torch.autograd.Function):
     """rows[idx] whose backward is index_add_ (float atomics) -- torch's own advanced-indexing backward sorts the indices
     (index_put_ with accumulate): tens of milliseconds for the 2.8 M events of a DSEC batch.  UNPINNED extension
