@@ -40,7 +40,9 @@ struct KnnParams {
     int l1, iwd, want_next;
     float off;   // sp/2 - 0.5 : centre of cell 0 (focus.py:117)
 };
+#ifndef KNN_RCAP
 #define KNN_RCAP 6                 // largest search radius (cells) of the strip kernel's main launch
+#endif
 #define KNN_RFAR 20                // ... of its launch for the FAR queries (no square up to KNN_RCAP cells holds enough points: the
                                    // inside of a band the flow field emptied); beyond it a query goes to the fallback kernel
 #define KNN_MARGIN (KNN_RCAP + 1)
