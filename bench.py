@@ -719,7 +719,8 @@ def main():
             'ms_per_step': round(1e3 * r_comm['dt'] / r_comm['steps'], 4),
             'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2), 'allreduce_alone': r_comm.get('comm_alone'),
             'per_rank': r_comm.get('per_rank'),
-            'note': 'same steps with the 124 MB network-gradient all-reduce (RCCL, 4 buckets, side stream) overlapping the next loss'}
+            'note': 'same steps with the 124 MB network-gradient all-reduce (RCCL, 4 buckets, side stream) overlapping the next loss; '
+                    'the buffer that is all-reduced is a zero buffer nobody produced (no network here): overlap with a real producer untested'}
     if rank == 0 and world == 1:
         also = {}
         for name in [a for a in args.also.split(',') if a and a != args.workload]:
