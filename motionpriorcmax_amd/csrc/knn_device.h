@@ -46,6 +46,9 @@ struct KnnParams {
 #define KNN_RFAR 20                // ... of its launch for the FAR queries (no square up to KNN_RCAP cells holds enough points: the
                                    // inside of a band the flow field emptied); beyond it a query goes to the fallback kernel
 #define KNN_MARGIN (KNN_RCAP + 1)
+#ifndef KNN_FAR_RINGS
+#define KNN_FAR_RINGS 2            // a K-th distance beyond r_init + this many rings: the far backward's query (knn_is_far_dk)
+#endif
 // smallest count of points in the (2r + 1)^2 cell square of a query for which radius r is tried (K / (pi / 4) at K = 32: the
 // disc of the ring bound holds K points if they are spread evenly over the square; calibrated on smooth flow fields)
 // (L1: the ball of the ring bound is a diamond, half of the square)
@@ -631,7 +634,7 @@ __device__ __forceinline__ void knn_far_mark_tiles(const KnnParams &p, const Knn
 // of the mean density: the odd query the fallback kernel finishes with a slightly larger square stays in the gather (its
 // tile searches a window two cells wider), a query of an emptied band goes on the far list (k_knn_bwd_far).
 __device__ __forceinline__ bool knn_is_far_dk(const KnnParams &p, float dK, int r_init) {
-    const float lim = ((float)(r_init + 2) + 0.5f) * (float)p.sp;
+    const float lim = ((float)(r_init + KNN_FAR_RINGS) + 0.5f) * (float)p.sp;
     return dK > (p.l1 ? lim : lim * lim);
 }
 // Search radius of a query from the summed-area table of the cell counts: the smallest r in [rmin, KNN_RCAP] whose square
