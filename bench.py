@@ -239,12 +239,19 @@ def cpu_baseline(wl, budget_s=20.0):
     # torch's CPU scatter/conv ops scale badly past a few dozen threads (36 s per step with 256
     # threads on the GPU host vs 0.24 s with 8): give the CPU its best thread count
     best = None
+    tried = {}
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
         event_step()
-        t0 = time.perf_counter()
-        event_step()
-        dt1 = time.perf_counter() - t0
+        ts_ = []
+        for _ in range(3):                       # median of three timed steps per candidate (one step is at the mercy of a host stall)
+            t0 = time.perf_counter()
+            event_step()
+            ts_.append(time.perf_counter() - t0)
+            if ts_[-1] > 5.0:
+                break
+        dt1 = sorted(ts_)[len(ts_) // 2]
+        tried[nt] = round(1e3 * dt1, 1)
         if best is None or dt1 < best[0]:
             best = (dt1, nt)
         if dt1 > 5.0:
@@ -270,13 +277,14 @@ def cpu_baseline(wl, budget_s=20.0):
     t_knn_sample = t_knn_bin * nb
     valid = float(ev[..., 5].sum())
     return {
-        # headline: the event path (warp -> IWE -> objective -> backward), measured in full on one sample
-        'value': valid / t_event / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'kind': 'port',
-        'sample': (f'1 sample of the batch ({int(valid)} valid events): event path fwd+bwd (LUT given) timed {reps}x = '
-                   f'{t_event * 1e3:.1f} ms per step'),
-        'with_knn_value': valid / (t_event + t_knn_sample) / 1e6,
-        'with_knn_sample': (f'brute-force K-min KNN (torch.topk) timed on one whole (sample, bin) = {t_knn_bin:.2f} s, '
-                            f'x{nb} bins = {t_knn_sample:.1f} s per sample, added to the event path'),
+        # `value` = the WHOLE path on the CPU (KNN LUT + event path), the counterpart of the GPU `value`; the event path alone beside it
+        'value': valid / (t_event + t_knn_sample) / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'kind': 'port',
+        'sample': (f'1 sample of the batch ({int(valid)} valid events): brute-force K-min KNN (torch.topk; what KeOps argKmin computes) timed '
+                   f'on one whole (sample, bin) = {t_knn_bin:.2f} s, x{nb} bins = {t_knn_sample:.1f} s per sample, + the event path fwd+bwd (LUT '
+                   f'given) timed {reps}x = {t_event * 1e3:.1f} ms per step'),
+        'event_path_value': valid / t_event / 1e6,
+        'event_path_note': 'warp -> IWE -> objective -> autograd backward to the LUT only (no KNN): NOT the counterpart of the GPU `value`',
+        'threads_tried_ms_per_event_step': tried,
     }
 
 
@@ -368,6 +376,9 @@ def main():
                     help='row order of the event tensor the timed steps run on: the reference loader\'s time order (default: the layout '
                          'whose cost is counted is the one that is timed) or as the library\'s ingest can deliver it (rows of a polarity '
                          'block grouped by (time bin, LUT strip) + offsets table; the ordering is then NOT inside the timed step)')
+    ap.add_argument('--batches', type=int, default=4,
+                    help='distinct resident batches (events + trajectories) the timed steps rotate over: a training loop sees a new batch '
+                         'every step; 1 = every step on the same batch, as rounds 1-4 timed it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-realistic', action='store_true', help='skip the realistic-input variants reported in also.realistic_inputs')
     ap.add_argument('--no-hip-graph', action='store_true', help='skip the HIP-graph replay timing reported beside the eager one')
@@ -409,23 +420,37 @@ def main():
 
     def run_workload(name, steps, warmup, with_comm, instrument=True):
         wl = WORKLOADS[name]
-        ev, num_pos, traj, times = synth_inputs(wl, seed=1000 * rank + 1)
         L = LossFactory.get_loss_calculator('FOCUS', loss_config(wl))
-        evd, times_d = ev.to(dev), times.to(dev)
-        trajd = traj.to(dev).requires_grad_(True)
-        batch_time = {'events': evd, 'num_pos_events': num_pos}
+        # The timed steps ROTATE over `args.batches` distinct resident batches (events + trajectories; C3: 4 x 101 MB), as a training
+        # loop sees a new batch every step (src/loader/dsec/loader.py:417-427): no step finds its inputs in the 256 MB Infinity
+        # Cache because the step before read them.  The same steps on ONE batch are timed beside it (`single_batch`).
+        nbat = max(1, args.batches)
+        sets = []
+        for j in range(nbat):
+            ev_j, num_pos, traj_j, times = synth_inputs(wl, seed=1000 * rank + 1 + 17 * j)
+            bt_j = {'events': ev_j.to(dev), 'num_pos_events': num_pos}
+            sets.append({'batch_time': bt_j, 'traj': traj_j.to(dev).requires_grad_(True), 'valid': float(ev_j[..., 5].sum())})
+            if j == 0:
+                ev, traj = ev_j, traj_j
+        times_d = times.to(dev)
+        evd, trajd, batch_time = sets[0]['batch_time']['events'], sets[0]['traj'], sets[0]['batch_time']
         # The timed steps run on the reference loader's time-ordered tensor (the layout whose cost is counted is the layout that
         # is timed).  The layout the library's own ingest can deliver instead (utils.ingest_events(order_for=loss): the rows of
         # each polarity block grouped by (time bin, LUT strip) + the offsets table) is timed beside it (`other_event_layout`,
         # the ordering outside the step); same loss and gradient bit for bit (tests/test_gpu_event_order.py).
-        batch = L.order_events(batch_time) if args.events_layout == 'bucket' else batch_time
-        valid_local = float(ev[..., 5].sum())
+        for st_ in sets:
+            st_['batch'] = L.order_events(st_['batch_time']) if args.events_layout == 'bucket' else st_['batch_time']
+        batch = sets[0]['batch']
+        valid_local = sum(sets[i % nbat]['valid'] for i in range(steps)) / steps      # valid events of an average timed step
         reducer = dp.GradAllReducer(device=comm_dev) if (with_comm and world > 1) else None
+        counter = [0]
 
-        def step():
-            loss, _, _ = L.calc(trajd, times_d, batch)
+        def step(rotate=True):
+            st_ = sets[counter[0] % nbat] if rotate else sets[0]
+            counter[0] += 1
+            loss, _, _ = L.calc(st_['traj'], times_d, st_['batch'])
             loss.backward()
-            trajd.grad = None
+            st_['traj'].grad = None
             if reducer is not None:
                 reducer.wait()       # previous step's all-reduce must be done before "the optimizer"
                 reducer.start()      # this step's network gradient; overlaps the next step's loss
@@ -446,6 +471,7 @@ def main():
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
+            counter[0] = 0           # (every block: the same `steps` steps, batch 0 first)
             t0 = time.perf_counter()
             for _ in range(steps):
                 last = step()
@@ -459,6 +485,24 @@ def main():
             blocks.append(dp.max_over_ranks(own, comm_dev))
         dt = sorted(blocks)[1]
         total_valid = dp.sum_over_ranks(valid_local, comm_dev)
+        # the same number of steps on ONE resident batch (what rounds 1-4 timed), beside the rotating figure
+        single = None
+        if nbat > 1 and reducer is None:
+            sb = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    last1 = step(rotate=False)
+                torch.cuda.synchronize()
+                sb.append(time.perf_counter() - t0)
+            s_dt = dp.max_over_ranks(sorted(sb)[1], comm_dev)
+            single = {'ms_per_step': round(1e3 * s_dt / steps, 4), 'value': round(dp.sum_over_ranks(sets[0]['valid'], comm_dev) * steps / s_dt / 1e6, 3),
+                      'unit': 'Mevents/s', 'note': 'every timed step on the same resident batch (inputs may sit in the Infinity Cache)'}
+            del last1
+        # (the last timed step ran on batch (steps - 1) % nbat: the cross-checks below compare against that one)
+        lastset = sets[(steps - 1) % nbat]
+        trajd, batch, batch_time, evd = lastset['traj'], lastset['batch'], lastset['batch_time'], lastset['batch_time']['events']
         # every rank's own time for the median block and its own event count (the headline uses the MAX over ranks)
         per_rank = None
         if world > 1:
@@ -491,20 +535,21 @@ def main():
         stages = {}
         kernels = {}
         if instrument:
-            ops.STAGE_TIMER = ops.StageTimer()
-            for _ in range(steps):
-                loss, _, _ = L.calc(trajd, times_d, batch)
+            def plain_step(i):          # (the timed loop's step without the reducer, rotating over the batches the same way)
+                st_ = sets[i % nbat]
+                loss, _, _ = L.calc(st_['traj'], times_d, st_['batch'])
                 loss.backward()
-                trajd.grad = None
+                st_['traj'].grad = None
+            ops.STAGE_TIMER = ops.StageTimer()
+            for i in range(steps):
+                plain_step(i)
             stages = ops.STAGE_TIMER.summary()
             ops.STAGE_TIMER = None
             # ... and HIP events around every KERNEL (recorded by the library on its launch stream), over the same steps issued
             # exactly as the timed loop issues them (mpc_focus_fwd / mpc_focus_bwd)
             with ops.KernelTimer() as kt:
-                for _ in range(steps):
-                    loss, _, _ = L.calc(trajd, times_d, batch)
-                    loss.backward()
-                    trajd.grad = None
+                for i in range(steps):
+                    plain_step(i)
             kernels = kt.summary()
         # the same step captured once into a HIP graph and replayed (static shapes; N = 1 only): what the host-side
         # launch overhead of the eager path costs -- reported beside the eager number, never as `value`
@@ -615,7 +660,7 @@ def main():
                      'grad_rel_l2_vs_atomic_path': float((ta.grad - tb.grad).norm() / tb.grad.norm())}
         return dict(wl=wl, dt=dt, blocks=blocks, steps=steps, total_valid=total_valid, stages=stages, kernels=kernels, graph_ms=graph_ms,
                     loss=float(last.item()), n=traj.shape[2], check=check, ordered=ordered, static=static_ms, per_rank=per_rank,
-                    comm_alone=comm_alone)
+                    comm_alone=comm_alone, single=single, nbat=nbat)
 
     r = run_workload(args.workload, args.steps, args.warmup, args.grad_allreduce)
     r_comm = None
@@ -672,8 +717,19 @@ def main():
             if ev_us > 0:
                 ev_path = {'us_per_step': round(ev_us, 1), 'achieved': round(path_b / (ev_us * 1e-6) / 1e9, 1),
                            'frac': round(path_b / (ev_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), 'from': 'per-kernel HIP events'}
+        knn_info = knn_ceiling(wname, per_step, wl_['B'], wl_['nb']) if wname else {}
+        # what bounds the dominant kernel: the KNN kernels issue vector instructions (exact K-nearest selection) and leave HBM idle --
+        # their ceiling is the SIMDs' issue rate (one wave64 instruction per 2 cycles, MI355X_MICROARCH.md), the HBM figures below
+        # stay as measured; every other kernel of the path is HBM-bound by nature
+        is_knn = dom.startswith('mpc_knn')
+        valu = None
+        kprof = (knn_info.get('from_committed_profile') or {}).get('kernels', {}).get(dom_k) if is_knn else None
+        if kprof:
+            valu = {'achieved': round(2.0 / kprof['simd_cycles_per_valu_instr'], 3), 'unit': 'fraction of 1 wave64 instruction per 2 SIMD cycles',
+                    'simd_cycles_per_valu_instr': kprof['simd_cycles_per_valu_instr'], 'from': 'committed SQ counters of this library (knn.from_committed_profile)'}
         return {
-            'bound': 'hbm', 'kernel': dom_k if dom_k is not None else (in_stage[0] if in_stage else dom), 'stage': dom,
+            'bound': 'valu_issue' if is_knn else 'hbm', 'valu_issue': valu,
+            'kernel': dom_k if dom_k is not None else (in_stage[0] if in_stage else dom), 'stage': dom,
             'note': 'kernel_us = the average launch of `kernel`, HIP events recorded by the library around that launch on its stream, '
                     'over the timed steps (kernels_us has every kernel); achieved = algorithmic bytes of its stage / kernel_us'
                     + ('; this stage is VALU-issue bound (exact K-nearest selection: `knn` below has its queries/s and issue-slot '
@@ -685,7 +741,7 @@ def main():
             'kernel_us': round(d['us_per_step'], 1), 'kernels_in_stage': in_stage, 'profile_summary': pfile,
             'kernels_us': live,
             'event_path': ev_path,
-            'knn': knn_ceiling(wname, per_step, wl_['B'], wl_['nb']) if wname else {},
+            'knn': knn_info,
             'path': {'algorithmic_MB': round(path_b / 1e6, 2), 'gpu_us_per_step': round(gpu_us, 1),
                      'achieved': round(path_b / (gpu_us * 1e-6) / 1e9, 1) if gpu_us > 0 else 0.0,
                      'frac': round(path_b / (gpu_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if gpu_us > 0 else 0.0},
@@ -699,11 +755,13 @@ def main():
         'blocks_ms_per_step': [round(1e3 * x / r['steps'], 4) for x in r['blocks']], 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f"{args.workload}: {wl['desc']}", 'batch_per_gpu': wl['B'], 'events_layout': args.events_layout,
+                   'resident_batches_rotated': r.get('nbat', 1),
                    'global_batch': wl['B'] * world, 'events_per_sample': wl['M'], 'num_bins': wl['nb'],
                    'num_knn': KNN, 'image': [H, W], 'parallelism': f'dp{world}',
                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2) if (world > 1 and args.grad_allreduce) else 0},
         'rccl_ranks': rccl_ranks, 'per_rank': r.get('per_rank'),
         'loss': r['loss'], 'loss_check': r.get('check'),
+        'single_batch': r.get('single'),
         'other_event_layout': r.get('ordered'),
         'static_shapes': r.get('static'),
         'roofline': roofline_of(r, args.workload),
@@ -728,11 +786,13 @@ def main():
             # (sized by the main workload) otherwise frees/reallocates inside the child's timed steps
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--steps', str(args.steps),
-                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--no-realistic', '--no-nondefault', '--also', '', '--events-layout', args.events_layout]
+                   '--warmup', str(args.warmup), '--no-cpu-baseline', '--no-realistic', '--no-nondefault', '--also', '', '--events-layout', args.events_layout,
+                   '--batches', str(args.batches)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 dj = json.loads(r.stdout.strip().splitlines()[-1])
                 also[name] = {'value': dj['value'], 'ms_per_step': dj['ms_per_step'],
+                              'single_batch_ms_per_step': (dj.get('single_batch') or {}).get('ms_per_step'),
                               'hip_graph_ms_per_step': dj.get('hip_graph', {}).get('ms_per_step'),
                               'static_shapes_ms_per_step': (dj.get('static_shapes') or {}).get('ms_per_step'),
                               'time_ordered_ms_per_step': (dj.get('other_event_layout') or {}).get('ms_per_step'),
@@ -761,6 +821,13 @@ def main():
                                                 'k_knn_bwd_tile_us': r['kernels_us_per_step'].get('k_knn_bwd_tile'),
                                                 'k_knn_bwd_far_us': r['kernels_us_per_step'].get('k_knn_bwd_far')} for r in rows},
                     'worst_vs_white': max(r['vs_first'] for r in rows)}
+                # the input the reference's own network produces (src/modules/trajectory_net.py:142-161: a smooth mixture, not white noise),
+                # beside the headline
+                un = next((r for r in rows if r['variant'] == 'unet'), None)
+                if un is not None:
+                    out['value_unet'] = {'value': round(un['valid_events'] / (un['ms_per_step'] * 1e-3) / 1e6, 1), 'unit': 'Mevents/s',
+                                         'ms_per_step': un['ms_per_step'], 'vs_white': un['vs_first'],
+                                         'note': 'the same C3-shaped step on a UNet-like smooth flow field (tools/realistic_probe.py, family unet)'}
             except Exception as e:
                 also['realistic_inputs'] = {'error': repr(e)[:300]}
         # configurations outside the shipped yaml files (served by the general KNN kernels, not the strip kernels): timed once
@@ -833,6 +900,61 @@ def main():
             del Lp, cgrid, bp
         except Exception as e:
             also['per_event_basis'] = {'error': repr(e)[:200]}
+        # the two UNPINNED extensions BASELINE.json's configs name, at the size their config names ("pyramid variant
+        # reported separately", "cubic B-spline (unpinned extension)"); the reference has neither
+        try:
+            if args.no_nondefault:
+                raise RuntimeError('skipped (--no-nondefault)')
+            from motionpriorcmax_amd import LossFactory as _LF3, utils as _U3
+            from motionpriorcmax_amd.utils.synth import synth_events as _se3, bin_mid_times as _bm3
+
+            def _time10(fn):
+                for _ in range(4):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / 10
+            # (a) configs[2]: 3-level IWE pyramid on the headline's workload (stage calls, no fused path)
+            wl3 = WORKLOADS['C3']
+            ev3, np3, tr3, tm3 = synth_inputs(wl3, seed=1)
+            Lp3 = _LF3.get_loss_calculator('FOCUS', dict(loss_config(wl3), pyramid_levels=3))
+            e3, t3, m3 = ev3.to(dev), tr3.to(dev).requires_grad_(True), tm3.to(dev)
+            b3 = {'events': e3, 'num_pos_events': np3}
+
+            def _p3():
+                l_, _, _ = Lp3.calc(t3, m3, b3)
+                l_.backward()
+                t3.grad = None
+            tp3 = _time10(_p3)
+            also['pyramid3_C3'] = {'ms_per_step': round(1e3 * tp3, 4), 'value': round(float(ev3[..., 5].sum()) / tp3 / 1e6, 1), 'unit': 'Mevents/s',
+                                   'note': 'UNPINNED extension: FocusLoss(pyramid_levels=3) on the C3 workload (2x2 averages of the raw IWE, the '
+                                           'reference objective on every level, focus = sum over levels); tests/test_gpu_xrows_fullsize.py'}
+            del Lp3, e3, t3, b3
+            # (b) configs[3]: cubic B-spline trajectories (10 free control points) on the C4 workload, basis evaluated on the device
+            wl4 = WORKLOADS['C4']
+            ev4, np4 = _se3(1, wl4['M'], (H, W), wl4['nb'], seed=1, pad_frac=0.02, time_sorted=True)
+            tm4 = torch.cat((torch.tensor([0.41]), _bm3(wl4['nb']))).to(dev)
+            g4 = torch.Generator().manual_seed(9)
+            pr4 = (torch.randn(1, 20, H // PATCH, W // PATCH, generator=g4) * 2.0).to(dev).requires_grad_(True)
+            L4 = _LF3.get_loss_calculator('FOCUS', loss_config(wl4))
+            b4 = {'events': ev4.to(dev), 'num_pos_events': np4}
+
+            def _b4():
+                tj, _ = _U3.trajectories_from_bspline(pr4, tm4, PATCH, (H, W))
+                l_, _, _ = L4.calc(tj, tm4, b4)
+                l_.backward()
+                pr4.grad = None
+            tb4 = _time10(_b4)
+            also['bspline_C4'] = {'ms_per_step': round(1e3 * tb4, 4), 'value': round(float(ev4[..., 5].sum()) / tb4 / 1e6, 1), 'unit': 'Mevents/s',
+                                  'note': 'UNPINNED extension: clamped uniform cubic B-spline flow curves (utils.trajectories_from_bspline, autograd to '
+                                          'the control points) through FocusLoss.calc on the C4 workload; the step includes the basis evaluation'}
+            del L4, b4, pr4
+        except Exception as e:
+            also['pyramid3_C3'] = also.get('pyramid3_C3', {'error': repr(e)[:200]})
+            also['bspline_C4'] = also.get('bspline_C4', {'error': repr(e)[:200]})
         # next row 8f-2: voxel-grid builder on the same window shape (network input; not part of `value`)
         try:
             from motionpriorcmax_amd.utils import voxel_grids

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 104
+#define MPC_VERSION 105
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -82,6 +82,11 @@ typedef struct mpc_shape {
 
 int mpc_version(void);
 const char *mpc_last_error_string(void);
+/* Bounds-checked debug build (-DMPC_BOUNDS, csrc/bounds.h; the reference has no sanitizer hooks): waits for
+ * the device, returns the number of out-of-range indices the checked accessors of the library's kernels recorded since the
+ * last call (and clears the records; the first one's file:line, workgroup, index, extent -> mpc_last_error_string()).
+ * 0 = clean; -1 = this library is the product build (the accessors compile to the bare index).                            */
+int mpc_bounds_check(void);
 
 /* Diagnostics (bench.py's instrumented pass; no reference counterpart): between mpc_profile_start() and mpc_profile_stop()
  * every kernel the library launches is bracketed by two HIP events on its launch stream.  mpc_profile_stop synchronises
@@ -194,6 +199,8 @@ int mpc_pe_grad(const mpc_shape *s, const float *rows, const float *phi, int32_t
 int mpc_pe_grad_ordered(const mpc_shape *s, const float *rows, const int32_t *offsets, const float *phi, int32_t k,
                         const float *t_ref, const float *grad_iwe, const float *scal, const float *grad_out,
                         float *grad_coef_rows, int32_t split, void *stream);
+/* 1 where mpc_pe_grad_ordered serves (shape, k), 0 where the caller takes mpc_pe_grad: the rule lives in the library only. */
+int32_t mpc_pe_grad_ordered_supported(const mpc_shape *s, int32_t k);
 
 int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *flow_lut,
                         const float *t_ref, const float *grad_iwe, const float *scal,

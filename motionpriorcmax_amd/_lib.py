@@ -21,6 +21,7 @@ F_UNIT_WEIGHT = 1 << 9
 F_ATOMIC_PATH = 1 << 10
 F_NO_BWD_RECORDS = 1 << 11
 
+E_NULL, E_SHAPE, E_UNSUPPORTED = -1, -2, -4        # include/mpcmax.h
 SCAL_LOSS, SCAL_FOCUS, SCAL_SMOOTH, SCAL_VAL, SCAL_GCOEF, SCAL_COUNT = 0, 1, 2, 3, 4, 8
 
 EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_knn_lut_fwd',
@@ -30,7 +31,7 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_fail_list_offset', 'mpc_knn_list_offsets', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
            'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
-           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add', 'mpc_event_pos_grad', 'mpc_pe_warp', 'mpc_pe_grad', 'mpc_pe_grad_ordered']
+           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add', 'mpc_event_pos_grad', 'mpc_pe_warp', 'mpc_pe_grad', 'mpc_pe_grad_ordered', 'mpc_pe_grad_ordered_supported', 'mpc_bounds_check']
 
 
 class Shape(ctypes.Structure):
@@ -96,6 +97,8 @@ def lib():
     L.mpc_pe_warp.argtypes = [sp, vp, vp, vp, ctypes.c_int32, vp, vp, vp]
     L.mpc_pe_grad.argtypes = [sp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
     L.mpc_pe_grad_ordered.argtypes = [sp, vp, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
+    L.mpc_pe_grad_ordered_supported.argtypes = [sp, ctypes.c_int32]
+    L.mpc_pe_grad_ordered_supported.restype = ctypes.c_int32
     L.mpc_scale.argtypes = [vp, vp, vp, i64, vp]
     fb = ctypes.POINTER(FocusBuffers)
     L.mpc_focus_fwd.argtypes = [sp, fb, vp, vp]
@@ -130,9 +133,10 @@ def lib():
     L.mpc_pool2_fwd.argtypes = [vp, vp, i32, i32, i32, vp]
     L.mpc_pool2_bwd_add.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.mpc_profile_start.argtypes = []
+    L.mpc_bounds_check.argtypes = []
     L.mpc_profile_stop.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(f32), i32]
-    if L.mpc_version() != 104:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (104)')
+    if L.mpc_version() != 105:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (105)')
     _lib = L
     return L
 

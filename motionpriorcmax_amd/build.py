@@ -19,16 +19,32 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    if not force and not needs_build():
+def build_library(force=False, verbose=False, out=None):
+    """hipcc every source to an object (in parallel: one process per file), then link.  `out`: another file name for the
+    library (diagnostic / bounds-checked builds loaded through MPC_AB_LIB); the product build is LIB."""
+    out = out or LIB
+    if not force and out == LIB and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     # MPC_EXTRA_HIPCC_FLAGS: tuning sweeps (-DEV_LUT_INFLIGHT=4 ...); never set for a product build
-    cmd = [hipcc] + FLAGS + os.environ.get('MPC_EXTRA_HIPCC_FLAGS', '').split() + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    extra = os.environ.get('MPC_EXTRA_HIPCC_FLAGS', '').split()
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory(prefix='mpcbuild_') as td:
+        def compile_one(src):
+            obj = os.path.join(td, src.replace('.hip', '.o'))
+            cmd = [hipcc, '-c'] + [f for f in FLAGS if f != '-shared'] + extra + ['-o', obj, os.path.join(CSRC, src)]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, SOURCES))
+        cmd = [hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', out] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return out
 
 
 if __name__ == '__main__':

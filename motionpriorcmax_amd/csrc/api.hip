@@ -1,5 +1,6 @@
 // libmpcmax: shape validation, workspace layout, version and error reporting.
 #include "common.h"
+#include "bounds.h"
 #include <stdarg.h>
 #include <string.h>
 #include <stdlib.h>
@@ -69,6 +70,35 @@ extern "C" int mpc_profile_stop(char *names, int32_t names_cap, float *ms, int32
 }
 extern "C" const char *mpc_last_error_string(void) { return g_err; }
 
+// ---- -DMPC_BOUNDS: the bounds-checked debug build (bounds.h) -------------------------------------------------------
+// Every translation unit with checked accessors registers a reader of its violation record; mpc_bounds_check() waits for the
+// device, reads and clears them all and returns the number of violations (0: clean; -1: this is not a bounds build); the first
+// violation's file:line, workgroup, index and extent go to mpc_last_error_string().
+#ifdef MPC_BOUNDS
+static mpc_bounds_unit *g_bounds_units = nullptr;
+void mpc_bounds_register(mpc_bounds_unit *u) { u->next = g_bounds_units; g_bounds_units = u; }
+#endif
+extern "C" int mpc_bounds_check(void) {
+#ifdef MPC_BOUNDS
+    (void)hipDeviceSynchronize();
+    int total = 0;
+    bool said = false;
+    for (mpc_bounds_unit *u = g_bounds_units; u; u = u->next) {
+        int r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (u->read(r, 1)) { mpc_set_error("mpc_bounds_check: cannot read the record of %s", u->file); return -2; }
+        if (r[0] > 0 && !said) {
+            const long long idx = ((long long)r[4] << 32) | (unsigned)r[3], ext = ((long long)r[6] << 32) | (unsigned)r[5];
+            mpc_set_error("MPC_BOUNDS: %d violation(s) in %s, first at line %d, workgroup %d: index %lld, extent %lld", r[0], u->file, r[1], r[2], idx, ext);
+            said = true;
+        }
+        total += r[0];
+    }
+    return total;
+#else
+    return -1;
+#endif
+}
+
 __global__ __launch_bounds__(256) void k_zero_words(unsigned *__restrict__ p, size_t n) {
     // up to 3 head words bring the pointer to 16-byte alignment, then 16-byte stores, then up to 3 tail words
     size_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) >> 2;
@@ -130,10 +160,10 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     const int km = mpc_knn_margin(s);
     const int64_t hb = s->hq + 2 * km, wb = s->wq + 2 * km, Gb = hb * wb;
     const int64_t ktiles = mpc_knn_tiles(s);
-    L.off_cell_start = off; off += mpc_align(bt * (Gb + 1) * sizeof(int32_t));
-    L.off_knn_sat = off;    off += mpc_align(bt * (hb + 1) * (wb + 1) * sizeof(int32_t));
+    L.off_cell_start = off; off += mpc_align(bt * (Gb + 1) * sizeof(uint16_t));       // (knn_device.h: knn_cs_t)
+    L.off_knn_sat = off;    off += mpc_align(bt * (hb + 1) * (wb + 1) * sizeof(uint16_t));
     L.off_spos = off;       off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
-    L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(int32_t));
+    L.off_sidx = off;       off += mpc_align(bt * (int64_t)s->n * sizeof(uint16_t));               // (knn_idx_t)
     L.off_knn_tmp_g = off;  off += mpc_align(bt * (int64_t)s->n * s->T * 2 * sizeof(float));
     L.off_knn_tmp_a = off;  off += mpc_align(bt * (int64_t)s->n * 2 * sizeof(float));
     L.off_knn_cursor = off; off += mpc_knn_big_sort(s) ? mpc_align(bt * Gb * sizeof(int32_t)) : 0;

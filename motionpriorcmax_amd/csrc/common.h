@@ -66,10 +66,10 @@ struct mpc_ws_layout {
     int64_t off_spart;   int32_t n_sblocks_max; // [n_sblocks_max][2] double
     int64_t off_counts;                         // int32[8] : n_sblocks used, ...
     // KNN
-    int64_t off_cell_start;  // int32 [B*nb][Gb+1]   first bucketed point of every cell of the bucket grid (query grid + margin)
-    int64_t off_knn_sat;     // int32 [B*nb][hb+1][wb+1]  summed-area table of the cell counts (strip forward only)
+    int64_t off_cell_start;  // uint16 [B*nb][Gb+1]   first bucketed point of every cell of the bucket grid (query grid + margin)
+    int64_t off_knn_sat;     // uint16 [B*nb][hb+1][wb+1]  summed-area table of the cell counts (strip forward only)
     int64_t off_spos;        // float2 [B*nb][n]
-    int64_t off_sidx;        // int32  [B*nb][n]
+    int64_t off_sidx;        // uint16 [B*nb][n]
     int64_t off_knn_tmp_g;   // float2 [B*nb][n][T]  backward partials
     int64_t off_knn_tmp_a;   // float2 [B*nb][n]
     int64_t off_knn_cursor;  // int32  [B*nb][Gb]  fill cursors of the global-memory bucket sort (only when Gb*4 B exceeds the LDS sort)

@@ -5,6 +5,7 @@
 // HBM-bound stencils: every image is read once and written once per kernel, tiles are staged
 // in LDS with their halo, reductions use wavefront shuffles and fp64 block partials.
 #include "common.h"
+#include "bounds.h"
 #include <stdlib.h>
 
 // torchvision gaussian_blur(kernel_size=3, sigma=1): [a, c, a] = exp(-x^2/2)/sum, fp32
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64) void k_contrast_march(const float *__restrict__
     if (c == 0) {
         const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         const size_t nb_ = (size_t)gridDim.x * gridDim.y * gridDim.z;
-        part[2 * bid] = acc;
+        part[2 * MPC_IDX(bid, nslots)] = acc;
         part[2 * bid + 1] = 0.0;
         for (size_t e = bid + nb_; e < (size_t)nslots; e += nb_) { part[2 * e] = 0.0; part[2 * e + 1] = 0.0; }
     }
@@ -622,3 +623,5 @@ extern "C" int mpc_pool2_bwd_add(const float *small, const float *coef_small, fl
     MPC_CHECK_LAUNCH();
     return 0;
 }
+
+MPC_BOUNDS_UNIT("contrast.hip")

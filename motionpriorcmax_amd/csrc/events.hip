@@ -7,6 +7,7 @@
 #include "common.h"
 #include "ev_count_device.h"
 #include "knn_device.h"
+#include "bounds.h"
 
 struct EvParams {
     int B, M, Mp, nb, T, H, W, sp, hq, wq, P;
@@ -266,12 +267,14 @@ __device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, i
                                         float4 rec) {
     if (lb < nf_loc) {
         const int g = (b * p.P + lb / L.NS) * L.NS + (lb % L.NS);
-        reinterpret_cast<rec3 *>(L.frec)[(size_t)g * L.fcap + slot] = rec3{rec.x, rec.y, rec.z};
+        MPC_EXPECT(g >= 0 && g < L.NF);
+        reinterpret_cast<rec3 *>(L.frec)[(size_t)g * L.fcap + MPC_IDX(slot, L.fcap)] = rec3{rec.x, rec.y, rec.z};
     } else {
         // (exact buckets: `slot` counts from the sample's first record -- the bucket starts behind the rows of the buckets
         // before it; else every bucket has room for all the rows of its sample)
         const size_t base = L.exact ? (size_t)b : (size_t)(b * p.nb * L.NCS + (lb - nf_loc));
-        L.brec[base * L.bcap + slot] = rec;
+        MPC_EXPECT((long long)base < (L.exact ? (long long)p.B : (long long)L.NBk));
+        L.brec[base * L.bcap + MPC_IDX(slot, L.bcap)] = rec;
     }
 }
 
@@ -344,12 +347,12 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
         // strip = row / SR without an integer division: (row + 0.5) / SR is at least 0.5 / SR away from an
         // integer, far more than the rounding of the float product, so the truncation is exact
         const int s0 = yin0 ? (int)(((float)o.y0 + 0.5f) * inv_SR) : -1, s1 = yin1 ? (int)(((float)o.y0 + 1.5f) * inv_SR) : -1;
-        if (s0 >= 0) { f0[k] = pol * L.NS + s0; r0[k] = atomicAdd(&s_cnt[f0[k]], 1); }
-        if (s1 >= 0 && s1 != s0) { f1[k] = pol * L.NS + s1; r1[k] = atomicAdd(&s_cnt[f1[k]], 1); }
+        if (s0 >= 0) { f0[k] = pol * L.NS + s0; r0[k] = atomicAdd(&s_cnt[MPC_IDX(f0[k], nf_loc)], 1); }
+        if (s1 >= 0 && s1 != s0) { f1[k] = pol * L.NS + s1; r1[k] = atomicAdd(&s_cnt[MPC_IDX(f1[k], nf_loc)], 1); }
         if (want_bwd && o.lut >= 0) {
             const int cst = (int)(((float)o.iy + 0.5f) * inv_CSR);
             bk[k] = nf_loc + o.it * L.NCS + cst;
-            rb[k] = atomicAdd(&s_cnt[bk[k]], 1);
+            rb[k] = atomicAdd(&s_cnt[MPC_IDX(bk[k], nloc)], 1);
             aux[k] = ((unsigned)pol << 31) | (unsigned)((o.iy - cst * L.CSR) * p.wq + o.ix);
         }
     }
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
         int first = 0;            // backward bucket: its first record among the sample's (ev_prefix_block, before this kernel)
         if (i < nf_loc) g = (b * p.P + i / L.NS) * L.NS + (i % L.NS);
         else { g = L.NF + b * p.nb * L.NCS + (i - nf_loc); if (L.exact) first = L.bcapcnt[L.NBk + b * p.nb * L.NCS + (i - nf_loc)]; }
-        s_base[i] = (c > 0 ? atomicAdd(&L.gcount[g], c) : 0) + first;
+        s_base[i] = (c > 0 ? atomicAdd(&L.gcount[MPC_IDX(g, L.NF + L.NBk)], c) : 0) + first;
     }
     // Local exclusive prefix of the counts: the records are first laid out in LDS bucket by bucket and then
     // written out in that order, so that neighbouring lanes store to neighbouring slots of the same bucket
@@ -397,21 +400,21 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
                 const int lb = h ? f1[k] : f0[k];
                 if (lb < 0) continue;
                 const int at = s_loc[lb] + (h ? r1[k] : r0[k]);
-                if (at < EV_STAGE) { s_rec[at] = rec; s_bid[at] = (unsigned short)lb; }
+                if (at < EV_STAGE) { s_rec[MPC_IDX(at, EV_STAGE)] = rec; s_bid[MPC_IDX(at, EV_STAGE)] = (unsigned short)lb; }
                 else ev_emit(p, L, b, nf_loc, lb, s_base[lb] + (h ? r1[k] : r0[k]), rec);
             }
         }
         if (bk[k] >= 0) {
             const float4 rec = make_float4(ry[k], rx[k], rw[k], __uint_as_float(aux[k]));
             const int at = s_loc[bk[k]] + rb[k];
-            if (at < EV_STAGE) { s_rec[at] = rec; s_bid[at] = (unsigned short)bk[k]; }
+            if (at < EV_STAGE) { s_rec[MPC_IDX(at, EV_STAGE)] = rec; s_bid[MPC_IDX(at, EV_STAGE)] = (unsigned short)bk[k]; }
             else ev_emit(p, L, b, nf_loc, bk[k], s_base[bk[k]] + rb[k], rec);
         }
     }
     __syncthreads();
     for (int r = tid; r < min(total, EV_STAGE); r += 256) {
         const int lb = s_bid[r];
-        ev_emit(p, L, b, nf_loc, lb, s_base[lb] + (r - s_loc[lb]), s_rec[r]);
+        ev_emit(p, L, b, nf_loc, lb, s_base[MPC_IDX(lb, nloc)] + (r - s_loc[lb]), s_rec[r]);
     }
     if (want_bwd && lblk == 0 && tid == 0) L.gcount[L.NF + L.NBk + 2] = EV_MARKER;
 }
@@ -454,11 +457,11 @@ __global__ __launch_bounds__(1024) void k_iwe_accum(const BinLayout L, float *__
             // tensor), a weighted `valid` column; event_image_converter.py:45-74 accepts any) takes the hi/lo split
             if (fabsf(e[u].w) <= 1.5f)
                 record_taps(e[u].y, e[u].x, e[u].w, H, W, row0, row1, [&](int yy, int xx, float v) {
-                    atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed_small(v));
+                    atomicAdd(&s_acc[MPC_IDX((yy - row0) * W + xx, npix)], (unsigned long long)ev_to_fixed_small(v));
                 });
             else
                 record_taps(e[u].y, e[u].x, e[u].w, H, W, row0, row1, [&](int yy, int xx, float v) {
-                    atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)ev_to_fixed(v));
+                    atomicAdd(&s_acc[MPC_IDX((yy - row0) * W + xx, npix)], (unsigned long long)ev_to_fixed(v));
                 });
         }
     }
@@ -492,8 +495,8 @@ __device__ __forceinline__ void record_grad(float y, float x, float w, const flo
     // 13.7 us of the 16.5 us a workgroup of k_lut_accum lives).
     const int xa = min(max(x0, 0), W - 2);
     const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
-    const pair4 a = *reinterpret_cast<const pair4 *>(g + (size_t)ya * W + xa);
-    const pair4 b = *reinterpret_cast<const pair4 *>(g + (size_t)yb * W + xa);
+    const pair4 a = *reinterpret_cast<const pair4 *>(g + MPC_IDX((size_t)ya * W + xa, (long long)H * W - 1));
+    const pair4 b = *reinterpret_cast<const pair4 *>(g + MPC_IDX((size_t)yb * W + xa, (long long)H * W - 1));
     const bool lo = (xa == x0);                 // column x0 is the first element of the pair
     const float g00 = (r0 && c0) ? (lo ? a.x : a.y) : 0.f;
     const float g01 = (r0 && c1) ? (lo ? a.y : a.x) : 0.f;
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
     const float tref = (ORDERED && (p.flags & MPC_F_SCALE_BY_DT)) ? t_ref[0] : 0.f;
     // record r of this bucket: from the forward's list, or rebuilt from event row r of the ordered tensor
     auto fetch = [&](int r) -> float4 {
-        if (!ORDERED) return rec[r];
+        if (!ORDERED) return rec[MPC_IDX(r, L.bcap)];
         const int pol = r >= n_pos ? 1 : 0;
         const int row = pol ? o_neg + (r - n_pos) : o_pos + r;
         float e[6];
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         // foreign tensor passed with offsets -- contributes nothing)
         const bool here = o.it == it && o.iy >= crow0 && o.iy < crow1;
         const int cell = here ? (o.iy - crow0) * p.wq + o.ix : 0;
-        const bool mine = warp_event_with(p, e, s_lut[cell], tref, o) && here;
+        const bool mine = warp_event_with(p, e, s_lut[MPC_IDX(cell, ncell)], tref, o) && here;
         const unsigned aux = ((unsigned)((p.P == 2) ? pol : 0) << 31) | (unsigned)cell;
         return make_float4(o.y, o.x, mine ? o.w : 0.f, __uint_as_float(aux));
     };
@@ -617,8 +620,8 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         for (int u = 0; u < NIF; ++u) {
             if (r0 + u * NT < n && (!ORDERED || e[u].z != 0.f)) {
                 const int cell = (int)(__float_as_uint(e[u].w) & 0x7fffffffu);
-                atomicAdd(&s_acc[2 * cell], (unsigned long long)ev_to_fixed(gy[u]));
-                atomicAdd(&s_acc[2 * cell + 1], (unsigned long long)ev_to_fixed(gx[u]));
+                atomicAdd(&s_acc[MPC_IDX(2 * cell, 2 * ncell)], (unsigned long long)ev_to_fixed(gy[u]));
+                atomicAdd(&s_acc[MPC_IDX(2 * cell + 1, 2 * ncell)], (unsigned long long)ev_to_fixed(gx[u]));
             }
         }
     }
@@ -991,6 +994,7 @@ __global__ __launch_bounds__(PE_NT) void k_pe_accum(const mpc_shape s, int CSR, 
 #pragma unroll
         for (int u = 0; u < PE_NIF; ++u) {
             const int lc = __float_as_int(e[u][4]) - cell0;
+            MPC_EXPECT(!on[u] || (gy[u] == 0.f && gx[u] == 0.f) || (lc >= 0 && lc < ncell));      // (a row outside its strip: the offsets table is not this tensor's)
             if (!on[u] || lc < 0 || lc >= ncell || (gy[u] == 0.f && gx[u] == 0.f)) continue;
             float ph[KB > 0 ? KB : PE_KMAX];
             pe_phi<KB>(phi, grow[u], k, e[u][2], tref, ph);
@@ -1044,6 +1048,16 @@ extern "C" int mpc_pe_grad(const mpc_shape *s, const float *rows, const float *p
     else MPC_LAUNCH(k_pe_grad<0>, dim3(grid), dim3(256), 0, st, *s, rows, phi, k, t_ref, grad_iwe, scal, grad_out, grad_coef_rows);
     MPC_CHECK_LAUNCH();
     return 0;
+}
+
+// 1 where mpc_pe_grad_ordered serves (shape, k) -- a LUT strip's [cell][2][k] accumulators fit the LDS, num_bins <= 64 --, 0 where
+// the caller has to take mpc_pe_grad (the one copy of the rule: the Python side asks instead of restating it)
+extern "C" int32_t mpc_pe_grad_ordered_supported(const mpc_shape *s, int32_t k) {
+    if (!s || mpc_validate_shape(s)) return 0;
+    if (!(s->flags & MPC_F_NO_WARP) || s->T != 1 || k < 1 || k > 64 || s->nb > 64 || s->B <= 0) return 0;
+    const mpc_ws_layout L = mpc_layout(s);
+    if (L.n_cstrips <= 0) return 0;
+    return (size_t)L.cstrip_rows * s->wq * 2 * k * 8 <= 150 * 1024 ? 1 : 0;
 }
 
 extern "C" int mpc_pe_grad_ordered(const mpc_shape *s, const float *rows, const int32_t *offsets, const float *phi, int32_t k,
@@ -1258,3 +1272,5 @@ extern "C" int mpc_event_bucket_order(const mpc_shape *s, const float *events_in
     MPC_CHECK_LAUNCH();
     return 0;
 }
+
+MPC_BOUNDS_UNIT("events.hip")

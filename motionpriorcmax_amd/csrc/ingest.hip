@@ -9,6 +9,7 @@
 // maxima) -> stable scatter (order inside each block is the input order, as boolean masking gives).
 // The caller reads the two batch maxima to size the output (the only host round trip of ingest).
 #include "common.h"
+#include "bounds.h"
 
 #define ING_CHUNK 1024          // events per workgroup (256 threads x 4 consecutive events)
 
@@ -221,9 +222,9 @@ __global__ __launch_bounds__(256) void k_ingest_scatter(const mpc_ingest_shape s
             if (cls[k] == 0) continue;
             const double tn = (double)(tv - tmin) / span;                       // loader.py:152 (float64)
             const int row = cls[k] == 1 ? rp++ : rn++;
-            s_rows[3 * row + 0] = make_float2(q.y[k], q.x[k]);
-            s_rows[3 * row + 1] = make_float2((float)tn, q.p[k]);
-            s_rows[3 * row + 2] = make_float2((float)bin_index(tn, s.nb), 1.f);
+            s_rows[MPC_IDX(3 * row + 0, ING_CHUNK * 3)] = make_float2(q.y[k], q.x[k]);
+            s_rows[MPC_IDX(3 * row + 1, ING_CHUNK * 3)] = make_float2((float)tn, q.p[k]);
+            s_rows[MPC_IDX(3 * row + 2, ING_CHUNK * 3)] = make_float2((float)bin_index(tn, s.nb), 1.f);
         }
     }
     __syncthreads();
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_ingest_keycount(const mpc_ingest_shape 
             const int c = classify(q.x[u], q.y[u], q.p[u], s.H, s.W);
             if (c == 0) continue;
             const double tn = (double)(q.t[u] - tmin) / span;
-            atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, q.y[u], tn)], 1);
+            atomicAdd(&s_k[MPC_IDX((c - 1) * (k.NK + 1) + ing_key(s, k, q.y[u], tn), 2 * (k.NK + 1))], 1);
         }
     }
     __syncthreads();
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_ingest_scatter_ordered(const mpc_ingest
             const int c = classify(q.x[u], q.y[u], q.p[u], s.H, s.W);
             if (c == 0) continue;
             const double tn = (double)(tv - tmin) / span;
-            const int row = atomicAdd(&s_k[(c - 1) * (k.NK + 1) + ing_key(s, k, q.y[u], tn)], 1);
+            const int row = atomicAdd(&s_k[MPC_IDX((c - 1) * (k.NK + 1) + ing_key(s, k, q.y[u], tn), 2 * (k.NK + 1))], 1);
             float2 *e = reinterpret_cast<float2 *>(events + ((size_t)b * M + row) * 6);      // (24-byte rows: 8-byte aligned)
             e[0] = make_float2(q.y[u], q.x[u]); e[1] = make_float2((float)tn, q.p[u]);
             e[2] = make_float2((float)bin_index(tn, s.nb), 1.f);
@@ -471,3 +472,5 @@ extern "C" int mpc_ingest_scatter_ordered(const mpc_ingest_shape *s, const mpc_s
     MPC_CHECK_LAUNCH();
     return 0;
 }
+
+MPC_BOUNDS_UNIT("ingest.hip")

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "knn_device.h"
 #include "ev_count_device.h"
+#include "bounds.h"
 #include <stdlib.h>
 #ifndef KNN_BW_CH
 #define KNN_BW_CH 4       // bwd_window_fast: cells of a window row whose LDS reads are issued together
@@ -56,8 +57,8 @@ __device__ __forceinline__ void knn_bitonic128(unsigned &k0, unsigned &k1, int l
 // NPT: points per thread held in registers (CACHED), a multiple of 4 >= ceil(n / 1024): 20 for the 19 200 points of a DSEC grid
 template <bool CACHED, int NPT>
 __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const float *__restrict__ traj,
-                                                     int *__restrict__ cell_start, int *__restrict__ sat,
-                                                     float2 *__restrict__ spos, int *__restrict__ sidx, int S,
+                                                     knn_cs_t *__restrict__ cell_start, knn_cs_t *__restrict__ sat,
+                                                     float2 *__restrict__ spos, knn_idx_t *__restrict__ sidx, int S,
                                                      float *__restrict__ tile_dkmax, int ntiles, const KnnLists ls,
                                                      int *__restrict__ zero_ptr, int zero_words) {
     extern __shared__ int s_cnt[];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     // ... and the work lists of the forward start empty (knn_device.h: KnnLists)
     if (part == 0 && ls.far != nullptr) {
         if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
-        if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
+        for (int i = tid; i < ls.ftwords; i += 1024) ls.ftbits[(size_t)bt * ls.ftwords + i] = 0u;
     }
     if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
     if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; }
@@ -115,13 +116,13 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     if (CACHED) {
 #pragma unroll
         for (int u = 0; u < NPT; ++u)
-            if (qc[u] >= g_lo && qc[u] < g_hi) atomicAdd(&s_cnt[qc[u] - g_lo], 1);
+            if (qc[u] >= g_lo && qc[u] < g_hi) atomicAdd(&s_cnt[MPC_IDX(qc[u] - g_lo, Gp)], 1);
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
             const int c = knn_cell_index(p, v.x, v.y);
             below += c < g_lo;
-            if (c >= g_lo && c < g_hi) atomicAdd(&s_cnt[c - g_lo], 1);
+            if (c >= g_lo && c < g_hi) atomicAdd(&s_cnt[MPC_IDX(c - g_lo, Gp)], 1);
         }
     }
 #pragma unroll
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     }
     __syncthreads();
     BK_STAMP(3);
-    int *cs = cell_start + (size_t)bt * (p.Gb + 1);
-    for (int g = tid; g < Gp; g += 1024) cs[g_lo + g] = base + s_cnt[g];      // coalesced
+    knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    for (int g = tid; g < Gp; g += 1024) cs[MPC_IDX(g_lo + g, p.Gb + 1)] = base + s_cnt[g];      // coalesced
     if (tid == 0 && part == S - 1) cs[p.Gb] = p.n;
     if (sat != nullptr && S == 1) {
         // the summed-area table of the cell counts while the first points of all cells are in LDS (one workgroup holds the
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     __syncthreads();
     BK_STAMP(4);
     float2 *sp_ = spos + (size_t)bt * p.n + base;
-    int *si_ = sidx + (size_t)bt * p.n + base;
+    knn_idx_t *si_ = sidx + (size_t)bt * p.n + base;
     // scatter the INDICES into LDS first: the slots inside a cell are handed out in the order the LDS atomics
     // happen to execute, so the (few) points of every cell are then ordered by trajectory index -- the bucket
     // order, and with it the fp32 summation order of the LUT, is the same in every run -- and only then are
@@ -176,12 +177,12 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     if (CACHED) {
 #pragma unroll
         for (int u = 0; u < NPT; ++u)
-            if (qc[u] >= g_lo && qc[u] < g_hi) l_idx[atomicAdd(&s_cnt[qc[u] - g_lo], 1)] = (unsigned short)(tid + u * 1024);
+            if (qc[u] >= g_lo && qc[u] < g_hi) l_idx[MPC_IDX(atomicAdd(&s_cnt[MPC_IDX(qc[u] - g_lo, Gp)], 1), p.n)] = (unsigned short)(tid + u * 1024);
     } else {
         for (int i = tid; i < p.n; i += 1024) {
             const float2 v = pts[i];
             const int c = knn_cell_index(p, v.x, v.y);
-            if (c >= g_lo && c < g_hi) l_idx[atomicAdd(&s_cnt[c - g_lo], 1)] = (unsigned short)i;
+            if (c >= g_lo && c < g_hi) l_idx[MPC_IDX(atomicAdd(&s_cnt[MPC_IDX(c - g_lo, Gp)], 1), p.n)] = (unsigned short)i;
         }
     }
     __syncthreads();
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     // the margin: everything that left the image by more than the margin, a hundred per cell) -- cells with more than
     // KNN_BK_SMALL points go on a list and are sorted by a whole wavefront (bitonic network, up to KNN_BK_WAVE keys), the few
     // with more than that by the whole workgroup (a bitmap over the trajectory indices: any number of keys).
+    // (Round 5 measured the ordering PER POINT instead -- a point's place = the indices of its cell below its own, up to
+    // KNN_BK_SMALL independent LDS reads -- : slowest workgroup 10.6 us in this phase instead of 13.2, but the mean 7.3 instead
+    // of 6.2 and 20 spilled registers in the phase before: launch 53.8 us against 50.4.  Not kept; profiles/HISTORY_r05.md.)
     for (int g = tid; g < Gp; g += 1024) {          // s_cnt[g] is now the END of cell g
         const int e = s_cnt[g], a = g ? s_cnt[g - 1] : 0;
         if (e - a > KNN_BK_SMALL) {
@@ -201,8 +205,8 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         for (int i = a + 1; i < e; ++i) {
             const unsigned short key = l_idx[i];
             int j = i - 1;
-            while (j >= a && l_idx[j] > key) { l_idx[j + 1] = l_idx[j]; --j; }
-            l_idx[j + 1] = key;
+            while (j >= a && l_idx[j] > key) { l_idx[MPC_IDX(j + 1, p.n)] = l_idx[j]; --j; }
+            l_idx[MPC_IDX(j + 1, p.n)] = key;
         }
     }
     __syncthreads();
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
             unsigned k0 = lane < c ? (unsigned)l_idx[a + lane] : 0xffffffffu;
             unsigned k1 = lane + 64 < c ? (unsigned)l_idx[a + 64 + lane] : 0xffffffffu;
             knn_bitonic128(k0, k1, lane);
-            if (lane < c) l_idx[a + lane] = (unsigned short)k0;
-            if (lane + 64 < c) l_idx[a + 64 + lane] = (unsigned short)k1;
+            if (lane < c) l_idx[MPC_IDX(a + lane, p.n)] = (unsigned short)k0;
+            if (lane + 64 < c) l_idx[MPC_IDX(a + 64 + lane, p.n)] = (unsigned short)k1;
         }
     }
     __syncthreads();
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
             if (c <= KNN_BK_WAVE) continue;                   // (workgroup-uniform)
             for (int w = tid; w < nw; w += 1024) bm[w] = 0u;
             __syncthreads();
-            for (int i = a + tid; i < e; i += 1024) atomicOr(&bm[l_idx[i] >> 5], 1u << (l_idx[i] & 31));
+            for (int i = a + tid; i < e; i += 1024) atomicOr(&bm[MPC_IDX(l_idx[MPC_IDX(i, p.n)] >> 5, nw)], 1u << (l_idx[i] & 31));
             __syncthreads();
             // prefix of the word popcounts: thread `tid` owns words [w0, w1)
             const int per = (nw + 1023) / 1024, w0 = min(tid * per, nw), w1 = min(w0 + per, nw);
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
             for (int w = 0; w < (tid >> 6); ++w) pos += s_wave[w];
             for (int w = w0; w < w1; ++w) {
                 unsigned bits = bm[w];
-                while (bits) { const int bit = __ffs(bits) - 1; bits &= bits - 1u; l_idx[pos++] = (unsigned short)(32 * w + bit); }
+                while (bits) { const int bit = __ffs(bits) - 1; bits &= bits - 1u; l_idx[MPC_IDX(pos, p.n)] = (unsigned short)(32 * w + bit); ++pos; }
             }
             __syncthreads();
         }
@@ -268,11 +272,11 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 #pragma unroll
         for (int u = 0; u < GB; ++u) i[u] = (sl0 + u * 1024 < own) ? (int)l_idx[sl0 + u * 1024] : 0;
 #pragma unroll
-        for (int u = 0; u < GB; ++u) v[u] = pts[i[u]];
+        for (int u = 0; u < GB; ++u) v[u] = pts[MPC_IDX(i[u], p.n)];
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             const int sl = sl0 + u * 1024;
-            if (sl < own) { si_[sl] = i[u]; sp_[sl] = v[u]; }
+            if (sl < own) { si_[MPC_IDX(base + sl, p.n) - base] = i[u]; sp_[sl] = v[u]; }
         }
     }
 #ifdef KNN_BK_STAMP
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 // every (column, group) item adds up its own rows behind the groups above it.  All threads of the workgroup call.
 // ------------------------------------------------------------------------------------------
 template <class F>
-__device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, int *__restrict__ S, int *s_part) {
+__device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, knn_cs_t *__restrict__ S, int *s_part) {
     const int W1 = p.wb + 1, ngrp = (p.hb + 7) >> 3, nthr = blockDim.x;
     // every (column, group of 8 rows) item keeps its 8 row prefixes in registers between the two phases; all 16 loads of an
     // item are in flight together (from global memory a dependent chain of them was the whole 18 us of the kernel at B = 1)
@@ -310,7 +314,7 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, in
             pre[u][k] = a - z;
             sum += pre[u][k];
         }
-        if (it < ngrp * W1) s_part[it] = sum;
+        if (it < ngrp * W1) s_part[MPC_IDX(it, ngrp * W1)] = sum;
     }
     for (int it = threadIdx.x + ITEMS * nthr; it < ngrp * W1; it += nthr) {        // (grids beyond ITEMS x threads items)
         const int g = it / W1, x = it - g * W1;
@@ -330,7 +334,7 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, in
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int y = g * 8 + k;
-            if (y < p.hb) { acc += pre[u][k]; S[(size_t)(y + 1) * W1 + x] = acc; }
+            if (y < p.hb) { acc += pre[u][k]; S[MPC_IDX((size_t)(y + 1) * W1 + x, (p.hb + 1) * W1)] = acc; }
         }
     }
     for (int it = threadIdx.x + ITEMS * nthr; it < ngrp * W1; it += nthr) {
@@ -345,10 +349,10 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, in
 }
 // from cell_start in global memory (the bucket sorts that do not hold a whole (sample, bin) in one workgroup's LDS)
 // grid B * nb, 1024 threads, dynamic LDS ceil(hb / 8) * (wb + 1) ints
-__global__ __launch_bounds__(1024) void k_knn_sat(const KnnParams p, const int *__restrict__ cell_start, int *__restrict__ sat) {
+__global__ __launch_bounds__(1024) void k_knn_sat(const KnnParams p, const knn_cs_t *__restrict__ cell_start, knn_cs_t *__restrict__ sat) {
     extern __shared__ int s_part[];
     const int bt = blockIdx.x;
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
     knn_sat_build(p, [&](int y, int x) { return cs[y * p.wb + x]; }, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), s_part);
 }
 
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(256) void k_knn_bucket_count(const KnnParams p, con
 
 // grid B*nb, 1024 threads
 __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int *__restrict__ cursor,
-                                                          int *__restrict__ cell_start,
+                                                          knn_cs_t *__restrict__ cell_start,
                                                           float *__restrict__ tile_dkmax, int ntiles, const KnnLists ls,
                                                           int *__restrict__ zero_ptr, int zero_words) {
     __shared__ int s_wave[16];
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
     for (int i = tid; i < ntiles * KNN_NCLS; i += 1024) tile_dkmax[(size_t)bt * ntiles * KNN_NCLS + i] = 0.f;       // (see k_knn_bucket)
     if (ls.far != nullptr) {
         if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
-        if (tid < ls.ftwords) ls.ftbits[(size_t)bt * ls.ftwords + tid] = 0u;
+        for (int i = tid; i < ls.ftwords; i += 1024) ls.ftbits[(size_t)bt * ls.ftwords + i] = 0u;
     }
     if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
     if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; }
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
     int *cur = cursor + (size_t)bt * p.Gb;
-    int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
     const int chunk = (p.Gb + 1023) / 1024;
     const int g0 = min(tid * chunk, p.Gb), g1 = min(g0 + chunk, p.Gb);
     int local = 0;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
 
 __global__ __launch_bounds__(256) void k_knn_bucket_scatter(const KnnParams p, const float *__restrict__ traj,
                                                             int *__restrict__ cursor,
-                                                            float2 *__restrict__ spos, int *__restrict__ sidx) {
+                                                            float2 *__restrict__ spos, knn_idx_t *__restrict__ sidx) {
     const int bt = blockIdx.y, b = bt / p.nb, t = bt - b * p.nb;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= p.n) return;
@@ -424,15 +428,15 @@ __global__ __launch_bounds__(256) void k_knn_bucket_scatter(const KnnParams p, c
 
 // one WAVEFRONT per cell: cells of up to 128 points by the bitonic network, larger ones by rank counting (every lane
 // counts the keys below its own: quadratic, but spread over 64 lanes; the rare pile of the outermost margin ring)
-__global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, const int *__restrict__ cell_start,
-                                                          float2 *__restrict__ spos, int *__restrict__ sidx,
+__global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
+                                                          float2 *__restrict__ spos, knn_idx_t *__restrict__ sidx,
                                                           const float *__restrict__ traj) {
     const int bt = blockIdx.y, b = bt / p.nb, t = bt - b * p.nb;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (g >= p.Gb) return;
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
     float2 *sp_ = spos + (size_t)bt * p.n;
-    int *si_ = sidx + (size_t)bt * p.n;
+    knn_idx_t *si_ = sidx + (size_t)bt * p.n;
     const float2 *pts = reinterpret_cast<const float2 *>(traj) + ((size_t)b * (p.T + p.nb) + p.T + t) * p.n;
     const int a = cs[g], e = cs[g + 1], c = e - a;
     if (c <= 1) return;
@@ -469,9 +473,9 @@ __global__ __launch_bounds__(256) void k_knn_bucket_order(const KnnParams p, con
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_knn_query(const KnnParams p, const float *__restrict__ traj,
-                                                   const int *__restrict__ cell_start,
+                                                   const knn_cs_t *__restrict__ cell_start,
                                                    const float2 *__restrict__ spos,
-                                                   const int *__restrict__ sidx,
+                                                   const knn_idx_t *__restrict__ sidx,
                                                    float *__restrict__ flow_lut,
                                                    float *__restrict__ flow_next,
                                                    float *__restrict__ knn_state,
@@ -663,9 +667,9 @@ __global__ __launch_bounds__(256) void k_knn_reach(const KnnParams p, const floa
 // ------------------------------------------------------------------------------------------
 #define KNN_RQ_MAX 9   // largest staged halo (cells); tiles whose reach needs more read the global arrays (7 -> 9: the 1 % of such tiles at C3 took 47 us each against 12, and were the whole duration of a B = 1 launch)
 template <int TS>
-__global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, const int *__restrict__ cell_start,
+__global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
                                                             const float2 *__restrict__ spos,
-                                                            const int *__restrict__ sidx,
+                                                            const knn_idx_t *__restrict__ sidx,
                                                             const float *__restrict__ glut,
                                                             const float *__restrict__ gnext,
                                                             const float *__restrict__ knn_state,
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
     const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
     int tcy0, tcy1, tcx0, tcx1;           // cells of the tile's points: a border tile owns the margin beside it (knn_tile_cells)
     knn_tile_cells(by_, p.hq, p.m, tcy0, tcy1); knn_tile_cells(bx_, p.wq, p.m, tcx0, tcx1);
     const int nrow = tcy1 - tcy0;
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
     const int total = s_rowbase[nrow];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
+    const knn_idx_t *si_ = sidx + (size_t)bt * p.n;
     for (int pi = tid; pi < total; pi += NT) {
         int lo = 0, hi = nrow;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
@@ -821,6 +825,7 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
         const float dy = ((float)__mul24(cyr, p.sp) + p.off) - pt.x;
         const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
         const int ro = __mul24(cyr - ry0, RP) + xb;
+        MPC_EXPECT(ro >= 0 && ro + CW <= RW * RP + 16);          // (every lane reads CW cells of the row: the slack behind the last row is there for that)
         const float *rdk = ldk + ro;
         const float2 *rg = lg + ro, *rown = lgn + ro;
         // The gradients as ONE ds_read_b64 each (knn_lds_f2: a volatile load the compiler may not pair).  Left alone it pairs
@@ -947,8 +952,8 @@ __global__ __launch_bounds__(256) void k_knn_reach_tiles(const KnnParams p, cons
 }
 
 template <bool L1, bool NEXT>
-__global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const int *__restrict__ cell_start,
-                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
+__global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
+                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                       const float *__restrict__ glut, const float *__restrict__ gnext,
                                                       const float *__restrict__ knn_state,
                                                       const float *__restrict__ tile_dkmax,
@@ -977,7 +982,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     const int by_ = bxy / gx, bx_ = bxy - by_ * gx;
     const int b = bt / p.nb, t = bt - b * p.nb;
     const size_t BQ = (size_t)p.B * p.nb * p.G;
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
     int tcy0, tcy1, tcx0, tcx1;           // cells of the tile's points: a border tile owns the margin beside it (knn_tile_cells)
     knn_tile_cells(by_, p.hq, p.m, tcy0, tcy1); knn_tile_cells(bx_, p.wq, p.m, tcx0, tcx1);
     const int nrow = tcy1 - tcy0;
@@ -996,11 +1001,11 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     } else if (tid < 128) {
         const int ln = tid - 64;
         int gs = 0, ge = 0;
-        if (ln < nrow) { gs = cs[knn_ci(p, tcy0 + ln, tcx0)]; ge = cs[knn_ci(p, tcy0 + ln, tcx1)]; }      // cell rows of the tile, margin included
+        if (ln < nrow) { gs = cs[MPC_IDX(knn_ci(p, tcy0 + ln, tcx0), p.Gb + 1)]; ge = cs[MPC_IDX(knn_ci(p, tcy0 + ln, tcx1), p.Gb + 1)]; }      // cell rows of the tile, margin included
         int run = ge - gs;
 #pragma unroll
         for (int o2 = 1; o2 < KNN_TROWS; o2 <<= 1) { const int v = __shfl_up(run, o2, 64); if (ln >= o2) run += v; }
-        if (ln < nrow) { s_rowg[ln] = gs; s_rowbase[ln + 1] = run; }
+        if (ln < nrow) { s_rowg[MPC_IDX(ln, KNN_TROWS)] = gs; s_rowbase[MPC_IDX(ln + 1, KNN_TROWS + 1)] = run; }
         if (ln == 0) s_rowbase[0] = 0;
     }
     // ---- phase 2 (after the reach is known; staging a guessed halo before it, so that the loads of the two phases
@@ -1051,13 +1056,13 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                     else tie |= ik & KNN_TIE_FLAG;
                     ik &= KNN_IDX_MASK;
                 }
-                ldk[rr * RP + cc] = dk; lg[rr * RP + cc] = g;
-                if (NEXT) { lik[rr * RP + cc] = ik; lgn[rr * RP + cc] = gn; }
+                ldk[MPC_IDX(rr * RP + cc, ncell)] = dk; lg[MPC_IDX(rr * RP + cc, ncell)] = g;
+                if (NEXT) { lik[MPC_IDX(rr * RP + cc, ncell)] = ik; lgn[MPC_IDX(rr * RP + cc, ncell)] = gn; }
             }
         }
         if (tid < KNN_BW_WMAX) {                    // slack behind the last row: never a member
-            ldk[RW * RP + tid] = -1.f; lg[RW * RP + tid] = make_float2(0.f, 0.f);
-            if (NEXT) { lik[RW * RP + tid] = -1; lgn[RW * RP + tid] = make_float2(0.f, 0.f); }
+            ldk[MPC_IDX(RW * RP + tid, ncell)] = -1.f; lg[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f);
+            if (NEXT) { lik[MPC_IDX(RW * RP + tid, ncell)] = -1; lgn[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f); }
         }
         const bool wt = __ballot(tie != 0) != 0ull;
         if ((tid & 63) == 0) s_tiew[tid >> 6] = wt ? 1 : 0;
@@ -1079,7 +1084,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     const int total = s_rowbase[nrow];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
+    const knn_idx_t *si_ = sidx + (size_t)bt * p.n;
     for (int base = 0; base < total; base += 256) {
         const int pi = base + tid;
         const bool act = pi < total;
@@ -1087,8 +1092,8 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
         int lo = 0, hi = nrow;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rowbase[mid] <= pi) lo = mid; else hi = mid; }
         const int g = act ? s_rowg[lo] + (pi - s_rowbase[lo]) : 0;
-        const float2 pt = sp_[g];
-        const int i = si_[g];
+        const float2 pt = sp_[MPC_IDX(g, p.n)];
+        const int i = si_[MPC_IDX(g, p.n)];
         // query cells within reach: |q - p| <= R per axis (R carries a 0.01 px + 1e-4 relative margin, which dominates
         // the rounding of these expressions)
         int y0 = (int)ceilf((pt.x - R - p.off) * inv_sp), y1 = (int)floorf((pt.x + R - p.off) * inv_sp);
@@ -1134,7 +1139,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                     for (int cx = x0; cx <= x1; ++cx) {
                         const float dx = ((float)(cx * p.sp) + p.off) - pt.y;
                         const float d = dy2 + (L1 ? fabsf(dx) : dx * dx);
-                        const float dk = ldk[ro + cx];
+                        const float dk = ldk[MPC_IDX(ro + cx, (long long)RW * RP + KNN_BW_WMAX)];
                         // (the K-th index: staged only with the flow_to_next gradient, else read where it lives -- a tie is rare)
                         const bool in = (d < dk) || (d == dk && i <= (NEXT ? lik[ro + cx]
                                                                             : (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & KNN_IDX_MASK)));
@@ -1167,10 +1172,10 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
             // no flow_to_next term: d traj(t_mid)[t] = -g goes straight to its place in the trajectory gradient (the value
             // k_knn_bwd_combine would write: -g + 0 - 0); k_knn_bwd_combine_direct then only adds the bins up
             if (gtraj_direct != nullptr)
-                gtraj_direct[((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i] = make_float2(-(invK * ay) + 0.f, -(invK * ax) + 0.f);
+                gtraj_direct[MPC_IDX(((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i, (long long)p.B * (p.T + p.nb) * p.n)] = make_float2(-(invK * ay) + 0.f, -(invK * ax) + 0.f);
             else {
-                tmp_g[(size_t)bt * p.n + i] = make_float2(invK * ay, invK * ax);
-                if (gnext != nullptr) tmp_a[(size_t)bt * p.n + i] = make_float2(invK * an.x, invK * an.y);
+                tmp_g[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(invK * ay, invK * ax);
+                if (gnext != nullptr) tmp_a[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(invK * an.x, invK * an.y);
             }
         }
     }
@@ -1208,8 +1213,8 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 #define KNN_FAR_BLOCKS 4096     // (2048: 237 us against 218 at a 48 px contraction band)
 #endif
 template <bool L1, bool NEXT>
-__global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const int *__restrict__ cell_start,
-                                                     const float2 *__restrict__ spos, const int *__restrict__ sidx,
+__global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
+                                                     const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
                                                      const float *__restrict__ knn_state, const KnnLists ls,
                                                      float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
@@ -1238,9 +1243,9 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const in
         const int b = bt / p.nb, t = bt - b * p.nb;
         const int *fl = ls.far + (size_t)bt * (p.G + 1);
         const int nfar = min(fl[0], p.G);
-        const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+        const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
         const float2 *sp_ = spos + (size_t)bt * p.n;
-        const int *si_ = sidx + (size_t)bt * p.n;
+        const knn_idx_t *si_ = sidx + (size_t)bt * p.n;
         const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
         const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
         const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
@@ -1556,10 +1561,10 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     if (s->B == 0) return 0;
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
-    int *cell_start = (int *)((char *)ws + L.off_cell_start);
-    int *sat = (int *)((char *)ws + L.off_knn_sat);
+    knn_cs_t *cell_start = (knn_cs_t *)((char *)ws + L.off_cell_start);
+    knn_cs_t *sat = (knn_cs_t *)((char *)ws + L.off_knn_sat);
     float2 *spos = (float2 *)((char *)ws + L.off_spos);
-    int *sidx = (int *)((char *)ws + L.off_sidx);
+    knn_idx_t *sidx = (knn_idx_t *)((char *)ws + L.off_sidx);
     float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
     const KnnLists ls = knn_lists(s, L, ws);
     const int ntiles = knn_tiles_x(s->wq, p.m) * knn_tiles_y(s->hq, p.m);
@@ -1696,9 +1701,9 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
     const KnnParams p = knn_params(s);
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
-    const int *cell_start = (const int *)((char *)ws + L.off_cell_start);
+    const knn_cs_t *cell_start = (const knn_cs_t *)((char *)ws + L.off_cell_start);
     const float2 *spos = (const float2 *)((char *)ws + L.off_spos);
-    const int *sidx = (const int *)((char *)ws + L.off_sidx);
+    const knn_idx_t *sidx = (const knn_idx_t *)((char *)ws + L.off_sidx);
     float2 *tmp_g = (float2 *)((char *)ws + L.off_knn_tmp_g);
     float2 *tmp_a = (float2 *)((char *)ws + L.off_knn_tmp_a);
     const float *tile_dkmax = knn_state + 3 * (size_t)s->B * s->nb * p.G;
@@ -1777,3 +1782,5 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
     MPC_CHECK_LAUNCH();
     return 0;
 }
+
+MPC_BOUNDS_UNIT("knn.hip")

@@ -34,6 +34,11 @@
 // which no search of the fast path reaches (m = KNN_RCAP + 1).  Without the margin every point outside the image piled up in
 // the border cells of the query grid (an expanding flow field: a hundred points per corner cell), and every border query
 // had to look at all of them.
+// The bucket tables are 16-bit: every value is a count of points of one (sample, bin) or a trajectory index, at most n <= 65535
+// (mpc_knn_lut_fwd refuses more).  Round 5: int32 tables were 56 of the 89 MB the bucket kernel wrote per C3 step, and that kernel's
+// table phases run at the HBM write rate.
+typedef unsigned short knn_cs_t;      // cell_start [B*nb][Gb + 1], summed-area table [B*nb][hb + 1][wb + 1]
+typedef unsigned short knn_idx_t;     // trajectory index of a bucketed point, sidx [B*nb][n]
 struct KnnParams {
     int B, nb, T, n, hq, wq, sp, K, G;      // G = hq * wq query cells
     int m, hb, wb, Gb;                       // margin; bucket grid hb x wb = (hq + 2m) x (wq + 2m), Gb cells
@@ -130,7 +135,7 @@ __host__ __device__ static inline void knn_tile_cells(int t, int n, int m, int &
     c1 = 16 * t + 16 >= n ? n + m : 16 * t + 16;
 }
 // summed-area table of the cell counts: sat[(y + m) * (wb + 1) + (x + m)] = points in cells (y', x') with y' < y and x' < x
-__device__ __forceinline__ int knn_square_count(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r) {
+__device__ __forceinline__ int knn_square_count(const KnnParams &p, const knn_cs_t *__restrict__ sat, int cy, int cx, int r) {
     const int y0 = max(cy - r, -p.m) + p.m, y1 = min(cy + r, p.hq + p.m - 1) + p.m + 1;
     const int x0 = max(cx - r, -p.m) + p.m, x1 = min(cx + r, p.wq + p.m - 1) + p.m + 1;
     const int W1 = p.wb + 1;
@@ -155,9 +160,9 @@ __device__ __forceinline__ float pair_dist(float qy, float qx, float py, float p
 // ------------------------------------------------------------------------------------------
 struct QueryCtx {
     // global
-    const int *cs;          // cell_start of this (sample, bin)
+    const knn_cs_t *cs;          // cell_start of this (sample, bin)
     const float2 *spos;
-    const int *sidx;
+    const knn_idx_t *sidx;
     const float2 *traj_b;   // trajectories of this sample: [T+nb][n]
     // LDS
     const unsigned short *lcs;   // [RW][RW+1]  (staged offsets < cap <= 65535)
@@ -639,7 +644,7 @@ __device__ __forceinline__ bool knn_is_far_dk(const KnnParams &p, float dK, int 
 }
 // Search radius of a query from the summed-area table of the cell counts: the smallest r in [rmin, KNN_RCAP] whose square
 // of (2r + 1)^2 cells (clipped to the bucket grid) holds at least `need` points; KNN_RCAP + 1 if none does.
-__device__ __forceinline__ int knn_sat_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int rmin, int need, int rcap = KNN_RCAP) {
+__device__ __forceinline__ int knn_sat_radius(const KnnParams &p, const knn_cs_t *__restrict__ sat, int cy, int cx, int rmin, int need, int rcap = KNN_RCAP) {
     int r = rmin;
     while (r <= rcap && knn_square_count(p, sat, cy, cx, r) < need) ++r;
     return r;
@@ -669,7 +674,7 @@ __device__ __forceinline__ int knn_chord_cells(int r, int j, int sp, bool l1) {
 bool mpc_knn_strip_usable(const mpc_shape *s, int r_init);
 bool mpc_knn_uses_far_list(const mpc_shape *s);
 struct EvCountArgs;      // ev_count_device.h: event rows to count per backward bucket in spare workgroups of the strip kernel, or null
-int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const int *sat, const float2 *spos, const int *sidx,
+int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *cell_start, const knn_cs_t *sat, const float2 *spos, const knn_idx_t *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, const KnnLists *lists, int r_init,
                          const EvCountArgs *evc, hipStream_t st);
 bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc);

@@ -30,6 +30,7 @@
 // K-nearest set for any input, ties to the lowest index.
 #include "knn_device.h"
 #include "ev_count_device.h"
+#include "bounds.h"
 #include <stdlib.h>
 
 #define KS_NT 256
@@ -91,8 +92,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 #define KS_NR_MAX (KS_NT / 2 + 2 * KNN_RFAR)
 template <int WS, bool L1, bool NEXT, bool IWD, int MODE>
 __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__restrict__ traj,
-                                           const int *__restrict__ cell_start, const int *__restrict__ sat,
-                                           const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                           const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
+                                           const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                            float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                            float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                            const KnnLists &ls, int r_init, int cap, int gx, int gy,
@@ -118,7 +119,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     if (MODE != 1) {
         // (main and second launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
         // the first bucketed slots of the rows go later (s_row); this early barrier costs nothing: every wavefront is here at once
-        if (tid < NR) reinterpret_cast<int2 *>(s_dyn)[tid].x = 0;
+        if (tid < NR) reinterpret_cast<int2 *>(s_dyn)[MPC_IDX(tid, NR)].x = 0;
         if (tid == 0) s_rq[0] = 0;                    // (main launch: "this strip holds far queries", set below; it has no other use for s_rq)
         __syncthreads();
     }
@@ -137,10 +138,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     float2 *lnext = reinterpret_cast<float2 *>(s_dyn + o); o += NEXT ? (size_t)(cap + KS_TAIL(MAXCH)) * 8 : 0;
     unsigned short *lidx = reinterpret_cast<unsigned short *>(s_dyn + o);
 
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
-    const int *sat_bt = sat + (size_t)bt * (p.hb + 1) * (p.wb + 1);
+    const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const knn_cs_t *sat_bt = sat + (size_t)bt * (p.hb + 1) * (p.wb + 1);
     const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
+    const knn_idx_t *si_ = sidx + (size_t)bt * p.n;
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
 
     // ---- the query of this thread and its search radius -------------------------------------------
@@ -229,8 +230,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 const int mid = (lo + hi) >> 1;
                 if (knn_square_count(p, sat_bt, cy, cx, mid) >= need_far) hi = mid; else lo = mid;
             }
-            reinterpret_cast<int *>(knn_state)[(size_t)bt * p.G + (size_t)cy * p.wq + cx] = hi;
-            atomicOr(ls.grow + aoff, 1u << (cx & 31)); s_rq[0] = 1;
+            reinterpret_cast<int *>(knn_state)[MPC_IDX((size_t)bt * p.G + (size_t)cy * p.wq + cx, (long long)p.B * p.nb * p.G)] = hi;
+            atomicOr(ls.grow + MPC_IDX(aoff, (long long)p.B * p.nb * ls.again_words), 1u << (cx & 31)); s_rq[0] = 1;
         }
     }
     if (FARK) {
@@ -248,7 +249,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         int rr = (mine && served) ? r : 0;
 #pragma unroll
         for (int o2 = 1; o2 < WS; o2 <<= 1) rr = max(rr, __shfl_xor(rr, o2, 64));
-        if (MODE == 1) { if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[cy - qy0] = (unsigned char)rr; }
+        if (MODE == 1) { if ((tid % WS) == 0 && cy - qy0 < TH) s_rq[MPC_IDX(cy - qy0, KS_NT / WS)] = (unsigned char)rr; }
         else if (MODE == 2) { }                          // (pushed per query after the compaction below)
         else if ((tid % WS) == 0 && rr > 0) {
             // main launch: every query row pushes the width of its disc's chord onto the region rows it uses -- 2 r + 1 LDS
@@ -265,7 +266,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 if (!KS_MAIN_CHORD) wc = rr;
                 else if (L1) wc = min(rr, rr - aj + 1);
                 else wc = aj == rr ? (int)((0x3332210u >> (4 * rr)) & 15u) : (aj == rr - 1 ? (int)((0x5443210u >> (4 * rr)) & 15u) : rr);
-                atomicMax(&s_w[rc + j].x, wc);
+                atomicMax(&s_w[MPC_IDX(rc + j, NR)].x, wc);
             }
         }
     }
@@ -290,7 +291,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         int base = 0, nmine = 0;
 #pragma unroll
         for (int w2 = 0; w2 < KS_NT / 64; ++w2) { const int c = s_wsum[w2]; if (w2 < wv) base += c; nmine += c; }
-        if (mine) s_list[base + __popcll(mm & ((1ull << lane) - 1ull))] = (cy - qy0) | ((cx - qx0) << 8) | (r << 12) | (served ? 1 << 20 : 0) | (isfar ? 1 << 21 : 0);
+        if (mine) s_list[MPC_IDX(base + __popcll(mm & ((1ull << lane) - 1ull)), KS_NT)] = (cy - qy0) | ((cx - qx0) << 8) | (r << 12) | (served ? 1 << 20 : 0) | (isfar ? 1 << 21 : 0);
         __syncthreads();
         mine = tid < nmine;
         served = false; isfar = false; r = 0;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 base = __shfl(base, first, 64);
                 const size_t qid = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
                 const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24)) ? (unsigned)min(max(r, 1), 63) << 24 : 0u;
-                if (mine) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)qid | hint | (1u << 30));
+                if (mine) fail[MPC_IDX(1 + base + __popcll(pm & ((1ull << lane) - 1ull)), 1 + (long long)p.B * p.nb * p.G)] = (int)((unsigned)qid | hint | (1u << 30));
             }
             return;
         }
@@ -318,7 +319,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (mine && served) {
             int2 *s_w = reinterpret_cast<int2 *>(s_dyn);
             const int rc = cy - qy0 + RC;
-            for (int j = -r; j <= r; ++j) atomicMax(&s_w[rc + j].x, (int)s_chord[r * (RC + 1) + abs(j)]);
+            for (int j = -r; j <= r; ++j) atomicMax(&s_w[MPC_IDX(rc + j, NR)].x, (int)s_chord[MPC_IDX(r * (RC + 1) + abs(j), (RC + 1) * (RC + 1))]);
         }
         __syncthreads();                                         // (before the row tables are read and the staging area is written)
         KS_STP();    // 2: compaction, chords pushed
@@ -347,8 +348,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
             if (R > 0 && y >= -p.m && y < p.hq + p.m) {
                 const int xl = max(qx0 - R, -p.m), xh = min(qx1 + R, p.wq + p.m - 1);
-                gs = cs[knn_ci(p, y, xl)];
-                len = cs[knn_ci(p, y, xh + 1)] - gs;
+                gs = cs[MPC_IDX(knn_ci(p, y, xl), p.Gb + 1)];
+                len = cs[MPC_IDX(knn_ci(p, y, xh + 1), p.Gb + 1)] - gs;
                 // (an EMPTY row takes no slot at all: a far query's square is mostly empty rows -- 28 of the 33 at radius 16 --
                 // and a dummy slot for each used to eat a quarter of its 128 slots)
                 padded = len == 0 ? 0 : len + ((len & 1) ? 0 : 1);
@@ -362,7 +363,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         __syncthreads();
         int run = incl - padded;
         for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
-        if (tid < NR) { s_rowstart[tid] = run; s_row[tid] = make_int2(gs, len); }
+        if (tid < NR) { s_rowstart[MPC_IDX(tid, NR + 1)] = run; s_row[MPC_IDX(tid, NR)] = make_int2(gs, len); }
         if (tid == NR - 1) s_rowstart[NR] = run + padded;
         // row pitch of the staging loop = the longest row of the region
         pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
@@ -377,8 +378,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (MODE == 0) {              // (workgroup-uniform) again in quarters: k_knn_strip_more
             const int nfq = anyfar ? __syncthreads_count(isfar ? 1 : 0) : 0;
             if (tid == 0) {
-                ls.retry[1 + atomicAdd(&ls.retry[0], 1)] = lblk;
-                if (anyfar) { ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk; atomicAdd(knn_marked_count(ls), nfq); }
+                ls.retry[MPC_IDX(1 + atomicAdd(&ls.retry[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk;
+                if (anyfar) { ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk; atomicAdd(knn_marked_count(ls), nfq); }
             }
             return;
         }
@@ -415,38 +416,38 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                     } else {
                         rr = min((int)(((float)it + 0.5f) * inv_pitch), NR - 1); k = it - rr * pitch;
                     }
-                    const int2 row = s_row[rr];                                     // {first bucketed slot, points}
+                    const int2 row = s_row[MPC_IDX(rr, NR)];                                     // {first bucketed slot, points}
                     in[u] = it < items && row.y > 0 && k < (row.y | 1);             // (an even row has one dummy slot: odd pitch; an empty row none)
                     real[u] = in[u] && k < row.y;
-                    slot[u] = FARK ? it : s_rowstart[rr] + k;
+                    slot[u] = FARK ? it : s_rowstart[MPC_IDX(rr, NR + 1)] + k;
                     pj[u] = make_float2(KS_FAR, KS_FAR); id[u] = 0;
-                    if (real[u]) { pj[u] = sp_[row.x + k]; id[u] = si_[row.x + k]; }
+                    if (real[u]) { pj[u] = sp_[MPC_IDX(row.x + k, p.n)]; id[u] = si_[MPC_IDX(row.x + k, p.n)]; }
                 }
 #pragma unroll
                 for (int u = 0; u < KS_SB; ++u) {
                     f0[u] = f1[u] = make_float2(0.f, 0.f);
                     if (real[u]) {
-                        const float2 a = tref0[id[u]];
+                        const float2 a = tref0[MPC_IDX(id[u], p.n)];
                         f0[u] = make_float2(a.x - pj[u].x, a.y - pj[u].y);      // traj(t_ref) - traj(t_mid)  focus.py:140-141
-                        if (has_next) { const float2 c = tnext[id[u]]; f1[u] = make_float2(c.x - pj[u].x, c.y - pj[u].y); }
+                        if (has_next) { const float2 c = tnext[MPC_IDX(id[u], p.n)]; f1[u] = make_float2(c.x - pj[u].x, c.y - pj[u].y); }
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < KS_SB; ++u) {
                     if (in[u]) {
-                        lpos[slot[u]] = pj[u];
-                        lflow[slot[u]] = f0[u];
-                        if (NEXT) lnext[slot[u]] = f1[u];
-                        lidx[slot[u]] = (unsigned short)id[u];
+                        lpos[MPC_IDX(slot[u], cap + KS_TAIL(MAXCH))] = pj[u];
+                        lflow[MPC_IDX(slot[u], cap + KS_TAIL(MAXCH))] = f0[u];
+                        if (NEXT) lnext[MPC_IDX(slot[u], cap + KS_TAIL(MAXCH))] = f1[u];
+                        lidx[MPC_IDX(slot[u], cap)] = (unsigned short)id[u];
                     }
                 }
             }
             // the tail behind the staged slots: far-away positions, zero flows (lanes whose range is shorter than the
             // wavefront's trip count read them, flagged off)
             for (int i = total + tid; i < total + KS_TAIL(MAXCH); i += KS_NT) {
-                lpos[i] = make_float2(KS_FAR, KS_FAR);
-                lflow[i] = make_float2(0.f, 0.f);
-                if (NEXT) lnext[i] = make_float2(0.f, 0.f);
+                lpos[MPC_IDX(i, cap + KS_TAIL(MAXCH))] = make_float2(KS_FAR, KS_FAR);
+                lflow[MPC_IDX(i, cap + KS_TAIL(MAXCH))] = make_float2(0.f, 0.f);
+                if (NEXT) lnext[MPC_IDX(i, cap + KS_TAIL(MAXCH))] = make_float2(0.f, 0.f);
             }
         }
         __syncthreads();
@@ -458,8 +459,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         unsigned why = (inpass && served && overflow) ? 2u : 0u;      // diagnostics: top two bits of a list entry (0 few candidates, 1 too many slots, 2 staging overflow)
         int s = 0, nsl = 0;
         if (act) {
-            s = s_rowstart[cy - r - ry_base];
-            nsl = s_rowstart[cy + r - ry_base + 1] - s;
+            s = s_rowstart[MPC_IDX(cy - r - ry_base, NR + 1)];
+            nsl = s_rowstart[MPC_IDX(cy + r - ry_base + 1, NR + 1)] - s;
             if (nsl > 4 * MAXCH) { failed = true; why = 1u; nsl = 0; s = 0; }
         }
         // anything outside the square is at least lb away along one axis
@@ -480,6 +481,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         const float nscale = -(float)(KS_NLEV - 1) * __builtin_amdgcn_rcpf(upper - lo_d), loff = -upper * nscale;
         const int nmax = __builtin_amdgcn_readfirstlane(wave_max_i(nsl));      // wave-uniform trip count (slots)
         const float2 *pp = lpos + s;
+        // (every lane reads its range rounded up to the wavefront's trip count: the dummy slots behind the staged ones are there for that)
+        MPC_EXPECT(s + ((nmax + 7) & ~7) <= cap + KS_TAIL(MAXCH));
         // pass 1: nearness byte of every slot; groups of 8 slots whose loads are issued together
         unsigned w[MAXCH];
 #pragma unroll
@@ -642,10 +645,10 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                     kraw[a] = k;
                     k = (k & ~31) + 4 * (k & 7) + ((k & 31) >> 3);                                  // ... and its slot
                     if (light && k >= 0) {
-                        const float2 pj = pp[k];
+                        const float2 pj = pp[MPC_IDX(k, cap + KS_TAIL(MAXCH) - s)];
                         jj[a] = k;
                         dd[a] = pair_dist(qy, qx, pj.x, pj.y, L1);
-                        ii[a] = (int)lidx[s + k];
+                        ii[a] = (int)lidx[MPC_IDX(s + k, cap)];
                     }
                 }
             }
@@ -744,15 +747,15 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             if (IWD) { }
             else if (kpow2) { ov.x = sy_ * rK; ov.y = sx_ * rK; }
             else { ov.x = (sy_ * 0.0078125f) / (float)p.K; ov.y = (sx_ * 0.0078125f) / (float)p.K; }
-            reinterpret_cast<float2 *>(flow_lut)[q] = ov;
+            reinterpret_cast<float2 *>(flow_lut)[MPC_IDX(q, (long long)p.B * p.nb * p.G)] = ov;
             if (do_next) {
                 float2 on;
                 if (kpow2) { on.x = ny_ * rK; on.y = nx_ * rK; }
                 else { on.x = (ny_ * 0.0078125f) / (float)p.K; on.y = (nx_ * 0.0078125f) / (float)p.K; }
                 reinterpret_cast<float2 *>(flow_next)[((size_t)(b * (p.nb - 1) + t)) * p.G + (size_t)cy * p.wq + cx] = on;
             }
-            knn_state[q] = dK;
-            reinterpret_cast<int *>(knn_state)[BQ + q] = iK | (tie ? KNN_TIE_FLAG : 0) | ((FARK && ls.far != nullptr && knn_is_far_dk(p, dK, r_init)) ? KNN_FAR_FLAG : 0);
+            knn_state[MPC_IDX(q, BQ)] = dK;
+            reinterpret_cast<int *>(knn_state)[BQ + MPC_IDX(q, BQ)] = iK | (tie ? KNN_TIE_FLAG : 0) | ((FARK && ls.far != nullptr && knn_is_far_dk(p, dK, r_init)) ? KNN_FAR_FLAG : 0);
 #ifdef KS_DEBUG_INBIN
             norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
             knn_state[2 * BQ + q] = norm;
@@ -772,13 +775,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             // ... or the strip goes there anyway for its far queries
             const bool to_more = MODE == 0 && (nlate > KS_MORE_MIN || anyfar);
             if (late && to_more) {
-                reinterpret_cast<int *>(knn_state)[q] = r;          // (the radius that was tried, for the second launch)
-                atomicOr(ls.again + aoff, 1u << (cx & 31));
-                if (why == 0u) atomicOr(ls.grow + aoff, 1u << (cx & 31));
+                reinterpret_cast<int *>(knn_state)[MPC_IDX(q, (long long)p.B * p.nb * p.G)] = r;          // (the radius that was tried, for the second launch)
+                atomicOr(ls.again + MPC_IDX(aoff, (long long)p.B * p.nb * ls.again_words), 1u << (cx & 31));
+                if (why == 0u) atomicOr(ls.grow + MPC_IDX(aoff, (long long)p.B * p.nb * ls.again_words), 1u << (cx & 31));
             }
             // (and the number of queries marked for it: with only a handful in the whole launch it hands them on to the fallback kernel)
             const int nfq = (MODE == 0 && anyfar) ? __syncthreads_count(isfar ? 1 : 0) : 0;
-            if (to_more && tid == 0) { ls.farstrip[1 + atomicAdd(&ls.farstrip[0], 1)] = lblk; atomicAdd(knn_marked_count(ls), nlate + nfq); }
+            if (to_more && tid == 0) { ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk; atomicAdd(knn_marked_count(ls), nlate + nfq); }
             const bool push = inpass && !live && !(late && to_more);
             const unsigned long long pm = __ballot(push);
             if (pm != 0ull) {
@@ -789,7 +792,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 // (entry: the query, why in bits 30..31 and -- where the query ids leave room: fewer than 2^24 queries -- the radius
                 // that was tried in bits 24..29, so that the fallback kernel need not read it off the summed-area table again)
                 const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24) && served) ? (unsigned)min(r, 63) << 24 : 0u;
-                if (push) fail[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = (int)((unsigned)q | hint | (why << 30));
+                if (push) fail[MPC_IDX(1 + base + __popcll(pm & ((1ull << lane) - 1ull)), 1 + (long long)p.B * p.nb * p.G)] = (int)((unsigned)q | hint | (why << 30));
             }
         }
         // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
@@ -825,7 +828,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 if (lane == first) base = atomicAdd(&fl[0], __popcll(pm));
                 base = __shfl(base, first, 64);
                 if (isf) {
-                    fl[1 + base + __popcll(pm & ((1ull << lane) - 1ull))] = cy * p.wq + cx;
+                    fl[MPC_IDX(1 + base + __popcll(pm & ((1ull << lane) - 1ull)), p.G + 1)] = cy * p.wq + cx;
                     // its tiles onto the work list of k_knn_bwd_far: through the workgroup's bit map in LDS where the (sample,
                     // bin)'s tiles fit it (a per-query chain of a load and an atomic per tile was a third of a work item's time)
                     if (ls.ftwords <= KNN_FT_LDS_WORDS) knn_far_mark_tiles_lds(p, s_ft, cy, cx, dK);
@@ -857,8 +860,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
 // dynamic LDS sized by the launcher
 template <int WS, bool L1, bool NEXT, bool IWD>
 __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
-                                                     const int *__restrict__ cell_start, const int *__restrict__ sat,
-                                                     const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                     const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
+                                                     const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                      const KnnLists ls, int r_init, int cap, int gx, int gy,
@@ -893,8 +896,8 @@ __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnPara
 // known on the device; nothing to do for the lattice-like point sets of the benchmark: both lists empty or nearly)
 template <int WS, bool L1, bool NEXT, bool IWD>
 __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
-                                                          const int *__restrict__ cell_start, const int *__restrict__ sat,
-                                                          const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                          const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
+                                                          const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                           float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                           float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                           const KnnLists ls, int r_init, int cap, int gx, int gy) {
@@ -935,7 +938,7 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const Knn
 // first radius of a fallback search from the summed-area table: up to KNN_RCAP the smallest square with 1.25 x the strip
 // kernel's count (which it has tried); beyond it the far queries' rule, found by doubling and bisection (a band 20 rings deep
 // costs 8 probes of four loads, not 20)
-__device__ __forceinline__ int fallback_radius(const KnnParams &p, const int *__restrict__ sat, int cy, int cx, int r0) {
+__device__ __forceinline__ int fallback_radius(const KnnParams &p, const knn_cs_t *__restrict__ sat, int cy, int cx, int r0) {
     const int need = knn_square_need(p.K, p.l1) + (knn_square_need(p.K, p.l1) >> 2), need_far = knn_square_need_far(p.K, p.l1);
     const int rmax = max(p.hb, p.wb);
     int r = max(r0, 2);
@@ -958,7 +961,7 @@ __device__ __forceinline__ void far_list_add(const KnnParams &p, const KnnLists 
     if (lane == 0) {
         int *fl = ls.far + (size_t)bt * (p.G + 1);
         const int k = atomicAdd(&fl[0], 1);
-        fl[1 + k] = cy * p.wq + cx;
+        fl[MPC_IDX(1 + k, p.G + 1)] = cy * p.wq + cx;
     }
     int ta, tb, tc, td;
     knn_far_tile_range(p, cy, cx, dK, ta, tb, tc, td);
@@ -973,8 +976,8 @@ __device__ __forceinline__ void far_list_add(const KnnParams &p, const KnnLists 
 }
 
 template <bool L1>
-__device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const int *__restrict__ cell_start,
-                                   const int *__restrict__ sat, const float2 *__restrict__ spos, const int *__restrict__ sidx,
+__device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const knn_cs_t *__restrict__ cell_start,
+                                   const knn_cs_t *__restrict__ sat, const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                    float *__restrict__ knn_state, float *__restrict__ tile_dkmax, const KnnLists &ls, int q, int r_init, int r_start,
                                    unsigned (*s_hist)[256], float4 (*s_comp)[256]) {
@@ -983,9 +986,9 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     const int bt = q / p.G, cell = q - bt * p.G;
     const int cy = cell / p.wq, cx = cell - cy * p.wq;
     const int b = bt / p.nb, t = bt - b * p.nb;
-    const int *cs = cell_start + (size_t)bt * (p.Gb + 1);
+    const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
     const float2 *sp_ = spos + (size_t)bt * p.n;
-    const int *si_ = sidx + (size_t)bt * p.n;
+    const knn_idx_t *si_ = sidx + (size_t)bt * p.n;
     const float2 *traj_b = reinterpret_cast<const float2 *>(traj) + (size_t)b * (p.T + p.nb) * p.n;
     const float qy = (float)(cy * p.sp) + p.off, qx = (float)(cx * p.sp) + p.off;
     const int ylo = -p.m, yhi = p.hq + p.m - 1, xlo = -p.m, xhi = p.wq + p.m - 1;
@@ -1010,7 +1013,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
                 xa = max(xa, cx - xr); xb = min(xb, cx + xr);
             }
             js = 0; ln = 0;
-            if (xa <= xb) { js = cs[knn_ci(p, y, xa)]; ln = cs[knn_ci(p, y, xb + 1)] - js; }
+            if (xa <= xb) { js = cs[MPC_IDX(knn_ci(p, y, xa), p.Gb + 1)]; ln = cs[MPC_IDX(knn_ci(p, y, xb + 1), p.Gb + 1)] - js; }
         };
         // lane l < nrows: the range of row y0 + l; exclusive scan over the lanes -> flat candidate numbering
         int js = 0, ln = 0;
@@ -1039,8 +1042,8 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
                 const int rjs = __shfl(js, lo, 64), rex = __shfl(excl, lo, 64);
                 if (k < N) {
                     const int g = rjs + (k - rex);
-                    const float2 pj = sp_[g];
-                    const int id = si_[g];                          // (with the position: one round trip, not two)
+                    const float2 pj = sp_[MPC_IDX(g, p.n)];
+                    const int id = si_[MPC_IDX(g, p.n)];                          // (with the position: one round trip, not two)
                     const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                     if (d < upper) { dd[m] = d; ii[m] = id; pq[m] = pj; ++cnt; }
                 }
@@ -1071,13 +1074,13 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
                     float d = 0.f; int id = 0; float2 pj = make_float2(0.f, 0.f);
                     if (k < Nr) {
                         const int g = rjs + (k - rex);
-                        pj = sp_[g]; id = si_[g];
+                        pj = sp_[MPC_IDX(g, p.n)]; id = si_[MPC_IDX(g, p.n)];
                         d = pair_dist(qy, qx, pj.x, pj.y, L1);
                         keep = d < upper;
                     }
                     const unsigned long long km = __ballot(keep);
                     const int slot = cnt + __popcll(km & ((1ull << lane) - 1ull));
-                    if (keep && slot < 64 * KS_FB_SLOTS) s_comp[wvi][slot] = make_float4(d, __int_as_float(id), pj.x, pj.y);
+                    if (keep && slot < 64 * KS_FB_SLOTS) s_comp[wvi][MPC_IDX(slot, 64 * KS_FB_SLOTS)] = make_float4(d, __int_as_float(id), pj.x, pj.y);
                     cnt += __popcll(km);
                 }
             }
@@ -1140,7 +1143,7 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     for (int m = 0; m < KS_FB_SLOTS; ++m) {
         if (dd[m] < INFINITY && key[m] <= V) {
             const float2 pj = pq[m];
-            const float2 a = traj_b[ii[m]];                                   // T == 1
+            const float2 a = traj_b[MPC_IDX(ii[m], p.n)];                                   // T == 1
             const float fy = a.x - pj.x, fx = a.y - pj.y;
             if (p.iwd) { const float wgt = 1.f / (dd[m] + 1e-9f); sy_ += wgt * fy; sx_ += wgt * fx; sw_ += wgt; }
             else { sy_ += fy; sx_ += fx; }
@@ -1176,8 +1179,8 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
 }
 
 __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const float *__restrict__ traj,
-                                                      const int *__restrict__ cell_start, const int *__restrict__ sat,
-                                                      const float2 *__restrict__ spos, const int *__restrict__ sidx,
+                                                      const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
+                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                       float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                       float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                       const KnnLists ls, int r_init, const EvCountArgs evc) {
@@ -1194,7 +1197,7 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
     const int nfail = min(fail[0], nq);
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     for (int i = wv; i < nfail; i += nw) {
-        const unsigned ent = (unsigned)fail[1 + i];
+        const unsigned ent = (unsigned)fail[MPC_IDX(1 + i, 1 + (long long)nq)];
         const bool hinted = (size_t)nq < (1u << 24);
         const int q = (int)(ent & (hinted ? 0x00ffffffu : 0x3fffffffu));
         // radius to start from: the one the strip kernel tried (one more ring if it held too few candidates), else from the table
@@ -1246,7 +1249,7 @@ bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc) {
     return (size_t)evc->nb * evc->NCS * sizeof(int) <= lds && evc->B <= 256;
 }
 
-int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_start, const int *sat, const float2 *spos, const int *sidx,
+int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *cell_start, const knn_cs_t *sat, const float2 *spos, const knn_idx_t *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, const KnnLists *lists, int r_init,
                          const EvCountArgs *evc, hipStream_t st) {
     const KnnParams p = knn_params(s);
@@ -1288,3 +1291,5 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const int *cell_
     MPC_CHECK_LAUNCH();
     return 0;
 }
+
+MPC_BOUNDS_UNIT("knn_strip.hip")

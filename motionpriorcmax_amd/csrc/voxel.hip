@@ -3,8 +3,9 @@
 // trilinear accumulation of +-1 polarity votes into [C][H][W], then normalisation of the non-zero
 // entries.  Same machinery as the IWE (events.hip): one binning pass appends 16-byte records to
 // per-(sample, channel, row-strip) buckets, one workgroup per bucket accumulates its strip in LDS as
-// Q33.30 fixed point (ds_add_u64) and writes it with plain stores; overflowing buckets spill to a
-// list that the workgroups of the buckets concerned read beside their own records.  With mean_std / max
+// Q33.30 fixed point (ds_add_u64) and writes it with plain stores; an overflowing bucket spills to its sample's
+// spill region in CHUNKS (one contiguous run per binning workgroup and bucket, named in a per-sample chunk list), and only
+// the workgroup of a bucket that did overflow looks at its sample's chunk list and reads its own runs.  With mean_std / max
 // normalisation the strips are accumulated twice -- statistics first, then written normalised -- so the
 // grid is written once and never read back (k_vox_accum).
 //
@@ -12,6 +13,7 @@
 // value * (1-|xl-x|) * (1-|yl-y|) * (1-|tl-t_norm|) (left to right; value = 2p-1 is +-1, so its sign
 // commutes exactly), t_norm = (C-1) * (t - t[0]) / (t[-1] - t[0]).
 #include "common.h"
+#include "bounds.h"
 
 #define VOX_FIX_SHIFT 30
 #ifndef VOX_STRIP_KB
@@ -22,8 +24,10 @@
 
 struct VoxLayout {
     int SR, NS, NBk, cap;
-    int *gcount;          // [NBk + 8]   (NBk+0: spill count)
-    float4 *rec, *ovf;
+    int spcap, chcap;     // spill records / chunk descriptors per sample
+    int *gcount;          // [NBk + 2 B]   fill of every bucket; then per sample: spilled records, chunks
+    float4 *rec, *ovf;    // ovf: [B][spcap]
+    int4 *chunk;          // [B][chcap]  {bucket within the sample, first spill record, records, -}
     double *part;         // [B][nblk][4]   partial statistics of k_vox_stats (quantile clipping: the entries change after the strips)
     double *spart;        // [NBk][4]       partial statistics of the strips (k_vox_accum<1>)
     float *stat;          // [B][4]  mean, 1/std (or 1/max), flag
@@ -57,7 +61,7 @@ __device__ __forceinline__ void vox_taps(float y, float x, float wt, int H, int 
     }
 }
 
-// grid (chunks * B rounded up to 8), 256 threads, dynamic LDS = C*NS*2 ints
+// grid (chunks * B rounded up to 8), 256 threads, dynamic LDS = C*NS*3 ints
 __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const VoxLayout L,
                                                  const float4 *__restrict__ ev, const int *__restrict__ counts) {
     extern __shared__ int s_cnt[];
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const Vo
     const int tid = threadIdx.x, b = lblk / chunks, chunk = lblk - b * chunks;
     const int nloc = s.C * L.NS;
     int *s_base = s_cnt + nloc;
+    int *s_spill = s_base + nloc;         // slot - s_spill[lb] = place in the sample's spill region, for the slots >= cap
     for (int i = tid; i < nloc; i += 256) s_cnt[i] = 0;
     __syncthreads();
     const int n = min(counts[b], s.N);
@@ -107,14 +112,24 @@ __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const Vo
                 prev = st;
                 const int lb = tl * L.NS + st;
                 bk[k][dt * 2 + dy] = lb;
-                rk[k][dt * 2 + dy] = atomicAdd(&s_cnt[lb], 1);
+                rk[k][dt * 2 + dy] = atomicAdd(&s_cnt[MPC_IDX(lb, nloc)], 1);
             }
         }
     }
     __syncthreads();
     for (int i = tid; i < nloc; i += 256) {
         const int c = s_cnt[i];
-        s_base[i] = c > 0 ? atomicAdd(&L.gcount[b * nloc + i], c) : 0;
+        const int base = c > 0 ? atomicAdd(&L.gcount[b * nloc + i], c) : 0;
+        s_base[i] = base;
+        // the slots [max(base, cap), base + c) of this workgroup lie beyond the bucket: ONE run of the sample's spill region,
+        // named in the sample's chunk list (the bucket's own workgroup reads the list and then only its runs)
+        const int first = max(base, L.cap), nsp = base + c - first;
+        if (nsp > 0) {
+            const int sp0 = atomicAdd(&L.gcount[L.NBk + 2 * b], nsp);
+            const int ci = atomicAdd(&L.gcount[L.NBk + 2 * b + 1], 1);
+            if (ci < L.chcap) L.chunk[(size_t)b * L.chcap + MPC_IDX(ci, L.chcap)] = make_int4(i, sp0, nsp, 0);
+            s_spill[i] = first - sp0;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -126,14 +141,15 @@ __global__ __launch_bounds__(256) void k_vox_bin(const mpc_vox_shape s, const Vo
             const int g = b * nloc + lb;
             const int slot = s_base[lb] + rk[k][u];
             const float4 rec = make_float4(ry[k], rx[k], rw[k][u >> 1], __int_as_float(g));
-            if (slot < L.cap) L.rec[(size_t)g * L.cap + slot] = rec;
-            else L.ovf[atomicAdd(&L.gcount[L.NBk], 1)] = rec;
+            if (slot < L.cap) L.rec[MPC_IDX((size_t)g * L.cap + slot, (long long)L.NBk * L.cap)] = rec;
+            else { const int k = slot - s_spill[lb]; MPC_EXPECT(k >= 0 && k < L.spcap); if (k >= 0 && k < L.spcap) L.ovf[(size_t)b * L.spcap + k] = rec; }
         }
 }
 
 // grid NBk, 1024 threads, dynamic LDS = SR * W * 8.  One strip of one channel image accumulated in LDS (64-bit fixed point:
-// integer sums, any order, bitwise reproducible) from its bucket of records and -- rare: a bucket beyond its capacity -- from
-// the records of the spill list that name it.
+// integer sums, any order, bitwise reproducible) from its bucket of records and -- only a bucket beyond its capacity (events
+// piled up in a few rows) -- from its runs of the sample's spill region: the workgroup reads the sample's chunk list once
+// (16 bytes per (binning workgroup, overflowed bucket) pair) and then its own runs, nothing of the other buckets' spills.
 //   MODE 0: the strip written as it is (no normalisation, or quantile clipping follows)
 //   MODE 1: nothing written -- the strip's share of the per-sample statistics of the non-zero entries (count, sum, sum of
 //           squares, largest magnitude) to spart[g]
@@ -151,20 +167,36 @@ __global__ __launch_bounds__(1024) void k_vox_accum(const VoxLayout L, float *__
     const int npix = (row1 - row0) * W;
     for (int i = tid; i < npix; i += 1024) s_acc[i] = 0ull;
     __syncthreads();
-    const int n = min(L.gcount[g], L.cap), nsp = L.gcount[L.NBk];
+    const int filled = L.gcount[g], n = min(filled, L.cap);
     const float4 *rec = L.rec + (size_t)g * L.cap;
     for (int r = tid; r < n; r += 1024) {
         const float4 e = rec[r];
         vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) {
-            atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)vox_to_fixed(v));
+            atomicAdd(&s_acc[MPC_IDX((yy - row0) * W + xx, npix)], (unsigned long long)vox_to_fixed(v));
         });
     }
-    for (int r = tid; r < nsp; r += 1024) {              // (the spill list: empty unless the events pile up in a few strips)
-        const float4 e = L.ovf[r];
-        if (__float_as_int(e.w) != g) continue;
-        vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) {
-            atomicAdd(&s_acc[(yy - row0) * W + xx], (unsigned long long)vox_to_fixed(v));
-        });
+    if (filled > L.cap) {                                 // (workgroup-uniform) this bucket spilled
+        const int nloc = C * L.NS, b = g / nloc, lb = g - b * nloc;
+        const int nch = min(L.gcount[L.NBk + 2 * b + 1], L.chcap);
+        const int4 *ch = L.chunk + (size_t)b * L.chcap;
+        const float4 *ovf = L.ovf + (size_t)b * L.spcap;
+        for (int c0 = 0; c0 < nch; c0 += 1024) {          // the chunk list, a descriptor per thread; a wavefront takes the runs its lanes found
+            int4 d = make_int4(-1, 0, 0, 0);
+            if (c0 + tid < nch) d = ch[c0 + tid];
+            unsigned long long mm = __ballot(d.x == lb);
+            while (mm != 0ull) {
+                const int l = __ffsll((long long)mm) - 1;
+                mm &= mm - 1ull;
+                const int sp0 = __shfl(d.y, l, 64);
+                const int cnt = min(__shfl(d.z, l, 64), max(L.spcap - sp0, 0));
+                for (int r = (tid & 63); r < cnt; r += 64) {
+                    const float4 e = ovf[MPC_IDX(sp0 + r, L.spcap)];
+                    vox_taps(e.x, e.y, e.z, H, W, row0, row1, [&](int yy, int xx, float v) {
+                        atomicAdd(&s_acc[MPC_IDX((yy - row0) * W + xx, npix)], (unsigned long long)vox_to_fixed(v));
+                    });
+                }
+            }
+        }
     }
     __syncthreads();
     if (MODE == 1) {
@@ -388,7 +420,7 @@ static int vox_validate(const mpc_vox_shape *s) {
     return 0;
 }
 
-struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_part, off_spart, off_stat, off_qhist, off_qstate, total; unsigned *qhist, *qstate; };
+struct VoxHostLayout { VoxLayout L; int64_t off_count, off_rec, off_ovf, off_chunk, off_part, off_spart, off_stat, off_qhist, off_qstate, total; unsigned *qhist, *qstate; };
 
 static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     VoxHostLayout h;
@@ -405,9 +437,19 @@ static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     L.cap = (int)(cap > 0 ? cap : 1);
     L.nstat_blocks = 256;
     int64_t off = 0;
-    h.off_count = off; off += mpc_align((int64_t)(L.NBk + 8) * 4);
+    // spill region of a sample: every record it can produce (an event votes into two channels x up to two strips); chunk
+    // list of a sample: one descriptor per (binning workgroup, bucket it overflowed) -- a binning workgroup holds
+    // 256 * VOX_PER_THREAD events, i.e. at most that many x 4 records, in at most C * NS buckets
+    L.spcap = (int)(4 * (int64_t)s->N > 0 ? 4 * (int64_t)s->N : 1);
+    {
+        const int64_t wgs = mpc_cdiv(s->N > 0 ? s->N : 1, 256 * VOX_PER_THREAD);
+        const int64_t per_wg = (int64_t)s->C * L.NS < 256 * VOX_PER_THREAD * 4 ? (int64_t)s->C * L.NS : 256 * VOX_PER_THREAD * 4;
+        L.chcap = (int)(wgs * per_wg);
+    }
+    h.off_count = off; off += mpc_align((int64_t)(L.NBk + 2 * (s->B > 0 ? s->B : 1) + 8) * 4);
     h.off_rec = off;   off += mpc_align((int64_t)L.NBk * L.cap * 16);
-    h.off_ovf = off;   off += mpc_align((int64_t)4 * s->B * s->N * 16 + 16);
+    h.off_ovf = off;   off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * L.spcap * 16 + 16);
+    h.off_chunk = off; off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * L.chcap * 16 + 16);
     h.off_part = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * L.nstat_blocks * 4 * 8);
     h.off_spart = off; off += mpc_align((int64_t)(L.NBk > 0 ? L.NBk : 1) * 4 * 8);
     h.off_stat = off;  off += mpc_align((int64_t)(s->B > 0 ? s->B : 1) * 4 * 4);
@@ -418,6 +460,7 @@ static VoxHostLayout vox_layout(const mpc_vox_shape *s, void *ws) {
     L.gcount = (int *)(w + h.off_count);
     L.rec = (float4 *)(w + h.off_rec);
     L.ovf = (float4 *)(w + h.off_ovf);
+    L.chunk = (int4 *)(w + h.off_chunk);
     L.part = (double *)(w + h.off_part);
     L.spart = (double *)(w + h.off_spart);
     L.stat = (float *)(w + h.off_stat);
@@ -450,11 +493,11 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
         if (e != hipSuccess) { mpc_set_error("%s: %s", __func__, hipGetErrorString(e)); return (int)e; }
         attr_once.mark();
     }
-    const int e0 = mpc_zero_async(L.gcount, (size_t)(L.NBk + 8) * 4, st);
+    const int e0 = mpc_zero_async(L.gcount, (size_t)(L.NBk + 2 * s->B + 8) * 4, st);
     if (e0) return e0;
     if (s->N > 0) {
         const int nblk = mpc_cdiv(s->N, 256 * VOX_PER_THREAD) * s->B;
-        MPC_LAUNCH(k_vox_bin, dim3(((nblk + 7) / 8) * 8), dim3(256), (size_t)s->C * L.NS * 2 * sizeof(int), st,
+        MPC_LAUNCH(k_vox_bin, dim3(((nblk + 7) / 8) * 8), dim3(256), (size_t)s->C * L.NS * 3 * sizeof(int), st,
                            *s, L, reinterpret_cast<const float4 *>(xytp), counts);
         MPC_CHECK_LAUNCH();
     }
@@ -492,3 +535,5 @@ extern "C" int mpc_voxel_grid(const mpc_vox_shape *s, const float *xytp, const i
     }
     return 0;
 }
+
+MPC_BOUNDS_UNIT("voxel.hip")

@@ -52,6 +52,7 @@ class GradAllReducer:
         self.is_cuda = self.device.type == 'cuda'
         self.stream = torch.cuda.Stream(device=self.device) if self.is_cuda else None
         self._works = []
+        self._scale_pending = False
 
     def start(self):
         if self.skip:
@@ -70,6 +71,25 @@ class GradAllReducer:
             for s, e in self.bounds:
                 self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
                                                    group=self.group, async_op=True))
+            self._scale_pending = True
+
+    def start_bucket(self, i: int):
+        """Enqueue the all-reduce of bucket i alone, behind what the producing (current) stream has enqueued so far: the
+        producer calls this the moment the bucket's last gradient has been written (OverlappedGradProducer)."""
+        if self.skip:
+            return
+        s, e = self.bounds[i]
+        if self.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                w = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w.wait()                # stream-level wait only
+                self.flat[s:e].mul_(1.0 / self.world)
+        else:
+            dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group)
+            self.flat[s:e].mul_(1.0 / self.world)
 
     def wait(self):
         if self.skip:
@@ -80,7 +100,87 @@ class GradAllReducer:
             for w in self._works:
                 w.wait()
             self._works = []
-            self.flat.mul_(1.0 / self.world)
+            if self._scale_pending:          # (start(): the whole buffer at once; start_bucket() scales its own bucket)
+                self.flat.mul_(1.0 / self.world)
+                self._scale_pending = False
+
+
+class StandInNetwork(torch.nn.Module):
+    """A gradient PRODUCER of the reference network's size for the data-parallel leg of the benchmark: a plain stack of 3x3
+    convolutions (strided, ReLU) with exactly UNET_GRAD_NUMEL = 31 044 610 fp32 parameters -- the parameter count of the
+    reference's UNet(15 -> 2) (src/models/unet/unet_model.py:6, src/modules/trajectory_net.py:27-28) -- so that its backward
+    writes 124 MB of gradients through MIOpen / rocBLAS kernels that compete with the loss kernels for CUs and HBM while the
+    buckets of the all-reduce fly.  NOT the reference's architecture (the UNet itself is out of scope): a
+    stand-in of the same parameter and gradient volume on a small input, so that the benchmark step stays short."""
+    CHANNELS = (15, 64, 128, 256, 512, 1024, 1024, 1024, 512, 254)
+
+    def __init__(self):
+        super().__init__()
+        layers = []
+        for i, (a, b) in enumerate(zip(self.CHANNELS[:-1], self.CHANNELS[1:])):
+            layers.append(torch.nn.Conv2d(a, b, 3, stride=2 if i in (1, 3) else 1, padding=1))
+            layers.append(torch.nn.ReLU(inplace=True))
+        self.body = torch.nn.Sequential(*layers)
+        self.head = torch.nn.Conv2d(self.CHANNELS[-1], 2, 1)
+        have = sum(p.numel() for p in self.parameters())
+        self.pad = torch.nn.Parameter(torch.zeros(UNET_GRAD_NUMEL - have))         # (390 values: the count is the UNet's exactly)
+        assert sum(p.numel() for p in self.parameters()) == UNET_GRAD_NUMEL
+
+    def forward(self, x):
+        return self.head(self.body(x)).mean() + self.pad.sum() * 0.0 + (self.pad * self.pad).sum()
+
+
+class OverlappedGradProducer:
+    """The network side of a data-parallel training step around the loss: `step()` runs the stand-in network's forward and
+    backward; every parameter's gradient is a VIEW into the GradAllReducer's flat buffer (as DDP's gradient_as_bucket_view),
+    and the moment the last gradient of a bucket has been written (post-accumulate hooks; backward produces them last layer
+    first) that bucket's all-reduce is enqueued on the reducer's side stream behind an event on the producing stream --
+    buckets are exchanged while the rest of the backward, and then the next step's loss, still run.  `wait()` before the
+    optimizer point.  Reference: Lightning DDP behind scripts/flow_training.py:125-130 (bucketed all-reduce during backward)."""
+
+    def __init__(self, reducer: GradAllReducer, batch: int = 2, hw=(120, 160), seed: int = 0):
+        self.r = reducer
+        dev = reducer.device
+        g = torch.Generator().manual_seed(seed)
+        self.net = StandInNetwork().to(dev)
+        self.x = torch.randn(batch, StandInNetwork.CHANNELS[0], *hw, generator=g).to(dev)
+        # parameters in the order their gradients are produced (last layer first), laid out back to back in the flat buffer
+        params = list(self.net.parameters())[::-1]
+        off = 0
+        self._bucket_of, self._left0 = {}, [0] * len(reducer.bounds)
+        for p_ in params:
+            n = p_.numel()
+            p_.grad = reducer.flat[off:off + n].view_as(p_)
+            # every bucket this parameter's gradient overlaps waits for it
+            over = [i for i, (s, e) in enumerate(reducer.bounds) if s < off + n and off < e]
+            self._bucket_of[p_] = over
+            for i in over:
+                self._left0[i] += 1
+            p_.register_post_accumulate_grad_hook(self._hook)
+            off += n
+        assert off == reducer.flat.numel()
+        self._left = list(self._left0)
+        self._fired = 0
+
+    def _hook(self, p_):
+        for b in self._bucket_of[p_]:
+            self._left[b] -= 1
+        # buckets complete in order (the parameters are laid out in production order): fire every bucket that is now whole
+        while self._fired < len(self._left) and self._left[self._fired] == 0:
+            self.r.start_bucket(self._fired)
+            self._fired += 1
+
+    def step(self):
+        self._left = list(self._left0)
+        self._fired = 0
+        self.r.flat.zero_()                       # (gradients accumulate into the views: the optimizer's zero_grad)
+        self.net(self.x).backward()
+        while self._fired < len(self._left):      # (buckets without a parameter of their own end)
+            self.r.start_bucket(self._fired)
+            self._fired += 1
+
+    def wait(self):
+        self.r.wait()
 
 
 def max_over_ranks(value: float, device=None, force_collective: bool = False) -> float:

@@ -164,7 +164,9 @@ def make_shape(cfg: PathConfig, B, M, Mp, n, extra_flags=0, K=None):
 
 
 def alloc_workspace(shape: C.Shape, device) -> torch.Tensor:
-    nbytes = C.lib().mpc_workspace_bytes(ctypes.byref(shape))
+    # (sized under the device the kernels will run on: the layout follows its CU count, api.hip: mpc_layout)
+    with torch.cuda.device(device):
+        nbytes = C.lib().mpc_workspace_bytes(ctypes.byref(shape))
     if nbytes < 0:
         C.check(int(nbytes), 'mpc_workspace_bytes')
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -373,7 +375,7 @@ def event_bucket_order(cfg: PathConfig, events, num_pos):
     dev = events.device
     ev = _f32c(events.detach())
     shape = make_shape(cfg, B, M, Mp, 1)
-    ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+    ncs = _lut_strips(shape, dev)
     if ncs <= 0:
         raise ValueError('no bucketed event layout for this configuration (num_tref > 1 or the atomic debugging path)')
     out = torch.empty_like(ev)
@@ -389,14 +391,22 @@ def event_bucket_order(cfg: PathConfig, events, num_pos):
 _NCS_CACHE = {}
 
 
+def _lut_strips(shape, device):
+    """LUT strips of the backward buckets for `shape` on `device` (the count follows the device's layout, so the query runs
+    under that device and the cache is keyed on it)."""
+    key = (shape.B, shape.M, shape.Mp, shape.nb, shape.T, shape.H, shape.W, shape.sp, shape.flags, device.index)
+    ncs = _NCS_CACHE.get(key)
+    if ncs is None:
+        with torch.cuda.device(device):
+            ncs = _NCS_CACHE[key] = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+    return ncs
+
+
 def _check_offsets(offs, cfg, shape, device):
     if offs is None:
         return None
     _require_gpu(offs, "batch['event_offsets']")
-    key = (cfg, shape.B, shape.flags)
-    ncs = _NCS_CACHE.get(key)
-    if ncs is None:
-        ncs = _NCS_CACHE[key] = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
+    ncs = _lut_strips(shape, device)
     want = (shape.B, 2, cfg.num_bins * ncs + 1)
     if ncs <= 0 or offs.dtype != torch.int32 or tuple(offs.shape) != want or offs.device != device:
         raise ValueError(f"event_offsets must be int32 {want} on {device} (from event_bucket_order with this configuration), "
@@ -762,34 +772,37 @@ class PerEventBasisFocusFn(torch.autograd.Function):
         scal = finalize(shape, 0, 0, 0.0, ws, dev)
         ctx.shape, ctx.k, ctx.n = shape, k, cr.shape[0]
         # bucket-ordered events: the backward accumulates per LUT strip in LDS (no global atomics) where a strip's accumulators fit
-        offs = _check_offsets(offsets, cfg, shape, dev) if offsets is not None else None
-        if offs is not None:
-            ncs = int(C.lib().mpc_event_lut_strips(ctypes.byref(shape)))
-            if ncs <= 0 or -(-shape.hq // ncs) * shape.wq * 2 * k * 8 > 150 * 1024 or cfg.num_bins > 64:
-                offs = None
-        ctx.offs = offs
+        # (the library says whether the ordered backward serves this shape -- one copy of the rule; where it does not, an offsets
+        # table is simply not used: the atomic backward needs none)
+        with torch.cuda.device(dev):
+            ordered = offsets is not None and int(C.lib().mpc_pe_grad_ordered_supported(ctypes.byref(shape), k)) == 1
+        offs = _check_offsets(offsets, cfg, shape, dev) if ordered else None
+        ctx.has_offs = offs is not None
         ctx.set_materialize_grads(False)
         ctx.has_phi = ph is not None
-        ctx.save_for_backward(rows, ph if ph is not None else tr, tr, gimg, scal)
+        # (the table goes through save_for_backward: autograd's version check then catches a refill between forward and backward)
+        ctx.save_for_backward(rows, ph if ph is not None else tr, tr, gimg, scal, offs if offs is not None else tr)
         ctx.mark_non_differentiable(blur)
         return scal[C.SCAL_FOCUS].clone(), blur
 
     @staticmethod
     def backward(ctx, g_focus, g_blur):
-        rows, ph, tr, gimg, scal = ctx.saved_tensors
+        rows, ph, tr, gimg, scal, offs = ctx.saved_tensors
         if not ctx.has_phi:
             ph = None
         if g_focus is None:
             return None, None, None, None, None, None, None
         go = _f32c(g_focus.reshape(1))
-        if ctx.offs is not None:
+        if ctx.has_offs:
             # (a few workgroups per (sample, LUT strip), each with a share of the strip's row ranges and a partial result)
-            split = max(1, min(16, 512 // max(1, ctx.shape.B * int(C.lib().mpc_event_lut_strips(ctypes.byref(ctx.shape))))))
+            split = max(1, min(16, 512 // max(1, ctx.shape.B * _lut_strips(ctx.shape, rows.device))))
             gp = torch.empty((split, ctx.n, 2 * ctx.k), dtype=torch.float32, device=rows.device)
             with _stage('mpc_pe_grad_ordered', rows.device):
-                C.check(C.lib().mpc_pe_grad_ordered(ctypes.byref(ctx.shape), _ptr(rows), _ptr(ctx.offs), _ptr(ph), ctx.k, _ptr(tr), _ptr(gimg),
-                                                    _ptr(scal), _ptr(go), _ptr(gp), split, _stream(rows.device)), 'mpc_pe_grad_ordered')
-            return (gp.sum(0) if split > 1 else gp[0]), None, None, None, None, None, None
+                rc = C.lib().mpc_pe_grad_ordered(ctypes.byref(ctx.shape), _ptr(rows), _ptr(offs), _ptr(ph), ctx.k, _ptr(tr), _ptr(gimg),
+                                                 _ptr(scal), _ptr(go), _ptr(gp), split, _stream(rows.device))
+            if rc != C.E_UNSUPPORTED:         # (unsupported after all: the atomic backward below serves every shape)
+                C.check(rc, 'mpc_pe_grad_ordered')
+                return (gp.sum(0) if split > 1 else gp[0]), None, None, None, None, None, None
         g = torch.empty((ctx.n, 2 * ctx.k), dtype=torch.float32, device=rows.device)
         with _stage('mpc_pe_grad', rows.device):
             C.check(C.lib().mpc_pe_grad(ctypes.byref(ctx.shape), _ptr(rows), _ptr(ph), ctx.k, _ptr(tr), _ptr(gimg), _ptr(scal),

@@ -32,7 +32,9 @@ def synth_events(b, m, image_shape, num_bins, seed=0, pad_frac=0.0, time_sorted=
     return ev, num_pos
 
 
-FLOW_FAMILIES = ('zero', 'translate10', 'translate20', 'translate40', 'diverge+30', 'diverge-30', 'rotate', 'shear', 'unet')
+# (translate60 / diverge+-45: scripts/dsec_inference.py:93 clamps the network's flow at 60 px -- flows up to there occur)
+FLOW_FAMILIES = ('zero', 'translate10', 'translate20', 'translate40', 'translate60', 'diverge+30', 'diverge-30', 'diverge+45', 'diverge-45',
+                 'rotate', 'shear', 'unet')
 
 
 def _smooth_field(b, c, image_shape, g, cells=(6, 8)):

@@ -26,6 +26,20 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _bounds_checked_build(request):
+    """With the bounds-checked debug build of the library loaded (-DMPC_BOUNDS, csrc/bounds.h; tools/bounds_run.sh), every GPU test
+    ends with mpc_bounds_check(): an out-of-range index into dynamic LDS or a workspace sub-buffer fails the test with the source
+    line that produced it.  The product build returns -1 there and nothing happens."""
+    yield
+    if 'gpu' not in request.keywords or not torch.cuda.is_available():
+        return
+    from motionpriorcmax_amd import _lib as C
+    n = C.lib().mpc_bounds_check()
+    if n > 0:
+        pytest.fail(C.lib().mpc_last_error_string().decode())
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     d = {k: z[k] for k in z.files}

@@ -75,3 +75,57 @@ def test_bucket_bounds_and_single_process_noop():
     assert torch.all(red.flat == 2.0)
     assert dp.max_over_ranks(3.5) == 3.5
     assert dp.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def _producer_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from motionpriorcmax_amd import dp
+        torch.manual_seed(0)                             # the same weights on every rank (DDP broadcasts them), its own input
+        red = dp.GradAllReducer(device='cpu')
+        fired = []
+        start_bucket = red.start_bucket
+        red.start_bucket = lambda i: (fired.append(i), start_bucket(i))
+        prod = dp.OverlappedGradProducer(red, batch=1, hw=(8, 8), seed=100 + rank)
+        assert sum(p.numel() for p in prod.net.parameters()) == dp.UNET_GRAD_NUMEL == red.flat.numel()
+        # this rank's own gradient, without the exchange
+        prod.net.zero_grad(set_to_none=False)
+        red.skip = True
+        prod.step()
+        own = red.flat.clone()
+        assert float(own.abs().sum()) > 0
+        red.skip = False
+        for _ in range(2):                               # two steps: the counters re-arm
+            fired.clear()
+            prod.step()
+            prod.wait()
+            assert fired == list(range(len(red.bounds))), fired      # every bucket once, in production order
+            both = [torch.empty_like(own) for _ in range(world)]
+            dist.all_gather(both, own)
+            want = sum(both) / world
+            assert torch.allclose(red.flat, want, rtol=1e-5, atol=1e-8), float((red.flat - want).abs().max())
+            # the parameters' .grad ARE the flat buffer (views): what the optimizer reads is the averaged gradient
+            p0 = next(iter(prod.net.parameters()))
+            assert p0.grad.data_ptr() >= red.flat.data_ptr() and p0.grad.data_ptr() < red.flat.data_ptr() + 4 * red.flat.numel()
+        out.put((rank, 'ok'))
+    except Exception as e:  # surfaced by the parent
+        out.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_grad_producer_world2():
+    """The stand-in network (31 044 610 parameters, the reference UNet's count) fills the reducer's flat buffer through gradient
+    views; every bucket is all-reduced once, as soon as its last gradient is written; the result is the mean over the ranks."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_producer_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res

@@ -37,7 +37,8 @@ def _brute(traj_b, t, q):
     return torch.cat(idx)
 
 
-FAMILIES = ['zero', 'translate10', 'translate40', 'diverge+30', 'diverge-30', 'rotate', 'shear', 'unet']
+# (translate60 / diverge+-45: scripts/dsec_inference.py:93 clamps the network's flow at 60 px)
+FAMILIES = ['zero', 'translate10', 'translate40', 'translate60', 'diverge+30', 'diverge-30', 'diverge+45', 'diverge-45', 'rotate', 'shear', 'unet']
 
 
 @pytest.mark.parametrize('family', FAMILIES)

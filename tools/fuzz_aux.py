@@ -94,6 +94,10 @@ def main():
             if abs(float(err[k]) - float(ref[k])) > 3e-5 * max(abs(float(ref[k])), 1e-6):
                 report('flow_error', tag, f'{k}: {float(err[k])} vs {float(ref[k])}')
     print(f'{n_cases} cases, {bad} bad')
+    # (the bounds-checked debug build, tools/bounds_run.sh: out-of-range indices its accessors recorded; -1 = product build)
+    from motionpriorcmax_amd import _lib as _C
+    _n = _C.lib().mpc_bounds_check()
+    print('mpc_bounds_check:', _n, _C.lib().mpc_last_error_string().decode() if _n > 0 else '')
 
 
 if __name__ == '__main__':

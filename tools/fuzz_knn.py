@@ -97,6 +97,10 @@ def main():
             bad += 1
             print('MISMATCH', tag, 'lut', e_lut, 'next', e_nxt, 'grad', e_grad, flush=True)
     print(f'{n_cases} cases, {bad} bad')
+    # (the bounds-checked debug build, tools/bounds_run.sh: out-of-range indices its accessors recorded; -1 = product build)
+    from motionpriorcmax_amd import _lib as _C
+    _n = _C.lib().mpc_bounds_check()
+    print('mpc_bounds_check:', _n, _C.lib().mpc_last_error_string().decode() if _n > 0 else '')
 
 
 if __name__ == '__main__':
