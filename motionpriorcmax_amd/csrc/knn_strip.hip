@@ -293,10 +293,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         for (int w2 = 0; w2 < KS_NT / 64; ++w2) { const int c = s_wsum[w2]; if (w2 < wv) base += c; nmine += c; }
         if (mine) s_list[MPC_IDX(base + __popcll(mm & ((1ull << lane) - 1ull)), KS_NT)] = (cy - qy0) | ((cx - qx0) << 8) | (r << 12) | (served ? 1 << 20 : 0) | (isfar ? 1 << 21 : 0);
         __syncthreads();
-        mine = tid < nmine;
+        // (round 5: WHICH wavefront takes the first 64 entries -- wavefront 0 of every workgroup, or a different one per workgroup so that
+        // the few workgroups of a CU search on different SIMDs -- makes no difference: 107.0 against 106.1 us on the UNet-like mixture)
+        const int vt = tid;
+        mine = vt < nmine;
         served = false; isfar = false; r = 0;
         if (mine) {
-            const int e = s_list[tid];
+            const int e = s_list[vt];
             cy = qy0 + (e & 0xff); cx = qx0 + ((e >> 8) & 0xf); r = (e >> 12) & 0xff; served = ((e >> 20) & 1) != 0; isfar = ((e >> 21) & 1) != 0;
         }
         if (forward) {
@@ -975,12 +978,30 @@ __device__ __forceinline__ void far_list_add(const KnnParams &p, const KnnLists 
     }
 }
 
+// the K-th smallest of the wavefront's keys (KS_FB_SLOTS per lane, the first `ns` in use; (distance bits << 32) | index, all
+// distinct; an empty slot holds (inf, 0x7fffffff)) by a bitwise search from the top: distances are non-negative floats (their
+// bit patterns order like unsigned integers), indices < 2^16.  Bit by bit: the smallest V with count(key <= V) >= K.  47
+// wave-uniform steps of one 64-bit compare per slot.
+__device__ __forceinline__ unsigned long long fb_kth_key(const unsigned long long (&key)[KS_FB_SLOTS], int ns, int K) {
+    unsigned long long V = 0ull;
+    for (int bit = 62; bit >= 0; --bit) {
+        if (bit == 31) bit = 15;                                // index bits 16..31 are zero for every candidate
+        const unsigned long long cand = V | ((1ull << bit) - 1ull);
+        int c = 0;
+#pragma unroll
+        for (int m = 0; m < KS_FB_SLOTS; ++m)
+            if (m < ns) c += __popcll(__ballot(key[m] <= cand));
+        if (c < K) V |= 1ull << bit;
+    }
+    return V;
+}
+
 template <bool L1>
 __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__ traj, const knn_cs_t *__restrict__ cell_start,
                                    const knn_cs_t *__restrict__ sat, const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                    float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                    float *__restrict__ knn_state, float *__restrict__ tile_dkmax, const KnnLists &ls, int q, int r_init, int r_start,
-                                   unsigned (*s_hist)[256], float4 (*s_comp)[256]) {
+                                   float4 (*s_comp)[256]) {
     int *const far = ls.far;
     const int lane = threadIdx.x & 63, wvi = threadIdx.x >> 6;
     const int bt = q / p.G, cell = q - bt * p.G;
@@ -995,7 +1016,6 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     int r = r_start > 0 ? r_start : fallback_radius(p, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), cy, cx, r_init);
     float dd[KS_FB_SLOTS]; int ii[KS_FB_SLOTS];
     float2 pq[KS_FB_SLOTS];
-    bool serial = false;
     int ns = KS_FB_SLOTS;                  // slots per lane actually in use (wave-uniform): ceil(candidates / 64)
     for (;;) {
         const int y0 = max(cy - r, ylo), y1 = min(cy + r, yhi), x0 = max(cx - r, xlo), x1 = min(cx + r, xhi);
@@ -1053,7 +1073,13 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         } else {
             // more rows than lanes (a band deeper than 30 rings) or more candidates than the lanes' slots (the outermost ring of
             // the margin in reach: everything that left the image lies there, nearly all of it beyond the ring bound): rows in
-            // rounds of 64, candidates in rounds of 64, those BELOW the bound compacted into LDS -- up to 256 of them
+            // rounds of 64, candidates in rounds of 64, those below the bound compacted into LDS -- up to 256 of them.  MORE than
+            // that below the bound (round 5; a query deep inside a band a contracting field emptied: one more ring of a large square
+            // brings in a long stretch of the dense front): the K smallest of the 256 at hand are kept -- their K-th key is a bound
+            // no neighbour exceeds -- and from there on only candidates below THAT key are admitted; exact for any number of
+            // candidates.  (Rounds 1-4 handed such a query to one lane's thread-serial search: ~170 us per query, 7 ms of a C3 step on
+            // a 45 % contraction.)
+            float tauD = upper; int tauI = 0;                   // admitted: d < tauD, or d == tauD and index < tauI
             for (int rb = 0; rb < nrows; rb += 64) {
                 if (rb > 0) { js = 0; ln = 0; if (rb + lane < nrows) row_range(y0 + rb + lane, js, ln); }
                 int inc2 = ln;
@@ -1070,21 +1096,52 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
                         if (ev <= k) lo = mid; else hi = mid;
                     }
                     const int rjs = __shfl(js, lo, 64), rex = __shfl(exc2, lo, 64);
-                    bool keep = false;
+                    bool have = false;
                     float d = 0.f; int id = 0; float2 pj = make_float2(0.f, 0.f);
                     if (k < Nr) {
                         const int g = rjs + (k - rex);
                         pj = sp_[MPC_IDX(g, p.n)]; id = si_[MPC_IDX(g, p.n)];
                         d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                        keep = d < upper;
+                        have = true;
                     }
-                    const unsigned long long km = __ballot(keep);
+                    bool keep = have && (d < tauD || (d == tauD && id < tauI));
+                    unsigned long long km = __ballot(keep);
+                    if (cnt + __popcll(km) > 64 * KS_FB_SLOTS) {            // (wave-uniform) no room: keep the K smallest of what is there
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        unsigned long long kk[KS_FB_SLOTS];
+#pragma unroll
+                        for (int m = 0; m < KS_FB_SLOTS; ++m) {
+                            kk[m] = 0x7f8000007fffffffull;
+                            if (lane + 64 * m < cnt) {
+                                const float4 e = s_comp[wvi][lane + 64 * m];
+                                kk[m] = ((unsigned long long)__float_as_uint(e.x) << 32) | (unsigned)__float_as_int(e.y);
+                            }
+                        }
+                        const unsigned long long V = fb_kth_key(kk, KS_FB_SLOTS, p.K);
+                        // the survivors move to the front, 64 entries at a time: a round's destinations lie at or before its own
+                        // sources (read into registers, fenced) and behind nothing that is still to be read
+                        int nk = 0;
+#pragma unroll
+                        for (int m = 0; m < KS_FB_SLOTS; ++m) {
+                            const bool sv = kk[m] <= V;
+                            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (sv) e = s_comp[wvi][lane + 64 * m];
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                            const unsigned long long sm = __ballot(sv);
+                            if (sv) s_comp[wvi][MPC_IDX(nk + __popcll(sm & ((1ull << lane) - 1ull)), 64 * KS_FB_SLOTS)] = e;
+                            nk += __popcll(sm);
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        }
+                        cnt = nk;                                           // (= K: the keys are distinct)
+                        tauD = __uint_as_float((unsigned)(V >> 32)); tauI = (int)(unsigned)(V & 0xffffffffull);
+                        keep = have && (d < tauD || (d == tauD && id < tauI));
+                        km = __ballot(keep);
+                    }
                     const int slot = cnt + __popcll(km & ((1ull << lane) - 1ull));
-                    if (keep && slot < 64 * KS_FB_SLOTS) s_comp[wvi][MPC_IDX(slot, 64 * KS_FB_SLOTS)] = make_float4(d, __int_as_float(id), pj.x, pj.y);
+                    if (keep) s_comp[wvi][MPC_IDX(slot, 64 * KS_FB_SLOTS)] = make_float4(d, __int_as_float(id), pj.x, pj.y);
                     cnt += __popcll(km);
                 }
             }
-            if (cnt > 64 * KS_FB_SLOTS) { serial = true; break; }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (the other lanes' LDS writes, before the reads below)
             ns = (cnt + 63) >> 6;
 #pragma unroll
@@ -1099,41 +1156,11 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
         if (cnt >= p.K || whole) break;
         r += 1 + (r >> 3);
     }
-    if (serial) {
-        // more rows or candidates than the lanes hold (a very dense place, a very deep band): the generic thread-serial search
-        float dK = 0.f;
-        if (lane == 0) {
-            QueryCtx c;
-            c.cs = cs; c.spos = sp_; c.sidx = si_; c.traj_b = traj_b;
-            c.lcs = nullptr; c.lpos = nullptr; c.lidx = nullptr; c.lf0 = nullptr; c.lf1 = nullptr;
-            c.ry0 = c.rx0 = c.RW = c.RWY = c.RH = 0;
-            knn_one_query<false, L1, 256, true>(p, c, b, t, cy, cx, r, s_hist, flow_lut, flow_next, knn_state, nullptr, dK, 0);
-        }
-        dK = __shfl(dK, 0, 64);
-        const bool isf = far != nullptr && knn_is_far_dk(p, dK, r_init);
-        if (isf) {
-            if (lane == 0) reinterpret_cast<int *>(knn_state)[(size_t)p.B * p.nb * p.G + q] |= KNN_FAR_FLAG;
-            far_list_add(p, ls, bt, cy, cx, dK, lane);
-        } else if (lane == 0) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);
-        return;
-    }
-    // the K-th smallest key (distance bits, index) by a bitwise search from the top: distances are non-negative floats
-    // (their bit patterns order like unsigned integers), indices are distinct and < 2^16, a slot without a candidate holds
-    // (inf, 0x7fffffff).  Bit by bit: the smallest V with count(key <= V) >= K.  47 wave-uniform steps of one 64-bit
-    // compare per slot -- the broadcast-every-candidate rank loop this replaces cost ~16 instructions per candidate.
+    // the K-th smallest key (distance bits, index): fb_kth_key
     unsigned long long key[KS_FB_SLOTS];
 #pragma unroll
     for (int m = 0; m < KS_FB_SLOTS; ++m) key[m] = ((unsigned long long)__float_as_uint(dd[m]) << 32) | (unsigned)ii[m];
-    unsigned long long V = 0ull;
-    for (int bit = 62; bit >= 0; --bit) {
-        if (bit == 31) bit = 15;                                // index bits 16..31 are zero for every candidate
-        const unsigned long long cand = V | ((1ull << bit) - 1ull);
-        int c = 0;
-#pragma unroll
-        for (int m = 0; m < KS_FB_SLOTS; ++m)
-            if (m < ns) c += __popcll(__ballot(key[m] <= cand));
-        if (c < p.K) V |= 1ull << bit;
-    }
+    const unsigned long long V = fb_kth_key(key, ns, p.K);
     // neighbours: rank < K (indices are distinct, so ranks are); sums in lane order
     const bool do_next = p.want_next && (t < p.nb - 1);
     float sy_ = 0.f, sx_ = 0.f, sw_ = 0.f, ny_ = 0.f, nx_ = 0.f;
@@ -1185,13 +1212,13 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
                                                       float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                       const KnnLists ls, int r_init, const EvCountArgs evc) {
     const int *fail = ls.fail;
-    __shared__ unsigned s_hist[KNN_HW][256];        // columns of the thread-serial search (one per thread)
+    __shared__ int s_tmp[4];                        // scratch of the event-count prefix
     __shared__ float4 s_comp[4][64 * KS_FB_SLOTS];  // per wavefront: the candidates below the ring bound, compacted (fallback_one_query)
     // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B workgroups turn
     // the counts of their sample into first records (the event kernels follow on the stream)
     if (evc.events != nullptr && (int)blockIdx.x < evc.B) {
-        ev_prefix_block(evc, (int)blockIdx.x, reinterpret_cast<int *>(&s_hist[0][0]));
-        __syncthreads();          // (s_hist was the prefix's scratch)
+        ev_prefix_block(evc, (int)blockIdx.x, s_tmp);
+        __syncthreads();
     }
     const int nq = p.B * p.nb * p.G;
     const int nfail = min(fail[0], nq);
@@ -1203,8 +1230,8 @@ __global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const f
         // radius to start from: the one the strip kernel tried (one more ring if it held too few candidates), else from the table
         const int why = (int)(ent >> 30), rh = hinted ? (int)((ent >> 24) & 63u) : 0;
         const int r_start = rh > 0 ? rh + (why == 0 ? 1 : 0) : 0;
-        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_hist, s_comp);
-        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_hist, s_comp);
+        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_comp);
+        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_comp);
     }
 }
 

@@ -71,6 +71,15 @@ class StageTimer:
 STAGE_TIMER = None   # set to a StageTimer to time every C-ABI call
 
 
+_KERNEL_TIMERS = [0]
+
+
+def kernel_timer_on():
+    """True inside `with KernelTimer()`: the library brackets every launch with HIP events then, which must not fall into a graph
+    capture -- and a replayed graph would show the timer nothing."""
+    return _KERNEL_TIMERS[0] > 0
+
+
 class KernelTimer:
     """Per-KERNEL HIP-event timing by the library itself (mpc_profile_start / mpc_profile_stop: two events around every
     launch, on the launch stream).  `with KernelTimer() as kt: ...steps...` then kt.summary() ->
@@ -78,10 +87,12 @@ class KernelTimer:
 
     def __enter__(self):
         C.lib().mpc_profile_start()
+        _KERNEL_TIMERS[0] += 1
         self.records = None
         return self
 
     def __exit__(self, *exc):
+        _KERNEL_TIMERS[0] -= 1
         torch.cuda.synchronize()
         cap = 1 << 16
         names = ctypes.create_string_buffer(cap * 48)
@@ -609,6 +620,11 @@ class PyramidFocusFn(torch.autograd.Function):
         return knn_lut_bwd(shape, traj, g_lut, g_next, state, ws), None, None, None, None, None
 
 
+class _Marker:
+    """Lives as long as the autograd context it is attached to (StaticFocusCalcFn, automatic mode)."""
+    __slots__ = ('__weakref__',)
+
+
 class StaticFocusPlan:
     """FocusLoss(static_shapes=True): `calc` + backward of ONE shape captured once into two HIP graphs (forward; backward)
     over buffers that never move, and replayed from then on -- what a B = 1 step costs on the host drops from two eager
@@ -636,6 +652,7 @@ class StaticFocusPlan:
         self.scratch = torch.empty(_bwd_scratch_floats(p), dtype=torch.float32, device=dev) if need_grad else None
         self.g_traj = torch.empty_like(traj) if need_grad else None
         self.generation = 0
+        self.pending = None              # weak reference to the marker of the latest calc that still waits for its backward (automatic mode)
         self.traj.copy_(traj); self.ev.copy_(ev); self.tr.copy_(tr)
         # one eager run on a side stream first: the library's one-time set-up must not fall into a capture
         side = torch.cuda.Stream(dev)
@@ -666,7 +683,21 @@ class StaticFocusCalcFn(torch.autograd.Function):
     """FocusCalcFn replayed from the HIP graphs of a StaticFocusPlan."""
 
     @staticmethod
-    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, event_offsets, plans: dict):
+    def plan_key(trajectories, events, cfg, num_pos, event_offsets):
+        """The key of the plan a calc of these inputs would use (shape only: every input is copied in)."""
+        B, M = int(events.shape[0]), int(events.shape[1])
+        Mp = int(num_pos) if cfg.polarity_split else M
+        return (B, M, Mp, int(trajectories.shape[2]), bool(trajectories.requires_grad), trajectories.device.index, event_offsets is not None)
+
+    @staticmethod
+    def plan_busy(plans, key):
+        """True while the latest calc of this plan still waits for its backward (its autograd context is alive and has not run):
+        the captured buffers hold that step, another calc of the same shape must not replay over them."""
+        sp = plans.get(key)
+        return sp is not None and sp.pending is not None and sp.pending() is not None
+
+    @staticmethod
+    def forward(ctx, trajectories, events, t_ref, cfg: PathConfig, num_pos: int, event_offsets, plans: dict, auto: bool = False):
         B, M, Mp, n, dev, traj, ev, tr = _calc_inputs(trajectories, events, t_ref, cfg, num_pos)
         need_grad = trajectories.requires_grad
         key = (B, M, Mp, n, need_grad, dev.index, event_offsets is not None)      # shape only: every input is copied in
@@ -690,19 +721,26 @@ class StaticFocusCalcFn(torch.autograd.Function):
         out = sp.buf[o:o + 3].clone()
         loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
         ctx.mark_non_differentiable(focus, smooth)
-        return loss, focus, smooth, sp.blur.detach()
+        # (the automatic mode keeps the reference's semantics: the images are the caller's own copy, and the plan is marked busy until
+        # this step's backward has run or its graph is dropped -- FocusLoss.calc then takes the eager path for a second calc)
+        sp.pending = None
+        if auto and need_grad:
+            ctx.marker = _Marker()
+            sp.pending = weakref.ref(ctx.marker)
+        return loss, focus, smooth, (sp.blur.clone() if auto else sp.blur.detach())
 
     @staticmethod
     def backward(ctx, g_loss, g_focus, g_smooth, g_iwes):
         if g_loss is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         sp = ctx.sp
+        sp.pending = None
         if ctx.gen != sp.generation:
             raise RuntimeError('FocusLoss(static_shapes=True): this backward belongs to an earlier calc() of the same shape; the '
                                'captured buffers hold the latest one (call backward before the next calc, or use static_shapes=False)')
         sp.gout.copy_(g_loss.reshape(1))
         sp.g_bwd.replay()
-        return sp.g_traj.clone(), None, None, None, None, None, None
+        return sp.g_traj.clone(), None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------

@@ -41,8 +41,29 @@ def basis_values(times, num_basis, basis_type, basis_network=None):
     raise ValueError(basis_type)
 
 
+_BASIS_CACHE = {}
+
+
+def _cached_basis(kind, times, *args):
+    """The [n_t, d] basis matrix of `kind` for these timestamps: the float64 evaluation runs on the host (as the reference's does,
+    bezier.py:104-107) and costs milliseconds -- a training loop asks for the same bin mid-times every step, so the last few
+    matrices are kept (keyed on the timestamps' bytes)."""
+    t = np.ascontiguousarray(np.asarray(times, dtype=np.float64).reshape(-1))
+    key = (kind, args, t.tobytes())
+    m = _BASIS_CACHE.get(key)
+    if m is None:
+        if len(_BASIS_CACHE) > 32:
+            _BASIS_CACHE.clear()
+        m = _BASIS_CACHE[key] = (_bernstein_basis_eval if kind == 'bernstein' else _bspline_basis_eval)(t, *args)
+    return m
+
+
 def bernstein_basis(times, degree):
     """[n_t] -> [n_t, degree]: C(d,i) (1-t)^(d-i) t^i for i = 1..d (P0 == 0), float64 then fp32."""
+    return _cached_basis('bernstein', times, int(degree))
+
+
+def _bernstein_basis_eval(times, degree):
     t = np.asarray(times, dtype=np.float64).reshape(-1)
     out = np.zeros((t.size, degree))
     for d_idx in range(degree):
@@ -82,6 +103,10 @@ def bspline_basis(times, num_ctrl, degree=3):
     t = 0).  Cox-de Boor in float64, then fp32.  UNPINNED EXTENSION: the reference has no B-spline curve
     (src/models/raft_spline/curves holds Bezier and polynomial curves only) -- BASELINE.json's configs[3]
     names a cubic B-spline, so the basis is provided, default OFF, and checked against scipy.interpolate.BSpline."""
+    return _cached_basis('bspline', times, int(num_ctrl), int(degree))
+
+
+def _bspline_basis_eval(times, num_ctrl, degree=3):
     m, p = int(num_ctrl), int(degree)
     assert m >= p + 1, 'need at least degree + 1 control points'
     t = np.clip(np.asarray(times, dtype=np.float64).reshape(-1), 0.0, 1.0)

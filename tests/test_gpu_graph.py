@@ -135,3 +135,53 @@ def test_static_shapes_replays_with_fresh_ordered_batches():
         assert torch.equal(ls.detach(), le.detach()), it
         assert torch.equal(ms['iwes'], me['iwes']) and torch.equal(ts.grad, te.grad), it
     assert len(Ls._static_plans) == 1
+
+
+def test_small_steps_switch_to_the_captured_plan_by_themselves():
+    """Automatic static shapes (FocusLoss.auto_static_shapes, default on): the third calc in a row of one small shape replays the
+    captured plan -- same loss, images and gradient as the eager path bit for bit; the images are the caller's own copy; a
+    second calc before the first one's backward takes the eager path (both backwards stay right); a shape that changes every step
+    never leaves the eager path."""
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(7)
+    cfg = bench.loss_config(wl)
+    Le = LossFactory.get_loss_calculator('FOCUS', dict(cfg, auto_static_shapes=False))
+    La = LossFactory.get_loss_calculator('FOCUS', cfg)
+    assert La.auto_static_shapes and not Le.auto_static_shapes
+    td = times.to(dev)
+    _, ev2, _, _, _ = _c2(8)
+    batches = [{'events': ev.to(dev), 'num_pos_events': num_pos}, {'events': ev2.to(dev), 'num_pos_events': num_pos}]
+    keep = []
+    for step in range(6):
+        tj = (traj + 0.01 * step).to(dev)
+        b = batches[step % 2]
+        te, ta = tj.clone().requires_grad_(True), tj.clone().requires_grad_(True)
+        le, loge, me = Le.calc(te, td, b)
+        la, loga, ma = La.calc(ta, td, b)
+        le.backward(); la.backward()
+        assert torch.equal(le.detach(), la.detach()) and torch.equal(te.grad, ta.grad), step
+        assert torch.equal(me['iwes'], ma['iwes']) and torch.equal(loge['focus_loss'], loga['focus_loss'])
+        keep.append((ma['iwes'], me['iwes'].clone()))
+    assert len(La._static_plans) == 1 and len(Le._static_plans) == 0        # captured once, from the third step on
+    for got, want in keep:                                                   # the images of earlier steps are still theirs
+        assert torch.equal(got, want)
+    # two calcs of the same shape before any backward: the second one cannot replay over the first one's buffers
+    t1, t2 = traj.to(dev).requires_grad_(True), (traj + 0.05).to(dev).requires_grad_(True)
+    l1, _, _ = La.calc(t1, td, batches[0])
+    l2, _, _ = La.calc(t2, td, batches[0])
+    l2.backward(); l1.backward()
+    r1, r2 = traj.to(dev).requires_grad_(True), (traj + 0.05).to(dev).requires_grad_(True)
+    k1, _, _ = Le.calc(r1, td, batches[0]); k1.backward()
+    k2, _, _ = Le.calc(r2, td, batches[0]); k2.backward()
+    assert torch.equal(l1.detach(), k1.detach()) and torch.equal(t1.grad, r1.grad)
+    assert torch.equal(l2.detach(), k2.detach()) and torch.equal(t2.grad, r2.grad)
+    # batches of different lengths (what a loader delivers): no plan is ever built
+    Lb = LossFactory.get_loss_calculator('FOCUS', cfg)
+    for step in range(6):
+        m = 40000 + 1000 * step
+        tb = traj.to(dev).requires_grad_(True)
+        lb, _, _ = Lb.calc(tb, td, {'events': ev[:, :m].contiguous().to(dev), 'num_pos_events': min(num_pos, m)})
+        lb.backward()
+    assert len(Lb._static_plans) == 0
