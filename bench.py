@@ -418,7 +418,7 @@ def main():
 
     from motionpriorcmax_amd import LossFactory, ops, dp
 
-    def run_workload(name, steps, warmup, with_comm, instrument=True):
+    def run_workload(name, steps, warmup, with_comm, instrument=True, force_group=False, net_only=False):
         wl = WORKLOADS[name]
         L = LossFactory.get_loss_calculator('FOCUS', loss_config(wl))
         # The timed steps ROTATE over `args.batches` distinct resident batches (events + trajectories; C3: 4 x 101 MB), as a training
@@ -442,7 +442,15 @@ def main():
             st_['batch'] = L.order_events(st_['batch_time']) if args.events_layout == 'bucket' else st_['batch_time']
         batch = sets[0]['batch']
         valid_local = sum(sets[i % nbat]['valid'] for i in range(steps)) / steps      # valid events of an average timed step
-        reducer = dp.GradAllReducer(device=comm_dev) if (with_comm and world > 1) else None
+        # with_comm: the data-parallel training step's one exchange, with a REAL producer -- a stand-in network of the reference UNet's
+        # 31 044 610 parameters (dp.StandInNetwork; the UNet itself is out of scope) runs forward + backward behind the loss; its
+        # gradients are views into the reducer's flat buffer, and every bucket is all-reduced (RCCL, side stream) the moment its last
+        # gradient is written, overlapping the rest of that backward and the next step's loss (dp.OverlappedGradProducer).
+        # `force_group`: a process group of ONE rank (N = 1) still goes through the RCCL call path.
+        reducer = dp.GradAllReducer(device=comm_dev, force_collective=force_group) if (with_comm and (world > 1 or force_group)) else None
+        producer = dp.OverlappedGradProducer(reducer) if (reducer is not None and comm_dev.type == 'cuda') else None
+        if net_only:                      # (the same step with the network but without any exchange: what the exchange itself costs)
+            producer = dp.OverlappedGradProducer(dp.GradAllReducer(device=comm_dev))
         counter = [0]
 
         def step(rotate=True):
@@ -451,9 +459,12 @@ def main():
             loss, _, _ = L.calc(st_['traj'], times_d, st_['batch'])
             loss.backward()
             st_['traj'].grad = None
-            if reducer is not None:
-                reducer.wait()       # previous step's all-reduce must be done before "the optimizer"
-                reducer.start()      # this step's network gradient; overlaps the next step's loss
+            if producer is not None:
+                producer.wait()      # the previous step's all-reduce must be done before "the optimizer" (and before the gradients are zeroed)
+                producer.step()      # network forward + backward; buckets are exchanged as they fill, overlapping the next step's loss
+            elif reducer is not None:
+                reducer.wait()
+                reducer.start()      # (gloo debugging backend: the flat buffer as it is)
             return loss
 
         # set-up, not part of the W warm-up steps: bring the caching allocator to its steady state (the
@@ -475,7 +486,9 @@ def main():
             t0 = time.perf_counter()
             for _ in range(steps):
                 last = step()
-            if reducer is not None:
+            if producer is not None:
+                producer.wait()
+            elif reducer is not None:
                 reducer.wait()
             if world > 1:
                 dist.barrier()
@@ -487,7 +500,7 @@ def main():
         total_valid = dp.sum_over_ranks(valid_local, comm_dev)
         # the same number of steps on ONE resident batch (what rounds 1-4 timed), beside the rotating figure
         single = None
-        if nbat > 1 and reducer is None:
+        if nbat > 1 and reducer is None and producer is None:
             sb = []
             for _ in range(3):
                 torch.cuda.synchronize()
@@ -514,7 +527,7 @@ def main():
             per_rank['balance_min_over_max'] = round(min(per_rank['value']) / max(per_rank['value']), 4)
         # the exchange alone (no loss step beside it): achieved all-reduce rate against the xGMI bounds
         comm_alone = None
-        if reducer is not None:
+        if reducer is not None and world > 1:
             for _ in range(2):
                 reducer.start(); reducer.wait()
             torch.cuda.synchronize(); dist.barrier()
@@ -777,10 +790,34 @@ def main():
             'ms_per_step': round(1e3 * r_comm['dt'] / r_comm['steps'], 4),
             'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2), 'allreduce_alone': r_comm.get('comm_alone'),
             'per_rank': r_comm.get('per_rank'),
-            'note': 'same steps with the 124 MB network-gradient all-reduce (RCCL, 4 buckets, side stream) overlapping the next loss; '
-                    'the buffer that is all-reduced is a zero buffer nobody produced (no network here): overlap with a real producer untested'}
+            'note': 'same steps + a stand-in network of the reference UNet\'s 31 044 610 parameters (dp.StandInNetwork: forward + backward on a '
+                    '2 x 15 x 120 x 160 input) whose gradients fill the flat buffer as views; every bucket of the 124 MB is all-reduced (RCCL, '
+                    'side stream) the moment its last gradient is written, overlapping the rest of that backward and the next step\'s loss'}
+        r_net = run_workload(args.workload, args.steps, args.warmup, False, instrument=False, net_only=True)
+        out['dp_with_grad_allreduce']['same_steps_without_the_exchange_ms'] = round(1e3 * r_net['dt'] / r_net['steps'], 4)
     if rank == 0 and world == 1:
         also = {}
+        # the data-parallel leg on ONE GPU: a process group of one rank, so that the bucketed all-reduce goes through the RCCL call path
+        # (stream ordering, bucket events) beside a real gradient producer; what it measures here is the contention of the network's
+        # backward and the exchange's kernels with the loss kernels -- the xGMI traffic itself needs the 8-GPU node
+        if not args.no_nondefault:
+            try:
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', str(_free_port()))
+                dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+                r1 = run_workload(args.workload, max(5, args.steps // 2), 2, True, instrument=False, force_group=True)
+                r0 = run_workload(args.workload, max(5, args.steps // 2), 2, False, instrument=False, net_only=True)
+                dist.destroy_process_group()
+                also['dp_producer_1gpu'] = {
+                    'loss_only_ms_per_step': round(ms_per_step, 4),
+                    'loss_plus_network_ms_per_step': round(1e3 * r0['dt'] / r0['steps'], 4),
+                    'loss_plus_network_plus_bucketed_allreduce_ms_per_step': round(1e3 * r1['dt'] / r1['steps'], 4),
+                    'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2),
+                    'note': 'RCCL group of ONE rank: stand-in network of 31 044 610 parameters (dp.StandInNetwork), gradients as views into the flat '
+                            'buffer, 4 buckets all-reduced on a side stream as they fill; the network step itself dominates these figures -- compare '
+                            'the last two'}
+            except Exception as e:      # informational
+                also['dp_producer_1gpu'] = {'error': repr(e)[:300]}
         for name in [a for a in args.also.split(',') if a and a != args.workload]:
             # each extra workload runs in a fresh child process: the caching allocator of this process
             # (sized by the main workload) otherwise frees/reallocates inside the child's timed steps
@@ -813,10 +850,10 @@ def main():
                     rows = json.load(open(tf.name))
                 also['realistic_inputs'] = {
                     'note': 'C3-shaped steps; vs_white = step time / step time on the white-noise coefficients of the headline; '
-                            'knn_fail_frac = queries the strip kernel handed to k_knn_fallback',
+                            'knn_fail_frac = queries the strip kernel handed to the one-wavefront-per-query search of k_knn_tail',
                     'variants': {r['variant']: {'ms_per_step': r['ms_per_step'], 'vs_white': r['vs_first'],
                                                 'knn_fail_frac': round(r['knn_fail_frac'], 5),
-                                                'k_knn_fallback_us': r['kernels_us_per_step'].get('k_knn_fallback'),
+                                                'k_knn_tail_us': r['kernels_us_per_step'].get('k_knn_tail'),
                                                 'k_knn_strip_us': r['kernels_us_per_step'].get('k_knn_strip'),
                                                 'k_knn_bwd_tile_us': r['kernels_us_per_step'].get('k_knn_bwd_tile'),
                                                 'k_knn_bwd_far_us': r['kernels_us_per_step'].get('k_knn_bwd_far')} for r in rows},

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <atomic>
 #include "../../include/mpcmax.h"
+#include "tuning.h"
 
 #define MPC_WAVE 64
 #define MPC_KNN_LDS_SORT_CELLS (150 * 1024 / 4)   // largest LUT grid the single-workgroup LDS counting sort holds
@@ -76,7 +77,7 @@ struct mpc_ws_layout {
     int64_t off_knn_reach;   // float  [B*nb][tiles of the bucket grid]  backward search reach per 16x16 tile
     int64_t off_knn_fail;    // int32  [1 + B*nb*G]  queries handed from the strip kernel to the fallback kernel
     int64_t off_knn_retry;   // int32  [1 + B*nb*ceil(wq/2)*ceil(hq/128)]  strips the strip kernel searches again in quarters (staging overflow)
-    int64_t off_knn_farstrip; // int32 [1 + strips]  strips that hold far queries (k_knn_strip_more<FARQ>)
+    int64_t off_knn_farstrip; // int32 [1 + strips]  strips that hold far queries (k_knn_tail)
     int64_t off_knn_ftlist;  // int32 [1 + B*nb*tiles]  (sample, bin, tile) work items of k_knn_bwd_far;  off_knn_ftbits: uint32 [B*nb][ceil(tiles/32)] the same as bits
     int64_t off_knn_ftbits;
     int64_t off_knn_chord;   // uint8 [21][21]  chord table of the strip kernels (knn_device.h: knn_chord_cells)
@@ -95,9 +96,6 @@ struct mpc_ws_layout {
 };
 
 // contrast tiles
-#ifndef MPC_CT_H
-#define MPC_CT_H 32
-#endif
 #define MPC_CT_W 64
 #define MPC_CF_TW 56   // fused kernel: tile + 2*4 halo columns = 64 = one wavefront row
 // smoothness tiles (LUT cells)

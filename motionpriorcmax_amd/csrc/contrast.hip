@@ -133,9 +133,6 @@ __device__ __forceinline__ float lane_right(float v) {     // value of lane + 1 
 // TH rows per band: MPC_CT_H (32) for batches, 16 when that leaves the chip short of wavefronts (B = 1: 360 bands of 32
 // rows on 256 CUs; measured at C2 18.2 -> 12.0 us, neutral at C3); `nslots` entries of the partial-sum array exist and
 // the finalize kernel adds them all, so the bands of the coarser tiling clear the entries they do not use
-#ifndef CM_PF
-#define CM_PF 4      // rows of the raw image in flight ahead of the row being processed (2: 35.5 us at C3, 4: 34.7, 8: 34.3)
-#endif
 template <bool L2N, int TH>
 __global__ __launch_bounds__(64) void k_contrast_march(const float *__restrict__ raw, float *__restrict__ blur,
                                                        float *__restrict__ gimg, double *__restrict__ part, int H, int W,
@@ -388,9 +385,6 @@ __global__ void k_scale(const float *__restrict__ x, const float *__restrict__ a
 // grid (ceil(wq/60), ceil(hq/MPC_SM_H), nimg*C/2), 64 threads
 // ------------------------------------------------------------------------------------------
 // TH rows per band: MPC_SM_H (16), or half of it for small fields (smooth_band_rows below)
-#ifndef MPC_SM_PF
-#define MPC_SM_PF 2
-#endif
 template <int TH>
 __global__ __launch_bounds__(64) void k_lut_smooth_march(const float *__restrict__ field, float *__restrict__ gfield,
                                                          double *__restrict__ part, int hq, int wq, int C, float gscale) {

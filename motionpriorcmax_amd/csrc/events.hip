@@ -8,6 +8,7 @@
 #include "ev_count_device.h"
 #include "knn_device.h"
 #include "bounds.h"
+#include "diag/stamps.h"
 
 struct EvParams {
     int B, M, Mp, nb, T, H, W, sp, hq, wq, P;
@@ -223,9 +224,6 @@ __global__ __launch_bounds__(256) void k_event_pos_grad(const mpc_shape s, const
 // than fp32 accumulation of the same taps, and integer sums are order independent, so the
 // image is bitwise reproducible from run to run.
 // ==========================================================================================
-#ifndef EV_PER_THREAD
-#define EV_PER_THREAD 2   // measured at C3: 2 -> 98.6 us, 4 -> 106.9, 8 -> 107.5 (whole forward splat)
-#endif
 #define EV_FIX_SHIFT 30
 #define EV_MARKER 0x6d706331   // 'mpc1': backward records of this workspace are valid
 
@@ -258,9 +256,6 @@ __device__ __forceinline__ int xcd_swizzle(int p, int n) {
     return (p & 7) * per + (p >> 3);
 }
 
-#ifndef EV_STAGE
-#define EV_STAGE 1152      // records of one workgroup laid out in LDS before they are written (>= 2.25 per event)
-#endif
 
 // one record into slot `slot` of local bucket `lb` (forward buckets first, then backward ones)
 __device__ __forceinline__ void ev_emit(const EvParams &p, const BinLayout &L, int b, int nf_loc, int lb, int slot,
@@ -508,18 +503,6 @@ __device__ __forceinline__ void record_grad(float y, float x, float w, const flo
 
 // grid NBk, 512 threads, dynamic LDS = CSR * wq * 2 * 8 bytes.
 // glut = grad_out * (GCOEF * sum + add_term): the smoothness gradient is folded in here.
-#ifndef EV_LUT_THREADS
-#define EV_LUT_THREADS 512
-#endif
-#ifndef EV_LUT_THREADS_ORD
-#define EV_LUT_THREADS_ORD 1024      // ordered variant: 72 KB of LDS per workgroup -> two per CU; 1024 threads keep the CU's waves
-#endif
-#ifndef EV_LUT_INFLIGHT_ORD
-#define EV_LUT_INFLIGHT_ORD 2
-#endif
-#ifndef EV_LUT_INFLIGHT
-#define EV_LUT_INFLIGHT 5   // 5 x 512 covers the largest bucket of C3 in one batch (4: 43.8 us, 5: 42.4, 6: 43.6, 8: 52.3)
-#endif
 // ORDERED: the events were ordered by mpc_event_bucket_order -- the rows of bucket (bin, LUT strip) of each polarity
 // block are contiguous (offsets table) -- so the kernel reads the event rows themselves and redoes the warp instead of
 // reading records that the forward would have had to write (section 7 of DESIGN.md).
@@ -534,13 +517,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
                                                     const float *__restrict__ t_ref, const int *__restrict__ offsets,
                                                     const KnnReachJob job) {
     extern __shared__ unsigned long long s_acc[];
-#ifdef EV_LA_STAMP
-    __shared__ unsigned s_stp[8];         // (in LDS, not registers: eight live 64-bit values took the kernel from 47 to > 64 VGPRs -- one workgroup per CU)
-#define LA_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) s_stp[k] = (unsigned)wall_clock64(); } while (0)
-    if (threadIdx.x < 8) s_stp[threadIdx.x] = (unsigned)wall_clock64();
-#else
-#define LA_STAMP(k) do { } while (0)
-#endif
+    LA_STAMP_DECL
     constexpr int NT = ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS, NIF = ORDERED ? EV_LUT_INFLIGHT_ORD : EV_LUT_INFLIGHT;
     const EvParams p = make_params(s);
     const int tid = threadIdx.x;
@@ -636,15 +613,7 @@ __global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void
         if (add) { const float2 o = add[i]; v.x += gout * o.x; v.y += gout * o.y; }
         dst[i] = v;
     }
-#ifdef EV_LA_STAMP
-    LA_STAMP(6);
-    __syncthreads();
-    if (tid == 0) {       // diagnostics build (tools/lut_accum_stamp_probe.py): phase stamps of wavefront 0 over the first cells of the strip
-        unsigned *d = reinterpret_cast<unsigned *>(dst);
-        for (int k = 0; k < 7; ++k) d[k] = s_stp[k] - s_stp[0];
-        d[7] = (unsigned)n; d[8] = s_stp[0];
-    }
-#endif
+    LA_STAMP_WRITE(tid, dst, n);
 }
 
 // the counting pass of ev_count_device.h as a launch of its own (stage entry points; the fused forward lets spare

@@ -13,10 +13,8 @@
 #include "knn_device.h"
 #include "ev_count_device.h"
 #include "bounds.h"
+#include "diag/stamps.h"
 #include <stdlib.h>
-#ifndef KNN_BW_CH
-#define KNN_BW_CH 4       // bwd_window_fast: cells of a window row whose LDS reads are issued together
-#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -68,12 +66,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     __shared__ int s_huge[32];
     __shared__ int s_big[1024];          // crowded cells of this workgroup (more than KNN_BK_SMALL points); the rest of them re-scan
     const int tid = threadIdx.x;
-#ifdef KNN_BK_STAMP
-    __shared__ unsigned s_stp[8];       // diagnostics build (tools/bucket_stamp_probe.py): phase stamps of thread 0, 10 ns units
-#define BK_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) s_stp[k] = (unsigned)wall_clock64(); } while (0)
-#else
-#define BK_STAMP(k) do { } while (0)
-#endif
+    BK_STAMP_DECL
     BK_STAMP(0);
     const int bt = blockIdx.x / S, part = blockIdx.x - bt * S, b = bt / p.nb, t = bt - b * p.nb;
     // set-up for the strip query kernel, which follows on the stream: its per-tile maxima are accumulated with
@@ -85,7 +78,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
         for (int i = tid; i < ls.ftwords; i += 1024) ls.ftbits[(size_t)bt * ls.ftwords + i] = 0u;
     }
     if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; }
+    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; *knn_late_count(ls) = 0; *knn_tail_done(ls) = 0; }
     if (blockIdx.x == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))      // (the chord table of the strip kernels' row tables)
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
@@ -279,11 +272,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
             if (sl < own) { si_[MPC_IDX(base + sl, p.n) - base] = i[u]; sp_[sl] = v[u]; }
         }
     }
-#ifdef KNN_BK_STAMP
-    BK_STAMP(7);
-    __syncthreads();
-    if (tid < 8) ls.fail[1 + 100000 + 8 * blockIdx.x + tid] = tid == 0 ? (int)s_stp[0] : (int)(s_stp[tid] - s_stp[0]);      // [0]: absolute start (low 32 bits)
-#endif
+    BK_STAMP_WRITE(ls, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -385,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
         for (int i = tid; i < ls.ftwords; i += 1024) ls.ftbits[(size_t)bt * ls.ftwords + i] = 0u;
     }
     if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
-    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; }
+    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; *knn_late_count(ls) = 0; *knn_tail_done(ls) = 0; }
     if (bt == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
@@ -878,22 +867,10 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 // grid: 1-D, XCD-contiguous, 256 threads, dynamic LDS (RWmax^2 float4 + KNN_BW_WMAX of slack [+ float2 per cell])
 // ------------------------------------------------------------------------------------------
 #define KNN_BW_WMAX 16
-#ifndef KNN_BW_CH
-#define KNN_BW_CH 4       // cells of a window row whose LDS reads are issued together
-#endif
-#ifndef KNN_BW_PITCH
-#define KNN_BW_PITCH 48   // row pitch (cells) of the staged arrays without the flow_to_next gradient; >= 16 + 2 * KNN_RQ_MAX
-#endif
 // Workgroups per CU the register budget is set for (7 -> 72 VGPRs, 8 -> 64).  Round 2 needed all eight (the kernel waited for its
 // LDS conflicts); without them, and with the reach phase gone, seven workgroups that spill 12 instead of 48 bytes per lane are
 // faster: 118 -> 114 us at C3.  With the flow_to_next gradient (C4: a larger register set of its own) eight remain better: 57.3
 // against 58.4 us.
-#ifndef KNN_BW_OCC
-#define KNN_BW_OCC 7
-#endif
-#ifndef KNN_BW_OCC_NEXT
-#define KNN_BW_OCC_NEXT 8
-#endif
 // Reach of one 16x16 tile, computed by ONE wavefront (lane = threadIdx.x & 63, all 64 lanes call): step A, the largest K-th
 // distance of any class of any tile of the slice; step B, the (tile, class) pairs within its D rings -- see k_knn_bwd_tile.
 template <bool L1>
@@ -959,16 +936,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                                                       const float *__restrict__ tile_dkmax,
                                                       float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
                                                       float2 *__restrict__ gtraj_direct, const float *__restrict__ reach_in,
-                                                      int gx, int gy, int bd
-#ifdef KNN_BW_STAMP
-                                                      , int *__restrict__ stamp
-#endif
-                                                      ) {
+                                                      int gx, int gy, int bd KB_STAMP_PARAM) {
     constexpr int TS = 16;
-#ifdef KNN_BW_STAMP
-    const unsigned long long st0 = wall_clock64();
-    int st_slow = 0;
-#endif
+    KB_STAMP_BEGIN
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_rowbase[KNN_TROWS + 1];
     __shared__ int s_rowg[KNN_TROWS];
@@ -1078,9 +1048,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     }
     __syncthreads();
     const bool anytie = (s_tiew[0] | s_tiew[1] | s_tiew[2] | s_tiew[3]) != 0;
-#ifdef KNN_BW_STAMP
-    const unsigned long long st1 = wall_clock64();
-#endif
+    KB_STAMP_MID
     const int total = s_rowbase[nrow];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
     const float2 *sp_ = spos + (size_t)bt * p.n;
@@ -1128,9 +1096,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                     }
                 }
             } else if (act) {
-#ifdef KNN_BW_STAMP
-                st_slow = 1;
-#endif
+                KB_STAMP_SLOW
                 // exact (distance, index) membership: queries with an excluded tie, or a window wider than KNN_BW_WMAX
                 for (int cy = y0; cy <= y1; ++cy) {
                     const float dy = ((float)(cy * p.sp) + p.off) - pt.x;
@@ -1179,20 +1145,12 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
             }
         }
     }
-#ifdef KNN_BW_STAMP
-    __syncthreads();
-    const bool anyslow = __syncthreads_or(st_slow) != 0;
-    if (tid == 0) {
-        const unsigned long long st2 = wall_clock64();
-        stamp[4 * lblk + 0] = (int)(st2 - st0); stamp[4 * lblk + 1] = (int)(st1 - st0);
-        stamp[4 * lblk + 2] = RQ | (use_lds ? 0 : 256) | (anytie ? 512 : 0) | (anyslow ? 1024 : 0); stamp[4 * lblk + 3] = total;
-    }
-#endif
+    KB_STAMP_END(tid, lblk, RQ, use_lds, anytie, total);
 }
 
 // ------------------------------------------------------------------------------------------
 // backward of the FAR queries (no square of up to KNN_RCAP cells around them holds K points: queries inside a band the flow
-// field emptied, whose K neighbours lie in a thin segment of a disc tens of pixels away; served by k_knn_strip_more<FARQ> or
+// field emptied, whose K neighbours lie in a thin segment of a disc tens of pixels away; served by k_knn_tail or
 // the fallback kernel).  Counting them in the tile maxima would make every point of the tiles around such a band search a
 // window of hundreds of query cells for the few dozen of them that hold it; k_knn_bwd_tile therefore leaves them out, and
 // here the search runs the other way round, as in the forward: the tile's bucketed points and cell offsets are staged in LDS,
@@ -1205,13 +1163,6 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 // the benchmark have a few hundred items per step)
 // ------------------------------------------------------------------------------------------
 #define KNN_FAR_CAP 640       // points of a tile per round of accumulators (a border tile with its margin cells: 24 x 24)
-#ifndef KNN_FAR_QB
-#define KNN_FAR_QB 256        // far queries tested against the tile per batch (one per thread); those that touch it: a list in LDS
-                              // (512 / 1024 per batch: 244 / 273 us against 237 at a 48 px contraction band)
-#endif
-#ifndef KNN_FAR_BLOCKS
-#define KNN_FAR_BLOCKS 4096     // (2048: 237 us against 218 at a 48 px contraction band)
-#endif
 template <bool L1, bool NEXT>
 __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
@@ -1737,14 +1688,9 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
             else MPC_LAUNCH(k_knn_reach_tiles<false>, dim3(s->B * s->nb), dim3(256), rl, st, p, tile_dkmax, reach, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)));
             reach_pre = reach;
         }
-#ifdef KNN_BW_STAMP
-#define KB_STAMP_ARG , (int *)((char *)ws + L.off_knn_fail)
-#else
-#define KB_STAMP_ARG
-#endif
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
         MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG)
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG(ws, L))
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH

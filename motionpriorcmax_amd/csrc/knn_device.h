@@ -4,12 +4,6 @@
 #pragma once
 #include "common.h"
 #include <math.h>
-#ifndef KNN_BINS
-#define KNN_BINS 32
-#endif
-#ifndef KNN_BATCH
-#define KNN_BATCH 2   // candidate positions loaded ahead of use in the two hot scans (B=14: 944 -> 874 us; 4: 867)
-#endif
 #define KNN_HW (KNN_BINS / 4)   // histogram words per query: four 8-bit bins per word
 #define KNN_LIST KNN_HW          // {candidate slot, trajectory index} pairs kept in a (dead) histogram column
 // bit 30 of the saved K-th index: some point lies at exactly the K-th distance but was excluded (tie resolved by
@@ -45,15 +39,9 @@ struct KnnParams {
     int l1, iwd, want_next;
     float off;   // sp/2 - 0.5 : centre of cell 0 (focus.py:117)
 };
-#ifndef KNN_RCAP
-#define KNN_RCAP 6                 // largest search radius (cells) of the strip kernel's main launch
-#endif
 #define KNN_RFAR 20                // ... of its launch for the FAR queries (no square up to KNN_RCAP cells holds enough points: the
                                    // inside of a band the flow field emptied); beyond it a query goes to the fallback kernel
 #define KNN_MARGIN (KNN_RCAP + 1)
-#ifndef KNN_FAR_RINGS
-#define KNN_FAR_RINGS 2            // a K-th distance beyond r_init + this many rings: the far backward's query (knn_is_far_dk)
-#endif
 // smallest count of points in the (2r + 1)^2 cell square of a query for which radius r is tried (K / (pi / 4) at K = 32: the
 // disc of the ring bound holds K points if they are spread evenly over the square; calibrated on smooth flow fields)
 // (L1: the ball of the ring bound is a diamond, half of the square)
@@ -66,7 +54,7 @@ __host__ __device__ static inline int knn_square_need_far(int K, int l1 = 0) { r
 int mpc_knn_margin(const mpc_shape *s);
 
 // Work lists of the KNN forward, all in the workspace, counters zeroed by the bucket kernels:
-//   fail     int [1 + B*nb*G]      queries for k_knn_fallback (bits 0..29 the query, bits 30..31 why)
+//   fail     int [1 + B*nb*G]      queries for the fallback workgroups of k_knn_tail (bits 0..29 the query, bits 30..31 why)
 //   retry    int [1 + strips]      strips whose points overflowed the staging area: k_knn_strip_retry searches them in quarters
 //   farstrip int [1 + strips]      strips that hold far queries: k_knn_strip_far
 //   far      int [B*nb][1 + G]     per (sample, bin): the cells (cy * wq + cx) of the far queries that were served (K-th key
@@ -74,7 +62,7 @@ int mpc_knn_margin(const mpc_shape *s);
 //   ftbits   u32 [B*nb][ftwords]   tiles whose points a far query's disc can touch; ftlist int [1 + B*nb*tiles]: the same as a
 //                                  list of (sample, bin) * tiles + tile: the work items of k_knn_bwd_far
 //   again    u32 [B*nb][hq][ceil(wq/32)]  queries the main launch of the strip kernel could not finish (fewer than K candidates
-//                                  below the ring bound after all, more slots than its registers hold): k_knn_strip_more<FARQ>
+//                                  below the ring bound after all, more slots than its registers hold): k_knn_tail
 //                                  searches them with one more ring, 128 slots and chord-shaped rows
 //   grow     u32, same shape: of those, the ones that need more RINGS (too few candidates below the bound; far queries)
 //   chord    u8 [KNN_RFAR + 1][KNN_RFAR + 1]  chord[r][j] = knn_chord_cells(r, j): written by the bucket kernels, read by the strip kernels
@@ -84,9 +72,14 @@ struct KnnLists {
     unsigned char *chord;
     int ftwords, again_words;       // words per (sample, bin)
 };
-// number of queries the main launch marked for the second one (behind the chord table, in the same 1 KB of the workspace)
+// number of queries the main launch marked for the second one (behind the chord table, in the same 1 KB of the workspace); next to it
+// the counters of the tail kernel (k_knn_tail): queries its strip workgroups handed to its fallback workgroups -- the LATE list,
+// which grows downwards from the end of the `fail` array (main list and late list together never exceed the number of queries) --
+// and the strip workgroups that have finished.  All zeroed by the bucket kernels.
 #ifdef __HIPCC__
 __device__ __forceinline__ int *knn_marked_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 512); }
+__device__ __forceinline__ int *knn_late_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 516); }
+__device__ __forceinline__ int *knn_tail_done(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 520); }
 #endif
 // Blocks of queries of the second launch of the strip kernel: the main launch's strips, 2 columns x 128 rows.  The far queries of
 // a band along the top or bottom border are a few rows of EVERY strip, so wider, shorter blocks were tried: 4 x 64 halves the

@@ -25,44 +25,24 @@
 //     slots at the K-th level are noted in a bit mask and ranked afterwards by exact (distance, index).
 // A query the fast path cannot serve (no square up to KNN_RCAP cells holds enough points: the inside of an emptied band;
 // fewer than K candidates below the ring bound after all; more slots than the registers hold; a strip whose points overflow
-// the staging area even in quarters) is marked for the second launch (k_knn_strip_more: radii up to KNN_RFAR, chord-shaped
-// regions, 192 slots) or appended to a list and searched by k_knn_fallback, one wavefront per query: the result is the exact
+// the staging area even in quarters) is marked for the strip workgroups of the tail launch (k_knn_tail: radii up to KNN_RFAR, chord-shaped
+// regions, 192 slots) or appended to a list and searched by its fallback workgroups, one wavefront per query: the result is the exact
 // K-nearest set for any input, ties to the lowest index.
 #include "knn_device.h"
 #include "ev_count_device.h"
 #include "bounds.h"
+#include "diag/stamps.h"
 #include <stdlib.h>
 
 #define KS_NT 256
-#ifndef KS_MORE_MIN
-#define KS_MORE_MIN 16               // a strip goes to the second launch for its unfinished queries if it has more than this many (or far queries)
-#endif
-#ifndef KS_MAIN_CHORD
-#define KS_MAIN_CHORD 1            // main launch: region rows as wide as the widest chord (1) or square (0) that uses them
-#endif
 #define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
 #define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
-#ifndef KS_MAXCH_FAR
-#define KS_MAXCH_FAR 48             // ... of the launch for the far queries (192 slots: a band along the left or right border -- every region row
-                                   // as wide as the widest chord -- needs ~160; 256 slots at three workgroups per CU measured slower, see KS_MORE_OCC)
-#endif
 #define KS_TAIL(MAXCH_) (4 * (MAXCH_) + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
-#ifndef KS_SB
-#define KS_SB 3                     // staging: items per thread whose global loads are in flight together
-#endif
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
-#ifndef KS_FORWARD_MAX
-#define KS_FORWARD_MAX 1024         // the second launch hands its queries on to the fallback kernel when the main launch marked at most this many
-#endif
-#ifndef KS_MORE_OCC
-#define KS_MORE_OCC 4               // workgroups per CU of the second launch = its register budget (128; 13 registers spill).  The launch is bound
-                                   // by the latency of its work items: C3, 40 px translation / 48 px contraction band: 4 per CU with 192 slots
-                                   // 161 / 308 us, 3 per CU with 192 slots 179 / 351, with 256 slots 190 / 368, 2 per CU 258 / -
-#endif
 #define KS_RETRY_BLOCKS (256 * KS_MORE_OCC)   // workgroups of the second launch
 static_assert(KNN_FAR_WS * KNN_FAR_TH == KS_NT, "a block of queries of the second launch = one workgroup");
 static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
@@ -98,30 +78,36 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                                            float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                            const KnnLists &ls, int r_init, int cap, int gx, int gy,
                                            int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq,
-                                           bool forward = false) {
+                                           bool forward = false, int *s_late = nullptr) {
+    // (Round 5 measured the far pass at WAVEFRONT level -- a wavefront per block of 2 x 24 queries with its own LDS slice, no
+    // workgroup barrier, four independent searches per workgroup instead of one wavefront searching while three wait: slower,
+    // UNet-like mixture 185 us against 160, 30 % contraction 725 against 492 -- six blocks per strip each stage their own +-20-row
+    // halo with 64 lanes instead of 256, and most blocks of a listed strip hold no marked query.  profiles/HISTORY_r05.md)
     constexpr bool SPLIT = MODE == 1, FARK = MODE == 2;
-#ifdef KS_STAMP2
-    // diagnostics build (tools/more_stamp_probe.py): phase stamps of thread 0 of a second-launch work item, 10 ns units, far inside the fallback list
-    unsigned long long stp_[8]; int nstp_ = 0;
-#define KS_STP() do { if (FARK && nstp_ < 8) { __builtin_amdgcn_s_waitcnt(0); stp_[nstp_++] = wall_clock64(); } } while (0)
-#else
-#define KS_STP() do { } while (0)
-#endif
+    constexpr int NT = KS_NT;
+#define KS_SYNC() __syncthreads()
+    KS_STP_DECL
     KS_STP();
     constexpr int MAXCH = FARK ? KS_MAXCH_FAR : KS_MAXCH;      // words of four slots per query
     (void)SPLIT;
     constexpr int RC = FARK ? KNN_RFAR : KNN_RCAP;
     constexpr int TH = KS_NT / WS;
     constexpr int NR = TH + 2 * RC;                     // region rows: the strip's query rows and the largest radius above and below
-    static_assert(NR <= KS_NT && NR <= KS_NR_MAX, "one thread per region row");
+    static_assert(NR <= NT && NR <= KS_NR_MAX, "one thread per region row");
+    // queries for the one-wavefront-per-query search: the main launch appends to the `fail` list (counter fail[0], entries upwards from
+    // fail[1]); the strip workgroups of the tail kernel append to the LATE list (counter knn_late_count, entries downwards from the end
+    // of the same array), which the tail kernel's fallback workgroups take once all strip workgroups are done
     int *const fail = ls.fail;
+    int *const fcount = MODE == 0 ? &fail[0] : knn_late_count(ls);
+    const long long fcap = (long long)p.B * p.nb * p.G;
+    auto fslot = [&](int k) -> long long { return MODE == 0 ? 1 + (long long)k : fcap - (long long)k; };
     const int tid = threadIdx.x;
     if (MODE != 1) {
         // (main and second launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
         // the first bucketed slots of the rows go later (s_row); this early barrier costs nothing: every wavefront is here at once
         if (tid < NR) reinterpret_cast<int2 *>(s_dyn)[MPC_IDX(tid, NR)].x = 0;
         if (tid == 0) s_rq[0] = 0;                    // (main launch: "this strip holds far queries", set below; it has no other use for s_rq)
-        __syncthreads();
+        KS_SYNC();
     }
     const int bt = lblk / (gx * gy), bxy = lblk - bt * gx * gy;
     const int sy = bxy / gx, sx = bxy - sy * gx;
@@ -178,18 +164,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     if (!FARK && valid) {
         const int need = need_q;
         r = min(r_init, KNN_RCAP);
-#ifdef KS_AB_NOSAT
-        nr = 1000;
-#else
         nr = knn_square_count(p, sat_bt, cy, cx, r);
-#endif
         if (nr >= need) {
-#ifndef KS_AB_NOSAT
-            if (2 * nr >= 3 * need)
-#else
-            if (false)
-#endif
-            {
+            if (2 * nr >= 3 * need) {
                 for (;;) {
                     const int nm = r > 1 ? knn_square_count(p, sat_bt, cy, cx, r - 1) : 0;
                     if (nm < need) break;
@@ -272,12 +249,12 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     }
     // chord of the disc of radius r at row offset j, for the row tables below (knn_device.h)
     __shared__ unsigned char s_chord[(RC + 1) * (RC + 1)];
-    __shared__ unsigned s_ft[FARK ? KNN_FT_LDS_WORDS : 1];          // second launch: tiles the served far queries' discs touch (knn_far_mark_tiles_lds)
+    __shared__ unsigned s_ft[FARK ? KNN_FT_LDS_WORDS : 1];          // far pass: tiles the served far queries' discs touch (knn_far_mark_tiles_lds)
     if (FARK && tid < KNN_FT_LDS_WORDS) s_ft[tid] = 0u;
-    if (FARK) for (int i = tid; i < (RC + 1) * (RC + 1); i += KS_NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
+    if (FARK) for (int i = tid; i < (RC + 1) * (RC + 1); i += NT) s_chord[i] = ls.chord[(i / (RC + 1)) * (KNN_RFAR + 1) + i % (RC + 1)];
     // (the barrier the row tables need anyway) MODE 0: any far query in this strip?  Then it goes on the list of
-    // k_knn_strip_more<FARQ> when this workgroup ends
-    __syncthreads();
+    // k_knn_tail when this workgroup ends
+    KS_SYNC();
     KS_STP();        // 1: marks read, radius from the table
     const bool anyfar = MODE == 0 && s_rq[0] != 0;
     if (FARK) {
@@ -302,6 +279,8 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const int e = s_list[vt];
             cy = qy0 + (e & 0xff); cx = qx0 + ((e >> 8) & 0xf); r = (e >> 12) & 0xff; served = ((e >> 20) & 1) != 0; isfar = ((e >> 21) & 1) != 0;
         }
+    }
+    if (FARK) {
         if (forward) {
             // (workgroup-uniform) the whole launch has only a few marked queries: a work item here is a chain of ~25 us whatever
             // its size, a round of the fallback kernel ~14 us for up to 4 096 queries -- they go onto its list, with the radius
@@ -310,11 +289,12 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             if (pm != 0ull) {
                 const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
                 int base = 0;
-                if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
+                if (lane == first) base = atomicAdd(fcount, __popcll(pm));
                 base = __shfl(base, first, 64);
                 const size_t qid = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
                 const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24)) ? (unsigned)min(max(r, 1), 63) << 24 : 0u;
-                if (mine) fail[MPC_IDX(1 + base + __popcll(pm & ((1ull << lane) - 1ull)), 1 + (long long)p.B * p.nb * p.G)] = (int)((unsigned)qid | hint | (1u << 30));
+                if (mine) fail[MPC_IDX(fslot(base + __popcll(pm & ((1ull << lane) - 1ull))), 1 + fcap)] = (int)((unsigned)qid | hint | (1u << 30));
+                if (lane == first) *s_late = 1;          // (late list: this workgroup's entries go out with ONE fence before it counts itself done, k_knn_tail)
             }
             return;
         }
@@ -324,7 +304,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const int rc = cy - qy0 + RC;
             for (int j = -r; j <= r; ++j) atomicMax(&s_w[MPC_IDX(rc + j, NR)].x, (int)s_chord[MPC_IDX(r * (RC + 1) + abs(j), (RC + 1) * (RC + 1))]);
         }
-        __syncthreads();                                         // (before the row tables are read and the staging area is written)
+        KS_SYNC();                                               // (before the row tables are read and the staging area is written)
         KS_STP();    // 2: compaction, chords pushed
     }
     const size_t q = (size_t)bt * p.G + (size_t)cy * p.wq + cx;       // global query id
@@ -363,14 +343,14 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         for (int o2 = 1; o2 < 64; o2 <<= 1) { const int v = __shfl_up(incl, o2, 64); if ((tid & 63) >= o2) incl += v; }
         const int wmx = wave_max_i(padded);
         if ((tid & 63) == 63) { s_wsum[tid >> 6] = incl; s_wmax[tid >> 6] = wmx; }
-        __syncthreads();
+        KS_SYNC();
         int run = incl - padded;
         for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
         if (tid < NR) { s_rowstart[MPC_IDX(tid, NR + 1)] = run; s_row[MPC_IDX(tid, NR)] = make_int2(gs, len); }
         if (tid == NR - 1) s_rowstart[NR] = run + padded;
         // row pitch of the staging loop = the longest row of the region
         pitch = max(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])), 1);
-        __syncthreads();
+        KS_SYNC();
         return s_rowstart[NR];
     };
     const bool inpass = mine && (cy - qy0) >= pr0 && (cy - qy0) < pr1;
@@ -378,7 +358,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     KS_STP();        // 3: row table
     bool overflow = false;
     if (total > cap) {
-        if (MODE == 0) {              // (workgroup-uniform) again in quarters: k_knn_strip_more
+        if (MODE == 0) {              // (workgroup-uniform) again in quarters: k_knn_tail
             const int nfq = anyfar ? __syncthreads_count(isfar ? 1 : 0) : 0;
             if (tid == 0) {
                 ls.retry[MPC_IDX(1 + atomicAdd(&ls.retry[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk;
@@ -403,13 +383,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             // main launch a workgroup walked 7 000 items for 300 points, nine rounds of dependent loads)
             const int items = FARK ? total : NR * pitch;
             const float inv_pitch = __builtin_amdgcn_rcpf((float)pitch);        // (1 ulp: the margin below is 0.5 / pitch)
-            for (int base = 0; base < items; base += KS_NT * KS_SB) {
+            for (int base = 0; base < items; base += NT * KS_SB) {
                 int slot[KS_SB], id[KS_SB];
                 bool in[KS_SB], real[KS_SB];
                 float2 pj[KS_SB], f0[KS_SB], f1[KS_SB];
 #pragma unroll
                 for (int u = 0; u < KS_SB; ++u) {
-                    const int it = base + u * KS_NT + tid;
+                    const int it = base + u * NT + tid;
                     int rr, k;
                     if (FARK) {
                         // the last row whose first slot is <= it (an empty row shares its first slot with the row behind it)
@@ -447,13 +427,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
             // the tail behind the staged slots: far-away positions, zero flows (lanes whose range is shorter than the
             // wavefront's trip count read them, flagged off)
-            for (int i = total + tid; i < total + KS_TAIL(MAXCH); i += KS_NT) {
+            for (int i = total + tid; i < total + KS_TAIL(MAXCH); i += NT) {
                 lpos[MPC_IDX(i, cap + KS_TAIL(MAXCH))] = make_float2(KS_FAR, KS_FAR);
                 lflow[MPC_IDX(i, cap + KS_TAIL(MAXCH))] = make_float2(0.f, 0.f);
                 if (NEXT) lnext[MPC_IDX(i, cap + KS_TAIL(MAXCH))] = make_float2(0.f, 0.f);
             }
         }
-        __syncthreads();
+        KS_SYNC();
         KS_STP();    // 4: staged
 
         // ---- search --------------------------------------------------------------------------------------
@@ -759,22 +739,15 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
             knn_state[MPC_IDX(q, BQ)] = dK;
             reinterpret_cast<int *>(knn_state)[BQ + MPC_IDX(q, BQ)] = iK | (tie ? KNN_TIE_FLAG : 0) | ((FARK && ls.far != nullptr && knn_is_far_dk(p, dK, r_init)) ? KNN_FAR_FLAG : 0);
-#ifdef KS_DEBUG_INBIN
-            norm = (float)inbin + 100.f * (float)nsl;      // diagnostics build: statistics of the fast path
-            knn_state[2 * BQ + q] = norm;
-#else
-            if (IWD) knn_state[2 * BQ + q] = norm;         // (the 'mean' backward never reads the normaliser)
-#endif
+            KS_INBIN_STAT(knn_state, BQ, q, inbin, nsl, IWD, norm);         // (the 'mean' backward never reads the normaliser)
         }
         {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
             // (main launch: a query with too few candidates below the ring bound or too many slots gets a second chance in
-            // k_knn_strip_more<FARQ> -- more rings, 128 slots, only such queries staged: its bit in the `again` map -- if the
+            // k_knn_tail -- more rings, 128 slots, only such queries staged: its bit in the `again` map -- if the
             // strip has more than KS_MORE_MIN of them or far queries; the odd one: the fallback list)
             const bool late = MODE == 0 && inpass && !live && why < 2u;
             int nlate = 0;
-#ifndef KS_AB_NOCOUNT
             if (MODE == 0) nlate = __syncthreads_count(late ? 1 : 0);
-#endif
             // ... or the strip goes there anyway for its far queries
             const bool to_more = MODE == 0 && (nlate > KS_MORE_MIN || anyfar);
             if (late && to_more) {
@@ -790,12 +763,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             if (pm != 0ull) {
                 const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
                 int base = 0;
-                if (lane == first) base = atomicAdd(&fail[0], __popcll(pm));
+                if (lane == first) base = atomicAdd(fcount, __popcll(pm));
                 base = __shfl(base, first, 64);
                 // (entry: the query, why in bits 30..31 and -- where the query ids leave room: fewer than 2^24 queries -- the radius
                 // that was tried in bits 24..29, so that the fallback kernel need not read it off the summed-area table again)
                 const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24) && served) ? (unsigned)min(r, 63) << 24 : 0u;
-                if (push) fail[MPC_IDX(1 + base + __popcll(pm & ((1ull << lane) - 1ull)), 1 + (long long)p.B * p.nb * p.G)] = (int)((unsigned)q | hint | (why << 30));
+                if (push) fail[MPC_IDX(fslot(base + __popcll(pm & ((1ull << lane) - 1ull))), 1 + fcap)] = (int)((unsigned)q | hint | (why << 30));
+                if (MODE != 0 && lane == first) *s_late = 1;      // (late list: see k_knn_tail)
             }
         }
         // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
@@ -839,24 +813,13 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 }
             }
             if (ls.ftwords <= KNN_FT_LDS_WORDS) {           // (workgroup-uniform)
-                __syncthreads();
+                KS_SYNC();
                 if (tid < ls.ftwords) { knn_far_flush_tiles(p, ls, bt, s_ft, tid); s_ft[tid] = 0u; }
             }
         } else if (live) knn_tile_max_add(tile_dkmax, p, bt, cy, cx, knn_band_depth(r_init), dK);      // (far query, general gather backward)
-#ifdef KS_STAMP2
-        if (FARK) {
-            __syncthreads();
-            KS_STP();    // 5: searched, lists written
-            const int nmk = __syncthreads_count(mine ? 1 : 0);
-            if (tid == 0) {
-                int *dst = ls.fail + 1 + 200000 + 8 * (int)blockIdx.x;         // (the LAST item of a workgroup stays)
-                dst[0] = (int)(stp_[0] & 0x7fffffffull);
-                for (int k = 1; k < 6; ++k) dst[k] = (int)(stp_[k] - stp_[0]);
-                dst[6] = total; dst[7] = nmk;
-            }
-        }
-#endif
+        KS_STP_WRITE(ls, tid, mine, total);      // 5: searched, lists written
     }
+#undef KS_SYNC
 }
 
 // 1-D grid of gx * gy * B * nb workgroups (gx strips, gy row blocks) in XCD-contiguous order, 256 threads,
@@ -894,35 +857,43 @@ __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnPara
                                      r_init, cap, gx, gy, lblk, 0, KS_NT / WS, s_dyn, s_wsum, s_wmax, s_rq);
 }
 
-// The strips on the retry list (a quarter of the query rows per workgroup and round), then the strips on the farstrip list (their
-// far queries and the queries the main launch could not finish).  grid: a fixed number of workgroups (the list lengths are only
-// known on the device; nothing to do for the lattice-like point sets of the benchmark: both lists empty or nearly)
+// strip workgroups of the tail kernel that have anything to do (the others neither work nor count themselves done): workgroup wg
+// takes the retry items wg, wg + nwg, ... and the far items likewise
+__device__ __forceinline__ int strip_more_busy(const KnnParams &p, const KnnLists &ls, int gx, int gy, int nwg) {
+    const int nstrips = gx * gy * p.B * p.nb;
+    const int gxf = knn_far_items_x(p.wq), gyf = knn_far_items_y(p.hq);
+    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
+    return min(nwg, max(nretry, nfar));
+}
+
+// Strip workgroups of the tail kernel (k_knn_tail): the strips on the retry list (a quarter of the query rows per workgroup and
+// round), then the strips on the farstrip list (their far queries and the queries the main launch could not finish).  `nwg` of them,
+// this one is number `wg` (the list lengths are only known on the device; nothing to do for the lattice-like point sets of the
+// benchmark: both lists empty or nearly)
 template <int WS, bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_strip_more(const KnnParams p, const float *__restrict__ traj,
-                                                          const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
-                                                          const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
-                                                          float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                                          float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                          const KnnLists ls, int r_init, int cap, int gx, int gy) {
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
-    __shared__ unsigned char s_rq[KS_NT / WS];
+__device__ __forceinline__ void strip_more_body(const KnnParams &p, const float *__restrict__ traj,
+                                                const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
+                                                const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
+                                                float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                                float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                                const KnnLists &ls, int r_init, int cap, int gx, int gy, int wg, int nwg,
+                                                unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq, int *s_late) {
     constexpr int TH = KS_NT / WS;
     const int nstrips = gx * gy * p.B * p.nb;
     const int gxf = knn_far_items_x(p.wq), gyf = knn_far_items_y(p.hq);
     const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
-    for (int w = (int)blockIdx.x; w < nretry; w += (int)gridDim.x) {
+    for (int w = wg; w < nretry; w += nwg) {
         const int quarter = w & 3;
         strip_body<WS, L1, NEXT, IWD, 1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                                         r_init, cap, gx, gy, ls.retry[1 + (w >> 2)], quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq);
+                                         r_init, cap, gx, gy, ls.retry[1 + (w >> 2)], quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq, false, s_late);
         __syncthreads();
     }
     // (only a few marked queries in the whole launch -- a B = 1 step with a dozen of them in three strips paid a full work item's
-    // 25 us for them: they are handed on to the fallback kernel, whose round takes them beside what it has anyway)
+    // 25 us for them: they are handed on to the fallback workgroups, whose round takes them beside what they have anyway)
     const bool forward = *knn_marked_count(ls) <= KS_FORWARD_MAX;
-    for (int w = (int)blockIdx.x; w < nfar; w += (int)gridDim.x) {
+    for (int w = wg; w < nfar; w += nwg) {
         strip_body<KNN_FAR_WS, L1, NEXT, IWD, 2>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq, forward);
+                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq, forward, s_late);
         __syncthreads();
     }
 }
@@ -1205,34 +1176,86 @@ __device__ void fallback_one_query(const KnnParams &p, const float *__restrict__
     if (far != nullptr && knn_is_far_dk(p, dK, r_init)) far_list_add(p, ls, bt, cy, cx, dK, lane);      // (dK is wave-uniform)
 }
 
-__global__ __launch_bounds__(256) void k_knn_fallback(const KnnParams p, const float *__restrict__ traj,
-                                                      const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
-                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
-                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                      const KnnLists ls, int r_init, const EvCountArgs evc) {
-    const int *fail = ls.fail;
-    __shared__ int s_tmp[4];                        // scratch of the event-count prefix
-    __shared__ float4 s_comp[4][64 * KS_FB_SLOTS];  // per wavefront: the candidates below the ring bound, compacted (fallback_one_query)
-    // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B workgroups turn
-    // the counts of their sample into first records (the event kernels follow on the stream)
-    if (evc.events != nullptr && (int)blockIdx.x < evc.B) {
-        ev_prefix_block(evc, (int)blockIdx.x, s_tmp);
+// One entry of the fail / late list: the query and where its search starts
+template <bool L1>
+__device__ __forceinline__ void fallback_entry(const KnnParams &p, const float *__restrict__ traj, const knn_cs_t *__restrict__ cell_start,
+                                               const knn_cs_t *__restrict__ sat, const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
+                                               float *__restrict__ flow_lut, float *__restrict__ flow_next, float *__restrict__ knn_state,
+                                               float *__restrict__ tile_dkmax, const KnnLists &ls, unsigned ent, int nq, int r_init, float4 (*s_comp)[256]) {
+    const bool hinted = (size_t)nq < (1u << 24);
+    const int q = (int)(ent & (hinted ? 0x00ffffffu : 0x3fffffffu));
+    // radius to start from: the one the strip kernel tried (one more ring if it held too few candidates), else from the table
+    const int why = (int)(ent >> 30), rh = hinted ? (int)((ent >> 24) & 63u) : 0;
+    const int r_start = rh > 0 ? rh + (why == 0 ? 1 : 0) : 0;
+    fallback_one_query<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_comp);
+}
+
+// ------------------------------------------------------------------------------------------
+// The TAIL of the KNN forward, one launch (round 5; rounds 2-4: k_knn_strip_more, then k_knn_fallback): everything the main launch
+// of the strip kernel left over.
+//   workgroups [0, KS_RETRY_BLOCKS): the strip work (strip_more_body) -- overflowed strips in quarters, the far queries; what they
+//     cannot finish goes on the LATE list; when a workgroup is through, it counts itself done;
+//   workgroups [KS_RETRY_BLOCKS, + KS_FB_BLOCKS): one wavefront per query of the main launch's `fail` list -- at once, BESIDE the strip
+//     workgroups: both halves are chains of dependent round trips at low occupancy (a work item of the far pass ~25 us on one
+//     wavefront of four, a fallback query ~14 us), side by side they cost what the longer one costs -- then, once every strip
+//     workgroup is done (they were dispatched first and wait for nobody: no deadlock), the late list.
+// One launch instead of two for the lattice-like point sets of the benchmark, whose lists are (nearly) empty.
+// grid: KS_RETRY_BLOCKS + KS_FB_BLOCKS workgroups (the list lengths are only known on the device), 256 threads, dynamic LDS of the
+// far pass (the fallback workgroups use its first 16 KB)
+// ------------------------------------------------------------------------------------------
+template <int WS, bool L1, bool NEXT, bool IWD>
+__global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams p, const float *__restrict__ traj,
+                                                     const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
+                                                     const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
+                                                     float *__restrict__ flow_lut, float *__restrict__ flow_next,
+                                                     float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
+                                                     const KnnLists ls, int r_init, int cap, int gx, int gy, const EvCountArgs evc) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
+    __shared__ unsigned char s_rq[KS_NT / WS];
+    __shared__ int s_late;                  // this strip workgroup put queries on the late list
+    if ((int)blockIdx.x < KS_RETRY_BLOCKS) {
+        if (threadIdx.x == 0) s_late = 0;
+        __syncthreads();
+        strip_more_body<WS, L1, NEXT, IWD>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy,
+                                           (int)blockIdx.x, KS_RETRY_BLOCKS, s_dyn, s_wsum, s_wmax, s_rq, &s_late);
+        // (its late-list entries go out with one device-wide fence -- an L2 write-back on this chip: only a workgroup that pushed any
+        // pays for it; 1 024 unconditional fences were 40 us of a 60 us launch, one per push 67 us of a 30 % contraction's 490 --
+        // then its count; a workgroup without work does not count: 1 024 atomics on one word were 17 us of a B = 1 launch)
+        __syncthreads();
+        if (threadIdx.x == 0 && (int)blockIdx.x < strip_more_busy(p, ls, gx, gy, KS_RETRY_BLOCKS)) {
+            if (s_late) __threadfence();
+            atomicAdd(knn_tail_done(ls), 1);
+        }
+        return;
+    }
+    const int fb = (int)blockIdx.x - KS_RETRY_BLOCKS;
+    float4 (*s_comp)[256] = reinterpret_cast<float4 (*)[256]>(s_dyn);      // per wavefront: the candidates below the ring bound, compacted (fallback_one_query)
+    // mpc_focus_fwd: the strip kernel before this one counted the event rows per backward bucket; the first B fallback workgroups
+    // turn the counts of their sample into first records (the event kernels follow on the stream)
+    if (evc.events != nullptr && fb < evc.B) {
+        ev_prefix_block(evc, fb, s_wsum);
         __syncthreads();
     }
+    const int *fail = ls.fail;
     const int nq = p.B * p.nb * p.G;
+    const int wv = fb * 4 + (threadIdx.x >> 6), nw = KS_FB_BLOCKS * 4;
     const int nfail = min(fail[0], nq);
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-    for (int i = wv; i < nfail; i += nw) {
-        const unsigned ent = (unsigned)fail[MPC_IDX(1 + i, 1 + (long long)nq)];
-        const bool hinted = (size_t)nq < (1u << 24);
-        const int q = (int)(ent & (hinted ? 0x00ffffffu : 0x3fffffffu));
-        // radius to start from: the one the strip kernel tried (one more ring if it held too few candidates), else from the table
-        const int why = (int)(ent >> 30), rh = hinted ? (int)((ent >> 24) & 63u) : 0;
-        const int r_start = rh > 0 ? rh + (why == 0 ? 1 : 0) : 0;
-        if (p.l1) fallback_one_query<true>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_comp);
-        else fallback_one_query<false>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, q, r_init, r_start, s_comp);
-    }
+    for (int i = wv; i < nfail; i += nw)
+        fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
+                           (unsigned)fail[MPC_IDX(1 + i, 1 + (long long)nq)], nq, r_init, s_comp);
+    // the late list: complete once every strip workgroup has counted itself done
+    // (counter, list length and entries are read with device-scope atomic loads, which do not hit a stale line of this XCD's L2:
+    // no acquire fence -- an L2 invalidate per wavefront)
+    const int busy = strip_more_busy(p, ls, gx, gy, KS_RETRY_BLOCKS);
+    if (busy == 0) return;                                       // (no strip work at all: no late list either)
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(knn_tail_done(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < busy) __builtin_amdgcn_s_sleep(64);
+    __syncthreads();
+    const int nlate = min(__hip_atomic_load(knn_late_count(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq - nfail);
+    for (int i = wv; i < nlate; i += nw)
+        fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
+                           (unsigned)__hip_atomic_load(&fail[MPC_IDX(nq - i, 1 + (long long)nq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq, r_init, s_comp);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1292,14 +1315,16 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *
     int evc_stride = n_evc > 0 ? (int)(total / (n_evc >> 3) / 8 * 8) : 8;       // a group of 8 counting workgroups every `stride` workgroups
     if (evc_stride < 8) evc_stride = 8;
     const dim3 grid((unsigned)total);
-    // (the follow-up launch: nothing to do unless a strip overflowed its staging area / holds far queries -- workgroups that
-    // read two words)
+    // (the tail launch: nothing to do unless a strip overflowed its staging area / holds far queries / the main launch listed
+    // queries for the one-wavefront-per-query search -- workgroups that read two words)
+    size_t lds_tail = lds_far > lds ? lds_far : lds;       // (far pass; the quarters of an overflowed strip use the main launch's carve-up)
+    if (lds_tail < 4 * 256 * sizeof(float4)) lds_tail = 4 * 256 * sizeof(float4);
 #define KS_LAUNCH(L1_, NEXT_, IWD_)                                                                                       \
     do {                                                                                                                  \
         MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, sat, spos, sidx, \
                            flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy, ec, n_evc, evc_stride);   \
-        MPC_LAUNCH((k_knn_strip_more<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS), dim3(KS_NT), lds_far, st, p, traj, cell_start, sat, spos, sidx, \
-                           flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy);                          \
+        MPC_LAUNCH((k_knn_tail<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS + KS_FB_BLOCKS), dim3(KS_NT), lds_tail, st, p, traj, cell_start, sat, spos, sidx, \
+                           flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy, ec);                      \
     } while (0)
     switch ((p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0)) {
     case 0: KS_LAUNCH(false, false, false); break;
@@ -1312,9 +1337,6 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *
     default: KS_LAUNCH(true, true, true); break;
     }
 #undef KS_LAUNCH
-    MPC_CHECK_LAUNCH();
-    MPC_LAUNCH(k_knn_fallback, dim3(KS_FB_BLOCKS), dim3(256), 0, st, p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next,
-                       knn_state, tile_dkmax, ls, r_init, ec);
     MPC_CHECK_LAUNCH();
     return 0;
 }

@@ -16,10 +16,6 @@
 #include "bounds.h"
 
 #define VOX_FIX_SHIFT 30
-#ifndef VOX_STRIP_KB
-#define VOX_STRIP_KB 75       // LDS budget of a strip: two workgroups per CU, whose zero / accumulate / write phases overlap (150 KB, one per CU:
-                              // 0.283 ms against 0.265 at the DSEC batch shape; 50 KB: the binning pass pays for the extra buckets)
-#endif
 #define VOX_PER_THREAD 2
 
 struct VoxLayout {

@@ -42,6 +42,60 @@ print('rccl-ok')
 '''
 
 
+CHILD_PRODUCER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, '.')
+import bench
+from motionpriorcmax_amd import LossFactory, dp
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+torch.manual_seed(0)
+red = dp.GradAllReducer(device=dev, force_collective=True)
+fired = []
+sb = red.start_bucket
+red.start_bucket = lambda i: (fired.append(i), sb(i))
+prod = dp.OverlappedGradProducer(red, batch=1, hw=(48, 64))
+assert sum(p.numel() for p in prod.net.parameters()) == dp.UNET_GRAD_NUMEL == red.flat.numel() == 31044610
+# the gradient of one step without the exchange
+red.skip = True
+prod.step(); torch.cuda.synchronize()
+own = red.flat.clone()
+red.skip = False
+wl = dict(bench.WORKLOADS['C2'])
+ev, num_pos, traj, times = bench.synth_inputs(wl, seed=5)
+L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+t = traj.to(dev).requires_grad_(True)
+batch = {'events': ev.to(dev), 'num_pos_events': num_pos}
+ref = None
+for step in range(3):
+    loss, _, _ = L.calc(t, times.to(dev), batch)       # the next loss overlaps the buckets of the step before
+    loss.backward(); t.grad = None
+    prod.wait()
+    if step > 0:
+        assert torch.allclose(red.flat, own, rtol=1e-5, atol=1e-8), float((red.flat - own).abs().max())      # all-reduce over one rank / 1
+    fired.clear()
+    prod.step()
+    assert fired == [0, 1, 2, 3], fired
+    ref = loss.detach().clone() if ref is None else ref
+    assert torch.equal(loss.detach(), ref)               # the loss is untouched by what runs beside it
+prod.wait(); torch.cuda.synchronize()
+assert torch.allclose(red.flat, own, rtol=1e-5, atol=1e-8)
+dist.destroy_process_group()
+print('PRODUCER_OK')
+'''
+
+
+def test_gradient_producer_fills_and_exchanges_the_buckets_beside_the_loss():
+    """dp.OverlappedGradProducer on the device with an RCCL group of one rank: the stand-in network of 31 044 610 parameters writes its
+    gradients into the reducer's flat buffer (views), every bucket is all-reduced once per step in production order on the side
+    stream, and the loss steps that run beside it are bitwise what they are alone."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29657', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', CHILD_PRODUCER], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and 'PRODUCER_OK' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_rccl_group_of_one_runs_the_bench_collectives():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29653', HSA_ENABLE_IPC_MODE_LEGACY='0')
