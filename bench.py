@@ -790,8 +790,8 @@ def main():
             'ms_per_step': round(1e3 * r_comm['dt'] / r_comm['steps'], 4),
             'grad_allreduce_MB': round(dp.UNET_GRAD_NUMEL * 4 / 1e6, 2), 'allreduce_alone': r_comm.get('comm_alone'),
             'per_rank': r_comm.get('per_rank'),
-            'note': 'same steps + a stand-in network of the reference UNet\'s 31 044 610 parameters (dp.StandInNetwork: forward + backward on a '
-                    '2 x 15 x 120 x 160 input) whose gradients fill the flat buffer as views; every bucket of the 124 MB is all-reduced (RCCL, '
+            'note': 'same steps + a stand-in network of the reference UNet\'s 31 044 610 parameters (dp.StandInNetwork: dense layers, forward + backward on '
+                    '512 rows) whose gradients fill the flat buffer as views; every bucket of the 124 MB is all-reduced (RCCL, '
                     'side stream) the moment its last gradient is written, overlapping the rest of that backward and the next step\'s loss'}
         r_net = run_workload(args.workload, args.steps, args.warmup, False, instrument=False, net_only=True)
         out['dp_with_grad_allreduce']['same_steps_without_the_exchange_ms'] = round(1e3 * r_net['dt'] / r_net['steps'], 4)

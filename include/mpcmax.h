@@ -230,6 +230,8 @@ typedef struct mpc_focus_buffers {
     float *scal;              /* [MPC_SCAL_COUNT]                     out */
     float smooth_weight;
     const int32_t *event_offsets;  /* offsets table of mpc_event_bucket_order if `events` is ordered, else NULL   in  */
+    float *scal_out;          /* [3] loss, focus, smooth once more, or NULL: the copy a caller hands out while `scal` stays saved for
+                                 the backward (round 5: spares the host a copy kernel per step)                  out */
 } mpc_focus_buffers;
 int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream);
 int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, const float *grad_out,

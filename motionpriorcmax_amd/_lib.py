@@ -44,7 +44,7 @@ class FocusBuffers(ctypes.Structure):
     """include/mpcmax.h: struct mpc_focus_buffers."""
     _fields_ = [(k, ctypes.c_void_p) for k in
                 ('traj', 'events', 't_ref', 'flow_lut', 'flow_next', 'knn_state', 'smooth_grad', 'iwe_raw', 'iwe_blur',
-                 'grad_iwe', 'scal')] + [('smooth_weight', ctypes.c_float), ('event_offsets', ctypes.c_void_p)]
+                 'grad_iwe', 'scal')] + [('smooth_weight', ctypes.c_float), ('event_offsets', ctypes.c_void_p), ('scal_out', ctypes.c_void_p)]
 
 
 class VoxShape(ctypes.Structure):

@@ -323,7 +323,7 @@ extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, vo
         if ((rc = mpc_event_splat_fwd_ex(&sf, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, done, io->event_offsets))) return rc;
     }
     if ((rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream))) return rc;
-    return mpc_finalize(s, s_nimg, s_C, io->smooth_weight, io->scal, ws, stream);
+    return mpc_finalize_ex(s, s_nimg, s_C, io->smooth_weight, io->scal, io->scal_out, ws, stream);
 }
 
 extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, const float *grad_out,

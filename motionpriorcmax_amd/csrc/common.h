@@ -116,6 +116,8 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets);
 int mpc_validate_shape(const mpc_shape *s);
+int mpc_finalize_ex(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C, float smooth_weight, float *scal, float *scal_out,
+                    void *ws, void *stream);
 // KNN (knn.hip): margin of the bucket grid; is the points' counting sort the global-memory one; does the forward keep a far list
 int mpc_knn_margin(const mpc_shape *s);
 int mpc_knn_tiles(const mpc_shape *s);          // 16 x 16 cell tiles of the bucket grid per (sample, bin)

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ cp
                                                   int tiles_per_img, int nimg, int HW,
                                                   const double *__restrict__ spart, int n_sblocks,
                                                   double smooth_count, float smooth_weight,
-                                                  int variance, float *__restrict__ scal) {
+                                                  int variance, float *__restrict__ scal, float *__restrict__ scal_out) {
     __shared__ double s_red[2][16];
     __shared__ double s_var;
     const int tid = threadIdx.x;
@@ -364,6 +364,7 @@ __global__ __launch_bounds__(1024) void k_finalize(const double *__restrict__ cp
         scal[MPC_SCAL_VAL] = (float)val;
         scal[MPC_SCAL_GCOEF] = (float)gcoef;
         scal[5] = scal[6] = scal[7] = 0.f;
+        if (scal_out != nullptr) { scal_out[0] = (float)(focus + smooth); scal_out[1] = (float)focus; scal_out[2] = (float)smooth; }
     }
 }
 
@@ -534,6 +535,12 @@ extern "C" int mpc_lut_smooth(const mpc_shape *s, const float *field, int32_t ni
 
 extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C,
                             float smooth_weight, float *scal, void *ws, void *stream) {
+    return mpc_finalize_ex(s, smooth_nimg, smooth_C, smooth_weight, scal, nullptr, ws, stream);
+}
+
+// scal_out: loss, focus, smooth once more (mpc_focus_fwd: the copy the caller hands out), or null
+int mpc_finalize_ex(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C, float smooth_weight, float *scal, float *scal_out,
+                    void *ws, void *stream) {
     MPC_CHECK_ARG(s && scal && ws, MPC_E_NULL, "null argument");
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
@@ -550,7 +557,7 @@ extern "C" int mpc_finalize(const mpc_shape *s, int32_t smooth_nimg, int32_t smo
     MPC_LAUNCH(k_finalize, dim3(1), dim3(1024), 0, (hipStream_t)stream,
                        (const double *)((char *)ws + L.off_cpart), L.n_cblocks, tiles, L.nimg,
                        s->H * s->W, (const double *)((char *)ws + L.off_spart), (int)nsblk, count,
-                       smooth_weight, (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0, scal);
+                       smooth_weight, (s->flags & MPC_F_OBJ_VARIANCE) ? 1 : 0, scal, scal_out);
     MPC_CHECK_LAUNCH();
     return 0;
 }

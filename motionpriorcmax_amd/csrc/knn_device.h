@@ -77,9 +77,16 @@ struct KnnLists {
 // which grows downwards from the end of the `fail` array (main list and late list together never exceed the number of queries) --
 // and the strip workgroups that have finished.  All zeroed by the bucket kernels.
 #ifdef __HIPCC__
+// (one 128-byte line each: knn_late_count and knn_tail_done take device-scope atomics from every XCD all through the tail launch, and a
+// plain load of knn_marked_count in the same line waited behind them -- the far pass of a UNet-like field 187 us instead of 146)
 __device__ __forceinline__ int *knn_marked_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 512); }
-__device__ __forceinline__ int *knn_late_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 516); }
-__device__ __forceinline__ int *knn_tail_done(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 520); }
+__device__ __forceinline__ int *knn_late_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 640); }
+__device__ __forceinline__ int *knn_tail_done(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 768); }
+// the MARKED list: every query the main launch marks for the tail's strip workgroups is also listed (same place as the late list, the
+// end of the `fail` array downwards; its length is knn_marked_count), with the radius its search would start from.  With few marked
+// queries in the whole launch (KS_FORWARD_MAX) the tail's fallback workgroups take the marked list straight away, the strip
+// workgroups skip their far pass and the late list (what the retry quarters cannot finish) starts behind the marked entries;
+// otherwise the far pass runs and the late list overwrites the (then dead) marked entries.
 #endif
 // Blocks of queries of the second launch of the strip kernel: the main launch's strips, 2 columns x 128 rows.  The far queries of
 // a band along the top or bottom border are a few rows of EVERY strip, so wider, shorter blocks were tried: 4 x 64 halves the

@@ -78,7 +78,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                                            float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                            const KnnLists &ls, int r_init, int cap, int gx, int gy,
                                            int lblk, int pr0, int pr1, unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq,
-                                           bool forward = false, int *s_late = nullptr) {
+                                           int unused_ = 0) {
     // (Round 5 measured the far pass at WAVEFRONT level -- a wavefront per block of 2 x 24 queries with its own LDS slice, no
     // workgroup barrier, four independent searches per workgroup instead of one wavefront searching while three wait: slower,
     // UNet-like mixture 185 us against 160, 30 % contraction 725 against 492 -- six blocks per strip each stage their own +-20-row
@@ -96,11 +96,28 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
     static_assert(NR <= NT && NR <= KS_NR_MAX, "one thread per region row");
     // queries for the one-wavefront-per-query search: the main launch appends to the `fail` list (counter fail[0], entries upwards from
     // fail[1]); the strip workgroups of the tail kernel append to the LATE list (counter knn_late_count, entries downwards from the end
-    // of the same array), which the tail kernel's fallback workgroups take once all strip workgroups are done
+    // of the same array, behind the marked list where that one is alive), which the tail kernel's fallback workgroups take once all
+    // strip workgroups are done.  (Everything about the lists is worked out where a push happens -- a rare path --, not kept live
+    // across the search: the kernel has no scalar register to spare, and a spilled one costs a vector register.)
     int *const fail = ls.fail;
-    int *const fcount = MODE == 0 ? &fail[0] : knn_late_count(ls);
-    const long long fcap = (long long)p.B * p.nb * p.G;
-    auto fslot = [&](int k) -> long long { return MODE == 0 ? 1 + (long long)k : fcap - (long long)k; };
+    (void)unused_;
+    // main launch: the queries a workgroup marks for the tail's strip workgroups also go on the MARKED list (knn_device.h) with the
+    // radius that search would start from.  Workgroup-level: the ONE atomic with which the workgroup adds its marked queries to the
+    // launch's count (it did that before) also reserves their places -- a list append per wavefront (a second global counter) cost
+    // the main launch 4 us on white noise and 50-220 us on band-heavy inputs.  All threads call (n = the workgroup's marked queries).
+    auto mark_list = [&](bool on, size_t qid, int rad, int n) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const unsigned long long pm = __ballot(on);
+        __syncthreads();                                   // (s_wsum / s_wmax are free again)
+        if (lane == 0) s_wsum[wv] = __popcll(pm);
+        if (threadIdx.x == 0) s_wmax[0] = atomicAdd(knn_marked_count(ls), n);
+        __syncthreads();
+        int rank = s_wmax[0] + __popcll(pm & ((1ull << lane) - 1ull));
+        for (int w2 = 0; w2 < wv; ++w2) rank += s_wsum[w2];
+        const long long fcap = (long long)p.B * p.nb * p.G;
+        const unsigned hint = (fcap < (1ll << 24)) ? (unsigned)min(max(rad, 1), 63) << 24 : 0u;
+        if (on && rank < fcap) fail[MPC_IDX(fcap - (long long)rank, 1 + fcap)] = (int)((unsigned)qid | hint | (1u << 30));
+    };
     const int tid = threadIdx.x;
     if (MODE != 1) {
         // (main and second launch) the width of every region row, collected below with LDS atomics: starts at 0.  The table lives where
@@ -209,7 +226,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             }
             reinterpret_cast<int *>(knn_state)[MPC_IDX((size_t)bt * p.G + (size_t)cy * p.wq + cx, (long long)p.B * p.nb * p.G)] = hi;
             atomicOr(ls.grow + MPC_IDX(aoff, (long long)p.B * p.nb * ls.again_words), 1u << (cx & 31)); s_rq[0] = 1;
+            r = hi;                                      // (the far pass starts there; so does the marked-list entry below)
         }
+
     }
     if (FARK) {
         served = false;
@@ -281,23 +300,6 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         }
     }
     if (FARK) {
-        if (forward) {
-            // (workgroup-uniform) the whole launch has only a few marked queries: a work item here is a chain of ~25 us whatever
-            // its size, a round of the fallback kernel ~14 us for up to 4 096 queries -- they go onto its list, with the radius
-            // worked out so far as the hint (why = 1: start exactly there)
-            const unsigned long long pm = __ballot(mine);
-            if (pm != 0ull) {
-                const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
-                int base = 0;
-                if (lane == first) base = atomicAdd(fcount, __popcll(pm));
-                base = __shfl(base, first, 64);
-                const size_t qid = (size_t)bt * p.G + (size_t)cy * p.wq + cx;
-                const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24)) ? (unsigned)min(max(r, 1), 63) << 24 : 0u;
-                if (mine) fail[MPC_IDX(fslot(base + __popcll(pm & ((1ull << lane) - 1ull))), 1 + fcap)] = (int)((unsigned)qid | hint | (1u << 30));
-                if (lane == first) *s_late = 1;          // (late list: this workgroup's entries go out with ONE fence before it counts itself done, k_knn_tail)
-            }
-            return;
-        }
         // every query pushes the chords of its disc onto the region rows it uses (as the main launch does per query row)
         if (mine && served) {
             int2 *s_w = reinterpret_cast<int2 *>(s_dyn);
@@ -362,8 +364,9 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             const int nfq = anyfar ? __syncthreads_count(isfar ? 1 : 0) : 0;
             if (tid == 0) {
                 ls.retry[MPC_IDX(1 + atomicAdd(&ls.retry[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk;
-                if (anyfar) { ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk; atomicAdd(knn_marked_count(ls), nfq); }
+                if (anyfar) ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk;
             }
+            if (anyfar) mark_list(isfar, (size_t)bt * p.G + (size_t)cy * p.wq + cx, r, nfq);      // (workgroup-uniform)
             return;
         }
         overflow = true;              // even a quarter of the strip (or the far queries' region) does not fit: to the fallback list
@@ -755,21 +758,29 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 atomicOr(ls.again + MPC_IDX(aoff, (long long)p.B * p.nb * ls.again_words), 1u << (cx & 31));
                 if (why == 0u) atomicOr(ls.grow + MPC_IDX(aoff, (long long)p.B * p.nb * ls.again_words), 1u << (cx & 31));
             }
+
             // (and the number of queries marked for it: with only a handful in the whole launch it hands them on to the fallback kernel)
             const int nfq = (MODE == 0 && anyfar) ? __syncthreads_count(isfar ? 1 : 0) : 0;
-            if (to_more && tid == 0) { ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk; atomicAdd(knn_marked_count(ls), nlate + nfq); }
+            if (to_more && tid == 0) ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk;
+            // (the far pass gives a query that held too few candidates two more rings, one with too many slots the same radius, a far
+            // query the radius the bisection above found)
+            if (to_more) mark_list((late && to_more) || (MODE == 0 && isfar), q, isfar ? r : (why == 0u ? min(r + 2, KNN_RFAR) : r), nlate + nfq);      // (workgroup-uniform)
             const bool push = inpass && !live && !(late && to_more);
             const unsigned long long pm = __ballot(push);
             if (pm != 0ull) {
                 const int lane = tid & 63, first = __ffsll((long long)pm) - 1;
                 int base = 0;
-                if (lane == first) base = atomicAdd(fcount, __popcll(pm));
+                const long long fcap = (long long)p.B * p.nb * p.G;
+                // (late list: behind the marked list where the fallback workgroups take that one -- few marked queries in the launch)
+                const int late_base = (MODE != 0 && *knn_marked_count(ls) <= KS_FORWARD_MAX) ? (int)min((long long)*knn_marked_count(ls), fcap) : 0;
+                if (lane == first) base = atomicAdd(MODE == 0 ? &fail[0] : knn_late_count(ls), __popcll(pm));
                 base = __shfl(base, first, 64);
                 // (entry: the query, why in bits 30..31 and -- where the query ids leave room: fewer than 2^24 queries -- the radius
                 // that was tried in bits 24..29, so that the fallback kernel need not read it off the summed-area table again)
                 const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24) && served) ? (unsigned)min(r, 63) << 24 : 0u;
-                if (push) fail[MPC_IDX(fslot(base + __popcll(pm & ((1ull << lane) - 1ull))), 1 + fcap)] = (int)((unsigned)q | hint | (why << 30));
-                if (MODE != 0 && lane == first) *s_late = 1;      // (late list: see k_knn_tail)
+                const int k = base + __popcll(pm & ((1ull << lane) - 1ull));
+                if (push) fail[MPC_IDX(MODE == 0 ? 1 + (long long)k : fcap - (long long)(late_base + k), 1 + fcap)] = (int)((unsigned)q | hint | (why << 30));
+                if (MODE != 0 && lane == first) s_wsum[KS_NT / 64] = 1;      // (late list: this workgroup pushed; one fence before it counts itself done, k_knn_tail)
             }
         }
         // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnPara
                                                      const KnnLists ls, int r_init, int cap, int gx, int gy,
                                                      const EvCountArgs evc, int n_evc, int evc_stride) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
+    __shared__ int s_wsum[KS_NT / 64 + 1], s_wmax[KS_NT / 64];      // (s_wsum[KS_NT / 64]: "pushed onto the late list", tail kernel only)
     __shared__ unsigned char s_rq[KS_NT / WS];          // radius of the widest square of every query row of the strip (0: none)
     // mpc_focus_fwd: some workgroups do not search -- they count the event rows per backward bucket for the event kernels
     // that follow (ev_count_device.h).  This kernel is bound by vector-instruction issue and leaves HBM idle, so the 67 MB of
@@ -859,10 +870,12 @@ __global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnPara
 
 // strip workgroups of the tail kernel that have anything to do (the others neither work nor count themselves done): workgroup wg
 // takes the retry items wg, wg + nwg, ... and the far items likewise
+// few marked queries in the whole launch: no far pass, the fallback workgroups take the marked list
+__device__ __forceinline__ bool strip_forward(const KnnLists &ls) { return *knn_marked_count(ls) <= KS_FORWARD_MAX; }
 __device__ __forceinline__ int strip_more_busy(const KnnParams &p, const KnnLists &ls, int gx, int gy, int nwg) {
     const int nstrips = gx * gy * p.B * p.nb;
     const int gxf = knn_far_items_x(p.wq), gyf = knn_far_items_y(p.hq);
-    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
+    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = strip_forward(ls) ? 0 : min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
     return min(nwg, max(nretry, nfar));
 }
 
@@ -877,23 +890,24 @@ __device__ __forceinline__ void strip_more_body(const KnnParams &p, const float 
                                                 float *__restrict__ flow_lut, float *__restrict__ flow_next,
                                                 float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                 const KnnLists &ls, int r_init, int cap, int gx, int gy, int wg, int nwg,
-                                                unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq, int *s_late) {
+                                                unsigned char *s_dyn, int *s_wsum, int *s_wmax, unsigned char *s_rq) {
     constexpr int TH = KS_NT / WS;
     const int nstrips = gx * gy * p.B * p.nb;
     const int gxf = knn_far_items_x(p.wq), gyf = knn_far_items_y(p.hq);
-    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
+    // (only a few marked queries in the whole launch -- a B = 1 step with a dozen of them in three strips paid a full work item's
+    // 25 us for them: the fallback workgroups take them from the MARKED list beside what they have anyway, no far pass.  As a zero
+    // trip count read before both loops: an early return between the loops cost the far pass 25 % -- 14 spilled registers instead
+    // of 8, reloaded inside its search)
+    const int nretry = 4 * min(ls.retry[0], nstrips), nfar = strip_forward(ls) ? 0 : min(ls.farstrip[0], gxf * gyf * p.B * p.nb);
     for (int w = wg; w < nretry; w += nwg) {
         const int quarter = w & 3;
         strip_body<WS, L1, NEXT, IWD, 1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                                         r_init, cap, gx, gy, ls.retry[1 + (w >> 2)], quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq, false, s_late);
+                                         r_init, cap, gx, gy, ls.retry[1 + (w >> 2)], quarter * (TH / 4), (quarter + 1) * (TH / 4), s_dyn, s_wsum, s_wmax, s_rq);
         __syncthreads();
     }
-    // (only a few marked queries in the whole launch -- a B = 1 step with a dozen of them in three strips paid a full work item's
-    // 25 us for them: they are handed on to the fallback workgroups, whose round takes them beside what they have anyway)
-    const bool forward = *knn_marked_count(ls) <= KS_FORWARD_MAX;
     for (int w = wg; w < nfar; w += nwg) {
         strip_body<KNN_FAR_WS, L1, NEXT, IWD, 2>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq, forward, s_late);
+                                                 r_init, cap, gxf, gyf, ls.farstrip[1 + w], 0, KNN_FAR_TH, s_dyn, s_wsum, s_wmax, s_rq);
         __syncthreads();
     }
 }
@@ -1211,20 +1225,19 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                      const KnnLists ls, int r_init, int cap, int gx, int gy, const EvCountArgs evc) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_wsum[KS_NT / 64], s_wmax[KS_NT / 64];
+    __shared__ int s_wsum[KS_NT / 64 + 1], s_wmax[KS_NT / 64];      // (s_wsum[KS_NT / 64]: this strip workgroup put queries on the late list)
     __shared__ unsigned char s_rq[KS_NT / WS];
-    __shared__ int s_late;                  // this strip workgroup put queries on the late list
     if ((int)blockIdx.x < KS_RETRY_BLOCKS) {
-        if (threadIdx.x == 0) s_late = 0;
+        if (threadIdx.x == 0) s_wsum[KS_NT / 64] = 0;
         __syncthreads();
         strip_more_body<WS, L1, NEXT, IWD>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy,
-                                           (int)blockIdx.x, KS_RETRY_BLOCKS, s_dyn, s_wsum, s_wmax, s_rq, &s_late);
+                                           (int)blockIdx.x, KS_RETRY_BLOCKS, s_dyn, s_wsum, s_wmax, s_rq);
         // (its late-list entries go out with one device-wide fence -- an L2 write-back on this chip: only a workgroup that pushed any
         // pays for it; 1 024 unconditional fences were 40 us of a 60 us launch, one per push 67 us of a 30 % contraction's 490 --
         // then its count; a workgroup without work does not count: 1 024 atomics on one word were 17 us of a B = 1 launch)
         __syncthreads();
         if (threadIdx.x == 0 && (int)blockIdx.x < strip_more_busy(p, ls, gx, gy, KS_RETRY_BLOCKS)) {
-            if (s_late) __threadfence();
+            if (s_wsum[KS_NT / 64]) __threadfence();
             atomicAdd(knn_tail_done(ls), 1);
         }
         return;
@@ -1241,9 +1254,12 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
     const int nq = p.B * p.nb * p.G;
     const int wv = fb * 4 + (threadIdx.x >> 6), nw = KS_FB_BLOCKS * 4;
     const int nfail = min(fail[0], nq);
-    for (int i = wv; i < nfail; i += nw)
+    // ... and the marked list, where the strip workgroups leave it to us (written by the main launch: complete): one round-robin over
+    // both, so that with two short lists no wavefront takes an entry of each, one behind the other
+    const int nmark = strip_forward(ls) ? min(*knn_marked_count(ls), nq - nfail) : 0;
+    for (int i = wv; i < nfail + nmark; i += nw)
         fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                           (unsigned)fail[MPC_IDX(1 + i, 1 + (long long)nq)], nq, r_init, s_comp);
+                           (unsigned)fail[MPC_IDX(i < nfail ? 1 + i : nq - (i - nfail), 1 + (long long)nq)], nq, r_init, s_comp);
     // the late list: complete once every strip workgroup has counted itself done
     // (counter, list length and entries are read with device-scope atomic loads, which do not hit a stale line of this XCD's L2:
     // no acquire fence -- an L2 invalidate per wavefront)
@@ -1252,10 +1268,10 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
     if (threadIdx.x == 0)
         while (__hip_atomic_load(knn_tail_done(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < busy) __builtin_amdgcn_s_sleep(64);
     __syncthreads();
-    const int nlate = min(__hip_atomic_load(knn_late_count(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq - nfail);
+    const int nlate = min(__hip_atomic_load(knn_late_count(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq - nfail - nmark);
     for (int i = wv; i < nlate; i += nw)
         fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                           (unsigned)__hip_atomic_load(&fail[MPC_IDX(nq - i, 1 + (long long)nq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq, r_init, s_comp);
+                           (unsigned)__hip_atomic_load(&fail[MPC_IDX(nq - nmark - i, 1 + (long long)nq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq, r_init, s_comp);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -106,28 +106,29 @@ class GradAllReducer:
 
 
 class StandInNetwork(torch.nn.Module):
-    """A gradient PRODUCER of the reference network's size for the data-parallel leg of the benchmark: a plain stack of 3x3
-    convolutions (strided, ReLU) with exactly UNET_GRAD_NUMEL = 31 044 610 fp32 parameters -- the parameter count of the
-    reference's UNet(15 -> 2) (src/models/unet/unet_model.py:6, src/modules/trajectory_net.py:27-28) -- so that its backward
-    writes 124 MB of gradients through MIOpen / rocBLAS kernels that compete with the loss kernels for CUs and HBM while the
-    buckets of the all-reduce fly.  NOT the reference's architecture (the UNet itself is out of scope): a
-    stand-in of the same parameter and gradient volume on a small input, so that the benchmark step stays short."""
-    CHANNELS = (15, 64, 128, 256, 512, 1024, 1024, 1024, 512, 254)
+    """A gradient PRODUCER of the reference network's size for the data-parallel leg of the benchmark: a plain stack of dense layers
+    (ReLU between them) with exactly UNET_GRAD_NUMEL = 31 044 610 fp32 parameters -- the parameter count of the reference's
+    UNet(15 -> 2) (src/models/unet/unet_model.py:6, src/modules/trajectory_net.py:27-28) -- so that its backward writes 124 MB of
+    gradients through rocBLAS / hipBLASLt kernels that compete with the loss kernels for CUs and HBM while the buckets of the
+    all-reduce fly.  NOT the reference's architecture (the UNet itself is out of scope; dense layers instead of
+    convolutions so that a fresh box pays no MIOpen kernel search inside the benchmark): a stand-in of the same parameter and
+    gradient volume on a small input, so that the benchmark step stays short."""
+    WIDTHS = (1024, 4096, 4096, 2400, 96, 2)
 
     def __init__(self):
         super().__init__()
         layers = []
-        for i, (a, b) in enumerate(zip(self.CHANNELS[:-1], self.CHANNELS[1:])):
-            layers.append(torch.nn.Conv2d(a, b, 3, stride=2 if i in (1, 3) else 1, padding=1))
-            layers.append(torch.nn.ReLU(inplace=True))
+        for i, (a, b) in enumerate(zip(self.WIDTHS[:-1], self.WIDTHS[1:])):
+            layers.append(torch.nn.Linear(a, b))
+            if i < len(self.WIDTHS) - 2:
+                layers.append(torch.nn.ReLU(inplace=True))
         self.body = torch.nn.Sequential(*layers)
-        self.head = torch.nn.Conv2d(self.CHANNELS[-1], 2, 1)
         have = sum(p.numel() for p in self.parameters())
-        self.pad = torch.nn.Parameter(torch.zeros(UNET_GRAD_NUMEL - have))         # (390 values: the count is the UNet's exactly)
+        self.pad = torch.nn.Parameter(torch.zeros(UNET_GRAD_NUMEL - have))         # (1 408 values: the count is the UNet's exactly)
         assert sum(p.numel() for p in self.parameters()) == UNET_GRAD_NUMEL
 
     def forward(self, x):
-        return self.head(self.body(x)).mean() + self.pad.sum() * 0.0 + (self.pad * self.pad).sum()
+        return self.body(x).mean() + (self.pad * self.pad).sum()
 
 
 class OverlappedGradProducer:
@@ -138,12 +139,12 @@ class OverlappedGradProducer:
     buckets are exchanged while the rest of the backward, and then the next step's loss, still run.  `wait()` before the
     optimizer point.  Reference: Lightning DDP behind scripts/flow_training.py:125-130 (bucketed all-reduce during backward)."""
 
-    def __init__(self, reducer: GradAllReducer, batch: int = 2, hw=(120, 160), seed: int = 0):
+    def __init__(self, reducer: GradAllReducer, rows: int = 512, seed: int = 0):
         self.r = reducer
         dev = reducer.device
         g = torch.Generator().manual_seed(seed)
         self.net = StandInNetwork().to(dev)
-        self.x = torch.randn(batch, StandInNetwork.CHANNELS[0], *hw, generator=g).to(dev)
+        self.x = torch.randn(rows, StandInNetwork.WIDTHS[0], generator=g).to(dev)
         # parameters in the order their gradients are produced (last layer first), laid out back to back in the flat buffer
         params = list(self.net.parameters())[::-1]
         off = 0

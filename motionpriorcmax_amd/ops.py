@@ -327,13 +327,13 @@ class _Plan:
         self.n_gnext = n_gf if (cfg.smooth_on_next and n_gf) else 0
         self.smooth_weight = float(cfg.smooth_weight)
 
-    def io(self, base, traj, ev, tr, blur, offs):
+    def io(self, base, traj, ev, tr, blur, offs, scal_out=None):
         def at(name):
             off, cnt = self.o[name]
             return base + 4 * off if cnt else None
         return C.FocusBuffers(traj=traj, events=ev, t_ref=tr, flow_lut=at('lut'), flow_next=at('nxt'), knn_state=at('state'),
                               smooth_grad=at('gf'), iwe_raw=at('raw'), iwe_blur=blur, grad_iwe=at('gimg'), scal=at('scal'),
-                              smooth_weight=self.smooth_weight, event_offsets=offs)
+                              smooth_weight=self.smooth_weight, event_offsets=offs, scal_out=scal_out)
 
     def view(self, buf, name):
         off, cnt = self.o[name]
@@ -355,8 +355,8 @@ def _plan(cfg, B, M, Mp, n, need_grad, has_offs, dev):
     return p
 
 
-def _focus_fwd_call(p, dev, traj, ev, tr, buf, blur, ws, offs):
-    io = p.io(buf.data_ptr(), traj.data_ptr(), ev.data_ptr(), tr.data_ptr(), blur.data_ptr(), _vp(offs))
+def _focus_fwd_call(p, dev, traj, ev, tr, buf, blur, ws, offs, out3=None):
+    io = p.io(buf.data_ptr(), traj.data_ptr(), ev.data_ptr(), tr.data_ptr(), blur.data_ptr(), _vp(offs), _vp(out3))
     with _stage('mpc_focus_fwd', dev):
         C.check(C.lib().mpc_focus_fwd(p.shape_ref, ctypes.byref(io), ctypes.c_void_p(ws.data_ptr()), _stream(dev)), 'mpc_focus_fwd')
 
@@ -475,11 +475,12 @@ class FocusCalcFn(torch.autograd.Function):
             ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
             buf = torch.empty(p.buf_floats, dtype=torch.float32, device=dev)
             blur = torch.empty(p.img_shape, dtype=torch.float32, device=dev)
-            _focus_fwd_call(p, dev, traj, ev, tr, buf, blur, ws, offs)
+            # (the outputs must not alias the saved scalars: the library writes loss / focus / smooth a second time into `out` --
+            # io.scal_out -- instead of the host cloning them with a kernel of its own)
+            out = torch.empty(3, dtype=torch.float32, device=dev)
+            _focus_fwd_call(p, dev, traj, ev, tr, buf, blur, ws, offs, out)
             ctx.plan, ctx.ws, ctx.offs = p, ws, offs
             ctx.save_for_backward(traj, ev, tr, buf)
-            o = p.o['scal'][0]
-            out = buf[o:o + 3].clone()            # one tiny copy: the outputs must not alias the saved scalars
             loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
             ctx.mark_non_differentiable(focus, smooth, blur)
             return loss, focus, smooth, blur

@@ -88,7 +88,7 @@ def _producer_worker(rank, world, port, out):
         fired = []
         start_bucket = red.start_bucket
         red.start_bucket = lambda i: (fired.append(i), start_bucket(i))
-        prod = dp.OverlappedGradProducer(red, batch=1, hw=(8, 8), seed=100 + rank)
+        prod = dp.OverlappedGradProducer(red, rows=16, seed=100 + rank)
         assert sum(p.numel() for p in prod.net.parameters()) == dp.UNET_GRAD_NUMEL == red.flat.numel()
         # this rank's own gradient, without the exchange
         prod.net.zero_grad(set_to_none=False)

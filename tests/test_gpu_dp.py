@@ -55,7 +55,7 @@ red = dp.GradAllReducer(device=dev, force_collective=True)
 fired = []
 sb = red.start_bucket
 red.start_bucket = lambda i: (fired.append(i), sb(i))
-prod = dp.OverlappedGradProducer(red, batch=1, hw=(48, 64))
+prod = dp.OverlappedGradProducer(red, rows=256)
 assert sum(p.numel() for p in prod.net.parameters()) == dp.UNET_GRAD_NUMEL == red.flat.numel() == 31044610
 # the gradient of one step without the exchange
 red.skip = True

@@ -19,6 +19,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from motionpriorcmax_amd import LossFactory, ops, utils, _lib as C  # noqa: E402
 from motionpriorcmax_amd.utils import synth  # noqa: E402
+if os.environ.get('MPC_AB_LIB'):          # A/B timing of two builds on the same box
+    C.LIB_PATH = os.path.abspath(os.environ['MPC_AB_LIB'])
 
 
 def trajectories(wl, family, seed, B):
