@@ -43,7 +43,9 @@
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
 #define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
-#define KS_RETRY_BLOCKS (256 * KS_MORE_OCC)   // workgroups of the second launch
+#ifndef KS_RETRY_BLOCKS
+#define KS_RETRY_BLOCKS (256 * KS_MORE_OCC)   // strip workgroups of the tail launch
+#endif
 static_assert(KNN_FAR_WS * KNN_FAR_TH == KS_NT, "a block of queries of the second launch = one workgroup");
 static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
