@@ -399,6 +399,12 @@ def main():
                          f'(it launches its own ranks) or under torch.distributed.run with --nproc-per-node N')
     if os.environ.get('MPC_BENCH_DRYRUN') == '1':
         return dry_run(args, rank, world)
+    # ONE line on stdout, whatever the libraries print: file descriptor 1 points at stderr for the whole run (RCCL's version banner
+    # -- C stdio, flushed when the process exits, i.e. BEHIND anything printed here -- landed behind the JSON line of a round-5 run),
+    # and the line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the CMax path has no CPU fallback')
     # MPC_BENCH_BACKEND=gloo: debugging aid for boxes with fewer GPUs than ranks -- the ranks share cuda:0 and the
@@ -1080,7 +1086,8 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(wl)
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -302,8 +302,12 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
 // every (column, group) item adds up its own rows behind the groups above it.  All threads of the workgroup call.
 // ------------------------------------------------------------------------------------------
 template <class F>
-__device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, knn_cs_t *__restrict__ S, int *s_part) {
+__device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, knn_cs_t *__restrict__ S, int *s_part, int x0 = 0, int ncol = -1) {
+    // (columns [x0, x0 + ncol) of the table: the columns are independent of each other -- k_knn_sat splits them over workgroups)
     const int W1 = p.wb + 1, ngrp = (p.hb + 7) >> 3, nthr = blockDim.x;
+    if (ncol < 0) ncol = W1;
+    ncol = min(ncol, W1 - x0);
+    const int nitem = ngrp * max(ncol, 0);
     // every (column, group of 8 rows) item keeps its 8 row prefixes in registers between the two phases; all 16 loads of an
     // item are in flight together (from global memory a dependent chain of them was the whole 18 us of the kernel at B = 1)
     constexpr int ITEMS = 4;                           // items per thread held in registers (more: a second round re-reads)
@@ -311,20 +315,20 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, kn
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
         const int it = threadIdx.x + u * nthr;
-        const int g = it / W1, x = it - g * W1;
+        const int g = it / ncol, x = x0 + (it - g * ncol);
         int sum = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int y = g * 8 + k;
-            const bool on = it < ngrp * W1 && y < p.hb;
+            const bool on = it < nitem && y < p.hb;
             const int a = on ? rowstart(y, x) : 0, z = on ? rowstart(y, 0) : 0;
             pre[u][k] = a - z;
             sum += pre[u][k];
         }
-        if (it < ngrp * W1) s_part[MPC_IDX(it, ngrp * W1)] = sum;
+        if (it < nitem) s_part[MPC_IDX(it, nitem)] = sum;
     }
-    for (int it = threadIdx.x + ITEMS * nthr; it < ngrp * W1; it += nthr) {        // (grids beyond ITEMS x threads items)
-        const int g = it / W1, x = it - g * W1;
+    for (int it = threadIdx.x + ITEMS * nthr; it < nitem; it += nthr) {        // (grids beyond ITEMS x threads items)
+        const int g = it / ncol, x = x0 + (it - g * ncol);
         int sum = 0;
         for (int y = g * 8; y < min(g * 8 + 8, p.hb); ++y) sum += rowstart(y, x) - rowstart(y, 0);
         s_part[it] = sum;
@@ -333,10 +337,10 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, kn
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
         const int it = threadIdx.x + u * nthr;
-        if (it >= ngrp * W1) continue;
-        const int g = it / W1, x = it - g * W1;
+        if (it >= nitem) continue;
+        const int g = it / ncol, xl = it - g * ncol, x = x0 + xl;
         int acc = 0;
-        for (int gg = 0; gg < g; ++gg) acc += s_part[gg * W1 + x];
+        for (int gg = 0; gg < g; ++gg) acc += s_part[gg * ncol + xl];
         if (g == 0) S[x] = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -344,10 +348,10 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, kn
             if (y < p.hb) { acc += pre[u][k]; S[MPC_IDX((size_t)(y + 1) * W1 + x, (p.hb + 1) * W1)] = acc; }
         }
     }
-    for (int it = threadIdx.x + ITEMS * nthr; it < ngrp * W1; it += nthr) {
-        const int g = it / W1, x = it - g * W1;
+    for (int it = threadIdx.x + ITEMS * nthr; it < nitem; it += nthr) {
+        const int g = it / ncol, xl = it - g * ncol, x = x0 + xl;
         int acc = 0;
-        for (int gg = 0; gg < g; ++gg) acc += s_part[gg * W1 + x];
+        for (int gg = 0; gg < g; ++gg) acc += s_part[gg * ncol + xl];
         for (int y = g * 8; y < min(g * 8 + 8, p.hb); ++y) {
             acc += rowstart(y, x) - rowstart(y, 0);
             S[(size_t)(y + 1) * W1 + x] = acc;
@@ -355,12 +359,16 @@ __device__ __forceinline__ void knn_sat_build(const KnnParams &p, F rowstart, kn
     }
 }
 // from cell_start in global memory (the bucket sorts that do not hold a whole (sample, bin) in one workgroup's LDS)
-// grid B * nb, 1024 threads, dynamic LDS ceil(hb / 8) * (wb + 1) ints
-__global__ __launch_bounds__(1024) void k_knn_sat(const KnnParams p, const knn_cs_t *__restrict__ cell_start, knn_cs_t *__restrict__ sat) {
+// grid (B * nb, column chunks), 256 threads, one item per thread: KNN_SAT_COLS(hb) columns per workgroup (the launch only runs
+// at small batches, where B * nb workgroups of 1 024 threads with three items each left the chip idle behind 15 chains of loads:
+// 14.5 us at B = 1)
+#define KNN_SAT_NT 256
+__host__ __device__ static inline int knn_sat_cols(int hb) { const int c = KNN_SAT_NT / ((hb + 7) >> 3); return c < 1 ? 1 : c; }
+__global__ __launch_bounds__(KNN_SAT_NT) void k_knn_sat(const KnnParams p, const knn_cs_t *__restrict__ cell_start, knn_cs_t *__restrict__ sat) {
     extern __shared__ int s_part[];
-    const int bt = blockIdx.x;
+    const int bt = blockIdx.x, ncol = knn_sat_cols(p.hb);
     const knn_cs_t *cs = cell_start + (size_t)bt * (p.Gb + 1);
-    knn_sat_build(p, [&](int y, int x) { return cs[y * p.wb + x]; }, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), s_part);
+    knn_sat_build(p, [&](int y, int x) { return cs[y * p.wb + x]; }, sat + (size_t)bt * (p.hb + 1) * (p.wb + 1), s_part, (int)blockIdx.y * ncol, ncol);
 }
 
 
@@ -1580,7 +1588,8 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
     // fast path (num_tref == 1, the shipped configurations): strip kernel + fallback (knn_strip.hip)
     if (strip) {
         if (sat_launch) {
-            MPC_LAUNCH(k_knn_sat, dim3(s->B * s->nb), dim3(1024), (size_t)((p.hb + 7) / 8) * (p.wb + 1) * sizeof(int), st, p, cell_start, sat);
+            const int scol = knn_sat_cols(p.hb);
+            MPC_LAUNCH(k_knn_sat, dim3(s->B * s->nb, (p.wb + 1 + scol - 1) / scol), dim3(KNN_SAT_NT), (size_t)((p.hb + 7) / 8) * scol * sizeof(int), st, p, cell_start, sat);
             MPC_CHECK_LAUNCH();
         }
         rc = mpc_knn_strip_launch(s, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, &ls, r_init,
