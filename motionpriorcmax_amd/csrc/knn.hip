@@ -1725,8 +1725,12 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         if (mpc_knn_uses_far_list(s)) {
             // the queries the forward's fallback kernel served (left out of the gather above)
             const KnnLists ls = knn_lists(s, L, ws);
+            // (no more workgroups than the list can hold items: at B = 1 a quarter of KNN_FAR_BLOCKS, and the launch usually finds
+            // a few items or none)
+            const long long far_items_max = (long long)s->B * s->nb * knn_tiles_x(p.wq, p.m) * knn_tiles_y(p.hq, p.m);
+            const unsigned far_blocks = (unsigned)(far_items_max < KNN_FAR_BLOCKS ? (far_items_max < 1 ? 1 : far_items_max) : KNN_FAR_BLOCKS);
 #define KF_LAUNCH(L1_, NEXT_)                                                                                            \
-            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), dim3(KNN_FAR_BLOCKS), dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
+            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), dim3(far_blocks), dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
                                knn_state, ls, tmp_g, tmp_a, direct)
             if (p.l1) { if (grad_flow_next) KF_LAUNCH(true, true); else KF_LAUNCH(true, false); }
             else { if (grad_flow_next) KF_LAUNCH(false, true); else KF_LAUNCH(false, false); }
