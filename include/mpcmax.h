@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 105
+#define MPC_VERSION 106
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -124,6 +124,11 @@ int64_t mpc_knn_fail_list_offset(const mpc_shape *s);
  * quarters, [1] strips with far queries or queries to search again, [2] / [3] the maps of such queries (bit per query; those
  * that need more rings), [4] far lists per (sample, bin), [5] tiles for the far queries' backward; -1: no such list. */
 int mpc_knn_list_offsets(const mpc_shape *s, int64_t *out);
+/* Diagnostics: byte offset of the counters of the KNN forward's tail launch inside the workspace (int32 each, read them after
+ * mpc_knn_lut_fwd): +0 queries the main launch marked for the tail's strip workgroups (at most 1 024: the tail took them from the
+ * marked list with its one-wavefront search and ran no far pass), +128 entries of the late list, +256 strip workgroups that counted
+ * themselves done.  Tests assert which path a launch took. */
+int64_t mpc_knn_tail_counters_offset(const mpc_shape *s);
 
 /* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants,
  * focus.py:157-163).  grad_flow_next may be NULL.  grad_traj [B][T+nb][n][2] is overwritten. */

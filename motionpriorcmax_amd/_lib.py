@@ -28,7 +28,7 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_lut_bwd', 'mpc_event_splat_fwd', 'mpc_contrast_fwd', 'mpc_lut_smooth',
            'mpc_finalize', 'mpc_event_splat_bwd', 'mpc_scale', 'mpc_voxel_workspace_bytes', 'mpc_voxel_grid', 'mpc_ingest_workspace_bytes', 'mpc_ingest_count',
            'mpc_ingest_scatter', 'mpc_dense_flow', 'mpc_flow_error_workspace_bytes', 'mpc_flow_error',
-           'mpc_knn_fail_list_offset', 'mpc_knn_list_offsets', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
+           'mpc_knn_fail_list_offset', 'mpc_knn_list_offsets', 'mpc_knn_tail_counters_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
            'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
            'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add', 'mpc_event_pos_grad', 'mpc_pe_warp', 'mpc_pe_grad', 'mpc_pe_grad_ordered', 'mpc_pe_grad_ordered_supported', 'mpc_bounds_check']
@@ -84,6 +84,7 @@ def lib():
     L.mpc_workspace_bytes.restype = i64
     L.mpc_workspace_bytes.argtypes = [sp]
     L.mpc_knn_fail_list_offset.argtypes = [sp]
+    L.mpc_knn_tail_counters_offset.argtypes = [sp]
     L.mpc_knn_list_offsets.argtypes = [sp, ctypes.POINTER(ctypes.c_int64)]
     L.mpc_knn_state_floats.argtypes = [sp]
     L.mpc_knn_lut_fwd.argtypes = [sp, vp, vp, vp, vp, vp, vp, vp]
@@ -110,6 +111,7 @@ def lib():
         getattr(L, name).restype = ctypes.c_int
     L.mpc_voxel_workspace_bytes.restype = i64
     L.mpc_knn_fail_list_offset.restype = i64
+    L.mpc_knn_tail_counters_offset.restype = i64
     L.mpc_knn_state_floats.restype = i64
     L.mpc_event_lut_strips.argtypes = [sp]
     L.mpc_event_order_workspace_bytes.argtypes = [sp]
@@ -135,8 +137,8 @@ def lib():
     L.mpc_profile_start.argtypes = []
     L.mpc_bounds_check.argtypes = []
     L.mpc_profile_stop.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(f32), i32]
-    if L.mpc_version() != 105:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (105)')
+    if L.mpc_version() != 106:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (106)')
     _lib = L
     return L
 

@@ -288,6 +288,13 @@ extern "C" int mpc_knn_list_offsets(const mpc_shape *s, int64_t *out) {
     return 0;
 }
 
+extern "C" int64_t mpc_knn_tail_counters_offset(const mpc_shape *s) {
+    if (!s) { mpc_set_error("mpc_knn_tail_counters_offset: null shape"); return MPC_E_NULL; }
+    int rc = mpc_validate_shape(s);
+    if (rc) return rc;
+    return mpc_layout(s).off_knn_chord + 512;          // (knn_device.h: knn_marked_count, knn_late_count, knn_tail_done)
+}
+
 extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {
     if (!s) { mpc_set_error("mpc_workspace_bytes: null shape"); return MPC_E_NULL; }
     int rc = mpc_validate_shape(s);

@@ -196,3 +196,38 @@ def test_fused_backward_with_far_queries_matches_the_staged_path(family):
     a, r = ta.grad, tb.grad
     assert torch.isfinite(a).all()
     assert float((a - r).norm()) <= 2e-5 * float(r.norm()) + 1e-9, float((a - r).norm() / r.norm())
+
+
+@pytest.mark.parametrize('family,B,forward', [('translate10', 1, True), ('white', 1, True), ('unet', 1, False), ('translate40', 2, False)])
+def test_tail_launch_paths_small_and_large_marked_counts(family, B, forward):
+    """The tail launch has two ways to serve the queries the main launch marks: with at most 1 024 of them in the whole launch its
+    one-wavefront search takes them from the MARKED list and no far pass runs (every B = 1 step of a lattice-like input); otherwise the
+    far pass of its strip workgroups, and what that cannot finish goes on the LATE list.  Both against the brute-force search, every
+    cell of three bins, and the counters say which path ran (mpc_knn_tail_counters_offset)."""
+    import bench
+    from motionpriorcmax_amd import ops, _lib as C
+    from motionpriorcmax_amd.utils import synth
+    from oracle import focus_oracle as O
+    dev = _dev()
+    if family == 'white':
+        _, _, traj, _ = bench.synth_inputs(dict(bench.WORKLOADS['C3'], B=B), seed=5)
+    else:
+        traj, _ = synth.synth_trajectories(B, 3, NB, (H, W), PATCH, family, seed=31)
+    L = _loss()
+    shape = ops.make_shape(L._cfg, B, 0, 0, traj.shape[2])
+    ws = ops.alloc_workspace(shape, dev)
+    td = traj.to(dev)
+    lut = ops.knn_lut_fwd(L._cfg, shape, td, ws)[0]
+    torch.cuda.synchronize()
+    off = C.lib().mpc_knn_tail_counters_offset(ctypes.byref(shape))
+    marked, late, done = (int(ws[off + o:off + o + 4].view(torch.int32).item()) for o in (0, 128, 256))
+    assert (marked <= 1024) == forward, (family, B, marked)
+    if not forward:
+        assert done > 0, (family, marked, late, done)          # strip workgroups of the tail launch had work and counted themselves
+    grid, _, _ = O.lut_grid_points((H, W), SP)
+    q = grid.to(dev)
+    for b, t in ((0, 0), (B - 1, NB - 1), (0, NB // 2)):
+        idx = _brute(td[b], t, q)
+        ref = (td[b, 0] - td[b, 1 + t])[idx].mean(1)
+        got = lut.reshape(B, NB, -1, 2)[b, t]
+        assert torch.allclose(got, ref, atol=1e-4, rtol=1e-5), (family, b, t, float((got - ref).abs().max()))
