@@ -952,14 +952,18 @@ def main():
             from motionpriorcmax_amd.utils.synth import synth_events as _se3, bin_mid_times as _bm3
 
             def _time10(fn):
+                """median of three blocks of ten steps (one block of ten caught an allocator refill on one box: 4.3 ms against 0.73)"""
                 for _ in range(4):
                     fn()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / 10
+                blocks_ = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        fn()
+                    torch.cuda.synchronize()
+                    blocks_.append((time.perf_counter() - t0) / 10)
+                return sorted(blocks_)[1]
             # (a) configs[2]: 3-level IWE pyramid on the headline's workload (stage calls, no fused path)
             wl3 = WORKLOADS['C3']
             ev3, np3, tr3, tm3 = synth_inputs(wl3, seed=1)
