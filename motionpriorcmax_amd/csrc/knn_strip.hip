@@ -28,6 +28,8 @@
 // the staging area even in quarters) is marked for the strip workgroups of the tail launch (k_knn_tail: radii up to KNN_RFAR, chord-shaped
 // regions, 192 slots) or appended to a list and searched by its fallback workgroups, one wavefront per query: the result is the exact
 // K-nearest set for any input, ties to the lowest index.
+// (Names in the comments below, from the rounds in which these were launches of their own: "second launch" / "far pass" = the strip
+// workgroups of k_knn_tail, strip_more_body; "fallback kernel" = its one-wavefront-per-query workgroups, fallback_one_query.)
 #include "knn_device.h"
 #include "ev_count_device.h"
 #include "bounds.h"
@@ -42,7 +44,7 @@
 #define KS_TAIL(MAXCH_) (4 * (MAXCH_) + 8)  // slots of far-away dummy points behind the staged ones (reads beyond a range)
 #define KS_FAR 1.0e18f              // coordinate of a dummy point: its distance is finite and beyond any bound
 #define KS_FB_SLOTS 4               // fallback, wavefront per query: candidates per lane (64 * 4 per query)
-#define KS_FB_BLOCKS 1024           // workgroups of the fallback kernel
+#define KS_FB_BLOCKS 1024           // one-wavefront-per-query workgroups of the tail launch
 #ifndef KS_RETRY_BLOCKS
 #define KS_RETRY_BLOCKS (256 * KS_MORE_OCC)   // strip workgroups of the tail launch
 #endif

@@ -67,7 +67,7 @@
 #define KS_SB 3                     // staging: items per thread whose global loads are in flight together
 #endif
 #ifndef KS_FORWARD_MAX
-#define KS_FORWARD_MAX 1024         // the second launch hands its queries on to the fallback kernel when the main launch marked at most this many
+#define KS_FORWARD_MAX 1024         // the main launch marked at most this many queries: the tail's one-wavefront search takes them from the marked list, no far pass
 #endif
 #ifndef KS_MORE_OCC
 #define KS_MORE_OCC 4               // workgroups per CU of the second launch = its register budget (128; 13 registers spill).  The launch is bound

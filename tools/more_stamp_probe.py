@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phases of a work item of the far pass of k_knn_strip_more (diagnostics build -DKS_STAMP2 of the in-tree library: thread 0
+"""Phases of a work item of the far pass of k_knn_tail (strip workgroups) (diagnostics build -DKS_STAMP2 of the in-tree library: thread 0
 stamps behind the barriers; the last item of every workgroup stays).  On the GPU box:
     MPC_EXTRA_HIPCC_FLAGS=-DKS_STAMP2 python motionpriorcmax_amd/build.py && python tools/more_stamp_probe.py translate40
 (restore the product build afterwards: python motionpriorcmax_amd/build.py)"""
