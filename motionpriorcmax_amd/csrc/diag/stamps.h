@@ -23,8 +23,8 @@
 #define KS_STP_DECL unsigned long long stp_[8]; int nstp_ = 0;
 #define KS_STP() do { if (FARK && nstp_ < 8) { __builtin_amdgcn_s_waitcnt(0); stp_[nstp_++] = wall_clock64(); } } while (0)
 #define KS_STP_WRITE(ls_, tid_, mine_, total_) do { if (FARK) { __syncthreads(); KS_STP(); const int nmk_ = __syncthreads_count((mine_) ? 1 : 0); \
-        if ((tid_) == 0) { int *dst_ = (ls_).fail + 1 + 200000 + 8 * (int)blockIdx.x; dst_[0] = (int)(stp_[0] & 0x7fffffffull); \
-            for (int k_ = 1; k_ < 6; ++k_) dst_[k_] = (int)(stp_[k_] - stp_[0]); dst_[6] = (total_); dst_[7] = nmk_; } } } while (0)
+        if ((tid_) == 0) { int *dst_ = (ls_).fail + 1 + 200000 + 12 * (int)blockIdx.x; dst_[0] = (int)(stp_[0] & 0x7fffffffull); \
+            for (int k_ = 1; k_ < 8; ++k_) dst_[k_] = (int)(stp_[k_] - stp_[0]); dst_[8] = (total_); dst_[9] = nmk_; } } } while (0)
 #else
 #define KS_STP_DECL
 #define KS_STP() do { } while (0)
@@ -68,4 +68,20 @@
 #define LA_STAMP_DECL
 #define LA_STAMP(k) do { } while (0)
 #define LA_STAMP_WRITE(tid_, dst_, n_) do { } while (0)
+#endif
+
+// ---- -DKT_TIMELINE: when the workgroups of k_knn_tail start, finish their lists and end (tools/tail_timeline_probe.py) -----------
+// every workgroup writes 8 ints far inside the `fail` list: [0] start, [1] strip workgroups: end of the items / fallback: main list done,
+// [2] fallback: wait over, [3] end (10 ns units of wall_clock64, low 31 bits), [4] items or entries of the main list this workgroup's
+// wavefront 0 took, [5] late entries it took
+#ifdef KT_TIMELINE
+#define KT_T(k_) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) kt_[k_] = (int)(wall_clock64() & 0x7fffffffull); } while (0)
+#define KT_DECL int kt_[6] = {0, 0, 0, 0, 0, 0};
+#define KT_COUNT(k_, n_) do { kt_[k_] = (n_); } while (0)
+#define KT_WRITE(ls_) do { if (threadIdx.x == 0) { int *d_ = (ls_).fail + 1 + 300000 + 8 * (int)blockIdx.x; for (int k_ = 0; k_ < 6; ++k_) d_[k_] = kt_[k_]; } } while (0)
+#else
+#define KT_T(k_) do { } while (0)
+#define KT_DECL
+#define KT_COUNT(k_, n_) do { } while (0)
+#define KT_WRITE(ls_) do { } while (0)
 #endif

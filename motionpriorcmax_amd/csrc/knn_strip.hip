@@ -1231,6 +1231,8 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ int s_wsum[KS_NT / 64 + 1], s_wmax[KS_NT / 64];      // (s_wsum[KS_NT / 64]: this strip workgroup put queries on the late list)
     __shared__ unsigned char s_rq[KS_NT / WS];
+    KT_DECL
+    KT_T(0);
     if ((int)blockIdx.x < KS_RETRY_BLOCKS) {
         if (threadIdx.x == 0) s_wsum[KS_NT / 64] = 0;
         __syncthreads();
@@ -1244,6 +1246,7 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
             if (s_wsum[KS_NT / 64]) __threadfence();
             atomicAdd(knn_tail_done(ls), 1);
         }
+        KT_T(1); KT_T(3); KT_WRITE(ls);
         return;
     }
     const int fb = (int)blockIdx.x - KS_RETRY_BLOCKS;
@@ -1267,15 +1270,18 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
     // the late list: complete once every strip workgroup has counted itself done
     // (counter, list length and entries are read with device-scope atomic loads, which do not hit a stale line of this XCD's L2:
     // no acquire fence -- an L2 invalidate per wavefront)
+    KT_T(1); KT_COUNT(4, (nfail + nmark - wv + nw - 1) / nw);
     const int busy = strip_more_busy(p, ls, gx, gy, KS_RETRY_BLOCKS);
-    if (busy == 0) return;                                       // (no strip work at all: no late list either)
+    if (busy == 0) { KT_T(3); KT_WRITE(ls); return; }            // (no strip work at all: no late list either)
     if (threadIdx.x == 0)
         while (__hip_atomic_load(knn_tail_done(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < busy) __builtin_amdgcn_s_sleep(64);
     __syncthreads();
+    KT_T(2);
     const int nlate = min(__hip_atomic_load(knn_late_count(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq - nfail - nmark);
     for (int i = wv; i < nlate; i += nw)
         fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
                            (unsigned)__hip_atomic_load(&fail[MPC_IDX(nq - nmark - i, 1 + (long long)nq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq, r_init, s_comp);
+    KT_COUNT(5, (nlate - wv + nw - 1) / nw); KT_T(3); KT_WRITE(ls);
 }
 
 // ------------------------------------------------------------------------------------------
