@@ -202,9 +202,8 @@ def knn_ceiling(workload, stages, B, nb):
                              'valu_issue_frac_at_4_cycles': round(k['valu_insts'] * 4.0 / slots, 3),
                              'lds_active_frac': k.get('lds_active_frac'), 'wait_any_frac': k.get('wait_any_frac')}
         # the counters belong to the library they were taken with: say so when the loaded one differs (stale figures)
-        import hashlib
-        libp = os.path.join(ROOT, 'motionpriorcmax_amd', 'libmpcmax.so')
-        cur = 'libmpcmax.so sha256 ' + hashlib.sha256(open(libp, 'rb').read()).hexdigest()[:16] if os.path.exists(libp) else None
+        from motionpriorcmax_amd import build as _build
+        cur = 'libmpcmax.so of sources ' + _build.source_hash()
         if d.get('_library') != cur:
             out['from_committed_profile'] = {'file': os.path.relpath(files[-1], ROOT), 'library': d.get('_library'), 'loaded_library': cur,
                                              'stale': True, 'note': 'taken with another build of the library: counters omitted'}

@@ -10,6 +10,22 @@ FLAGS = ['-shared', '-fPIC', '-O3', '--offload-arch=gfx950', '-ffp-contract=off'
          '-Wall', '-Wno-unused-function']
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the C header: the identity of the library for the profiles that are
+    committed beside it.  (The hash of libmpcmax.so itself changes with every build: hipcc puts a random unit id into every
+    translation unit -- a profile taken before a rebuild of the same sources would count as stale.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for root, _, names in os.walk(CSRC):
+        files += [os.path.join(root, n) for n in names if n.endswith(('.hip', '.h'))]
+    files.append(os.path.join(HERE, '..', 'include', 'mpcmax.h'))
+    for f in sorted(files):
+        h.update(os.path.relpath(f, HERE).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

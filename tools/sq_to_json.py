@@ -31,7 +31,9 @@ def main():
     # which library the counters belong to: bench.py prints it beside the figures it takes from this file
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'motionpriorcmax_amd', 'libmpcmax.so')
     if os.path.exists(lib):
-        out['_library'] = 'libmpcmax.so sha256 ' + hashlib.sha256(open(lib, 'rb').read()).hexdigest()[:16]
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from motionpriorcmax_amd import build as _build
+        out['_library'] = 'libmpcmax.so of sources ' + _build.source_hash()       # (the file's own hash changes with every build)
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(out, indent=1)[:1500])
 
