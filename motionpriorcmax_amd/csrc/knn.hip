@@ -962,10 +962,11 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                                                       const float *__restrict__ tile_dkmax,
                                                       float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
                                                       float2 *__restrict__ gtraj_direct, const float *__restrict__ reach_in,
-                                                      int gx, int gy, int bd KB_STAMP_PARAM) {
+                                                      int gx, int gy, int bd, int *far_next KB_STAMP_PARAM) {
     constexpr int TS = 16;
     KB_STAMP_BEGIN
     extern __shared__ __align__(16) unsigned char s_dyn[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && far_next != nullptr) *far_next = 0;       // (k_knn_bwd_far, the next launch: its dynamic items)
     __shared__ int s_rowbase[KNN_TROWS + 1];
     __shared__ int s_rowg[KNN_TROWS];
     __shared__ float s_wr[1];
@@ -1213,7 +1214,11 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
     const int nwork = min(ls.ftlist[0], p.B * p.nb * nt);
     const size_t BQ = (size_t)p.B * p.nb * p.G;
     const float invK = 1.f / (float)p.K;
-    for (int w = (int)blockIdx.x; w < nwork; w += (int)gridDim.x) {
+    // A workgroup's first item is item blockIdx.x; further ones come from a counter (the launch has up to twice as many items as
+    // workgroups on band-heavy fields, and an item takes 30-100 us depending on how many discs touch the tile: with the static deal
+    // w, w + gridDim.x the slowest pair set the launch's time).  At most one read-modify-write per workgroup and item.
+    __shared__ int s_next_item;
+    for (int w = (int)blockIdx.x; w < nwork; ) {
         const int item = ls.ftlist[1 + w];
         const int bt = item / nt, tile = item - bt * nt;
         const int by_ = tile / ntx, bx_ = tile - by_ * ntx;
@@ -1379,7 +1384,9 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
             }
             __syncthreads();
         }
+        if (tid == 0) s_next_item = (int)gridDim.x + atomicAdd(knn_bwd_far_next(ls), 1);
         __syncthreads();          // (the next item reuses the tables)
+        w = s_next_item;
     }
 }
 
@@ -1709,6 +1716,8 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         // where that pays: from about four rounds of workgroups (C3: 8.2; B = 1: 0.6 -- there it would cost 3 us).
         const bool reach_launch = !reach_ready && (int64_t)gxb * gyb * s->B * s->nb >= 4 * 2048;
         const float *reach_pre = reach_ready ? reach : nullptr;
+        int *far_next = nullptr;              // (the counter of the far backward's dynamic items: zeroed by the gather's launch)
+        if (mpc_knn_uses_far_list(s)) { const KnnLists ls0 = knn_lists(s, L, ws); far_next = reinterpret_cast<int *>(ls0.chord + 896); }
         if (reach_launch) {
             const size_t rl = ((size_t)gxb * gyb * (KNN_NCLS + 1) + 16) * sizeof(float);
             if (p.l1) MPC_LAUNCH(k_knn_reach_tiles<true>, dim3(s->B * s->nb), dim3(256), rl, st, p, tile_dkmax, reach, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)));
@@ -1717,7 +1726,7 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         }
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
         MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG(ws, L))
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)), far_next KB_STAMP_ARG(ws, L))
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH

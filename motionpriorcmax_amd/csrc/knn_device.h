@@ -82,6 +82,7 @@ struct KnnLists {
 __device__ __forceinline__ int *knn_marked_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 512); }
 __device__ __forceinline__ int *knn_late_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 640); }
 __device__ __forceinline__ int *knn_tail_done(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 768); }
+__device__ __forceinline__ int *knn_bwd_far_next(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 896); }      // k_knn_bwd_far: items beyond a workgroup's first (zeroed by k_knn_bwd_tile)
 // the MARKED list: every query the main launch marks for the tail's strip workgroups is also listed (same place as the late list, the
 // end of the `fail` array downwards; its length is knn_marked_count), with the radius its search would start from.  With few marked
 // queries in the whole launch (KS_FORWARD_MAX) the tail's fallback workgroups take the marked list straight away, the strip
