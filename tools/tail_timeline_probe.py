@@ -20,7 +20,10 @@ if os.environ.get('MPC_AB_LIB'):
 fam = sys.argv[1] if len(sys.argv) > 1 else 'unet'
 wl = bench.WORKLOADS['C3']
 B = wl['B']
-traj, _ = synth.synth_trajectories(B, 3, wl['nb'], (bench.H, bench.W), bench.PATCH, fam, seed=11)
+if fam == 'white':
+    _, _, traj, _ = bench.synth_inputs(wl, seed=1)
+else:
+    traj, _ = synth.synth_trajectories(B, 3, wl['nb'], (bench.H, bench.W), bench.PATCH, fam, seed=11)
 dev = torch.device('cuda:0')
 L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
 shape = ops.make_shape(L._cfg, B, 0, 0, traj.shape[2])
