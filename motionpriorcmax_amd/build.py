@@ -30,8 +30,9 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
-           [os.path.join(HERE, '..', 'include', 'mpcmax.h')]
+    deps = [os.path.join(HERE, '..', 'include', 'mpcmax.h')]
+    for root, _, names in os.walk(CSRC):          # (csrc/diag/*.h too)
+        deps += [os.path.join(root, n) for n in names]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -53,6 +53,11 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream(device=self.device) if self.is_cuda else None
         self._works = []
         self._scale_pending = False
+        # RCCL averages inside the collective (ReduceOp.AVG): no pass of its own over the 124 MB to divide by the world size -- four
+        # `mul_` kernels on the side stream that took HBM bandwidth from the loss kernels they ran beside (round 5).  gloo (CPU tests)
+        # has no AVG: SUM, then the division.
+        self.avg = bool(self.is_cuda and dist.is_initialized() and dist.get_backend(group) == 'nccl')
+        self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
 
     def start(self):
         if self.skip:
@@ -61,17 +66,18 @@ class GradAllReducer:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
                 for s, e in self.bounds:
-                    self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
+                    self._works.append(dist.all_reduce(self.flat[s:e], op=self.op,
                                                        group=self.group, async_op=True))
                 for w in self._works:
                     w.wait()            # stream-level wait only (no host block) on NCCL/RCCL
                 self._works = []
-                self.flat.mul_(1.0 / self.world)
+                if not self.avg:
+                    self.flat.mul_(1.0 / self.world)
         else:
             for s, e in self.bounds:
-                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM,
+                self._works.append(dist.all_reduce(self.flat[s:e], op=self.op,
                                                    group=self.group, async_op=True))
-            self._scale_pending = True
+            self._scale_pending = not self.avg
 
     def start_bucket(self, i: int):
         """Enqueue the all-reduce of bucket i alone, behind what the producing (current) stream has enqueued so far: the
@@ -84,12 +90,14 @@ class GradAllReducer:
             ev.record(torch.cuda.current_stream(self.device))
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                w = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w = dist.all_reduce(self.flat[s:e], op=self.op, group=self.group, async_op=True)
                 w.wait()                # stream-level wait only
-                self.flat[s:e].mul_(1.0 / self.world)
+                if not self.avg:
+                    self.flat[s:e].mul_(1.0 / self.world)
         else:
-            dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group)
-            self.flat[s:e].mul_(1.0 / self.world)
+            dist.all_reduce(self.flat[s:e], op=self.op, group=self.group)
+            if not self.avg:
+                self.flat[s:e].mul_(1.0 / self.world)
 
     def wait(self):
         if self.skip:
@@ -174,6 +182,9 @@ class OverlappedGradProducer:
     def step(self):
         self._left = list(self._left0)
         self._fired = 0
+        # (the previous step's buckets may still be in flight on the reducer's stream if the caller did not wait(): zeroing the
+        # buffer under them would corrupt the exchange silently -- the producing stream waits for them first; free if wait() ran)
+        self.r.wait()
         self.r.flat.zero_()                       # (gradients accumulate into the views: the optimizer's zero_grad)
         self.net(self.x).backward()
         while self._fired < len(self._left):      # (buckets without a parameter of their own end)

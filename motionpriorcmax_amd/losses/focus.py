@@ -66,6 +66,7 @@ class FocusLoss(base.TrajectoryLossBase):
         # length never leaves the eager path).  The caller (src/modules/trajectory_net.py:152-158) writes no capture code.
         self.auto_static_shapes = bool(auto_static_shapes)
         self._auto_key, self._auto_run = None, 0
+        self._auto_never = set()              # shapes whose plan could not be captured: eager from then on
         self.is_needing_offsets = True
         self.imager = EventImageConverter(self.image_shape)
 
@@ -194,6 +195,8 @@ class FocusLoss(base.TrajectoryLossBase):
         if events.shape[0] * events.shape[1] > self.AUTO_STATIC_MAX_EVENTS or torch.cuda.is_current_stream_capturing():
             return False
         key = ops.StaticFocusCalcFn.plan_key(trajectories, events, self._cfg, int(num_pos_events), offsets)
+        if key in self._auto_never:
+            return False
         if key == self._auto_key:
             self._auto_run += 1
         else:
@@ -220,7 +223,13 @@ class FocusLoss(base.TrajectoryLossBase):
         elif self.static_shapes and ops.STAGE_TIMER is None and not torch.cuda.is_current_stream_capturing():
             out = ops.StaticFocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets, self._static_plans)
         elif self._auto_static(trajectories, events, num_pos_events, offsets):
-            out = ops.StaticFocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets, self._static_plans, True)
+            try:
+                out = ops.StaticFocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets, self._static_plans, True)
+            except ops.AutoPlanFailed:
+                # the plan of this shape could not be captured (another thread of the training process used the device in the
+                # capture window, no memory for the plan's buffers, ...): this step and every later one of the shape run eagerly
+                self._auto_never.add(ops.StaticFocusCalcFn.plan_key(trajectories, events, self._cfg, int(num_pos_events), offsets))
+                out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets)
         elif self.profiler is not None:
             with torch.profiler.record_function('mpcmax::FocusLoss.calc'):
                 out = ops.FocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets)

@@ -664,13 +664,17 @@ class StaticFocusPlan:
                 self._bwd()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # capture_error_mode='thread_local': only THIS thread's calls are held to the capture rules.  In the reference's training
+        # process other threads use the device meanwhile (the DataLoader's pin_memory thread, src/modules/data_loading.py:141-142;
+        # DDP's side streams and the RCCL watchdog, scripts/flow_training.py:125-130): in the default global mode an allocation of
+        # theirs inside this window would invalidate the capture.
         self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd):
+        with torch.cuda.graph(self.g_fwd, capture_error_mode='thread_local'):
             self._fwd()
         self.g_bwd = None
         if need_grad:
             self.g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd):
+            with torch.cuda.graph(self.g_bwd, capture_error_mode='thread_local'):
                 self._bwd()
 
     def _fwd(self):
@@ -678,6 +682,10 @@ class StaticFocusPlan:
 
     def _bwd(self):
         _focus_bwd_call(self.plan, self.dev, self.traj, self.ev, self.tr, self.buf, self.ws, self.offs, self.gout, self.scratch, self.g_traj)
+
+
+class AutoPlanFailed(RuntimeError):
+    """Automatic static shapes: the plan of a shape could not be captured (FocusLoss.calc then stays on the eager path)."""
 
 
 class StaticFocusCalcFn(torch.autograd.Function):
@@ -706,7 +714,16 @@ class StaticFocusCalcFn(torch.autograd.Function):
         if sp is None:
             if len(plans) >= 8:              # every shape holds its buffers: keep the set small
                 plans.pop(next(iter(plans)))
-            sp = plans[key] = StaticFocusPlan(cfg, B, M, Mp, n, dev, need_grad, traj, ev, tr, event_offsets)
+            if auto:
+                # nobody asked for a capture: whatever goes wrong while the plan is built (a capture error, no memory for the
+                # plan's buffers) must not reach the training step -- the caller takes the eager path for this shape from now on
+                try:
+                    sp = StaticFocusPlan(cfg, B, M, Mp, n, dev, need_grad, traj, ev, tr, event_offsets)
+                except Exception as e:          # noqa: BLE001
+                    raise AutoPlanFailed(f'{type(e).__name__}: {e}') from e
+                plans[key] = sp
+            else:
+                sp = plans[key] = StaticFocusPlan(cfg, B, M, Mp, n, dev, need_grad, traj, ev, tr, event_offsets)
         sp.traj.copy_(traj)
         if sp.ev_src is None or sp.ev_src() is not events or events._version != sp.ev_version:
             sp.ev.copy_(ev)                 # a new batch (or one modified in place): copied once
@@ -725,9 +742,12 @@ class StaticFocusCalcFn(torch.autograd.Function):
         # (the automatic mode keeps the reference's semantics: the images are the caller's own copy, and the plan is marked busy until
         # this step's backward has run or its graph is dropped -- FocusLoss.calc then takes the eager path for a second calc)
         sp.pending = None
+        ctx.redo = None
         if auto and need_grad:
             ctx.marker = _Marker()
             sp.pending = weakref.ref(ctx.marker)
+            # (what an eager step needs, should this backward come after the plan has moved on: references, no copies)
+            ctx.redo = (traj, ev, tr, cfg, num_pos, event_offsets)
         return loss, focus, smooth, (sp.blur.clone() if auto else sp.blur.detach())
 
     @staticmethod
@@ -735,7 +755,18 @@ class StaticFocusCalcFn(torch.autograd.Function):
         if g_loss is None:
             return None, None, None, None, None, None, None, None
         sp = ctx.sp
-        sp.pending = None
+        if ctx.gen == sp.generation:
+            sp.pending = None
+        elif ctx.redo is not None:
+            # automatic mode, and the captured buffers hold a later calc of this shape (a second backward of a retained graph
+            # after the next step): the caller never asked for static shapes, so it gets what the eager path gives -- the
+            # step once more, eagerly, from the inputs this context kept
+            traj, ev, tr, cfg, num_pos, offs = ctx.redo
+            with torch.enable_grad():
+                t = traj.detach().requires_grad_(True)
+                out = FocusCalcFn.apply(t, ev, tr, cfg, num_pos, offs)
+                (g,) = torch.autograd.grad(out[0], t, g_loss.reshape(()).to(out[0].dtype))
+            return g, None, None, None, None, None, None, None
         if ctx.gen != sp.generation:
             raise RuntimeError('FocusLoss(static_shapes=True): this backward belongs to an earlier calc() of the same shape; the '
                                'captured buffers hold the latest one (call backward before the next calc, or use static_shapes=False)')

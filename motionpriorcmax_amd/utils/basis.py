@@ -2,6 +2,7 @@
 times x ~19k trajectories).  Mirrors reference src/utils/basis.py:4-46 and the Bernstein basis of
 src/models/raft_spline/curves/bezier.py:69-107."""
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -68,8 +69,12 @@ def _device_basis(kind, times, args, device, dtype):
     returned without reading the timestamps back to the host (a device synchronisation, the float64 evaluation and an upload: 9 ms
     of a 0.3 ms step)."""
     if torch.is_tensor(times):
+        # an entry belongs to a tensor OBJECT (weak reference: the cache keeps no caller tensor alive; a dead entry cannot match, so
+        # an address handed to another tensor is no hit), unmodified as far as torch can tell (_version) and still at the same
+        # storage address with the same shape (`.data` assignments and set_() do not bump the version)
+        _DEV_BASIS_CACHE[:] = [e for e in _DEV_BASIS_CACHE if e[0]() is not None]
         for ent in _DEV_BASIS_CACHE:
-            if ent[0] is times and ent[1] == times._version and ent[2:6] == (kind, args, device, dtype):
+            if ent[0]() is times and ent[1] == (times._version, times.data_ptr(), tuple(times.shape)) and ent[2:6] == (kind, args, device, dtype):
                 return ent[6]
         t = times.detach().cpu().numpy()
     else:
@@ -78,12 +83,14 @@ def _device_basis(kind, times, args, device, dtype):
     if torch.is_tensor(times):
         if len(_DEV_BASIS_CACHE) >= 8:
             _DEV_BASIS_CACHE.pop(0)
-        _DEV_BASIS_CACHE.append((times, times._version, kind, args, device, dtype, m))
+        _DEV_BASIS_CACHE.append((weakref.ref(times), (times._version, times.data_ptr(), tuple(times.shape)), kind, args, device, dtype, m))
     return m
 
 
 def _tile_positions(H, W, tile_size, device, dtype):
-    """(tile centres as a LongTensor on the host -- what the adapters return --, the same on `device` in `dtype`), built once."""
+    """(tile centres as a LongTensor on the host -- what the adapters return --, the same on `device` in `dtype`), built once.
+    The adapters hand the host tensor out as it is (a copy per step would be host time of a host-bound step): their docstrings say
+    that `pixel_positions` is shared and must not be modified in place."""
     from .trajectories import get_optical_flow_tile_mask
     key = (H, W, tile_size, str(device), dtype)
     ent = _TILE_POS_CACHE.get(key)
@@ -96,8 +103,9 @@ def _tile_positions(H, W, tile_size, device, dtype):
 
 
 def bernstein_basis(times, degree):
-    """[n_t] -> [n_t, degree]: C(d,i) (1-t)^(d-i) t^i for i = 1..d (P0 == 0), float64 then fp32."""
-    return _cached_basis('bernstein', times, int(degree))
+    """[n_t] -> [n_t, degree]: C(d,i) (1-t)^(d-i) t^i for i = 1..d (P0 == 0), float64 then fp32.  (The caller's own copy: the cached
+    matrix is shared by every later step.)"""
+    return _cached_basis('bernstein', times, int(degree)).clone()
 
 
 def _bernstein_basis_eval(times, degree):
@@ -118,7 +126,7 @@ def trajectories_from_bezier(params, times, tile_size, image_shape, scale=1.0):
     t is `CurveBase.get_flow_from_reference(t)` = sum_i B_i(t) P_i (bezier.py:92-113), which is zero at the
     anchor t = 0.  Returns (trajectories [B, n_t, n, 2] in (y, x) pixel coordinates, pixel_positions [n, 2]) with
     the tile centres of `get_optical_flow_tile_mask` as start points -- the layout `calc` expects
-    (focus.py:66-72).  `scale` multiplies the flow (8.0 if the curve lives on RAFT's 1/8 grid units).
+    (focus.py:66-72); `pixel_positions` is a cached tensor shared by all calls: do not modify it in place.  `scale` multiplies the flow (8.0 if the curve lives on RAFT's 1/8 grid units).
     Differentiable w.r.t. `params` (plain torch: 2*d*n_t multiply-adds per tile)."""
     from .trajectories import get_optical_flow_tile_mask
     B, c2, h, w = params.shape
@@ -139,7 +147,7 @@ def bspline_basis(times, num_ctrl, degree=3):
     t = 0).  Cox-de Boor in float64, then fp32.  UNPINNED EXTENSION: the reference has no B-spline curve
     (src/models/raft_spline/curves holds Bezier and polynomial curves only) -- BASELINE.json's configs[3]
     names a cubic B-spline, so the basis is provided, default OFF, and checked against scipy.interpolate.BSpline."""
-    return _cached_basis('bspline', times, int(num_ctrl), int(degree))
+    return _cached_basis('bspline', times, int(num_ctrl), int(degree)).clone()          # (the caller's own copy)
 
 
 def _bspline_basis_eval(times, num_ctrl, degree=3):

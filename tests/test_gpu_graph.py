@@ -185,3 +185,120 @@ def test_small_steps_switch_to_the_captured_plan_by_themselves():
         lb, _, _ = Lb.calc(tb, td, {'events': ev[:, :m].contiguous().to(dev), 'num_pos_events': min(num_pos, m)})
         lb.backward()
     assert len(Lb._static_plans) == 0
+
+
+def test_automatic_capture_survives_other_threads_and_streams():
+    """The plan of the automatic mode is captured inside the caller's training step: in the reference's training process a
+    DataLoader thread allocates pinned memory (src/modules/data_loading.py:141-142) and DDP runs side streams
+    (scripts/flow_training.py:125-130) meanwhile.  The capture is thread-local, so neither may break the step; losses and gradients
+    stay those of the eager path bit for bit."""
+    import threading
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(11)
+    cfg = bench.loss_config(wl)
+    Le = LossFactory.get_loss_calculator('FOCUS', dict(cfg, auto_static_shapes=False))
+    La = LossFactory.get_loss_calculator('FOCUS', cfg)
+    td = times.to(dev)
+    batch = {'events': ev.to(dev), 'num_pos_events': num_pos}
+    stop = threading.Event()
+    errors = []
+
+    def pinner():                        # what a pin_memory thread does: pinned allocations + async copies on a stream of its own
+        try:
+            s = torch.cuda.Stream(dev)
+            while not stop.is_set():
+                h = torch.empty(1 << 18, dtype=torch.float32, pin_memory=True)
+                with torch.cuda.stream(s):
+                    d = h.to(dev, non_blocking=True)
+                    d.add_(1.0)
+                s.synchronize()
+        except Exception as e:           # noqa: BLE001
+            errors.append(e)
+
+    def cruncher():                      # a side stream busy with matrix products (DDP / the network)
+        try:
+            s = torch.cuda.Stream(dev)
+            a = torch.randn(1024, 1024, device=dev)
+            while not stop.is_set():
+                with torch.cuda.stream(s):
+                    for _ in range(8):
+                        a = (a @ a).clamp_(-1, 1)
+                s.synchronize()
+        except Exception as e:           # noqa: BLE001
+            errors.append(e)
+    ths = [threading.Thread(target=pinner), threading.Thread(target=cruncher)]
+    for t in ths:
+        t.start()
+    try:
+        for step in range(8):
+            tj = (traj + 0.01 * step).to(dev)
+            te, ta = tj.clone().requires_grad_(True), tj.clone().requires_grad_(True)
+            le, _, me = Le.calc(te, td, batch); le.backward()
+            la, _, ma = La.calc(ta, td, batch); la.backward()
+            assert torch.equal(le.detach(), la.detach()) and torch.equal(te.grad, ta.grad), step
+            assert torch.equal(me['iwes'], ma['iwes']), step
+    finally:
+        stop.set()
+        for t in ths:
+            t.join()
+    assert not errors, errors
+    # either the plan was captured (the usual outcome) or the shape was marked "never": both are fine, an exception is not
+    assert len(La._static_plans) + len(La._auto_never) == 1
+
+
+def test_automatic_capture_failure_falls_back_to_eager(monkeypatch):
+    """If the plan cannot be built, calc() stays eager for that shape instead of raising out of the training step."""
+    import bench
+    from motionpriorcmax_amd import LossFactory, ops
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(12)
+    cfg = bench.loss_config(wl)
+    Le = LossFactory.get_loss_calculator('FOCUS', dict(cfg, auto_static_shapes=False))
+    La = LossFactory.get_loss_calculator('FOCUS', cfg)
+    calls = []
+
+    def boom(*a, **k):
+        calls.append(1)
+        raise RuntimeError('capture failed (injected)')
+    monkeypatch.setattr(ops, 'StaticFocusPlan', boom)
+    td = times.to(dev)
+    batch = {'events': ev.to(dev), 'num_pos_events': num_pos}
+    for step in range(6):
+        tj = (traj + 0.01 * step).to(dev)
+        te, ta = tj.clone().requires_grad_(True), tj.clone().requires_grad_(True)
+        le, _, _ = Le.calc(te, td, batch); le.backward()
+        la, _, _ = La.calc(ta, td, batch); la.backward()
+        assert torch.equal(le.detach(), la.detach()) and torch.equal(te.grad, ta.grad), step
+    assert len(calls) == 1 and len(La._auto_never) == 1 and len(La._static_plans) == 0
+
+
+def test_automatic_mode_second_backward_of_a_retained_graph():
+    """backward(retain_graph=True), another calc of the same shape, then the first graph's backward again: the caller never asked
+    for static shapes, so this must give what the eager path gives."""
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = torch.device('cuda:0')
+    wl, ev, num_pos, traj, times = _c2(13)
+    cfg = bench.loss_config(wl)
+    Le = LossFactory.get_loss_calculator('FOCUS', dict(cfg, auto_static_shapes=False))
+    La = LossFactory.get_loss_calculator('FOCUS', cfg)
+    td = times.to(dev)
+    batch = {'events': ev.to(dev), 'num_pos_events': num_pos}
+    for _ in range(3):                                       # get the shape onto the captured plan
+        t0 = traj.to(dev).requires_grad_(True)
+        l0, _, _ = La.calc(t0, td, batch); l0.backward()
+    assert len(La._static_plans) == 1
+    t1 = (traj + 0.02).to(dev).requires_grad_(True)
+    l1, _, _ = La.calc(t1, td, batch)
+    l1.backward(retain_graph=True)
+    g_first = t1.grad.clone()
+    t2 = (traj + 0.04).to(dev).requires_grad_(True)
+    l2, _, _ = La.calc(t2, td, batch); l2.backward()         # the plan moves on
+    t1.grad = None
+    l1.backward()                                            # ... and the retained graph is walked again
+    assert torch.equal(t1.grad, g_first)
+    r1 = (traj + 0.02).to(dev).requires_grad_(True)
+    k1, _, _ = Le.calc(r1, td, batch); k1.backward()
+    assert torch.equal(g_first, r1.grad) and torch.equal(l1.detach(), k1.detach())
