@@ -17,12 +17,7 @@
  *    sequence of calls can be captured into a HIP graph and replayed;
  *  - no mutable global state takes part in a result: the last-error string is thread local, and the only
  *    process-wide state is one-time, idempotent set-up (raising the dynamic-LDS limit of the kernels, tuning
- *    switches read once from the environment, listed in csrc/knn.hip, and -- since version 107 -- one SIDE STREAM
- *    per (device, caller stream), created on first use by mpc_focus_fwd / mpc_focus_bwd: stages that do not depend
- *    on each other run side by side on it, forked from and joined to `stream` with events only (captured into a
- *    HIP graph like the kernels), so that for the caller all work is still ordered by `stream` and complete, in
- *    stream order, when the call returns; results are bit for bit those of the single-stream order;
- *    mpc_side_stream_enable(0) or MPC_SIDE_STREAM=0 in the environment switches it off);
+ *    switches read once from the environment, listed in csrc/knn.hip);
  *  - return value: 0 ok, >0 a hipError_t, <0 an argument error (MPC_E_*).  No C++ exception
  *    crosses the ABI.
  *
@@ -40,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 107
+#define MPC_VERSION 106
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -100,10 +95,6 @@ int mpc_bounds_check(void);
  * a graph capture. */
 int mpc_profile_start(void);
 int mpc_profile_stop(char *names, int32_t names_cap, float *ms, int32_t cap);
-
-/* Scheduling switch (no reference counterpart; never changes a result): may mpc_focus_fwd / mpc_focus_bwd use the library's side
- * stream (see the conventions above)?  Returns the previous setting.  Default: on, unless MPC_SIDE_STREAM=0 is in the environment. */
-int mpc_side_stream_enable(int on);
 
 /* Bytes of scratch needed by any call with this shape. */
 int64_t mpc_workspace_bytes(const mpc_shape *s);

@@ -39,7 +39,7 @@ def needs_build():
 def build_library(force=False, verbose=False, out=None):
     """hipcc every source to an object (in parallel: one process per file), then link.  `out`: another file name for the
     library (diagnostic / bounds-checked builds loaded through MPC_AB_LIB); the product build is LIB."""
-    out = out or LIB
+    out = os.path.abspath(out) if out else LIB          # (the compiler runs in csrc/)
     if not force and out == LIB and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

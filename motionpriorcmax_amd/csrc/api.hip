@@ -70,68 +70,6 @@ extern "C" int mpc_profile_stop(char *names, int32_t names_cap, float *ms, int32
 }
 extern "C" const char *mpc_last_error_string(void) { return g_err; }
 
-// ---- the library-owned side stream (common.h: mpc_side_ctx) ---------------------------------------------------------
-// One context per (device, caller stream), kept for the life of the process (a caller stream that is destroyed leaves its
-// entry behind: a stream handle that comes back gets the old context, which is as good as a new one).  A table under a mutex:
-// two host threads (forward and autograd thread) may ask at once.
-#include <map>
-static std::atomic<int> g_side_on{-1};          // -1: not asked yet (MPC_SIDE_STREAM in the environment, default on)
-static std::mutex g_side_mu;
-static std::map<std::pair<int, hipStream_t>, mpc_side_ctx *> g_side;
-static bool side_enabled() {
-    int v = g_side_on.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("MPC_SIDE_STREAM");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-        g_side_on.store(v);
-    }
-    return v != 0;
-}
-extern "C" int mpc_side_stream_enable(int on) {
-    const bool was = side_enabled();
-    g_side_on.store(on ? 1 : 0);
-    return was ? 1 : 0;
-}
-const mpc_side_ctx *mpc_side_get(hipStream_t caller) {
-    if (!side_enabled()) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    auto it = g_side.find({dev, caller});
-    if (it != g_side.end()) return it->second;
-    // (a context that cannot be created is remembered as "none": the stages then share the caller's stream)
-    mpc_side_ctx *sc = new mpc_side_ctx{};
-    sc->main = caller;
-    bool ok = hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking) == hipSuccess;
-    int made = 0;
-    for (; ok && made < 4; ++made) ok = hipEventCreateWithFlags(&sc->e[made], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError();
-        for (int i = 0; i < made; ++i) (void)hipEventDestroy(sc->e[i]);
-        if (sc->side) (void)hipStreamDestroy(sc->side);
-        delete sc;
-        sc = nullptr;
-    }
-    g_side[{dev, caller}] = sc;
-    return sc;
-}
-int mpc_side_fork(const mpc_side_ctx *sc) {
-    hipError_t e = hipEventRecord(sc->e[MPC_EV_FORK], sc->main);
-    if (e == hipSuccess) e = hipStreamWaitEvent(sc->side, sc->e[MPC_EV_FORK], 0);
-    if (e != hipSuccess) { mpc_set_error("mpc_side_fork: %s", hipGetErrorString(e)); return (int)e; }
-    return 0;
-}
-int mpc_side_mark(const mpc_side_ctx *sc, int ev) {
-    const hipError_t e = hipEventRecord(sc->e[ev], sc->side);
-    if (e != hipSuccess) { mpc_set_error("mpc_side_mark: %s", hipGetErrorString(e)); return (int)e; }
-    return 0;
-}
-int mpc_side_join(const mpc_side_ctx *sc, int ev) {
-    const hipError_t e = hipStreamWaitEvent(sc->main, sc->e[ev], 0);
-    if (e != hipSuccess) { mpc_set_error("mpc_side_join: %s", hipGetErrorString(e)); return (int)e; }
-    return 0;
-}
-
 // ---- -DMPC_BOUNDS: the bounds-checked debug build (bounds.h) -------------------------------------------------------
 // Every translation unit with checked accessors registers a reader of its violation record; mpc_bounds_check() waits for the
 // device, reads and clears them all and returns the number of violations (0: clean; -1: this is not a bounds build); the first
@@ -239,8 +177,6 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
     L.off_knn_chord = off;  off += mpc_align(1024);
     L.off_knn_again = off;  off += mpc_align(2 * bt * (int64_t)s->hq * ((s->wq + 31) / 32) * sizeof(int32_t));      // (`again` and `grow`)
     L.off_knn_far = off;    off += mpc_knn_uses_far_list(s) ? mpc_align(bt * (1 + (int64_t)L.G) * sizeof(int32_t)) : 0;
-    L.off_knn_farbits = off; off += mpc_knn_uses_far_list(s) ? mpc_align(bt * (((int64_t)s->n + 31) / 32) * sizeof(int32_t)) : 0;
-    L.off_knn_far_acc = off; off += (mpc_knn_uses_far_list(s) && (s->flags & MPC_F_WANT_NEXT)) ? mpc_align(2 * bt * (int64_t)s->n * 2 * sizeof(float)) : 0;
     // event partition of the LDS-tiled path (events.hip): strips sized to ~150 KB of 64-bit accumulators
     const int64_t lds_budget = 150 * 1024;
     L.strip_rows = (int)(lds_budget / ((int64_t)s->W * 8));
@@ -316,12 +252,8 @@ mpc_ws_layout mpc_layout(const mpc_shape *s) {
         L.off_fcount = off; off += mpc_align((int64_t)(L.nfb + 3 * L.nbb + 8) * sizeof(int32_t));      // fill counters, marker, capacities, first records
         L.off_frec = off;   off += mpc_align((int64_t)L.nfb * L.fcap * 12);
         L.off_brec = off;   off += (s->flags & MPC_F_NO_BWD_RECORDS) ? 0 : mpc_align((int64_t)(L.b_exact ? s->B : L.nbb) * L.bcap * 16);
-        // rows whose LUT cell the KNN forward's tail had not finished when k_ev_bin ran beside it (mpc_focus_fwd, side stream)
-        L.off_ev_defer = -1;
-        if ((int64_t)s->B * s->M < (1LL << 31) && !(s->flags & MPC_F_NO_WARP)) { L.off_ev_defer = off; off += mpc_align((int64_t)s->B * s->M * sizeof(uint32_t)); }
     } else {
         L.strip_rows = L.cstrip_rows = 0;
-        L.off_ev_defer = -1;
     }
     L.total = off;
     return L;
@@ -371,53 +303,36 @@ extern "C" int64_t mpc_workspace_bytes(const mpc_shape *s) {
 }
 
 // ---- A4: FocusLoss.calc and its backward as one call each (reference src/losses/focus.py:66-113) -----------------
-// Stage order and what runs beside what (round 6; `sc` = the library's side stream, common.h):
-//   caller's stream: bucket -> strip | k_ev_bin (pending rows deferred) | join TAIL | k_ev_bin_deferred -> k_iwe_accum -> contrast | join SMOOTH | finalize
-//   side stream    :                 | k_knn_tail -> mark TAIL -> k_lut_smooth_march -> mark SMOOTH
-// The dependencies are those of focus.py:82-94: the smoothness term and the event warp both read the finished LUT; nothing else
-// of the forward reads what they write until the scalars are put together.  Without a side stream (switched off, or the context
-// could not be created) the same launches go out on the caller's stream in the order of round 5.
 extern "C" int mpc_focus_fwd(const mpc_shape *s, const mpc_focus_buffers *io, void *ws, void *stream) {
     MPC_CHECK_ARG(s && io && ws, MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(io->traj && io->flow_lut && io->knn_state && io->iwe_raw && io->iwe_blur && io->scal, MPC_E_NULL, "null buffer");
     // the KNN forward's kernels also zero the event bucket counters and (unless the backward reads the rows themselves) count
-    // the rows per backward bucket: `done` says what of that happened (bit 0 zeroed, bit 1 counted, bit 2 tail on the side stream)
+    // the rows per backward bucket: `done` says what of that happened (bit 0 zeroed, bit 1 counted)
     const bool rec_bwd = io->grad_iwe && !io->event_offsets && !(s->flags & MPC_F_NO_BWD_RECORDS);
     int done = 0;
-    const mpc_side_ctx *sc = (s->B > 0) ? mpc_side_get((hipStream_t)stream) : nullptr;
-    int rc = mpc_knn_lut_fwd_ex(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream, 1, rec_bwd ? io->events : nullptr, &done, sc);
+    int rc = mpc_knn_lut_fwd_ex(s, io->traj, io->flow_lut, io->flow_next, io->knn_state, nullptr, ws, stream, 1, rec_bwd ? io->events : nullptr, &done);
     if (rc) return rc;
-    const bool tail_forked = (done & 4) != 0;
     int s_nimg = 0, s_C = 0;
-    bool smooth_forked = false;
     if (io->smooth_weight > 0.f) {
         const bool on_next = (s->flags & MPC_F_WANT_NEXT) != 0;
         const float *field = on_next ? io->flow_next : io->flow_lut;
         s_nimg = on_next ? s->B * (s->nb - 1) : s->B * s->nb;
         s_C = on_next ? 2 : 2 * s->T;
         if (s_nimg > 0) {
-            // beside the event kernels: behind the tail on the side stream, or behind a fork of its own where the KNN forward
-            // was not the strip kernel
-            if (sc && !tail_forked) rc = mpc_side_fork(sc);
-            if (!rc) rc = mpc_lut_smooth(s, field, s_nimg, s_C, io->smooth_weight, io->smooth_grad, ws, sc ? (void *)sc->side : stream);
-            if (!rc && sc) { rc = mpc_side_mark(sc, MPC_EV_SMOOTH); smooth_forked = true; }
+            if ((rc = mpc_lut_smooth(s, field, s_nimg, s_C, io->smooth_weight, io->smooth_grad, ws, stream))) return rc;
         } else s_C = 0;
     }
     // (the bucket counters were zeroed by the first kernel of the KNN forward, unless the event path is not the tiled one)
-    if (!rc) {
+    {
         // ordered events: no record per event for the backward (it reads the rows themselves)
         mpc_shape sf = *s;
         if (io->event_offsets) sf.flags |= MPC_F_NO_BWD_RECORDS;
-        rc = mpc_event_splat_fwd_ex(&sf, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, done, io->event_offsets, tail_forked ? sc : nullptr);
-    } else if (tail_forked) (void)mpc_side_join(sc, MPC_EV_TAIL);
-    if (!rc) rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream);
-    // (whatever happened above, the caller's stream leaves with the side stream joined)
-    if (smooth_forked) { const int rj = mpc_side_join(sc, MPC_EV_SMOOTH); if (!rc) rc = rj; }
-    if (rc) return rc;
+        if ((rc = mpc_event_splat_fwd_ex(&sf, io->events, io->flow_lut, io->t_ref, io->iwe_raw, ws, stream, done, io->event_offsets))) return rc;
+    }
+    if ((rc = mpc_contrast_fwd(s, io->iwe_raw, io->iwe_blur, io->grad_iwe, ws, stream))) return rc;
     return mpc_finalize_ex(s, s_nimg, s_C, io->smooth_weight, io->scal, io->scal_out, ws, stream);
 }
 
-// Backward: the far queries' share of the KNN backward runs beside the gather on the side stream (knn.hip: mpc_knn_lut_bwd_ex).
 extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, const float *grad_out,
                              float *grad_lut_scratch, float *grad_next_scratch, float *grad_traj, void *ws, void *stream) {
     MPC_CHECK_ARG(s && io && ws && grad_lut_scratch && grad_traj, MPC_E_NULL, "null argument");
@@ -437,6 +352,5 @@ extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, co
         if (grad_out) { if ((rc = mpc_scale(io->smooth_grad, grad_out, grad_next_scratch, cnt, stream))) return rc; g_next = grad_next_scratch; }
         else g_next = io->smooth_grad;
     }
-    const mpc_side_ctx *sc = (s->B > 0) ? mpc_side_get((hipStream_t)stream) : nullptr;
-    return mpc_knn_lut_bwd_ex(s, io->traj, grad_lut_scratch, g_next, io->knn_state, grad_traj, ws, stream, reach_done, sc);
+    return mpc_knn_lut_bwd_ex(s, io->traj, grad_lut_scratch, g_next, io->knn_state, grad_traj, ws, stream, reach_done);
 }

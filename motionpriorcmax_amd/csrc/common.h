@@ -46,28 +46,6 @@ void mpc_prof_post(const char *name, hipStream_t st);
         if (pr__) mpc_prof_post(#kern, st);                                          \
     } while (0)
 
-// ---- library-owned side stream (round 6) ---------------------------------------------------------------------------------
-// mpc_focus_fwd / mpc_focus_bwd run the stages that do not depend on each other side by side: the irregular tail of the KNN
-// forward (k_knn_tail) and the smoothness term beside the event kernels, the far queries' backward (k_knn_bwd_far) beside the
-// gather.  The second stream belongs to the library: one per (device, caller stream), created on first use (one-time, idempotent
-// set-up; mpcmax.h), forked from and joined to the caller's stream with events only (hipEventRecord / hipStreamWaitEvent: both
-// are captured into a HIP graph with the kernels), so that for the caller everything still happens in the order of ITS stream:
-// the call returns with the side work joined, no host synchronisation, no allocation.  mpc_side_get() returns nullptr when the
-// feature is switched off (mpc_side_stream_enable(0), MPC_SIDE_STREAM=0) or a stream / event could not be created: every
-// stage then runs on the caller's stream as before.  Results are bit for bit the same either way.
-struct mpc_side_ctx {
-    hipStream_t main, side;
-    hipEvent_t e[4];            // MPC_EV_FORK: main -> side;  MPC_EV_TAIL / MPC_EV_SMOOTH / MPC_EV_FAR: side -> main
-};
-#define MPC_EV_FORK 0
-#define MPC_EV_TAIL 1
-#define MPC_EV_SMOOTH 2
-#define MPC_EV_FAR 3
-const mpc_side_ctx *mpc_side_get(hipStream_t caller);
-int mpc_side_fork(const mpc_side_ctx *sc);             // the side stream waits for everything enqueued on the caller's stream so far
-int mpc_side_mark(const mpc_side_ctx *sc, int ev);     // e[ev] := everything enqueued on the side stream so far
-int mpc_side_join(const mpc_side_ctx *sc, int ev);     // the caller's stream waits for e[ev]
-
 // One-time, idempotent set-up that is PER DEVICE (raising the dynamic-LDS cap of a kernel): one bit per HIP device.
 // need() is true until mark() ran for the current device; two threads (forward and autograd thread) may both run the
 // set-up, which is harmless because it is idempotent -- the flag itself is atomic.
@@ -105,13 +83,10 @@ struct mpc_ws_layout {
     int64_t off_knn_chord;   // uint8 [21][21]  chord table of the strip kernels (knn_device.h: knn_chord_cells)
     int64_t off_knn_again;   // uint32 [2][B*nb][hq][ceil(wq/32)]  queries the strip kernel's main launch hands to its second launch; those that need more rings
     int64_t off_knn_far;     // int32  [B*nb][1 + G]  per (sample, bin): the queries the fallback kernel served, for k_knn_bwd_far
-    int64_t off_knn_farbits; // uint32 [B*nb][ceil(n/32)]  bucketed points k_knn_bwd_far wrote a contribution for (zeroed by the bucket kernels)
-    int64_t off_knn_far_acc; // float2 [2][B*nb][n]  those contributions when the gather itself uses tmp_g / tmp_a (MPC_F_WANT_NEXT); else they go to tmp_g
     // event partition (LDS-tiled path)
     int64_t off_fcount;      // int32 [nfb + nbb + 8] bucket fill counters, marker; then [nbb] capacities and [nbb] first records of the backward buckets
     int64_t off_frec;        // float4 [nfb][fcap]
     int64_t off_brec;        // float4 [B][bcap = M]: the backward buckets of a sample back to back, each as large as its count of rows
-    int64_t off_ev_defer;    // uint32 [B*M]  rows k_ev_bin left to k_ev_bin_deferred (their LUT cell was not finished when it ran beside k_knn_tail); -1: none
     int32_t P, nimg, G;
     int32_t strip_rows, n_strips;   // destination strips of the IWE (forward buckets)
     int32_t cstrip_rows, n_cstrips; // source strips of LUT cell rows (backward buckets)
@@ -131,17 +106,15 @@ mpc_ws_layout mpc_layout(const mpc_shape *s);
 // internal variants of two entry points used by mpc_focus_fwd (api.hip): the KNN forward's first kernel zeroes the event
 // bucket counters, so that the event forward can skip its own zeroing launch
 int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
-                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done,
-                       const mpc_side_ctx *sc);
+                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done);
 int mpc_event_splat_bwd_job(const mpc_shape *s, const float *events, const int32_t *offsets, const float *flow_lut,
                             const float *t_ref, const float *grad_iwe, const float *scal,
                             const float *grad_out, float *grad_flow_lut, const float *add_term,
                             void *ws, void *stream, const float *knn_state, int *reach_done);
 int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut, const float *grad_flow_next,
-                       const float *knn_state, float *grad_traj, void *ws, void *stream, int reach_ready, const mpc_side_ctx *sc);
+                       const float *knn_state, float *grad_traj, void *ws, void *stream, int reach_ready);
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                           float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets,
-                           const mpc_side_ctx *sc);
+                           float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets);
 int mpc_validate_shape(const mpc_shape *s);
 int mpc_finalize_ex(const mpc_shape *s, int32_t smooth_nimg, int32_t smooth_C, float smooth_weight, float *scal, float *scal_out,
                     void *ws, void *stream);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
                                                 const float *__restrict__ events,
                                                 const float *__restrict__ lut,
                                                 const float *__restrict__ t_ref, int want_bwd,
-                                                const int *__restrict__ offsets, unsigned *__restrict__ defer) {
+                                                const int *__restrict__ offsets) {
     extern __shared__ __align__(16) int s_cnt[];          // [nloc] local counts, [nloc] global bases, [nloc+1] local offsets, ids, records
     __shared__ int s_wsum[4];
     const EvParams p = make_params(s);
@@ -321,36 +321,10 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
         const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
         load_event(events, (size_t)b * p.M + min(i, p.M - 1), ev[k]);
     }
-    // `defer` (mpc_focus_fwd with the side stream): this kernel runs BESIDE k_knn_tail, which is still filling in the LUT cells the
-    // strip kernel's main launch left over -- they read KNN_LUT_PENDING until then (knn_device.h).  A row whose cell is pending
-    // goes on the deferred list (one atomic per wavefront that has any: 0.02 % of the rows on white-noise coefficients, <= 1 % on
-    // smooth fields) and k_ev_bin_deferred bins it behind the join.  Bucket order does not matter to anything downstream: the
-    // accumulators are integers.
-    bool dfr[EV_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
         const int i = (chunk * EV_PER_THREAD + k) * 256 + tid;
-        const bool inrow = (i < p.M) && !((i >= pad0 && i < blk1) || i >= pad1);
-        wo[k].lut = -1;
-        float2 f = make_float2(0.f, 0.f);
-        if (!(p.flags & MPC_F_NO_WARP)) {
-            warp_cell(p, ev[k], b, 0, wo[k]);
-            f = reinterpret_cast<const float2 *>(lut)[wo[k].lut];
-        }
-        dfr[k] = defer != nullptr && inrow && __float_as_int(f.x) == KNN_LUT_PENDING && __float_as_int(f.y) == KNN_LUT_PENDING;
-        live[k] = warp_event_with(p, ev[k], f, tref, wo[k]) && inrow && !dfr[k];
-    }
-    if (defer != nullptr) {
-#pragma unroll
-        for (int k = 0; k < EV_PER_THREAD; ++k) {
-            const unsigned long long dm = __ballot(dfr[k]);
-            if (dm == 0ull) continue;                              // (wave-uniform: the usual case)
-            const int lane = tid & 63, first = __ffsll((long long)dm) - 1;
-            int base = 0;
-            if (lane == first) base = atomicAdd(&L.gcount[L.NF + L.NBk + 4], __popcll(dm));
-            base = __shfl(base, first, 64);
-            if (dfr[k]) defer[MPC_IDX((size_t)base + __popcll(dm & ((1ull << lane) - 1ull)), (long long)p.B * p.M)] = (unsigned)((size_t)b * p.M + (chunk * EV_PER_THREAD + k) * 256 + tid);
-        }
+        live[k] = warp_event(p, ev[k], b, 0, lut, tref, wo[k]) && (i < p.M) && !((i >= pad0 && i < blk1) || i >= pad1);
     }
 #pragma unroll
     for (int k = 0; k < EV_PER_THREAD; ++k) {
@@ -438,52 +412,6 @@ __global__ __launch_bounds__(256) void k_ev_bin(const mpc_shape s, const BinLayo
         ev_emit(p, L, b, nf_loc, lb, s_base[MPC_IDX(lb, nloc)] + (r - s_loc[lb]), s_rec[r]);
     }
     if (want_bwd && lblk == 0 && tid == 0) L.gcount[L.NF + L.NBk + 2] = EV_MARKER;
-}
-
-// The rows k_ev_bin left over (their LUT cell was pending: see there), binned one row per thread once k_knn_tail is through: the
-// same records into the same buckets, a slot at a time from the buckets' global counters (a few thousand rows per step -- no LDS
-// staging pays).  grid: a fixed number of workgroups (the list length is only known on the device), 256 threads
-#define EV_DEFER_BLOCKS 256
-__global__ __launch_bounds__(256) void k_ev_bin_deferred(const mpc_shape s, const BinLayout L,
-                                                         const float *__restrict__ events, const float *__restrict__ lut,
-                                                         const float *__restrict__ t_ref, int want_bwd,
-                                                         const unsigned *__restrict__ defer) {
-    const EvParams p = make_params(s);
-    const long long total = (long long)p.B * p.M;
-    const int n = (int)min((long long)L.gcount[L.NF + L.NBk + 4], total);
-    const int nf_loc = p.P * L.NS;
-    const float tref = (p.flags & MPC_F_SCALE_BY_DT) ? t_ref[0] : 0.f;
-    const float inv_SR = 1.f / (float)L.SR, inv_CSR = 1.f / (float)L.CSR;
-    for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < n; e += EV_DEFER_BLOCKS * 256) {
-        const size_t row = defer[e];
-        if ((long long)row >= total) continue;
-        const int b = (int)(row / p.M), i = (int)(row - (size_t)b * p.M);
-        float ev[6];
-        load_event(events, row, ev);
-        Warped o;
-        if (!warp_event(p, ev, b, 0, lut, tref, o)) continue;
-        const bool xin = (o.x0 + 1 >= 0) && (o.x0 < p.W);
-        const bool yin0 = o.y0 >= 0 && o.y0 < p.H, yin1 = o.y0 + 1 >= 0 && o.y0 + 1 < p.H;
-        if (!xin || !(yin0 || yin1)) continue;            // no tap inside the image
-        const int pol = (p.P == 2 && i >= p.Mp) ? 1 : 0;
-        const int s0 = yin0 ? (int)(((float)o.y0 + 0.5f) * inv_SR) : -1, s1 = yin1 ? (int)(((float)o.y0 + 1.5f) * inv_SR) : -1;
-        const float4 rec = make_float4(o.y, o.x, o.w, __int_as_float(b * p.P + pol));
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int st = h ? s1 : s0;
-            if (st < 0 || (h && s1 == s0)) continue;
-            const int lb = pol * L.NS + st, g = (b * p.P + pol) * L.NS + st;
-            ev_emit(p, L, b, nf_loc, lb, atomicAdd(&L.gcount[MPC_IDX(g, L.NF + L.NBk)], 1), rec);
-        }
-        if (want_bwd && o.lut >= 0) {
-            const int cst = (int)(((float)o.iy + 0.5f) * inv_CSR);
-            const int kb = o.it * L.NCS + cst, g = L.NF + b * p.nb * L.NCS + kb;
-            const int first = L.exact ? L.bcapcnt[L.NBk + b * p.nb * L.NCS + kb] : 0;
-            const unsigned aux = ((unsigned)pol << 31) | (unsigned)((o.iy - cst * L.CSR) * p.wq + o.ix);
-            ev_emit(p, L, b, nf_loc, nf_loc + kb, atomicAdd(&L.gcount[MPC_IDX(g, L.NF + L.NBk)], 1) + first,
-                    make_float4(o.y, o.x, o.w, __uint_as_float(aux)));
-        }
-    }
 }
 
 // taps of one record restricted to rows [row0, row1): calls f(yy, xx, value)
@@ -736,12 +664,11 @@ static int set_max_lds_ev(const void *fn, const char *who) {
 // ------------------------------------------------------------------------------------------
 extern "C" int mpc_event_splat_fwd(const mpc_shape *s, const float *events, const float *flow_lut,
                                    const float *t_ref, float *iwe_raw, void *ws, void *stream) {
-    return mpc_event_splat_fwd_ex(s, events, flow_lut, t_ref, iwe_raw, ws, stream, 0, nullptr, nullptr);
+    return mpc_event_splat_fwd_ex(s, events, flow_lut, t_ref, iwe_raw, ws, stream, 0, nullptr);
 }
 
 static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed, const int32_t *offsets = nullptr,
-                          const mpc_side_ctx *sc = nullptr);
+                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed, const int32_t *offsets = nullptr);
 
 // Event-axis sharding ("optional finer split" for batches smaller than the number of ranks): the raw IWE of
 // THIS rank's events as the Q33.30 accumulators themselves; integer partial images sum exactly, so an all-reduce(SUM) of
@@ -762,18 +689,13 @@ extern "C" int mpc_iwe_from_fixed(const int64_t *iwe_fixed, float *iwe_raw, int6
     return 0;
 }
 
-// sc (mpc_focus_fwd; counters_zeroed bit 2): k_knn_tail is still running on the side stream `sc` -- rows whose LUT cell is pending
-// are deferred, MPC_EV_TAIL is joined behind k_ev_bin and k_ev_bin_deferred bins them before the image is accumulated.  The join
-// happens here whatever path is taken.
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                           float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets, const mpc_side_ctx *sc) {
-    return splat_fwd_impl(s, events, flow_lut, t_ref, iwe_raw, ws, stream, counters_zeroed, false, offsets, sc);
+                           float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets) {
+    return splat_fwd_impl(s, events, flow_lut, t_ref, iwe_raw, ws, stream, counters_zeroed, false, offsets);
 }
 
 static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
-                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed, const int32_t *offsets,
-                          const mpc_side_ctx *sc) {
-    // (argument errors below return before anything is enqueued: the caller joins the side stream itself on an error)
+                          float *iwe_raw, void *ws, void *stream, int counters_zeroed, bool fixed, const int32_t *offsets) {
     MPC_CHECK_ARG(s && iwe_raw && ws && (events || s->M == 0 || s->B == 0), MPC_E_NULL, "null argument");
     MPC_CHECK_ARG((s->flags & MPC_F_NO_WARP) || flow_lut, MPC_E_NULL, "flow_lut is null");
     MPC_CHECK_ARG(!(s->flags & MPC_F_SCALE_BY_DT) || t_ref, MPC_E_NULL, "t_ref is null");
@@ -806,17 +728,9 @@ static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *
             }
             const int nloc = L.P * L.n_strips + s->nb * L.n_cstrips;
             const size_t lds = (size_t)(((3 * nloc + 1 + EV_STAGE / 2) + 3) & ~3) * sizeof(int) + (size_t)EV_STAGE * 16;
-            // (rows are deferred only where the list has room for all of them and the counters came zeroed with the KNN forward)
-            unsigned *defer = (sc && L.off_ev_defer >= 0 && (counters_zeroed & 1)) ? (unsigned *)((char *)ws + L.off_ev_defer) : nullptr;
-            if (sc && !defer && (rc = mpc_side_join(sc, MPC_EV_TAIL))) return rc;          // (no list: the LUT has to be complete first)
-            MPC_LAUNCH(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd, want_bwd ? nullptr : offsets, defer);
+            MPC_LAUNCH(k_ev_bin, grid, dim3(256), lds, st, *s, BL, events, flow_lut, t_ref, want_bwd, want_bwd ? nullptr : offsets);
             MPC_CHECK_LAUNCH();
-            if (defer) {
-                if ((rc = mpc_side_join(sc, MPC_EV_TAIL))) return rc;
-                MPC_LAUNCH(k_ev_bin_deferred, dim3(EV_DEFER_BLOCKS), dim3(256), 0, st, *s, BL, events, flow_lut, t_ref, want_bwd, defer);
-                MPC_CHECK_LAUNCH();
-            }
-        } else if (sc && (rc = mpc_side_join(sc, MPC_EV_TAIL))) return rc;
+        }
         if (L.nfb > 0) {
             if (fixed) MPC_LAUNCH(k_iwe_accum<true>, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
             else MPC_LAUNCH(k_iwe_accum<false>, dim3(L.nfb), dim3(1024), (size_t)L.strip_rows * s->W * 8, st, BL, iwe_raw, s->H, s->W);
@@ -825,7 +739,6 @@ static int splat_fwd_impl(const mpc_shape *s, const float *events, const float *
         return 0;
     }
     MPC_CHECK_ARG(!fixed, MPC_E_UNSUPPORTED, "fixed-point images need the LDS-tiled path");
-    if (sc && (rc = mpc_side_join(sc, MPC_EV_TAIL))) return rc;          // (the global-atomic path reads the finished LUT)
     const size_t img_bytes = (size_t)L.nimg * s->H * s->W * sizeof(float);
     const int e = mpc_zero_async(iwe_raw, img_bytes, st);
     if (e) return e;

@@ -76,10 +76,9 @@ __global__ __launch_bounds__(1024) void k_knn_bucket(const KnnParams p, const fl
     if (part == 0 && ls.far != nullptr) {
         if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
         for (int i = tid; i < ls.ftwords; i += 1024) ls.ftbits[(size_t)bt * ls.ftwords + i] = 0u;
-        for (int i = tid; i < ls.farbits_words; i += 1024) ls.farbits[(size_t)bt * ls.farbits_words + i] = 0u;
     }
     if (part == 0 && ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; *knn_late_count(ls) = 0; *knn_tail_done(ls) = 0; *knn_bwd_far_next(ls) = 0; }
+    if (blockIdx.x == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; *knn_late_count(ls) = 0; *knn_tail_done(ls) = 0; }
     if (blockIdx.x == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))      // (the chord table of the strip kernels' row tables)
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (blockIdx.x == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;      // (mpc_focus_fwd: the event bucket counters)
@@ -399,10 +398,9 @@ __global__ __launch_bounds__(1024) void k_knn_bucket_scan(const KnnParams p, int
     if (ls.far != nullptr) {
         if (tid == 0) ls.far[(size_t)bt * (p.G + 1)] = 0;
         for (int i = tid; i < ls.ftwords; i += 1024) ls.ftbits[(size_t)bt * ls.ftwords + i] = 0u;
-        for (int i = tid; i < ls.farbits_words; i += 1024) ls.farbits[(size_t)bt * ls.farbits_words + i] = 0u;
     }
     if (ls.again != nullptr) for (int i = tid; i < ls.again_words; i += 1024) { ls.again[(size_t)bt * ls.again_words + i] = 0u; ls.grow[(size_t)bt * ls.again_words + i] = 0u; }
-    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; *knn_late_count(ls) = 0; *knn_tail_done(ls) = 0; *knn_bwd_far_next(ls) = 0; }
+    if (bt == 0 && tid == 0) { ls.fail[0] = 0; ls.retry[0] = 0; ls.farstrip[0] = 0; if (ls.ftlist) ls.ftlist[0] = 0; *knn_marked_count(ls) = 0; *knn_late_count(ls) = 0; *knn_tail_done(ls) = 0; }
     if (bt == 0 && tid < (KNN_RFAR + 1) * (KNN_RFAR + 1))
         ls.chord[tid] = (unsigned char)max(knn_chord_cells(tid / (KNN_RFAR + 1), tid % (KNN_RFAR + 1), p.sp, p.l1 != 0), 0);
     if (bt == 0) for (int i = tid; i < zero_words; i += 1024) zero_ptr[i] = 0;
@@ -964,10 +962,11 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                                                       const float *__restrict__ tile_dkmax,
                                                       float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
                                                       float2 *__restrict__ gtraj_direct, const float *__restrict__ reach_in,
-                                                      int gx, int gy, int bd KB_STAMP_PARAM) {
+                                                      int gx, int gy, int bd, int *far_next KB_STAMP_PARAM) {
     constexpr int TS = 16;
     KB_STAMP_BEGIN
     extern __shared__ __align__(16) unsigned char s_dyn[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && far_next != nullptr) *far_next = 0;       // (k_knn_bwd_far, the next launch: its dynamic items)
     __shared__ int s_rowbase[KNN_TROWS + 1];
     __shared__ int s_rowg[KNN_TROWS];
     __shared__ float s_wr[1];
@@ -1196,7 +1195,8 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
                                                      const float *__restrict__ knn_state, const KnnLists ls,
-                                                     float2 *__restrict__ far_g, float2 *__restrict__ far_a) {
+                                                     float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
+                                                     float2 *__restrict__ gtraj_direct) {
     constexpr int NA = NEXT ? 4 : 2;
     __shared__ unsigned long long s_acc[KNN_FAR_CAP * NA];
     __shared__ float2 s_pos[KNN_FAR_CAP];
@@ -1367,12 +1367,20 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
                 if ((ay | ax | any_ | anx) == 0ll) continue;
                 const int i = (int)s_idx[li];
                 const float vy = invK * (float)((double)ay * inv_scale), vx = invK * (float)((double)ax * inv_scale);
-                // the contribution goes to this kernel's own buffer and the point's bit is set: the combine kernel adds it to what
-                // the gather wrote (a point lies in one tile and a tile is one work item: written once, no order to fix)
-                far_g[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(vy, vx);
-                if (NEXT && far_a != nullptr)
-                    far_a[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(invK * (float)((double)any_ * inv_scale), invK * (float)((double)anx * inv_scale));
-                atomicOr(ls.farbits + (size_t)bt * ls.farbits_words + (i >> 5), 1u << (i & 31));
+                if (gtraj_direct != nullptr) {
+                    float2 *dst = gtraj_direct + ((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i;
+                    const float2 o = *dst;
+                    *dst = make_float2(o.x - vy, o.y - vx);
+                } else {
+                    float2 *dst = tmp_g + (size_t)bt * p.n + i;
+                    const float2 o = *dst;
+                    *dst = make_float2(o.x + vy, o.y + vx);
+                    if (NEXT && gnext != nullptr) {
+                        float2 *da = tmp_a + (size_t)bt * p.n + i;
+                        const float2 oa = *da;
+                        *da = make_float2(oa.x + invK * (float)((double)any_ * inv_scale), oa.y + invK * (float)((double)anx * inv_scale));
+                    }
+                }
             }
             __syncthreads();
         }
@@ -1384,20 +1392,10 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
 
 // backward, step 2: one thread per (sample, trajectory point): combine the per-bin partials.
 //   d traj(t_ref)[tr] = sum_t g[t][tr];   d traj(t_mid)[t] = -sum_tr g[t][tr] - a[t] + a[t-1]
-// farbits != nullptr (the tile gather's backward): where the point's bit of a bin is set, k_knn_bwd_far wrote the far queries'
-// share of g (and a) into far_g / far_a -- it ran beside the gather -- and it is added here, as that kernel itself used to add it
-// to the gather's output: the same sum in the same order.  far_next: the far backward's item counter, zeroed for the next
-// backward of this forward (the bucket kernels zero it for the first).
-struct KnnFarAdd {
-    const unsigned *bits; int words;
-    const float2 *g, *a;
-    int *next;
-};
 __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, const float2 *__restrict__ tmp_g,
                                                          const float2 *__restrict__ tmp_a,   // nullptr: no flow_to_next term
-                                                         float *__restrict__ gtraj, const KnnFarAdd fa) {
+                                                         float *__restrict__ gtraj) {
     const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gi == 0 && fa.next != nullptr) *fa.next = 0;
     if (gi >= (size_t)p.B * p.n) return;
     const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
     float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (p.T + p.nb) * p.n;
@@ -1406,13 +1404,8 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
         float2 carry = make_float2(0.f, 0.f);
 #pragma unroll 5
         for (int t = 0; t < p.nb; ++t) {
-            float2 g = tmp_g[(size_t)(b * p.nb + t) * p.n + i];
-            float2 a = tmp_a ? tmp_a[(size_t)(b * p.nb + t) * p.n + i] : make_float2(0.f, 0.f);
-            if (fa.bits != nullptr && ((fa.bits[(size_t)(b * p.nb + t) * fa.words + (i >> 5)] >> (i & 31)) & 1u) != 0u) {
-                const float2 fg = fa.g[(size_t)(b * p.nb + t) * p.n + i];
-                g = make_float2(g.x + fg.x, g.y + fg.y);
-                if (tmp_a) { const float2 fn = fa.a[(size_t)(b * p.nb + t) * p.n + i]; a = make_float2(a.x + fn.x, a.y + fn.y); }
-            }
+            const float2 g = tmp_g[(size_t)(b * p.nb + t) * p.n + i];
+            const float2 a = tmp_a ? tmp_a[(size_t)(b * p.nb + t) * p.n + i] : make_float2(0.f, 0.f);
             sy += g.x; sx += g.y;
             g2[(size_t)(1 + t) * p.n + i] = make_float2(-g.x + carry.x - a.x, -g.y + carry.y - a.y);
             carry = a;
@@ -1444,23 +1437,16 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
 
 // num_tref == 1 without the flow_to_next term, after a k_knn_bwd_tile that wrote d traj(t_mid) in place: only
 //   d traj(t_ref)[i] = sum_t g[t][i] = sum_t -(d traj(t_mid)[t][i])    (same order, same bits: a - (-g) == a + g)
-// is left -- 15 coalesced reads and one write per point instead of 15 + 16 -- and the far queries' share where k_knn_bwd_far left one
-// (d traj(t_mid) -= share, written back).
-__global__ __launch_bounds__(256) void k_knn_bwd_combine_direct(const KnnParams p, float *__restrict__ gtraj, const KnnFarAdd fa) {
+// is left -- 15 coalesced reads and one write per point instead of 15 + 16.
+__global__ __launch_bounds__(256) void k_knn_bwd_combine_direct(const KnnParams p, float *__restrict__ gtraj) {
     const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gi == 0 && fa.next != nullptr) *fa.next = 0;
     if (gi >= (size_t)p.B * p.n) return;
     const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
     float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (1 + p.nb) * p.n;
     float sy = 0.f, sx = 0.f;
 #pragma unroll 5
     for (int t = 0; t < p.nb; ++t) {
-        float2 m = g2[(size_t)(1 + t) * p.n + i];
-        if (fa.bits != nullptr && ((fa.bits[(size_t)(b * p.nb + t) * fa.words + (i >> 5)] >> (i & 31)) & 1u) != 0u) {
-            const float2 fg = fa.g[(size_t)(b * p.nb + t) * p.n + i];
-            m = make_float2(m.x - fg.x, m.y - fg.y);
-            g2[(size_t)(1 + t) * p.n + i] = m;
-        }
+        const float2 m = g2[(size_t)(1 + t) * p.n + i];
         sy -= m.x; sx -= m.y;
     }
     g2[i] = make_float2(sy, sx);
@@ -1525,8 +1511,6 @@ static KnnLists knn_lists(const mpc_shape *s, const mpc_ws_layout &L, void *ws) 
     ls.ftlist = far ? (int *)((char *)ws + L.off_knn_ftlist) : nullptr;
     ls.ftbits = far ? (unsigned *)((char *)ws + L.off_knn_ftbits) : nullptr;
     ls.ftwords = (mpc_knn_tiles(s) + 31) / 32;
-    ls.farbits = far ? (unsigned *)((char *)ws + L.off_knn_farbits) : nullptr;
-    ls.farbits_words = (s->n + 31) / 32;
     ls.again = (unsigned *)((char *)ws + L.off_knn_again);
     ls.again_words = s->hq * ((s->wq + 31) / 32);
     ls.chord = (unsigned char *)ws + L.off_knn_chord;
@@ -1542,17 +1526,14 @@ static int set_max_lds(const void *fn, const char *who) {
 
 extern "C" int mpc_knn_lut_fwd(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next,
                                float *knn_state, int32_t *idx_out, void *ws, void *stream) {
-    return mpc_knn_lut_fwd_ex(s, traj, flow_lut, flow_next, knn_state, idx_out, ws, stream, 0, nullptr, nullptr, nullptr);
+    return mpc_knn_lut_fwd_ex(s, traj, flow_lut, flow_next, knn_state, idx_out, ws, stream, 0, nullptr, nullptr);
 }
 
 // zero_event_counters: the first kernel also zeroes the bucket counters of mpc_event_splat_fwd (mpc_focus_fwd: one launch less);
 // events (with it): the strip kernel also counts these event rows per backward bucket (ev_count_device.h).  *done receives
-// what of the two was done: bit 0 zeroed, bit 1 counted; bit 2: the tail launch went to the side stream `sc` (mpc_focus_fwd: it
-// then runs beside the event kernels; the caller joins MPC_EV_TAIL before anything reads a LUT cell that may be unfinished --
-// such cells hold KNN_LUT_PENDING until the tail has served them, knn_device.h).
+// what of the two was done: bit 0 zeroed, bit 1 counted.
 int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, float *flow_next, float *knn_state,
-                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done,
-                       const mpc_side_ctx *sc) {
+                       int32_t *idx_out, void *ws, void *stream, int zero_event_counters, const float *events, int *done) {
     if (done) *done = 0;
     MPC_CHECK_ARG(s && traj && flow_lut && knn_state && ws, MPC_E_NULL, "null argument");
     MPC_CHECK_ARG(!(s->flags & MPC_F_WANT_NEXT) || flow_next, MPC_E_NULL, "flow_next is null");
@@ -1618,11 +1599,9 @@ int mpc_knn_lut_fwd_ex(const mpc_shape *s, const float *traj, float *flow_lut, f
             MPC_LAUNCH(k_knn_sat, dim3(s->B * s->nb, (p.wb + 1 + scol - 1) / scol), dim3(KNN_SAT_NT), (size_t)((p.hb + 7) / 8) * scol * sizeof(int), st, p, cell_start, sat);
             MPC_CHECK_LAUNCH();
         }
-        // (the tail's first workgroups turn the event counts into first records, which k_ev_bin needs: no fork then)
-        const mpc_side_ctx *sct = evc.events ? nullptr : sc;
         rc = mpc_knn_strip_launch(s, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, &ls, r_init,
-                                  evc.events ? &evc : nullptr, st, sct);
-        if (!rc && done) *done = (zero_words > 0 ? 1 : 0) | (evc.events ? 2 : 0) | (sct ? 4 : 0);
+                                  evc.events ? &evc : nullptr, st);
+        if (!rc && done) *done = (zero_words > 0 ? 1 : 0) | (evc.events ? 2 : 0);
         return rc;
     }
     // everything else (num_tref > 1, idx_out wanted, K or densities the strip kernel does not hold): the tile kernel, one
@@ -1693,14 +1672,13 @@ bool mpc_knn_reach_job(const mpc_shape *s, const float *knn_state, void *ws, Knn
 extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                                const float *grad_flow_next, const float *knn_state, float *grad_traj,
                                void *ws, void *stream) {
-    return mpc_knn_lut_bwd_ex(s, traj, grad_flow_lut, grad_flow_next, knn_state, grad_traj, ws, stream, 0, nullptr);
+    return mpc_knn_lut_bwd_ex(s, traj, grad_flow_lut, grad_flow_next, knn_state, grad_traj, ws, stream, 0);
 }
 
 // reach_ready: the reaches of the tiles are in the workspace already (the event backward's kernel computed them: mpc_focus_bwd)
-// sc: the library's side stream (mpc_focus_bwd), or nullptr: everything on `stream`
 int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                        const float *grad_flow_next, const float *knn_state, float *grad_traj,
-                       void *ws, void *stream, int reach_ready, const mpc_side_ctx *sc) {
+                       void *ws, void *stream, int reach_ready) {
     MPC_CHECK_ARG(s && traj && grad_flow_lut && knn_state && grad_traj && ws, MPC_E_NULL, "null argument");
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
@@ -1738,50 +1716,40 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         // where that pays: from about four rounds of workgroups (C3: 8.2; B = 1: 0.6 -- there it would cost 3 us).
         const bool reach_launch = !reach_ready && (int64_t)gxb * gyb * s->B * s->nb >= 4 * 2048;
         const float *reach_pre = reach_ready ? reach : nullptr;
+        int *far_next = nullptr;              // (the counter of the far backward's dynamic items: zeroed by the gather's launch)
+        if (mpc_knn_uses_far_list(s)) { const KnnLists ls0 = knn_lists(s, L, ws); far_next = reinterpret_cast<int *>(ls0.chord + 896); }
         if (reach_launch) {
             const size_t rl = ((size_t)gxb * gyb * (KNN_NCLS + 1) + 16) * sizeof(float);
             if (p.l1) MPC_LAUNCH(k_knn_reach_tiles<true>, dim3(s->B * s->nb), dim3(256), rl, st, p, tile_dkmax, reach, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)));
             else MPC_LAUNCH(k_knn_reach_tiles<false>, dim3(s->B * s->nb), dim3(256), rl, st, p, tile_dkmax, reach, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)));
             reach_pre = reach;
         }
-        // The far queries' backward (the queries the forward's tail served: left out of the gather) writes into a buffer of its
-        // own -- tmp_g where the gather writes d traj(t_mid) in place, else the far_acc area -- and sets the bits of the points it
-        // wrote; the combine kernel adds it.  It depends on nothing the gather does: with a side stream (mpc_focus_bwd) it runs
-        // BESIDE the gather (an irregular, latency-bound launch -- 6 us on white noise, 45 on a UNet-like field, 400 on a 45 %
-        // contraction -- next to a kernel bound by vector-instruction issue), else before it on the same stream.
-        KnnFarAdd fa{};
+#define KB_LAUNCH(L1_, NEXT_)                                                                                            \
+        MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)), far_next KB_STAMP_ARG(ws, L))
+        if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
+        else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
+#undef KB_LAUNCH
+        MPC_CHECK_LAUNCH();
         if (mpc_knn_uses_far_list(s)) {
+            // the queries the forward's fallback kernel served (left out of the gather above)
             const KnnLists ls = knn_lists(s, L, ws);
-            float2 *far_g = direct ? tmp_g : (float2 *)((char *)ws + L.off_knn_far_acc);
-            float2 *far_a = direct ? nullptr : far_g + (size_t)s->B * s->nb * s->n;
-            fa.bits = ls.farbits; fa.words = ls.farbits_words; fa.g = far_g; fa.a = far_a;
-            fa.next = reinterpret_cast<int *>(ls.chord + 896);          // (knn_device.h: knn_bwd_far_next)
             // (no more workgroups than the list can hold items: at B = 1 a quarter of KNN_FAR_BLOCKS, and the launch usually finds
             // a few items or none)
             const long long far_items_max = (long long)s->B * s->nb * knn_tiles_x(p.wq, p.m) * knn_tiles_y(p.hq, p.m);
             const unsigned far_blocks = (unsigned)(far_items_max < KNN_FAR_BLOCKS ? (far_items_max < 1 ? 1 : far_items_max) : KNN_FAR_BLOCKS);
-            hipStream_t sf = st;
-            if (sc) { if ((rc = mpc_side_fork(sc))) return rc; sf = sc->side; }
 #define KF_LAUNCH(L1_, NEXT_)                                                                                            \
-            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), dim3(far_blocks), dim3(256), 0, sf, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
-                               knn_state, ls, far_g, far_a)
+            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), dim3(far_blocks), dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
+                               knn_state, ls, tmp_g, tmp_a, direct)
             if (p.l1) { if (grad_flow_next) KF_LAUNCH(true, true); else KF_LAUNCH(true, false); }
             else { if (grad_flow_next) KF_LAUNCH(false, true); else KF_LAUNCH(false, false); }
 #undef KF_LAUNCH
-            if (sc && (rc = mpc_side_mark(sc, MPC_EV_FAR))) return rc;
+            MPC_CHECK_LAUNCH();
         }
-#define KB_LAUNCH(L1_, NEXT_)                                                                                            \
-        MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)) KB_STAMP_ARG(ws, L))
-        if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
-        else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
-#undef KB_LAUNCH
-        if (sc && fa.bits != nullptr && (rc = mpc_side_join(sc, MPC_EV_FAR))) return rc;
-        MPC_CHECK_LAUNCH();
         const int64_t totalb = (int64_t)s->B * s->n;
-        if (direct) MPC_LAUNCH(k_knn_bwd_combine_direct, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, grad_traj, fa);
+        if (direct) MPC_LAUNCH(k_knn_bwd_combine_direct, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, grad_traj);
         else MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
-                           grad_flow_next ? tmp_a : nullptr, grad_traj, fa);
+                           grad_flow_next ? tmp_a : nullptr, grad_traj);
         MPC_CHECK_LAUNCH();
         return 0;
     }
@@ -1796,7 +1764,7 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
     MPC_CHECK_LAUNCH();
     const int64_t total = (int64_t)s->B * s->n;
     MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(total, 256)), dim3(256), 0, st, p, tmp_g,
-                       (grad_flow_next || s->T != 1 || p.iwd) ? tmp_a : nullptr, grad_traj, KnnFarAdd{});
+                       (grad_flow_next || s->T != 1 || p.iwd) ? tmp_a : nullptr, grad_traj);
     MPC_CHECK_LAUNCH();
     return 0;
 }

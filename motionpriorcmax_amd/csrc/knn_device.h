@@ -21,12 +21,6 @@
 // Layout: tile_dkmax[((b*nb + bin) * ntiles + tile) * KNN_NCLS + class].
 #define KNN_NCLS 5
 #define KNN_SLACK 0.01f   // px, absorbs fp32 rounding of the cell assignment in the ring bound
-// A LUT cell the main launch of the strip kernel did not finish (its query is marked for / listed for / part of a strip handed to
-// k_knn_tail) holds this pattern in both floats -- a quiet NaN with a payload no arithmetic produces -- until the tail has served
-// it.  mpc_focus_fwd runs the tail on the library's side stream BESIDE the event kernels: k_ev_bin leaves an event whose cell
-// reads PENDING to a second, small pass behind the join (events.hip).  If a finished cell ever held exactly this pattern, its
-// events would take that second pass too and read the same bits there: the result does not depend on the pattern being unique.
-#define KNN_LUT_PENDING 0x7fc5a5a5
 
 // The points are bucketed into a grid of cells that extends `m` cells beyond the query grid on every side (cell (y, x),
 // y in [-m, hq + m), x in [-m, wq + m): the query cells are y in [0, hq), x in [0, wq)).  Trajectory points that a flow has
@@ -72,15 +66,11 @@ int mpc_knn_margin(const mpc_shape *s);
 //                                  searches them with one more ring, 128 slots and chord-shaped rows
 //   grow     u32, same shape: of those, the ones that need more RINGS (too few candidates below the bound; far queries)
 //   chord    u8 [KNN_RFAR + 1][KNN_RFAR + 1]  chord[r][j] = knn_chord_cells(r, j): written by the bucket kernels, read by the strip kernels
-//   farbits  u32 [B*nb][ceil(n/32)] bucketed points (by trajectory index) for which k_knn_bwd_far wrote a contribution into its own
-//                                  buffer (round 6: it runs BESIDE the gather, on the library's side stream; the combine kernels add the
-//                                  contribution where the bit is set).  Zeroed by the bucket kernels; a second backward of the same
-//                                  forward sets the same bits again
 struct KnnLists {
     int *fail, *retry, *farstrip, *far, *ftlist;
-    unsigned *ftbits, *again, *grow, *farbits;
+    unsigned *ftbits, *again, *grow;
     unsigned char *chord;
-    int ftwords, again_words, farbits_words;       // words per (sample, bin)
+    int ftwords, again_words;       // words per (sample, bin)
 };
 // number of queries the main launch marked for the second one (behind the chord table, in the same 1 KB of the workspace); next to it
 // the counters of the tail kernel (k_knn_tail): queries its strip workgroups handed to its fallback workgroups -- the LATE list,
@@ -92,7 +82,7 @@ struct KnnLists {
 __device__ __forceinline__ int *knn_marked_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 512); }
 __device__ __forceinline__ int *knn_late_count(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 640); }
 __device__ __forceinline__ int *knn_tail_done(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 768); }
-__device__ __forceinline__ int *knn_bwd_far_next(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 896); }      // k_knn_bwd_far: items beyond a workgroup's first (zeroed by the bucket kernels, then by the combine kernel of every backward)
+__device__ __forceinline__ int *knn_bwd_far_next(const KnnLists &ls) { return reinterpret_cast<int *>(ls.chord + 896); }      // k_knn_bwd_far: items beyond a workgroup's first (zeroed by k_knn_bwd_tile)
 // the MARKED list: every query the main launch marks for the tail's strip workgroups is also listed (same place as the late list, the
 // end of the `fail` array downwards; its length is knn_marked_count), with the radius its search would start from.  With few marked
 // queries in the whole launch (KS_FORWARD_MAX) the tail's fallback workgroups take the marked list straight away, the strip
@@ -687,7 +677,7 @@ bool mpc_knn_uses_far_list(const mpc_shape *s);
 struct EvCountArgs;      // ev_count_device.h: event rows to count per backward bucket in spare workgroups of the strip kernel, or null
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *cell_start, const knn_cs_t *sat, const float2 *spos, const knn_idx_t *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, const KnnLists *lists, int r_init,
-                         const EvCountArgs *evc, hipStream_t st, const mpc_side_ctx *sc);
+                         const EvCountArgs *evc, hipStream_t st);
 bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc);
 
 // ------------------------------------------------------------------------------------------

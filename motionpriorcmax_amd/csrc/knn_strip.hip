@@ -371,8 +371,6 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 if (anyfar) ls.farstrip[MPC_IDX(1 + atomicAdd(&ls.farstrip[0], 1), 1 + (long long)gx * gy * p.B * p.nb)] = lblk;
             }
             if (anyfar) mark_list(isfar, (size_t)bt * p.G + (size_t)cy * p.wq + cx, r, nfq);      // (workgroup-uniform)
-            // (none of the strip's queries is served here: KNN_LUT_PENDING, knn_device.h)
-            if (valid) reinterpret_cast<float2 *>(flow_lut)[MPC_IDX(q, (long long)p.B * p.nb * p.G)] = make_float2(__int_as_float(KNN_LUT_PENDING), __int_as_float(KNN_LUT_PENDING));
             return;
         }
         overflow = true;              // even a quarter of the strip (or the far queries' region) does not fit: to the fallback list
@@ -749,10 +747,6 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
             knn_state[MPC_IDX(q, BQ)] = dK;
             reinterpret_cast<int *>(knn_state)[BQ + MPC_IDX(q, BQ)] = iK | (tie ? KNN_TIE_FLAG : 0) | ((FARK && ls.far != nullptr && knn_is_far_dk(p, dK, r_init)) ? KNN_FAR_FLAG : 0);
             KS_INBIN_STAT(knn_state, BQ, q, inbin, nsl, IWD, norm);         // (the 'mean' backward never reads the normaliser)
-        } else if (MODE == 0 && valid) {
-            // the main launch leaves this query to k_knn_tail (far, too few candidates, too many slots): its LUT cell says so until
-            // that kernel has served it (KNN_LUT_PENDING, knn_device.h)
-            reinterpret_cast<float2 *>(flow_lut)[MPC_IDX(q, (long long)p.B * p.nb * p.G)] = make_float2(__int_as_float(KNN_LUT_PENDING), __int_as_float(KNN_LUT_PENDING));
         }
         {   // queries for the fallback kernel: one atomic per wavefront reserves their places in the list
             // (main launch: a query with too few candidates below the ring bound or too many slots gets a second chance in
@@ -790,6 +784,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 const unsigned hint = ((size_t)p.B * p.nb * p.G < (1u << 24) && served) ? (unsigned)min(r, 63) << 24 : 0u;
                 const int k = base + __popcll(pm & ((1ull << lane) - 1ull));
                 if (push) fail[MPC_IDX(MODE == 0 ? 1 + (long long)k : fcap - (long long)(late_base + k), 1 + fcap)] = (int)((unsigned)q | hint | (why << 30));
+                if (MODE != 0 && lane == first) s_wsum[KS_NT / 64] = 1;      // (late list: this workgroup pushed; one fence before it counts itself done, k_knn_tail)
             }
         }
         // largest K-th distance per 16x16 tile of the bucket grid and class of query (bounds the search windows of the gather
@@ -1214,20 +1209,15 @@ __device__ __forceinline__ void fallback_entry(const KnnParams &p, const float *
 }
 
 // ------------------------------------------------------------------------------------------
-// The TAIL of the KNN forward (round 5: one launch for what rounds 2-4 did in k_knn_strip_more, then k_knn_fallback): everything the
-// main launch of the strip kernel left over.
+// The TAIL of the KNN forward, one launch (round 5; rounds 2-4: k_knn_strip_more, then k_knn_fallback): everything the main launch
+// of the strip kernel left over.
 //   workgroups [0, KS_RETRY_BLOCKS): the strip work (strip_more_body) -- overflowed strips in quarters, the far queries; what they
-//     cannot finish goes on the LATE list;
-//   workgroups [KS_RETRY_BLOCKS, + KS_FB_BLOCKS): one wavefront per query of the main launch's `fail` list (and of the marked list
-//     where the strip workgroups leave it to them) -- at once, BESIDE the strip workgroups: both halves are chains of dependent
-//     round trips at low occupancy (a work item of the far pass ~25 us on one wavefront of four, a fallback query ~14 us), side by
-//     side they cost what the longer one costs.
-// The late list is served by k_knn_late, the launch behind this one.  Round 5 had the fallback workgroups of THIS launch take it,
-// after spinning on a counter until every strip workgroup had counted itself done: that relied on the hardware dispatching the
-// workgroups of a launch in blockIdx order -- which HIP does not promise; a spinning workgroup resident before a strip workgroup
-// was scheduled would have hung the GPU -- and cost a device-wide fence per pushing workgroup plus the counting atomics.  A kernel
-// boundary orders the two halves with no assumption at all: no spin, no fence, no counter; what it costs is a launch that finds an
-// empty list on lattice-like inputs (~2 us, and on the side stream of mpc_focus_fwd nobody waits for it).
+//     cannot finish goes on the LATE list; when a workgroup is through, it counts itself done;
+//   workgroups [KS_RETRY_BLOCKS, + KS_FB_BLOCKS): one wavefront per query of the main launch's `fail` list -- at once, BESIDE the strip
+//     workgroups: both halves are chains of dependent round trips at low occupancy (a work item of the far pass ~25 us on one
+//     wavefront of four, a fallback query ~14 us), side by side they cost what the longer one costs -- then, once every strip
+//     workgroup is done (they were dispatched first and wait for nobody: no deadlock), the late list.
+// One launch instead of two for the lattice-like point sets of the benchmark, whose lists are (nearly) empty.
 // grid: KS_RETRY_BLOCKS + KS_FB_BLOCKS workgroups (the list lengths are only known on the device), 256 threads, dynamic LDS of the
 // far pass (the fallback workgroups use its first 16 KB)
 // ------------------------------------------------------------------------------------------
@@ -1239,13 +1229,23 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
                                                      float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
                                                      const KnnLists ls, int r_init, int cap, int gx, int gy, const EvCountArgs evc) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ int s_wsum[KS_NT / 64 + 1], s_wmax[KS_NT / 64];
+    __shared__ int s_wsum[KS_NT / 64 + 1], s_wmax[KS_NT / 64];      // (s_wsum[KS_NT / 64]: this strip workgroup put queries on the late list)
     __shared__ unsigned char s_rq[KS_NT / WS];
     KT_DECL
     KT_T(0);
     if ((int)blockIdx.x < KS_RETRY_BLOCKS) {
+        if (threadIdx.x == 0) s_wsum[KS_NT / 64] = 0;
+        __syncthreads();
         strip_more_body<WS, L1, NEXT, IWD>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy,
                                            (int)blockIdx.x, KS_RETRY_BLOCKS, s_dyn, s_wsum, s_wmax, s_rq);
+        // (its late-list entries go out with one device-wide fence -- an L2 write-back on this chip: only a workgroup that pushed any
+        // pays for it; 1 024 unconditional fences were 40 us of a 60 us launch, one per push 67 us of a 30 % contraction's 490 --
+        // then its count; a workgroup without work does not count: 1 024 atomics on one word were 17 us of a B = 1 launch)
+        __syncthreads();
+        if (threadIdx.x == 0 && (int)blockIdx.x < strip_more_busy(p, ls, gx, gy, KS_RETRY_BLOCKS)) {
+            if (s_wsum[KS_NT / 64]) __threadfence();
+            atomicAdd(knn_tail_done(ls), 1);
+        }
         KT_T(1); KT_T(3); KT_WRITE(ls);
         return;
     }
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
     }
     const int *fail = ls.fail;
     const int nq = p.B * p.nb * p.G;
-    const int wv = fb * 4 + (threadIdx.x >> 6), nw = KS_FB_BLOCKS * 4;
+    const int wv = fb * 4 + (threadIdx.x >> 6), nw = ((int)gridDim.x - KS_RETRY_BLOCKS) * 4;
     const int nfail = min(fail[0], nq);
     // ... and the marked list, where the strip workgroups leave it to us (written by the main launch: complete): one round-robin over
     // both, so that with two short lists no wavefront takes an entry of each, one behind the other
@@ -1267,34 +1267,21 @@ __global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_tail(const KnnParams
     for (int i = wv; i < nfail + nmark; i += nw)
         fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
                            (unsigned)fail[MPC_IDX(i < nfail ? 1 + i : nq - (i - nfail), 1 + (long long)nq)], nq, r_init, s_comp);
-    KT_T(1); KT_COUNT(4, (nfail + nmark - wv + nw - 1) / nw); KT_T(3); KT_WRITE(ls);
-}
-
-// The LATE list -- what the strip workgroups of k_knn_tail could not finish -- one wavefront per query, in a launch of its own behind
-// that kernel (see there).  Thread 0 of the launch also leaves the number of strip workgroups that had work where round 5's "done"
-// counter was (diagnostics: mpc_knn_tail_counters_offset + 256).
-// grid: KS_FB_BLOCKS workgroups, 256 threads, dynamic LDS 16 KB
-template <bool L1>
-__global__ __launch_bounds__(KS_NT, KS_MORE_OCC) void k_knn_late(const KnnParams p, const float *__restrict__ traj,
-                                                     const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
-                                                     const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
-                                                     float *__restrict__ flow_lut, float *__restrict__ flow_next,
-                                                     float *__restrict__ knn_state, float *__restrict__ tile_dkmax,
-                                                     const KnnLists ls, int r_init, int gx, int gy) {
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    float4 (*s_comp)[256] = reinterpret_cast<float4 (*)[256]>(s_dyn);
+    // the late list: complete once every strip workgroup has counted itself done
+    // (counter, list length and entries are read with device-scope atomic loads, which do not hit a stale line of this XCD's L2:
+    // no acquire fence -- an L2 invalidate per wavefront)
+    KT_T(1); KT_COUNT(4, (nfail + nmark - wv + nw - 1) / nw);
     const int busy = strip_more_busy(p, ls, gx, gy, KS_RETRY_BLOCKS);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *knn_tail_done(ls) = busy;
-    if (busy == 0) return;                                   // (no strip work at all: no late list either)
-    const int *fail = ls.fail;
-    const int nq = p.B * p.nb * p.G;
-    const int wv = (int)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int)gridDim.x * 4;
-    const int nfail = min(fail[0], nq);
-    const int nmark = strip_forward(ls) ? min(*knn_marked_count(ls), nq - nfail) : 0;
-    const int nlate = min(*knn_late_count(ls), nq - nfail - nmark);
+    if (busy == 0) { KT_T(3); KT_WRITE(ls); return; }            // (no strip work at all: no late list either)
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(knn_tail_done(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < busy) __builtin_amdgcn_s_sleep(64);
+    __syncthreads();
+    KT_T(2);
+    const int nlate = min(__hip_atomic_load(knn_late_count(ls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq - nfail - nmark);
     for (int i = wv; i < nlate; i += nw)
         fallback_entry<L1>(p, traj, cell_start, sat, spos, sidx, flow_lut, flow_next, knn_state, tile_dkmax, ls,
-                           (unsigned)fail[MPC_IDX(nq - nmark - i, 1 + (long long)nq)], nq, r_init, s_comp);
+                           (unsigned)__hip_atomic_load(&fail[MPC_IDX(nq - nmark - i, 1 + (long long)nq)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nq, r_init, s_comp);
+    KT_COUNT(5, (nlate - wv + nw - 1) / nw); KT_T(3); KT_WRITE(ls);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1338,9 +1325,30 @@ bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc) {
     return (size_t)evc->nb * evc->NCS * sizeof(int) <= lds && evc->B <= 256;
 }
 
+// Fallback workgroups of a tail launch: as many as KS_FB_BLOCKS, but at least one workgroup slot per CU fewer than the chip holds
+// workgroups of this kernel at once (see k_knn_tail: a fallback workgroup may spin until the strip workgroups are done, and those
+// must always find a free slot), and no fewer than `min_fb` (the event-count prefix of mpc_focus_fwd rides in the first B of them).
+static int tail_fallback_blocks(const void *kernel, size_t lds_tail, int min_fb) {
+    int dev = 0, ncu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KS_NT, lds_tail) != hipSuccess) {
+        (void)hipGetLastError();
+        mpc_set_error("mpc_knn_strip_launch: occupancy query failed");
+        return MPC_E_UNSUPPORTED;
+    }
+    const long long slots = (long long)ncu * per_cu;
+    long long fb = slots - ncu;
+    if (fb > KS_FB_BLOCKS) fb = KS_FB_BLOCKS;
+    if (fb < 64 || fb < min_fb) {
+        mpc_set_error("mpc_knn_strip_launch: %d workgroup(s) of the tail kernel per CU on %d CUs leave no room for its fallback workgroups", per_cu, ncu);
+        return MPC_E_UNSUPPORTED;
+    }
+    return (int)fb;
+}
+
 int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *cell_start, const knn_cs_t *sat, const float2 *spos, const knn_idx_t *sidx,
                          float *flow_lut, float *flow_next, float *knn_state, float *tile_dkmax, const KnnLists *lists, int r_init,
-                         const EvCountArgs *evc, hipStream_t st, const mpc_side_ctx *sc) {
+                         const EvCountArgs *evc, hipStream_t st) {
     const KnnParams p = knn_params(s);
     const KnnLists ls = *lists;
     int cap = 0; size_t lds = 0, lds_far = 0;
@@ -1362,17 +1370,11 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *
     do {                                                                                                                  \
         MPC_LAUNCH((k_knn_strip<WS, L1_, NEXT_, IWD_>), grid, dim3(KS_NT), lds, st, p, traj, cell_start, sat, spos, sidx, \
                            flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy, ec, n_evc, evc_stride);   \
-        if (sc && (fork_rc = mpc_side_fork(sc))) break;                                                                   \
-        MPC_LAUNCH((k_knn_tail<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS + KS_FB_BLOCKS), dim3(KS_NT), lds_tail, st_tail, p, traj, cell_start, sat, spos, sidx, \
+        const int fb_ = tail_fallback_blocks((const void *)k_knn_tail<WS, L1_, NEXT_, IWD_>, lds_tail, ec.events ? ec.B : 0); \
+        if (fb_ < 0) return fb_;                                                                                          \
+        MPC_LAUNCH((k_knn_tail<WS, L1_, NEXT_, IWD_>), dim3(KS_RETRY_BLOCKS + fb_), dim3(KS_NT), lds_tail, st, p, traj, cell_start, sat, spos, sidx, \
                            flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, cap, gx, gy, ec);                      \
-        MPC_LAUNCH((k_knn_late<L1_>), dim3(KS_FB_BLOCKS), dim3(KS_NT), 4 * 256 * sizeof(float4), st_tail, p, traj, cell_start, sat, spos, sidx, \
-                           flow_lut, flow_next, knn_state, tile_dkmax, ls, r_init, gx, gy);                               \
-        if (sc) fork_rc = mpc_side_mark(sc, MPC_EV_TAIL);                                                                 \
     } while (0)
-    // sc: the tail launch goes to the library's side stream behind an event on `st` (mpc_focus_fwd: the event kernels run
-    // beside it; MPC_EV_TAIL is recorded behind it for the caller to join)
-    hipStream_t st_tail = sc ? sc->side : st;
-    int fork_rc = 0;
     switch ((p.l1 ? 4 : 0) | (p.want_next ? 2 : 0) | (p.iwd ? 1 : 0)) {
     case 0: KS_LAUNCH(false, false, false); break;
     case 1: KS_LAUNCH(false, false, true); break;
@@ -1384,7 +1386,6 @@ int mpc_knn_strip_launch(const mpc_shape *s, const float *traj, const knn_cs_t *
     default: KS_LAUNCH(true, true, true); break;
     }
 #undef KS_LAUNCH
-    if (fork_rc) return fork_rc;
     MPC_CHECK_LAUNCH();
     return 0;
 }

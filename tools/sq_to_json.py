@@ -22,6 +22,10 @@ def main():
         out[name] = {'valu_insts': float(r['SQ_INSTS_VALU']), 'waves': float(r['SQ_WAVES']), 'kernel_us': ks[name],
                      'valu_per_wave': float(r['valu_per_wave'] or 0), 'wait_any_frac': float(r['wait_any_frac'] or 0),
                      'wait_inst_frac': float(r['wait_inst_frac'] or 0), 'lds_per_wave': float(r['lds_per_wave'] or 0)}
+        # (round 6) vector instructions by class (third PMC pass of tools/sq_profile.sh): what tools/valu_floor.py prices
+        mix = {c[len('SQ_INSTS_VALU_'):]: float(r[c]) for c in r if c.startswith('SQ_INSTS_VALU_') and r[c] not in ('', None)}
+        if mix:
+            out[name]['valu_mix'] = mix
         # share of the kernel's cycles in which a CU's LDS was busy (SQ_BUSY_CYCLES is summed over the 32 shader engines of 8 CUs
         # each, SQ_LDS_IDX_ACTIVE over the CUs), and the share of those cycles that were bank-conflict cycles
         busy, act = float(r.get('SQ_BUSY_CYCLES') or 0), float(r.get('SQ_LDS_IDX_ACTIVE') or 0)
