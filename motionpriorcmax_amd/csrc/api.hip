@@ -345,12 +345,10 @@ extern "C" int mpc_focus_bwd(const mpc_shape *s, const mpc_focus_buffers *io, co
     int rc = mpc_event_splat_bwd_job(s, io->events, io->event_offsets, io->flow_lut, io->t_ref, io->grad_iwe, io->scal, grad_out,
                                      grad_lut_scratch, (smooth && !on_next) ? io->smooth_grad : nullptr, ws, stream, io->knn_state, &reach_done);
     if (rc) return rc;
-    const float *g_next = nullptr;
-    if (smooth && on_next && s->nb > 1) {
-        MPC_CHECK_ARG(grad_next_scratch, MPC_E_NULL, "grad_next_scratch is null");
-        const int64_t cnt = (int64_t)s->B * (s->nb - 1) * s->hq * s->wq * 2;
-        if (grad_out) { if ((rc = mpc_scale(io->smooth_grad, grad_out, grad_next_scratch, cnt, stream))) return rc; g_next = grad_next_scratch; }
-        else g_next = io->smooth_grad;
-    }
-    return mpc_knn_lut_bwd_ex(s, io->traj, grad_lut_scratch, g_next, io->knn_state, grad_traj, ws, stream, reach_done);
+    // (smoothness on flow_to_next: dL/dflow_next = grad_out * the saved smoothness gradient -- the KNN backward's kernels multiply as
+    // they read it, no pass over the field)
+    const bool next_grad = smooth && on_next && s->nb > 1;
+    MPC_CHECK_ARG(!next_grad || !grad_out || grad_next_scratch, MPC_E_NULL, "grad_next_scratch is null");
+    return mpc_knn_lut_bwd_ex(s, io->traj, grad_lut_scratch, next_grad ? io->smooth_grad : nullptr, io->knn_state, grad_traj, ws, stream, reach_done,
+                              next_grad ? grad_out : nullptr, grad_next_scratch);
 }

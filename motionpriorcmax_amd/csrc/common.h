@@ -112,7 +112,8 @@ int mpc_event_splat_bwd_job(const mpc_shape *s, const float *events, const int32
                             const float *grad_out, float *grad_flow_lut, const float *add_term,
                             void *ws, void *stream, const float *knn_state, int *reach_done);
 int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut, const float *grad_flow_next,
-                       const float *knn_state, float *grad_traj, void *ws, void *stream, int reach_ready);
+                       const float *knn_state, float *grad_traj, void *ws, void *stream, int reach_ready,
+                       const float *gnext_scale, float *gnext_scratch);
 int mpc_event_splat_fwd_ex(const mpc_shape *s, const float *events, const float *flow_lut, const float *t_ref,
                            float *iwe_raw, void *ws, void *stream, int counters_zeroed, const int32_t *offsets);
 int mpc_validate_shape(const mpc_shape *s);

@@ -825,10 +825,14 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
 
 // window loop of k_knn_bwd_tile, CW columns wide (fully unrolled: the squared column offsets live in registers).
 // Membership is `d <= K-th distance` (callers: no excluded tie among the staged queries).
-template <int CW, bool L1, bool NEXT>
+// IWD ('iwd' interpolation, focus.py:155-163; round 6): a member's weight is (1 / (d + 1e-9)) / normaliser of the query instead of
+// 1 / K -- lwn holds the normalisers, and the weight is the membership flag times ONE hardware reciprocal of (d + 1e-9) * normaliser
+// (v_rcp_f32: 1 ulp; the two IEEE divisions of the formula as written are ~20 instructions per visited cell in a loop of 6, and the
+// weights are constants of the backward: their rounding is a relative 2e-7 of the gradient).  The flow_to_next term stays a mean.
+template <int CW, bool L1, bool NEXT, bool IWD>
 __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2 pt, int x0, int y0, int nxw, int nyw, int nymax,
                                                 int ry0, int RW, int RP, int xb, const float *ldk, const float2 *lg,
-                                                const float2 *lgn, float &ay, float &ax, float2 &an) {
+                                                const float2 *lgn, const float *lwn, float &ay, float &ax, float2 &an) {
     float dx2[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
@@ -841,7 +845,7 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
         const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
         const int ro = __mul24(cyr - ry0, RP) + xb;
         MPC_EXPECT(ro >= 0 && ro + CW <= RW * RP + 16);          // (every lane reads CW cells of the row: the slack behind the last row is there for that)
-        const float *rdk = ldk + ro;
+        const float *rdk = ldk + ro, *rwn = lwn + ro;
         const float2 *rg = lg + ro, *rown = lgn + ro;
         // The gradients as ONE ds_read_b64 each (knn_lds_f2: a volatile load the compiler may not pair).  Left alone it pairs
         // the reads of neighbouring cells into ds_read2_b64, which the LDS serves at half the rate of two single reads (8
@@ -853,13 +857,14 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += KNN_BW_CH) {
             float2 e[KNN_BW_CH], gq[KNN_BW_CH];
-            float dkc[KNN_BW_CH];
+            float dkc[KNN_BW_CH], wnc[KNN_BW_CH];
 #pragma unroll
             for (int c = 0; c < KNN_BW_CH; ++c) {
                 if (c0 + c < CW) {
                     e[c] = knn_lds_f2(rg + c0 + c);
                     if (NEXT) gq[c] = knn_lds_f2(rown + c0 + c);
                     dkc[c] = rdk[c0 + c];
+                    if (IWD) wnc[c] = rwn[c0 + c];
                 }
             }
 #pragma unroll
@@ -872,7 +877,11 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
                     // this chip issues at twice the rate of the compare + select they replace (profiles/r02_ubench_valu_rate.txt).
                     const float d = dy2 + dx2[c0 + c];
                     const float w = fminf(fmaxf(fmaf(dkc[c] - d, 0x1p100f, 1.f), 0.f), 1.f);
-                    ay = fmaf(w, e[c].x, ay); ax = fmaf(w, e[c].y, ax);
+                    if (IWD) {
+                        // (d = inf beyond the window: the reciprocal is 0; a cell that is no query holds normaliser 1)
+                        const float wi = w * __builtin_amdgcn_rcpf((d + 1e-9f) * wnc[c]);
+                        ay = fmaf(wi, e[c].x, ay); ax = fmaf(wi, e[c].y, ax);
+                    } else { ay = fmaf(w, e[c].x, ay); ax = fmaf(w, e[c].y, ax); }
                     if (NEXT) { an.x = fmaf(w, gq[c].x, an.x); an.y = fmaf(w, gq[c].y, an.y); }
                 }
             }
@@ -954,15 +963,15 @@ __global__ __launch_bounds__(256) void k_knn_reach_tiles(const KnnParams p, cons
     knn_reach_slice<L1>(p, tile_dkmax, reach, blockIdx.x, gx, gy, bd, s_reach_mem);
 }
 
-template <bool L1, bool NEXT>
-__global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
+template <bool L1, bool NEXT, bool IWD>
+__global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
                                                       const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                       const float *__restrict__ glut, const float *__restrict__ gnext,
                                                       const float *__restrict__ knn_state,
                                                       const float *__restrict__ tile_dkmax,
                                                       float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
                                                       float2 *__restrict__ gtraj_direct, const float *__restrict__ reach_in,
-                                                      int gx, int gy, int bd, int *far_next KB_STAMP_PARAM) {
+                                                      int gx, int gy, int bd, int *far_next, const float *__restrict__ gnext_scale KB_STAMP_PARAM) {
     constexpr int TS = 16;
     KB_STAMP_BEGIN
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -1008,11 +1017,14 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     // ---- phase 2 (after the reach is known; staging a guessed halo before it, so that the loads of the two phases
     //      travel together, measured slower: too many tiles stage twice): the K-th distance, K-th index | tie flag and
     //      dL/dLUT of the tile's query cells and the halo the reach asks for ------------------------------------------
-    float *ldk; int *lik; float2 *lg, *lgn;
+    float *ldk, *lwn; float2 *lg, *lgn;
     int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS, rx0 = bx_ * TS;
     const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
     const float2 *gl2 = reinterpret_cast<const float2 *>(glut) + (size_t)bt * p.G;
+    // gnext_scale (mpc_focus_bwd): dL/dflow_next = grad_out * the smoothness gradient, multiplied as the cells are read -- the values
+    // a pass of mpc_scale over the whole field would have written (round 5: 16 us of a C4 batch-6 step), bit for bit
+    const float gns = (NEXT && gnext_scale != nullptr) ? gnext_scale[0] : 1.f;
     auto stage = [&]() {
         RW = TS + 2 * RQ;
         // Row pitch of the staged arrays.  The window loop reads one K-th distance (4 bytes) and one gradient (8 bytes) per
@@ -1022,44 +1034,55 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
         // put consecutive rows 16 banks (4-byte array: 32 banks) resp. 32 banks (8-byte array: 64 banks) apart: no conflict.
         // The K-th INDEX (only read on the exact path, for a tie) stays in global memory then, which keeps the workgroup
         // at 19.5 KB -- eight per CU as before.  With the flow_to_next gradient (8 more bytes per cell) the pitch stays 32.
-        RP = NEXT ? (RW <= 32 ? 32 : RW) : KNN_BW_PITCH;
+        // With the flow_to_next gradient (20 bytes per cell; the allocation holds (16 + 2 KNN_RQ_MAX)^2 cells: six workgroups per
+        // CU) the pitch is the widest conflict-free one the tile's own region leaves room for: 48 up to a halo of 4 cells -- nearly
+        // every tile --, 40 up to 6, else the region's width (round 6; a fixed 32 before: the 2-way conflict of round 2).
+        if (NEXT) {
+            constexpr int CELLS = (TS + 2 * KNN_RQ_MAX) * (TS + 2 * KNN_RQ_MAX);
+            RP = (RW * 48 <= CELLS) ? 48 : ((RW * 40 <= CELLS) ? 40 : (RW <= KNN_BW_PITCH_NEXT ? KNN_BW_PITCH_NEXT : RW));
+        } else RP = KNN_BW_PITCH;
         ry0 = by_ * TS - RQ; rx0 = bx_ * TS - RQ;
         // separate arrays (the hot loop reads the K-th distance and the gradient only; neighbouring lanes then read
         // neighbouring 4- and 8-byte words): K-th distance, [K-th index,] dL/dLUT, [dL/dflow_next]
         const size_t ncell = (size_t)RW * RP + KNN_BW_WMAX;
         ldk = reinterpret_cast<float *>(s_dyn);
         if (NEXT) {
-            lik = reinterpret_cast<int *>(s_dyn + ncell * 4);
-            lg = reinterpret_cast<float2 *>(s_dyn + ncell * 8);
-            lgn = reinterpret_cast<float2 *>(s_dyn + ncell * 16);
+            // (the K-th INDEX -- read on the exact path only, for a tie -- stays in global memory here too, round 6: 20 bytes per cell
+            // instead of 24, one workgroup more per CU)
+            lg = reinterpret_cast<float2 *>(s_dyn + ncell * 4);
+            lgn = reinterpret_cast<float2 *>(s_dyn + ncell * 12);
         } else {
-            lik = nullptr; lgn = nullptr;
+            lgn = nullptr;
             lg = reinterpret_cast<float2 *>(s_dyn + ncell * 4);          // (ncell is even: 8-byte aligned)
         }
+        lwn = IWD ? reinterpret_cast<float *>(s_dyn + ncell * (NEXT ? 20 : 12)) : nullptr;      // 'iwd': the queries' normalisers
         int tie = 0;
         for (int rr = tid >> 5; rr < RW; rr += 8) {
             const int yy = ry0 + rr;
             for (int cc = tid & 31; cc < RP; cc += 32) {          // (columns RW..RP-1: padding, never a member)
                 const int xx = rx0 + cc;
-                float dk = -1.f; int ik = -1;
+                float dk = -1.f, wn = 1.f; int ik = -1;
                 float2 g = make_float2(0.f, 0.f), gn = make_float2(0.f, 0.f);
                 if (cc < RW && yy >= 0 && yy < p.hq && xx >= 0 && xx < p.wq) {
                     const size_t q = (size_t)bt * p.G + (size_t)yy * p.wq + xx;
                     dk = knn_state[q];
                     ik = reinterpret_cast<const int *>(knn_state)[BQ + q];
+                    if (IWD) wn = knn_state[2 * BQ + q];
                     g = gl2[(size_t)yy * p.wq + xx];
-                    if (has_next) gn = gn2[(size_t)yy * p.wq + xx];
+                    if (has_next) { gn = gn2[(size_t)yy * p.wq + xx]; if (gnext_scale != nullptr) gn = make_float2(gn.x * gns, gn.y * gns); }
                     if (ik & KNN_FAR_FLAG) dk = -1.f;        // served by the fallback kernel: k_knn_bwd_far adds its gradient
                     else tie |= ik & KNN_TIE_FLAG;
                     ik &= KNN_IDX_MASK;
                 }
                 ldk[MPC_IDX(rr * RP + cc, ncell)] = dk; lg[MPC_IDX(rr * RP + cc, ncell)] = g;
-                if (NEXT) { lik[MPC_IDX(rr * RP + cc, ncell)] = ik; lgn[MPC_IDX(rr * RP + cc, ncell)] = gn; }
+                if (NEXT) lgn[MPC_IDX(rr * RP + cc, ncell)] = gn;
+                if (IWD) lwn[MPC_IDX(rr * RP + cc, ncell)] = (dk >= 0.f) ? wn : 1.f;
             }
         }
         if (tid < KNN_BW_WMAX) {                    // slack behind the last row: never a member
             ldk[MPC_IDX(RW * RP + tid, ncell)] = -1.f; lg[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f);
-            if (NEXT) { lik[MPC_IDX(RW * RP + tid, ncell)] = -1; lgn[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f); }
+            if (NEXT) lgn[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f);
+            if (IWD) lwn[MPC_IDX(RW * RP + tid, ncell)] = 1.f;
         }
         const bool wt = __ballot(tie != 0) != 0ull;
         if ((tid & 63) == 0) s_tiew[tid >> 6] = wt ? 1 : 0;
@@ -1078,6 +1101,7 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
     KB_STAMP_MID
     const int total = s_rowbase[nrow];
     const float invK = 1.f / (float)p.K, inv_sp = 1.f / (float)p.sp;
+    const float wK = IWD ? 1.f : invK;                 // ('iwd': the weights are in the sums already)
     const float2 *sp_ = spos + (size_t)bt * p.n;
     const knn_idx_t *si_ = sidx + (size_t)bt * p.n;
     for (int base = 0; base < total; base += 256) {
@@ -1113,13 +1137,13 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                 // windows wider than 8 columns (border tiles: clipped queries reach twice as far) go in two column chunks, 8 +
                 // 2 / 5 / 8: the squared column offsets of 16 columns, live across the row loop, do not fit the 64-register
                 // budget beside the single-read form of the gradient loads (bwd_window_fast)
-                if (nxmax <= 7) bwd_window_fast<7, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                if (nxmax <= 7) bwd_window_fast<7, L1, NEXT, IWD>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, lwn, ay, ax, an);
                 else {
-                    bwd_window_fast<8, L1, NEXT>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
+                    bwd_window_fast<8, L1, NEXT, IWD>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, lwn, ay, ax, an);
                     if (nxmax > 8) {
-                        if (nxmax <= 10) bwd_window_fast<2, L1, NEXT>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
-                        else if (nxmax <= 13) bwd_window_fast<5, L1, NEXT>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
-                        else bwd_window_fast<8, L1, NEXT>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
+                        if (nxmax <= 10) bwd_window_fast<2, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, lwn, ay, ax, an);
+                        else if (nxmax <= 13) bwd_window_fast<5, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, lwn, ay, ax, an);
+                        else bwd_window_fast<8, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, lwn, ay, ax, an);
                     }
                 }
             } else if (act) {
@@ -1134,11 +1158,11 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                         const float d = dy2 + (L1 ? fabsf(dx) : dx * dx);
                         const float dk = ldk[MPC_IDX(ro + cx, (long long)RW * RP + KNN_BW_WMAX)];
                         // (the K-th index: staged only with the flow_to_next gradient, else read where it lives -- a tie is rare)
-                        const bool in = (d < dk) || (d == dk && i <= (NEXT ? lik[ro + cx]
-                                                                            : (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & KNN_IDX_MASK)));
+                        const bool in = (d < dk) || (d == dk && i <= (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & KNN_IDX_MASK));
                         if (in) {
                             const float2 e = lg[ro + cx];
-                            ay += e.x; ax += e.y;
+                            if (IWD) { const float wi = __builtin_amdgcn_rcpf((d + 1e-9f) * lwn[ro + cx]); ay = fmaf(wi, e.x, ay); ax = fmaf(wi, e.y, ax); }
+                            else { ay += e.x; ax += e.y; }
                             if (NEXT) { const float2 gq = lgn[ro + cx]; an.x += gq.x; an.y += gq.y; }
                         }
                     }
@@ -1156,8 +1180,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
                     const int ikf = reinterpret_cast<const int *>(knn_state)[BQ + q];
                     if ((ikf & KNN_FAR_FLAG) || (d == dk && i > (ikf & KNN_IDX_MASK))) continue;
                     const float2 gq = gl2[(size_t)cy * p.wq + cx];
-                    ay += gq.x; ax += gq.y;
-                    if (has_next) { const float2 gnq = gn2[(size_t)cy * p.wq + cx]; an.x += gnq.x; an.y += gnq.y; }
+                    if (IWD) { const float wi = __builtin_amdgcn_rcpf((d + 1e-9f) * knn_state[2 * BQ + q]); ay = fmaf(wi, gq.x, ay); ax = fmaf(wi, gq.y, ax); }
+                    else { ay += gq.x; ax += gq.y; }
+                    if (has_next) { float2 gnq = gn2[(size_t)cy * p.wq + cx]; if (gnext_scale != nullptr) gnq = make_float2(gnq.x * gns, gnq.y * gns); an.x += gnq.x; an.y += gnq.y; }
                 }
             }
         }
@@ -1165,9 +1190,9 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
             // no flow_to_next term: d traj(t_mid)[t] = -g goes straight to its place in the trajectory gradient (the value
             // k_knn_bwd_combine would write: -g + 0 - 0); k_knn_bwd_combine_direct then only adds the bins up
             if (gtraj_direct != nullptr)
-                gtraj_direct[MPC_IDX(((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i, (long long)p.B * (p.T + p.nb) * p.n)] = make_float2(-(invK * ay) + 0.f, -(invK * ax) + 0.f);
+                gtraj_direct[MPC_IDX(((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i, (long long)p.B * (p.T + p.nb) * p.n)] = make_float2(-(wK * ay) + 0.f, -(wK * ax) + 0.f);
             else {
-                tmp_g[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(invK * ay, invK * ax);
+                tmp_g[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(wK * ay, wK * ax);
                 if (gnext != nullptr) tmp_a[MPC_IDX((size_t)bt * p.n + i, (long long)p.B * p.nb * p.n)] = make_float2(invK * an.x, invK * an.y);
             }
         }
@@ -1190,14 +1215,15 @@ __global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_kn
 // the benchmark have a few hundred items per step)
 // ------------------------------------------------------------------------------------------
 #define KNN_FAR_CAP 640       // points of a tile per round of accumulators (a border tile with its margin cells: 24 x 24)
-template <bool L1, bool NEXT>
+template <bool L1, bool NEXT, bool IWD>
 __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                      const float *__restrict__ glut, const float *__restrict__ gnext,
                                                      const float *__restrict__ knn_state, const KnnLists ls,
                                                      float2 *__restrict__ tmp_g, float2 *__restrict__ tmp_a,
-                                                     float2 *__restrict__ gtraj_direct) {
+                                                     float2 *__restrict__ gtraj_direct, const float *__restrict__ gnext_scale) {
     constexpr int NA = NEXT ? 4 : 2;
+    const float gns = (NEXT && gnext_scale != nullptr) ? gnext_scale[0] : 1.f;          // (see k_knn_bwd_tile)
     __shared__ unsigned long long s_acc[KNN_FAR_CAP * NA];
     __shared__ float2 s_pos[KNN_FAR_CAP];
     __shared__ unsigned short s_idx[KNN_FAR_CAP];
@@ -1209,6 +1235,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
     __shared__ int2 s_qc[KNN_FAR_QB];                      // K-th distance, gradient(s) in fixed point
     __shared__ float s_qd[KNN_FAR_QB];
     __shared__ longlong2 s_qg[KNN_FAR_QB * (NA / 2)];
+    __shared__ float4 s_qf[IWD ? KNN_FAR_QB : 1];          // 'iwd': the gradient as floats and the query's normaliser (the weight differs per member)
     const int tid = threadIdx.x;
     const int ntx = knn_tiles_x(p.wq, p.m), nty = knn_tiles_y(p.hq, p.m), nt = ntx * nty;
     const int nwork = min(ls.ftlist[0], p.B * p.nb * nt);
@@ -1265,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
                 if (cellv[u] < 0) continue;
                 const float2 g = gl2[cellv[u]];
                 gm = fmaxf(gm, fmaxf(fabsf(g.x), fabsf(g.y)));
-                if (has_next) { const float2 gn = gn2[cellv[u]]; gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
+                if (has_next) { float2 gn = gn2[cellv[u]]; if (gnext_scale != nullptr) gn = make_float2(gn.x * gns, gn.y * gns); gm = fmaxf(gm, fmaxf(fabsf(gn.x), fabsf(gn.y))); }
             }
         }
 #pragma unroll
@@ -1316,11 +1343,13 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
                 if ((L1 ? gy_ + gx_ : gy_ * gy_ + gx_ * gx_) > dk) continue;
                 const int ik = iks[cell] & KNN_IDX_MASK;
                 const float2 g = gl2[cell];
-                const float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
+                float2 gn = has_next ? gn2[cell] : make_float2(0.f, 0.f);
+                if (has_next && gnext_scale != nullptr) gn = make_float2(gn.x * gns, gn.y * gns);
                 const int k = atomicAdd(&s_nq, 1);
                 s_qc[k] = make_int2(cell, ik);
                 s_qd[k] = dk;
                 s_qg[k * (NA / 2) + 0] = make_longlong2(__double2ll_rn((double)g.x * scale), __double2ll_rn((double)g.y * scale));
+                if (IWD) s_qf[k] = make_float4(g.x, g.y, knn_state[2 * BQ + (size_t)bt * p.G + cell], 0.f);
                 if (NEXT) s_qg[k * (NA / 2) + 1] = make_longlong2(__double2ll_rn((double)gn.x * scale), __double2ll_rn((double)gn.y * scale));
               }
               __syncthreads();
@@ -1350,8 +1379,17 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
                     const float2 pj = s_pos[li];
                     const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
                     if (d > dk || (d == dk && (int)s_idx[li] > ik)) continue;
-                    atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fg.x);
-                    atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fg.y);
+                    if (IWD) {
+                        // the member's weight as the formula has it (focus.py:159-161): (1 / (d + 1e-9)) / sum -- at most 1, so the
+                        // fixed-point scale of the largest gradient still holds
+                        const float4 qf = s_qf[qi];
+                        const float wgt = (1.f / (d + 1e-9f)) / qf.z;
+                        atomicAdd(&s_acc[li * NA + 0], (unsigned long long)__double2ll_rn((double)(wgt * qf.x) * scale));
+                        atomicAdd(&s_acc[li * NA + 1], (unsigned long long)__double2ll_rn((double)(wgt * qf.y) * scale));
+                    } else {
+                        atomicAdd(&s_acc[li * NA + 0], (unsigned long long)fg.x);
+                        atomicAdd(&s_acc[li * NA + 1], (unsigned long long)fg.y);
+                    }
                     if (NEXT && has_next) {
                         const longlong2 fn = s_qg[qi * (NA / 2) + 1];
                         atomicAdd(&s_acc[li * NA + 2], (unsigned long long)fn.x); atomicAdd(&s_acc[li * NA + 3], (unsigned long long)fn.y);
@@ -1366,7 +1404,8 @@ __global__ __launch_bounds__(256) void k_knn_bwd_far(const KnnParams p, const kn
                 const long long any_ = NEXT ? (long long)s_acc[li * NA + 2] : 0ll, anx = NEXT ? (long long)s_acc[li * NA + 3] : 0ll;
                 if ((ay | ax | any_ | anx) == 0ll) continue;
                 const int i = (int)s_idx[li];
-                const float vy = invK * (float)((double)ay * inv_scale), vx = invK * (float)((double)ax * inv_scale);
+                const float wKf = IWD ? 1.f : invK;              // ('iwd': the weights are in the sums)
+                const float vy = wKf * (float)((double)ay * inv_scale), vx = wKf * (float)((double)ax * inv_scale);
                 if (gtraj_direct != nullptr) {
                     float2 *dst = gtraj_direct + ((size_t)b * (p.T + p.nb) + 1 + t) * p.n + i;
                     const float2 o = *dst;
@@ -1477,7 +1516,7 @@ static bool knn_fwd_is_strip(const mpc_shape *s, const int32_t *idx_out) {
 }
 // true where the backward of this shape is k_knn_bwd_tile + k_knn_bwd_far (the gather with per-tile reaches)
 static bool knn_bwd_is_tile(const mpc_shape *s) {
-    return s->B > 0 && s->T == 1 && !((s->flags & MPC_F_SCHEME_IWD) && s->K > 1);
+    return s->B > 0 && s->T == 1;          // (round 6: 'iwd' too -- the gather weights a member by its distance)
 }
 // the fallback kernel lists the queries it served for k_knn_bwd_far (and keeps them out of the tile maxima)
 bool mpc_knn_uses_far_list(const mpc_shape *s) { return knn_bwd_is_tile(s) && knn_fwd_is_strip(s, nullptr); }
@@ -1672,17 +1711,25 @@ bool mpc_knn_reach_job(const mpc_shape *s, const float *knn_state, void *ws, Knn
 extern "C" int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                                const float *grad_flow_next, const float *knn_state, float *grad_traj,
                                void *ws, void *stream) {
-    return mpc_knn_lut_bwd_ex(s, traj, grad_flow_lut, grad_flow_next, knn_state, grad_traj, ws, stream, 0);
+    return mpc_knn_lut_bwd_ex(s, traj, grad_flow_lut, grad_flow_next, knn_state, grad_traj, ws, stream, 0, nullptr, nullptr);
 }
 
 // reach_ready: the reaches of the tiles are in the workspace already (the event backward's kernel computed them: mpc_focus_bwd)
+// gnext_scale (device scalar or null): dL/dflow_next = gnext_scale[0] * grad_flow_next.  The tile gather and the far backward
+// multiply as they read; the general gather gets the product from a pass of mpc_scale into gnext_scratch [like grad_flow_next].
 int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                        const float *grad_flow_next, const float *knn_state, float *grad_traj,
-                       void *ws, void *stream, int reach_ready) {
+                       void *ws, void *stream, int reach_ready, const float *gnext_scale, float *gnext_scratch) {
     MPC_CHECK_ARG(s && traj && grad_flow_lut && knn_state && grad_traj && ws, MPC_E_NULL, "null argument");
     int rc = mpc_validate_shape(s);
     if (rc) return rc;
     if (s->B == 0) return 0;
+    if (grad_flow_next && gnext_scale && !knn_bwd_is_tile(s)) {
+        MPC_CHECK_ARG(gnext_scratch, MPC_E_NULL, "grad_next_scratch is null");
+        if ((rc = mpc_scale(grad_flow_next, gnext_scale, gnext_scratch, (int64_t)s->B * (s->nb - 1) * s->hq * s->wq * 2, stream))) return rc;
+        grad_flow_next = gnext_scratch; gnext_scale = nullptr;
+    }
+    if (!grad_flow_next) gnext_scale = nullptr;
     const KnnParams p = knn_params(s);
     const mpc_ws_layout L = mpc_layout(s);
     hipStream_t st = (hipStream_t)stream;
@@ -1696,17 +1743,21 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
     static mpc_device_once attr_once;   // raising the dynamic-LDS cap: idempotent, once per device
     if (attr_once.need()) {
         if ((rc = set_max_lds((const void *)k_knn_bwd_points<16>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, false>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, true>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, false>, __func__))) return rc;
-        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, true>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, false, false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, true, false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, false, false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, true, false>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, false, true>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<false, true, true>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, false, true>, __func__))) return rc;
+        if ((rc = set_max_lds((const void *)k_knn_bwd_tile<true, true, true>, __func__))) return rc;
         attr_once.mark();
     }
     const int gxb = knn_tiles_x(s->wq, p.m), gyb = knn_tiles_y(s->hq, p.m), ntiles = gxb * gyb;
     if (knn_bwd_is_tile(s)) {
         const int RWm = 16 + 2 * KNN_RQ_MAX;
-        const size_t ldsb = grad_flow_next ? ((size_t)RWm * RWm + KNN_BW_WMAX) * 24                 // RWm >= 32: covers pitch 32 too
-                                           : ((size_t)RWm * KNN_BW_PITCH + KNN_BW_WMAX) * 12;
+        const size_t ldsb = grad_flow_next ? ((size_t)RWm * (RWm > KNN_BW_PITCH_NEXT ? RWm : KNN_BW_PITCH_NEXT) + KNN_BW_WMAX) * (p.iwd ? 24 : 20)
+                                           : ((size_t)RWm * KNN_BW_PITCH + KNN_BW_WMAX) * (p.iwd ? 16 : 12);
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
         float2 *direct = (grad_flow_next == nullptr) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
         // The reach of every tile NOT as the first phase of every workgroup: the gather is a chain of phases per workgroup at
@@ -1725,11 +1776,14 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
             reach_pre = reach;
         }
 #define KB_LAUNCH(L1_, NEXT_)                                                                                            \
-        MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
-                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)), far_next KB_STAMP_ARG(ws, L))
+        do { if (p.iwd) KB_LAUNCH3(L1_, NEXT_, true); else KB_LAUNCH3(L1_, NEXT_, false); } while (0)
+#define KB_LAUNCH3(L1_, NEXT_, IWD_)                                                                                     \
+        MPC_LAUNCH((k_knn_bwd_tile<L1_, NEXT_, IWD_>), gridb, dim3(256), ldsb, st, p, cell_start, spos, sidx, grad_flow_lut, \
+                           grad_flow_next, knn_state, tile_dkmax, tmp_g, tmp_a, direct, reach_pre, gxb, gyb, knn_band_depth(mpc_knn_r_init(s)), far_next, gnext_scale KB_STAMP_ARG(ws, L))
         if (p.l1) { if (grad_flow_next) KB_LAUNCH(true, true); else KB_LAUNCH(true, false); }
         else { if (grad_flow_next) KB_LAUNCH(false, true); else KB_LAUNCH(false, false); }
 #undef KB_LAUNCH
+#undef KB_LAUNCH3
         MPC_CHECK_LAUNCH();
         if (mpc_knn_uses_far_list(s)) {
             // the queries the forward's fallback kernel served (left out of the gather above)
@@ -1739,11 +1793,14 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
             const long long far_items_max = (long long)s->B * s->nb * knn_tiles_x(p.wq, p.m) * knn_tiles_y(p.hq, p.m);
             const unsigned far_blocks = (unsigned)(far_items_max < KNN_FAR_BLOCKS ? (far_items_max < 1 ? 1 : far_items_max) : KNN_FAR_BLOCKS);
 #define KF_LAUNCH(L1_, NEXT_)                                                                                            \
-            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_>), dim3(far_blocks), dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
-                               knn_state, ls, tmp_g, tmp_a, direct)
+            do { if (p.iwd) KF_LAUNCH3(L1_, NEXT_, true); else KF_LAUNCH3(L1_, NEXT_, false); } while (0)
+#define KF_LAUNCH3(L1_, NEXT_, IWD_)                                                                                     \
+            MPC_LAUNCH((k_knn_bwd_far<L1_, NEXT_, IWD_>), dim3(far_blocks), dim3(256), 0, st, p, cell_start, spos, sidx, grad_flow_lut, grad_flow_next, \
+                               knn_state, ls, tmp_g, tmp_a, direct, gnext_scale)
             if (p.l1) { if (grad_flow_next) KF_LAUNCH(true, true); else KF_LAUNCH(true, false); }
             else { if (grad_flow_next) KF_LAUNCH(false, true); else KF_LAUNCH(false, false); }
 #undef KF_LAUNCH
+#undef KF_LAUNCH3
             MPC_CHECK_LAUNCH();
         }
         const int64_t totalb = (int64_t)s->B * s->n;

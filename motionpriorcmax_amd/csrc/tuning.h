@@ -38,11 +38,17 @@
 #ifndef KNN_BW_PITCH
 #define KNN_BW_PITCH 48   // row pitch (cells) of the staged arrays without the flow_to_next gradient; >= 16 + 2 * KNN_RQ_MAX
 #endif
+#ifndef KNN_BW_PITCH_NEXT
+#define KNN_BW_PITCH_NEXT 32   // ... with the flow_to_next gradient (20 bytes per cell)
+#endif
 #ifndef KNN_BW_OCC
 #define KNN_BW_OCC 7
 #endif
 #ifndef KNN_BW_OCC_NEXT
-#define KNN_BW_OCC_NEXT 8
+#define KNN_BW_OCC_NEXT 6     // with the flow_to_next gradient (and for 'iwd'): 80 VGPRs, 23 KB of LDS per workgroup.  C4 batch 6, k_knn_bwd_tile:
+                              // 8 per CU by registers (64, 31 spilled; the LDS -- 24 bytes per cell then -- allowed 5) 242 us; the K-th index
+                              // out of the LDS (20 bytes per cell: 6 per CU) at 8 / 6 / 5: 218 / 206 / 215; + the conflict-free pitch where the
+                              // region leaves room (k_knn_bwd_tile: RP) at 7 / 6 / 5: 209 / 202 / 212  (profiles/r06_ab_bwd_next.txt)
 #endif
 #ifndef KNN_FAR_QB
 #define KNN_FAR_QB 256        // far queries tested against the tile per batch (one per thread); those that touch it: a list in LDS
