@@ -212,6 +212,22 @@ def knn_ceiling(workload, stages, B, nb):
                                          'assumes': f'{simds} SIMDs at {ghz:.2f} GHz (nominal); valu_issue_frac_at_4_cycles can exceed 1: fp32 '
                                                     'instructions issue in fewer than 4 cycles',
                                          'kernels': prof}
+        # (round 6) the INSTRUCTION-MIX floor of the two issue-bound kernels: their own dynamic mix (SQ class counters of the same
+        # committed profile) priced with the measured issue cost of every instruction class (tools/valu_floor.py, which also
+        # disassembles the loaded library for the mix inside a class) -- the ceiling the 2-cycle figure is not
+        try:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import valu_floor as _vf
+            fl = {}
+            for kname in ('k_knn_strip', 'k_knn_bwd_tile'):
+                if kname in d:
+                    r = _vf.floor_of(kname, 'false, false', d[kname])
+                    fl[kname] = {k2: r[k2] for k2 in ('floor_us', 'two_cycle_ideal_us', 'kernel_us_in_profile', 'achieved_over_floor', 'mean_issue_cycles',
+                                                    'dynamic_valu_wave_instructions', 'mix_source')}
+            out['valu_floor'] = dict(fl, note='floor_us = sum over instruction classes (dynamic count x measured issue cycles, profiles/r03_ubench_op_cycles.txt) '
+                                              '/ (SIMDs x clock); achieved_over_floor = floor_us / measured kernel time; tools/valu_floor.py')
+        except Exception as e:          # noqa: BLE001
+            out['valu_floor'] = {'error': repr(e)[:200]}
     return out
 
 
@@ -277,7 +293,8 @@ def cpu_baseline(wl, budget_s=20.0):
     valid = float(ev[..., 5].sum())
     return {
         # `value` = the WHOLE path on the CPU (KNN LUT + event path), the counterpart of the GPU `value`; the event path alone beside it
-        'value': valid / (t_event + t_knn_sample) / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'kind': 'port',
+        'value': valid / (t_event + t_knn_sample) / 1e6, 'unit': 'Mevents/s', 'cores': cores, 'host_cpu_count': ncpu, 'kind': 'port',
+        'cores_note': f'`cores` = the torch thread count that ran the timed steps (the fastest of those tried below); the host has {ncpu} logical CPUs',
         'sample': (f'1 sample of the batch ({int(valid)} valid events): brute-force K-min KNN (torch.topk; what KeOps argKmin computes) timed '
                    f'on one whole (sample, bin) = {t_knn_bin:.2f} s, x{nb} bins = {t_knn_sample:.1f} s per sample, + the event path fwd+bwd (LUT '
                    f'given) timed {reps}x = {t_event * 1e3:.1f} ms per step'),
@@ -745,6 +762,15 @@ def main():
         if kprof:
             valu = {'achieved': round(2.0 / kprof['simd_cycles_per_valu_instr'], 3), 'unit': 'fraction of 1 wave64 instruction per 2 SIMD cycles',
                     'simd_cycles_per_valu_instr': kprof['simd_cycles_per_valu_instr'], 'from': 'committed SQ counters of this library (knn.from_committed_profile)'}
+            # (round 6) ... and against the floor of ITS OWN instruction mix (tools/valu_floor.py): the 2-cycle figure is an ideal no mix reaches
+            fl = (knn_info.get('valu_floor') or {}).get(dom_k.split('<')[0]) if dom_k else None
+            if fl:
+                live_us = live[dom_k]['us_per_launch'] if dom_k in live else None
+                valu.update({'floor_us': fl['floor_us'], 'two_cycle_ideal_us': fl['two_cycle_ideal_us'],
+                             'achieved_over_floor': round(fl['floor_us'] / live_us, 3) if live_us else fl['achieved_over_floor'],
+                             'mean_issue_cycles_of_the_mix': fl['mean_issue_cycles'],
+                             'floor_note': 'floor_us: the kernel\'s own dynamic instruction mix at the measured issue cost of every class '
+                                           '(knn.valu_floor, tools/valu_floor.py); achieved_over_floor = floor_us / live kernel_us'})
         return {
             'bound': 'valu_issue' if is_knn else 'hbm', 'valu_issue': valu,
             'kernel': dom_k if dom_k is not None else (in_stage[0] if in_stage else dom), 'stage': dom,

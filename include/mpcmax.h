@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MPC_VERSION 106
+#define MPC_VERSION 107
 
 /* flags (mpc_shape.flags) -- one bit per FocusLoss constructor switch (focus.py:28-45) */
 #define MPC_F_SCALE_BY_DT     (1u << 0)  /* scale_iwe_by_dt        focus.py:204-206 */
@@ -206,6 +206,21 @@ int mpc_pe_grad_ordered(const mpc_shape *s, const float *rows, const int32_t *of
                         float *grad_coef_rows, int32_t split, void *stream);
 /* 1 where mpc_pe_grad_ordered serves (shape, k), 0 where the caller takes mpc_pe_grad: the rule lives in the library only. */
 int32_t mpc_pe_grad_ordered_supported(const mpc_shape *s, int32_t k);
+/* Same extension: the dense <-> per-tile operators around the two calls above (csrc/tiles.hip; version 107: kernels instead of two
+ * dozen torch operators -- the per-event step was bound by the host).
+ *   mpc_pe_tile_rows      coef_rows [B*hq*wq][c2] = sum over the S scales of grid [B][S][c2][H][W] at the tile centres
+ *                         (y, x) = (iy * tile + tile / 2, ix * tile + tile / 2): get_optical_flow_tile_mask + coeffs_grid_to_list,
+ *                         src/utils/trajectories.py:3-52, scales summed as compute_basis does (basis.py:29-31); hq = ceil(H / tile)
+ *   mpc_pe_tile_rows_bwd  its adjoint: EVERY element of grad_grid [B][S][c2][H][W] is written (0 off the tile centres)
+ *   mpc_pe_basis_field    field [B*nb][G][2] = sum_j coef_rows[(b, cell)][d][j] * phim[t][j] -- the flow from the bin mid-times to
+ *                         t_ref per tile, the field the smoothness term takes (mpc_lut_smooth: nimg = B * nb, C = 2); k <= 8, nb <= 64
+ *   mpc_pe_rows_grad_finish  grad_coef_rows [B*G][2][k] = sum over the `split` partial results of mpc_pe_grad_ordered (split = 1: of
+ *                         mpc_pe_grad) + grad_out[0] * (adjoint of mpc_pe_basis_field applied to grad_field, or nothing if NULL)  */
+int mpc_pe_tile_rows(const float *grid, float *coef_rows, int32_t B, int32_t S, int32_t c2, int32_t H, int32_t W, int32_t tile, void *stream);
+int mpc_pe_tile_rows_bwd(const float *grad_rows, float *grad_grid, int32_t B, int32_t S, int32_t c2, int32_t H, int32_t W, int32_t tile, void *stream);
+int mpc_pe_basis_field(const float *coef_rows, const float *phim, float *field, int32_t B, int32_t G, int32_t k, int32_t nb, void *stream);
+int mpc_pe_rows_grad_finish(const float *grad_parts, int32_t split, const float *grad_field, const float *phim, const float *grad_out,
+                            float *grad_coef_rows, int32_t B, int32_t G, int32_t k, int32_t nb, void *stream);
 
 int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *flow_lut,
                         const float *t_ref, const float *grad_iwe, const float *scal,
@@ -334,6 +349,20 @@ typedef struct mpc_err_shape {
 int64_t mpc_flow_error_workspace_bytes(const mpc_err_shape *s);
 int mpc_flow_error(const mpc_err_shape *s, const float *flow_gt, const float *flow_pred,
                    const uint8_t *event_mask, const float *time_scale, float *out, void *ws, void *stream);
+
+/* ---- next row + BASELINE.json configs[3]: flow curves sampled at the tile centres as `trajectories` for the loss.
+ * Reference: src/models/raft_spline/curves/base.py:88-123 (CurveBase.get_flow_from_reference: flow(t) = sum_k B_k(t) P_k, P_0 == 0),
+ * bezier.py:92-113 (Bernstein basis, evaluated on the host in float64 as the reference does), polynomial.py:60-61 (dim 1 = (x, y)).
+ *   params [B][2][d][n]  control points 1..d of every tile, channel 0 = x, channel 1 = y (the network's [B, 2d, h, w] output, n = h*w)
+ *   basis  [T][d]        basis functions at the T reconstruction times (Bernstein: pinned by bezier.py; clamped cubic B-spline:
+ *                        UNPINNED extension -- the reference has no such curve)
+ *   pos    [n][2]        tile centres (y, x) (src/utils/trajectories.py:3-13)
+ *   traj   [B][T][n][2]  (out)  (y, x) = pos + scale * sum_k basis[t][k] * (P_k.y, P_k.x)
+ * mpc_curve_traj_bwd: grad_params [B][2][d][n] (out, overwritten) = the adjoint of the above applied to grad_traj [B][T][n][2].  */
+int mpc_curve_traj_fwd(const float *params, const float *basis, const float *pos, float scale, float *traj,
+                       int32_t B, int32_t d, int32_t T, int32_t n, void *stream);
+int mpc_curve_traj_bwd(const float *grad_traj, const float *basis, float scale, float *grad_params,
+                       int32_t B, int32_t d, int32_t T, int32_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ EXPORTS = ['mpc_version', 'mpc_last_error_string', 'mpc_workspace_bytes', 'mpc_k
            'mpc_knn_fail_list_offset', 'mpc_knn_list_offsets', 'mpc_knn_tail_counters_offset', 'mpc_knn_state_floats', 'mpc_focus_fwd', 'mpc_focus_bwd',
            'mpc_event_lut_strips', 'mpc_event_order_workspace_bytes', 'mpc_event_bucket_order', 'mpc_event_splat_bwd_ordered',
            'mpc_profile_start', 'mpc_profile_stop', 'mpc_event_splat_fwd_fixed', 'mpc_iwe_from_fixed',
-           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add', 'mpc_event_pos_grad', 'mpc_pe_warp', 'mpc_pe_grad', 'mpc_pe_grad_ordered', 'mpc_pe_grad_ordered_supported', 'mpc_bounds_check']
+           'mpc_ingest_ordered_workspace_bytes', 'mpc_ingest_scatter_ordered', 'mpc_pool2_fwd', 'mpc_pool2_bwd_add', 'mpc_event_pos_grad', 'mpc_pe_warp', 'mpc_pe_grad', 'mpc_pe_grad_ordered', 'mpc_pe_grad_ordered_supported', 'mpc_bounds_check', 'mpc_curve_traj_fwd', 'mpc_curve_traj_bwd',
+           'mpc_pe_tile_rows', 'mpc_pe_tile_rows_bwd', 'mpc_pe_basis_field', 'mpc_pe_rows_grad_finish']
 
 
 class Shape(ctypes.Structure):
@@ -138,9 +139,15 @@ def lib():
     L.mpc_pool2_bwd_add.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.mpc_profile_start.argtypes = []
     L.mpc_bounds_check.argtypes = []
+    L.mpc_curve_traj_fwd.argtypes = [vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]
+    L.mpc_curve_traj_bwd.argtypes = [vp, vp, f32, vp, i32, i32, i32, i32, vp]
+    L.mpc_pe_tile_rows.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.mpc_pe_tile_rows_bwd.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.mpc_pe_basis_field.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    L.mpc_pe_rows_grad_finish.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mpc_profile_stop.argtypes = [ctypes.c_char_p, i32, ctypes.POINTER(f32), i32]
-    if L.mpc_version() != 106:
-        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (106)')
+    if L.mpc_version() != 107:
+        raise RuntimeError(f'libmpcmax.so version {L.mpc_version()} does not match the binding (107)')
     _lib = L
     return L
 

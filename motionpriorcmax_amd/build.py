@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmpcmax.so')
-SOURCES = ['api.hip', 'contrast.hip', 'events.hip', 'knn.hip', 'knn_strip.hip', 'voxel.hip', 'ingest.hip', 'flow.hip']
+SOURCES = ['api.hip', 'contrast.hip', 'events.hip', 'knn.hip', 'knn_strip.hip', 'voxel.hip', 'ingest.hip', 'flow.hip', 'curves.hip', 'tiles.hip']
 FLAGS = ['-shared', '-fPIC', '-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-std=c++17',
          '-Wall', '-Wno-unused-function']
 

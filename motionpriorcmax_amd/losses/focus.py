@@ -67,6 +67,7 @@ class FocusLoss(base.TrajectoryLossBase):
         self.auto_static_shapes = bool(auto_static_shapes)
         self._auto_key, self._auto_run = None, 0
         self._auto_never = set()              # shapes whose plan could not be captured: eager from then on
+        self._tmid_dev = {}                   # bin mid-times per device (calc_per_event_basis)
         self.is_needing_offsets = True
         self.imager = EventImageConverter(self.image_shape)
 
@@ -152,14 +153,34 @@ class FocusLoss(base.TrajectoryLossBase):
         # tile // 2, row-major -- as a strided view, whose backward is a strided copy), scales summed as compute_basis does
         if coeff_grid.dim() != 5 or coeff_grid.shape[2] != 2 * num_basis or -(-coeff_grid.shape[3] // tile) != hq or -(-coeff_grid.shape[4] // tile) != wq:
             raise ValueError(f'coeff_grid {tuple(coeff_grid.shape)} is not [B, scales, {2 * num_basis}, H, W] of this image shape')
-        c_rows = ops.TileCoeffRowsFn.apply(coeff_grid, tile)                                       # [B*G, 2k]: per tile (y: k, x: k)
-        t_ref = torch.as_tensor(t_ref, dtype=torch.float32, device=dev).reshape(1)
+        # (no host -> device copy inside the step: a copy from pageable memory waits for the stream, and the host then no longer runs
+        # ahead of the device -- round 6: 0.86 ms per step of which 0.36 were kernels.  A float t_ref becomes a fill kernel, the bin
+        # mid-times are kept on the device.)
+        if torch.is_tensor(t_ref):
+            t_ref = t_ref.to(device=dev, dtype=torch.float32).reshape(1)
+        else:
+            t_ref = torch.full((1,), float(t_ref), dtype=torch.float32, device=dev)
+        offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events / ingest (optional)
         phi = None           # (fused + polynomial basis of up to 8 orders: worked out inside the kernels)
         if not (fused and basis_type == 'polynomial' and num_basis <= 8):
             with torch.no_grad():
                 phi = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(events[..., 2], num_basis, basis_type, basis_network)
+        phim = None
+        if self.smooth_weight > 0:
+            from ..utils.synth import bin_mid_times
+            tm = self._tmid_dev.get(dev)
+            if tm is None:
+                tm = self._tmid_dev[dev] = bin_mid_times(self.num_bins).to(dev)
+            with torch.no_grad():
+                phim = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(tm, num_basis, basis_type, basis_network)   # [nb, k]
+        if fused and num_basis <= 8 and self.num_bins <= 64:
+            # one autograd node of library calls (ops.PerEventBasisCalcFn): the step is no longer bound by the host
+            loss, focus, smooth, iwes = ops.PerEventBasisCalcFn.apply(coeff_grid, events, phi, phim, t_ref, self._cfg, int(num_pos_events), offsets,
+                                                                      int(num_basis), tile)
+            iwes = iwes.reshape(B, 1, 2, h, w) if self.polarity_aware_batching else iwes.reshape(B, 1, h, w)
+            return loss, {'focus_loss': focus.detach(), 'smoothness_loss': smooth.detach()}, {'iwes': iwes.detach()}
+        c_rows = ops.TileCoeffRowsFn.apply(coeff_grid, tile)                                       # [B*G, 2k]: per tile (y: k, x: k)
         if fused:
-            offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events / ingest (optional)
             focus, iwes = ops.PerEventBasisFocusFn.apply(c_rows, events, phi, t_ref, self._cfg, int(num_pos_events), offsets)
         else:
             # the same in plain torch around the vote / objective kernels (cross-check of the fused kernels)
@@ -171,11 +192,7 @@ class FocusLoss(base.TrajectoryLossBase):
             warped = events[..., :2] + (ce * phi[:, :, None, :]).sum(-1)                              # [B, M, 2]  (y, x)
             focus, iwes = ops.PrewarpedFocusFn.apply(warped, events, t_ref, self._cfg, int(num_pos_events))
         smooth = torch.zeros((), device=dev)
-        if self.smooth_weight > 0:
-            from ..utils.synth import bin_mid_times
-            tm = bin_mid_times(self.num_bins).to(dev)
-            with torch.no_grad():
-                phim = basis_values(t_ref, num_basis, basis_type, basis_network) - basis_values(tm, num_basis, basis_type, basis_network)   # [nb, k]
+        if phim is not None:
             field = ops.BasisFieldFn.apply(c_rows, phim, B, hq, wq)                                # [B*nb, hq, wq, 2]
             smooth = ops.LutSmoothFn.apply(field, self._cfg, float(self.smooth_weight))
         loss = focus + smooth

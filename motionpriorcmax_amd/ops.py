@@ -880,6 +880,107 @@ class PerEventBasisFocusFn(torch.autograd.Function):
         return g, None, None, None, None, None, None
 
 
+class PerEventBasisCalcFn(torch.autograd.Function):
+    """UNPINNED extension (FocusLoss.calc_per_event_basis), the whole step as ONE autograd node of library calls (round 6):
+    dense coefficient grid -> tile rows -> per-event warp -> vote -> blur + objective [-> smoothness field -> Charbonnier term]
+    -> scalars, and back: position gradient per LUT strip -> (+ smoothness adjoint) -> dense gradient.  Rounds 4-5 spelt the dense <->
+    per-tile operators and the smoothness field in torch (TileCoeffRowsFn, BasisFieldFn, LutSmoothFn below: kept for the unfused
+    cross-check): two dozen operators around 0.30 ms of kernels, and the step was bound by the host (0.74-0.97 ms at the DSEC batch
+    shape).  Returns (loss, focus, smooth, iwes_blurred); differentiable w.r.t. coeff_grid through `loss`."""
+
+    @staticmethod
+    def forward(ctx, coeff_grid, events, phi, phim, t_ref, cfg: PathConfig, num_pos: int, offsets, k: int, tile: int):
+        _require_gpu(coeff_grid, 'coeff_grid')
+        B, M, Mp = _check_events(events, cfg, num_pos)
+        dev = coeff_grid.device
+        cg = _f32c(coeff_grid.detach())
+        ev = _f32c(events.detach())
+        ph = _f32c(phi.detach()) if phi is not None else None       # None: the polynomial basis, worked out in the kernels
+        pm = _f32c(phim.detach()) if phim is not None else None     # [nb, k]: basis(t_ref) - basis(bin mid-times), or None: no smoothness term
+        tr = _f32c(t_ref.detach().to(dev))
+        need_grad = coeff_grid.requires_grad
+        Bc, S, c2, H, W = cg.shape
+        shape = make_shape(cfg, B, M, Mp, 0, K=0, extra_flags=C.F_NO_WARP | C.F_NO_BWD_RECORDS)
+        hq, wq = shape.hq, shape.wq
+        G = hq * wq
+        if Bc != B or c2 != 2 * k or (ph is not None and tuple(ph.shape) != (B, M, k)) or (ph is None and k > 8):
+            raise ValueError(f'coeff_grid {tuple(cg.shape)} / phi do not match [B, S, 2k, H, W] / [B, M, k] (k <= 8 without phi)')
+        st = _stream(dev)
+        L = C.lib()
+        c_rows = torch.empty((B * G, 2 * k), dtype=torch.float32, device=dev)
+        with _stage('mpc_pe_tile_rows', dev):
+            C.check(L.mpc_pe_tile_rows(_ptr(cg), _ptr(c_rows), B, S, c2, H, W, tile, st), 'mpc_pe_tile_rows')
+        ws = alloc_workspace(shape, dev)
+        rows = torch.empty_like(ev)
+        if B * M > 0:
+            with _stage('mpc_pe_warp', dev):
+                C.check(L.mpc_pe_warp(ctypes.byref(shape), _ptr(ev), _ptr(c_rows), _ptr(ph), k, _ptr(tr), _ptr(rows), st), 'mpc_pe_warp')
+        raw = event_splat_fwd(shape, rows, None, tr, ws)
+        blur, gimg = contrast_fwd(shape, raw, ws, need_grad)
+        g_field, s_nimg = None, 0
+        if pm is not None and cfg.smooth_weight > 0:
+            nb = pm.shape[0]
+            field = torch.empty((B * nb, hq, wq, 2), dtype=torch.float32, device=dev)
+            with _stage('mpc_pe_basis_field', dev):
+                C.check(L.mpc_pe_basis_field(_ptr(c_rows), _ptr(pm), _ptr(field), B, G, k, nb, st), 'mpc_pe_basis_field')
+            s_nimg = B * nb
+            g_field = lut_smooth(shape, field, s_nimg, 2, cfg.smooth_weight, ws, need_grad)
+        scal = finalize(shape, s_nimg, 2 if s_nimg else 0, cfg.smooth_weight if s_nimg else 0.0, ws, dev)
+        with torch.cuda.device(dev):
+            ordered = offsets is not None and int(L.mpc_pe_grad_ordered_supported(ctypes.byref(shape), k)) == 1
+        offs = _check_offsets(offsets, cfg, shape, dev) if ordered else None
+        ctx.shape, ctx.k, ctx.tile, ctx.grid_shape = shape, k, tile, (B, S, c2, H, W)
+        ctx.has = (ph is not None, pm is not None and g_field is not None, offs is not None)
+        ctx.set_materialize_grads(False)
+        none = tr
+        ctx.save_for_backward(rows, ph if ph is not None else none, tr, gimg if gimg is not None else none, scal,
+                              offs if offs is not None else none, g_field if g_field is not None else none, pm if pm is not None else none)
+        out = scal[:3].clone()
+        loss, focus, smooth = out[C.SCAL_LOSS], out[C.SCAL_FOCUS], out[C.SCAL_SMOOTH]
+        ctx.mark_non_differentiable(focus, smooth, blur)
+        return loss, focus, smooth, blur
+
+    @staticmethod
+    def backward(ctx, g_loss, g_focus, g_smooth, g_blur):
+        if g_loss is None:
+            return (None,) * 10
+        rows, ph, tr, gimg, scal, offs, g_field, pm = ctx.saved_tensors
+        has_phi, has_smooth, has_offs = ctx.has
+        ph = ph if has_phi else None
+        shape, k = ctx.shape, ctx.k
+        B, S, c2, H, W = ctx.grid_shape
+        G = shape.hq * shape.wq
+        dev = rows.device
+        st = _stream(dev)
+        L = C.lib()
+        go = _f32c(g_loss.reshape(1))
+        split, gp = 1, None
+        if has_offs:
+            split = max(1, min(16, 512 // max(1, B * _lut_strips(shape, dev))))
+            gp = torch.empty((split, B * G, 2 * k), dtype=torch.float32, device=dev)
+            with _stage('mpc_pe_grad_ordered', dev):
+                rc = L.mpc_pe_grad_ordered(ctypes.byref(shape), _ptr(rows), _ptr(offs), _ptr(ph), k, _ptr(tr), _ptr(gimg), _ptr(scal), _ptr(go),
+                                           _ptr(gp), split, st)
+            if rc == C.E_UNSUPPORTED:
+                gp = None
+            else:
+                C.check(rc, 'mpc_pe_grad_ordered')
+        if gp is None:
+            split = 1
+            gp = torch.empty((1, B * G, 2 * k), dtype=torch.float32, device=dev)
+            with _stage('mpc_pe_grad', dev):
+                C.check(L.mpc_pe_grad(ctypes.byref(shape), _ptr(rows), _ptr(ph), k, _ptr(tr), _ptr(gimg), _ptr(scal), _ptr(go), _ptr(gp), st), 'mpc_pe_grad')
+        g_rows = torch.empty((B * G, 2 * k), dtype=torch.float32, device=dev)
+        nb = pm.shape[0] if has_smooth else 0
+        with _stage('mpc_pe_rows_grad_finish', dev):
+            C.check(L.mpc_pe_rows_grad_finish(_ptr(gp), split, _ptr(g_field) if has_smooth else None, _ptr(pm) if has_smooth else None, _ptr(go),
+                                              _ptr(g_rows), B, G, k, max(nb, 1), st), 'mpc_pe_rows_grad_finish')
+        g_grid = torch.empty(ctx.grid_shape, dtype=torch.float32, device=dev)
+        with _stage('mpc_pe_tile_rows_bwd', dev):
+            C.check(L.mpc_pe_tile_rows_bwd(_ptr(g_rows), _ptr(g_grid), B, S, c2, H, W, ctx.tile, st), 'mpc_pe_tile_rows_bwd')
+        return (g_grid,) + (None,) * 9
+
+
 class TileCoeffRowsFn(torch.autograd.Function):
     """coeff_grid [B, S, 2k, H, W] -> the coefficients at the tile centres (offset tile // 2, row-major: trajectories.py:3-52),
     scales summed, one row per tile: [B*hq*wq, 2k].  One autograd node with a strided copy each way instead of the half dozen
@@ -1033,6 +1134,36 @@ class LutSmoothFn(torch.autograd.Function):
     def backward(ctx, g_out):
         (g,) = ctx.saved_tensors
         return scale(g, _f32c(g_out.reshape(1))), None, None
+
+
+class CurveTrajFn(torch.autograd.Function):
+    """Flow curves -> `trajectories` (BASELINE.json configs[3]): params [B, 2d, h, w] ((x, y) channel order,
+    reference curves/polynomial.py:60-61), basis [T, d] on the device, tile centres [n, 2] (y, x) -> [B, T, n, 2], one kernel each
+    way (csrc/curves.hip) instead of the einsum / stack / add chain of plain torch and its adjoints."""
+
+    @staticmethod
+    def forward(ctx, params, basis, pos, scale: float):
+        _require_gpu(params, 'params')
+        B, c2, h, w = params.shape
+        d, n, T = c2 // 2, h * w, basis.shape[0]
+        dev = params.device
+        p = _f32c(params.detach())
+        bm = _f32c(basis.detach())
+        ps = _f32c(pos.detach())
+        traj = torch.empty((B, T, n, 2), dtype=torch.float32, device=dev)
+        C.check(C.lib().mpc_curve_traj_fwd(_ptr(p), _ptr(bm), _ptr(ps), float(scale), _ptr(traj), B, d, T, n, _stream(dev)), 'mpc_curve_traj_fwd')
+        ctx.save_for_backward(bm)
+        ctx.dims = (B, d, T, n, h, w, float(scale))
+        return traj
+
+    @staticmethod
+    def backward(ctx, g):
+        (bm,) = ctx.saved_tensors
+        B, d, T, n, h, w, scale = ctx.dims
+        g = _f32c(g)
+        gp = torch.empty((B, 2 * d, h, w), dtype=torch.float32, device=g.device)
+        C.check(C.lib().mpc_curve_traj_bwd(_ptr(g), _ptr(bm), scale, _ptr(gp), B, d, T, n, _stream(g.device)), 'mpc_curve_traj_bwd')
+        return gp, None, None, None
 
 
 def knn_indices(cfg: PathConfig, trajectories):

@@ -102,6 +102,22 @@ def _tile_positions(H, W, tile_size, device, dtype):
     return ent
 
 
+def _curve_trajectories(params, bm, tile_size, H, W, scale):
+    """pos + scale * (basis x control points), (y, x) order: on the GPU one kernel each way (ops.CurveTrajFn, csrc/curves.hip:
+    mpc_curve_traj_fwd / _bwd -- a training step calls this every iteration and a B = 1 step is bound by the host); for CPU tensors
+    (the host-side tests against the reference's curves) the same in plain torch."""
+    B, c2, h, w = params.shape
+    d = c2 // 2
+    pos, pos_dev = _tile_positions(H, W, tile_size, params.device, params.dtype)
+    assert pos.shape[0] == h * w, 'image shape must be a multiple of the tile size'
+    if params.is_cuda and params.dtype == torch.float32 and d <= 16:
+        from .. import ops
+        return ops.CurveTrajFn.apply(params, bm, pos_dev, float(scale)), pos
+    flow = torch.einsum('bcdhw,td->btchw', params.view(B, 2, d, h, w), bm) * scale  # [B, n_t, (x, y), h, w]
+    disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), dim=-1).reshape(B, bm.shape[0], h * w, 2)
+    return disp + pos_dev[None, None], pos
+
+
 def bernstein_basis(times, degree):
     """[n_t] -> [n_t, degree]: C(d,i) (1-t)^(d-i) t^i for i = 1..d (P0 == 0), float64 then fp32.  (The caller's own copy: the cached
     matrix is shared by every later step.)"""
@@ -134,11 +150,7 @@ def trajectories_from_bezier(params, times, tile_size, image_shape, scale=1.0):
     assert c2 % 2 == 0 and h == H // tile_size and w == W // tile_size, (params.shape, image_shape, tile_size)
     d = c2 // 2
     bm = _device_basis('bernstein', times, (int(d),), params.device, params.dtype)    # [n_t, d]
-    flow = torch.einsum('bcdhw,td->btchw', params.view(B, 2, d, h, w), bm) * scale  # [B, n_t, (x, y), h, w]
-    pos, pos_dev = _tile_positions(H, W, tile_size, params.device, params.dtype)
-    assert pos.shape[0] == h * w, 'image shape must be a multiple of the tile size'
-    disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), dim=-1).reshape(B, bm.shape[0], h * w, 2)
-    return disp + pos_dev[None, None], pos
+    return _curve_trajectories(params, bm, tile_size, H, W, scale)
 
 
 def bspline_basis(times, num_ctrl, degree=3):
@@ -184,8 +196,4 @@ def trajectories_from_bspline(params, times, tile_size, image_shape, scale=1.0, 
     assert c2 % 2 == 0 and h == H // tile_size and w == W // tile_size, (params.shape, image_shape, tile_size)
     d = c2 // 2
     bm = _device_basis('bspline', times, (int(d + 1), int(degree)), params.device, params.dtype)      # [n_t, d]
-    flow = torch.einsum('bcdhw,td->btchw', params.view(B, 2, d, h, w), bm) * scale
-    pos, pos_dev = _tile_positions(H, W, tile_size, params.device, params.dtype)
-    assert pos.shape[0] == h * w, 'image shape must be a multiple of the tile size'
-    disp = torch.stack((flow[:, :, 1], flow[:, :, 0]), dim=-1).reshape(B, bm.shape[0], h * w, 2)
-    return disp + pos_dev[None, None], pos
+    return _curve_trajectories(params, bm, tile_size, H, W, scale)

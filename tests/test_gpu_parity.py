@@ -31,7 +31,7 @@ def _loss_obj(cfg, **kw):
 
 def test_native_library_is_loaded():
     from motionpriorcmax_amd import _lib
-    assert _lib.lib().mpc_version() == 106
+    assert _lib.lib().mpc_version() == 107
     with open('/proc/self/maps') as f:
         assert 'libmpcmax.so' in f.read()
 
