@@ -925,8 +925,9 @@ def main():
                 torch.cuda.synchronize()
                 nd[tag] = {'ms_per_step': round(1e2 * (time.perf_counter() - t0), 4)}
                 del Ln, trd_, evd_
-            nd['note'] = ('same workload and inputs as the headline with one loss setting changed; iwd: strip forward, point-gather backward '
-                          '(k_knn_bwd_points); num_tref = 2: tile kernel k_knn_query forward and k_knn_bwd_points backward')
+            nd['note'] = ('same workload and inputs as the headline with one loss setting changed; iwd: strip forward, tile-gather backward with '
+                          'distance weights (round 6; the point gather k_knn_bwd_points before: 1.14 ms); dist_l1: tile kernel k_knn_query forward; '
+                          'num_tref = 2: k_knn_query forward and k_knn_bwd_points backward (DESIGN.md section 4.1: what fast paths would need)')
             also['non_default_configs'] = nd
         except Exception as e:
             also['non_default_configs'] = {'error': repr(e)[:200]}

@@ -41,7 +41,7 @@ class GradAllReducer:
     stream (after the producer stream's current work), `wait()` makes the consumer stream wait."""
 
     def __init__(self, numel: int = UNET_GRAD_NUMEL, n_buckets: int = 4, device=None, group=None,
-                 force_collective: bool = False):
+                 force_collective: bool = False, prescaled: bool = False):
         self.device = torch.device(device) if device is not None else torch.device('cpu')
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -53,11 +53,13 @@ class GradAllReducer:
         self.stream = torch.cuda.Stream(device=self.device) if self.is_cuda else None
         self._works = []
         self._scale_pending = False
-        # RCCL averages inside the collective (ReduceOp.AVG): no pass of its own over the 124 MB to divide by the world size -- four
-        # `mul_` kernels on the side stream that took HBM bandwidth from the loss kernels they ran beside (round 5).  gloo (CPU tests)
-        # has no AVG: SUM, then the division.
-        self.avg = bool(self.is_cuda and dist.is_initialized() and dist.get_backend(group) == 'nccl')
-        self.op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        # The division by the world size.  Round 5: a `mul_` pass over every bucket behind its all-reduce, on the side stream -- 124 MB
+        # read and written beside the loss kernels.  Round 6 tried ReduceOp.AVG instead (RCCL builds a pre-multiplied sum per call):
+        # the one-rank leg of the benchmark went from +0.26 to +0.90 ms per step -- worse.  Now the PRODUCER pre-scales: a caller
+        # whose gradients arrive already divided by the world size (OverlappedGradProducer scales the network's output, as DDP
+        # divides in its hook) sets `prescaled` and the exchange is the SUM alone.
+        self.avg = bool(prescaled)          # "nothing left to divide": the buffer holds gradients / world already
+        self.op = dist.ReduceOp.SUM
 
     def start(self):
         if self.skip:
@@ -149,6 +151,7 @@ class OverlappedGradProducer:
 
     def __init__(self, reducer: GradAllReducer, rows: int = 512, seed: int = 0):
         self.r = reducer
+        reducer.avg = True                        # (step() scales the network's output by 1 / world: the gradients arrive divided)
         dev = reducer.device
         g = torch.Generator().manual_seed(seed)
         self.net = StandInNetwork().to(dev)
@@ -186,7 +189,7 @@ class OverlappedGradProducer:
         # buffer under them would corrupt the exchange silently -- the producing stream waits for them first; free if wait() ran)
         self.r.wait()
         self.r.flat.zero_()                       # (gradients accumulate into the views: the optimizer's zero_grad)
-        self.net(self.x).backward()
+        (self.net(self.x) * (1.0 / self.r.world)).backward()
         while self._fired < len(self._left):      # (buckets without a parameter of their own end)
             self.r.start_bucket(self._fired)
             self._fired += 1

@@ -90,7 +90,8 @@ def _producer_worker(rank, world, port, out):
         red.start_bucket = lambda i: (fired.append(i), start_bucket(i))
         prod = dp.OverlappedGradProducer(red, rows=16, seed=100 + rank)
         assert sum(p.numel() for p in prod.net.parameters()) == dp.UNET_GRAD_NUMEL == red.flat.numel()
-        # this rank's own gradient, without the exchange
+        # this rank's own gradient, without the exchange -- ALREADY divided by the world size: the producer scales the network's
+        # output by 1 / world (as DDP divides in its hook), so that the exchange is a plain sum with no pass of its own to divide
         prod.net.zero_grad(set_to_none=False)
         red.skip = True
         prod.step()
@@ -104,7 +105,7 @@ def _producer_worker(rank, world, port, out):
             assert fired == list(range(len(red.bounds))), fired      # every bucket once, in production order
             both = [torch.empty_like(own) for _ in range(world)]
             dist.all_gather(both, own)
-            want = sum(both) / world
+            want = sum(both)                                  # = the mean over the ranks of the undivided gradients
             assert torch.allclose(red.flat, want, rtol=1e-5, atol=1e-8), float((red.flat - want).abs().max())
             # the parameters' .grad ARE the flat buffer (views): what the optimizer reads is the averaged gradient
             p0 = next(iter(prod.net.parameters()))
