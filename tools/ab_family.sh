@@ -1,9 +1,7 @@
 #!/bin/bash
-# A/B of compile-time variants on one input family of tools/realistic_probe.py: tools/ab_family.sh <family> "<flags A>" "<flags B>" ...
-fam=$1; shift
-for flags in "$@"; do
-  MPC_EXTRA_HIPCC_FLAGS="$flags" python motionpriorcmax_amd/build.py > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
-  echo "== flags: [$flags]"
-  python tools/realistic_probe.py --families $fam --steps 10 2>&1 | grep "^$fam" | cut -c1-600
+# A/B of prebuilt libraries on several input families (one box):  tools/ab_family.sh "<fam,fam>" build_ab/a.so build_ab/b.so ...
+fams=$1; shift
+for lib in "$@"; do
+  echo "== $lib"
+  MPC_AB_LIB=$lib python tools/realistic_probe.py --families $fams --steps 10 2>&1 | grep -v amdgpu | grep -v "^{" | cut -c1-200
 done
-python motionpriorcmax_amd/build.py > /dev/null 2>&1
