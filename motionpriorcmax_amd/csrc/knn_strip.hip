@@ -1216,7 +1216,13 @@ __device__ __forceinline__ void fallback_entry(const KnnParams &p, const float *
 //   workgroups [KS_RETRY_BLOCKS, + KS_FB_BLOCKS): one wavefront per query of the main launch's `fail` list -- at once, BESIDE the strip
 //     workgroups: both halves are chains of dependent round trips at low occupancy (a work item of the far pass ~25 us on one
 //     wavefront of four, a fallback query ~14 us), side by side they cost what the longer one costs -- then, once every strip
-//     workgroup is done (they were dispatched first and wait for nobody: no deadlock), the late list.
+//     workgroup is done, the late list.
+//     FORWARD PROGRESS of that wait (round 6): the strip workgroups wait for nobody, so they finish as soon as they are resident; a
+//     waiting fallback workgroup holds a slot of the chip while it spins.  The launcher therefore starts FEWER fallback workgroups
+//     than the chip can hold workgroups of this kernel at once (tail_fallback_blocks: occupancy query x CU count minus 32 slots -- 992
+//     of 1 024 on an MI355X), so a strip workgroup that has not started always finds a free slot whatever order the hardware
+//     dispatches in.  Round 5 relied on dispatch in blockIdx order, which HIP does not promise; the late list in a launch
+//     of its own was measured too: +9 us on the white-noise step (profiles/HISTORY_r06.md section 2).
 // One launch instead of two for the lattice-like point sets of the benchmark, whose lists are (nearly) empty.
 // grid: KS_RETRY_BLOCKS + KS_FB_BLOCKS workgroups (the list lengths are only known on the device), 256 threads, dynamic LDS of the
 // far pass (the fallback workgroups use its first 16 KB)
@@ -1325,7 +1331,7 @@ bool mpc_knn_strip_counts_events(const mpc_shape *s, const EvCountArgs *evc) {
     return (size_t)evc->nb * evc->NCS * sizeof(int) <= lds && evc->B <= 256;
 }
 
-// Fallback workgroups of a tail launch: as many as KS_FB_BLOCKS, but at least one workgroup slot per CU fewer than the chip holds
+// Fallback workgroups of a tail launch: as many as KS_FB_BLOCKS, but at least 32 workgroup slots fewer than the chip holds
 // workgroups of this kernel at once (see k_knn_tail: a fallback workgroup may spin until the strip workgroups are done, and those
 // must always find a free slot), and no fewer than `min_fb` (the event-count prefix of mpc_focus_fwd rides in the first B of them).
 static int tail_fallback_blocks(const void *kernel, size_t lds_tail, int min_fb) {
@@ -1337,7 +1343,10 @@ static int tail_fallback_blocks(const void *kernel, size_t lds_tail, int min_fb)
         return MPC_E_UNSUPPORTED;
     }
     const long long slots = (long long)ncu * per_cu;
-    long long fb = slots - ncu;
+    // (32 slots -- one per group of 8 CUs -- stay free of spinners whatever happens: enough for forward progress in ANY dispatch order;
+    // with the hardware's usual order the strip workgroups hold their slots before a fallback workgroup starts, and what counts is how
+    // many one-wavefront searchers the late list of a band-heavy field gets: a whole slot per CU kept free cost a 45 % contraction 7 %)
+    long long fb = slots - 32;
     if (fb > KS_FB_BLOCKS) fb = KS_FB_BLOCKS;
     if (fb < 64 || fb < min_fb) {
         mpc_set_error("mpc_knn_strip_launch: %d workgroup(s) of the tail kernel per CU on %d CUs leave no room for its fallback workgroups", per_cu, ncu);
