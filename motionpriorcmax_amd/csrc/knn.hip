@@ -1001,9 +1001,20 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
     // over the classes -- ~300 vector instructions for one or two wavefronts of the workgroup, the maximum of each class a
     // dependent round trip behind the loop's `continue`.  With step A on all four wavefronts and a barrier before step B the
     // kernel was slower than that: 142 vs 139 us.)  Wavefront 1 meanwhile looks up the bucketed ranges of the tile rows.
+    // (round 6) With the reaches precomputed (mpc_focus_bwd: by the event backward's kernel; large stage calls: by a launch of their
+    // own) the tile's reach is ONE word at a workgroup-uniform address: every thread loads it itself -- a scalar load -- instead of
+    // wavefront 0 loading it and handing it over through LDS behind a barrier.  The staging loads then go out at once, beside the row
+    // ranges' round trip of wavefront 1 instead of behind it: the workgroup is a chain of dependent round trips at seven per CU, and
+    // that chain -- not the window loop -- is the kernel's time (hack builds with two thirds of the loop's LDS reads or half of its
+    // arithmetic removed: 119.5 -> 114 / 111 us; the pre-loop phase was 6.1 of a workgroup's 11.6 us, tools/bwd_stamp_probe.py).
+    const bool pre = reach_in != nullptr;
+    float Rpre = 0.f;
+    if (pre) Rpre = reach_in[(size_t)bt * gx * gy + bxy];
     if (tid < 64) {
-        const float r = reach_in ? reach_in[(size_t)bt * gx * gy + bxy] : knn_tile_reach<L1>(p, tile_dkmax, bt, by_, bx_, gx, gy, bd);
-        if (tid == 0) s_wr[0] = r;
+        if (!pre) {
+            const float r = knn_tile_reach<L1>(p, tile_dkmax, bt, by_, bx_, gx, gy, bd);
+            if (tid == 0) s_wr[0] = r;
+        }
     } else if (tid < 128) {
         const int ln = tid - 64;
         int gs = 0, ge = 0;
@@ -1088,8 +1099,8 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
         if ((tid & 63) == 0) s_tiew[tid >> 6] = wt ? 1 : 0;
     };
     if ((tid & 63) == 0) s_tiew[tid >> 6] = 0;
-    __syncthreads();
-    const float R = s_wr[0];
+    if (!pre) __syncthreads();                 // (workgroup-uniform; with `pre` the barrier behind the staging covers the row tables too)
+    const float R = pre ? Rpre : s_wr[0];
     const int RQ_need = (int)ceilf(R / (float)p.sp) + 1;      // halo the reach asks for, in cells
     const bool use_lds = RQ_need <= KNN_RQ_MAX;
     if (use_lds) {
