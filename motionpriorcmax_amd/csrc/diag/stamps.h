@@ -19,10 +19,16 @@
 #endif
 
 // ---- -DKS_STAMP2: phases of a work item of the far pass of k_knn_tail (tools/more_stamp_probe.py) --------------------------
-#ifdef KS_STAMP2
+// (-DKS_STAMP0, round 6: the same stamps for the MAIN launch, one record per strip workgroup: tools/strip_stamp_probe.py)
+#if defined(KS_STAMP2) || defined(KS_STAMP0)
+#ifdef KS_STAMP0
+#define KS_STP_ON (MODE == 0)
+#else
+#define KS_STP_ON (FARK)
+#endif
 #define KS_STP_DECL unsigned long long stp_[8]; int nstp_ = 0;
-#define KS_STP() do { if (FARK && nstp_ < 8) { __builtin_amdgcn_s_waitcnt(0); stp_[nstp_++] = wall_clock64(); } } while (0)
-#define KS_STP_WRITE(ls_, tid_, mine_, total_) do { if (FARK) { __syncthreads(); KS_STP(); const int nmk_ = __syncthreads_count((mine_) ? 1 : 0); \
+#define KS_STP() do { if (KS_STP_ON && nstp_ < 8) { __builtin_amdgcn_s_waitcnt(0); stp_[nstp_++] = wall_clock64(); } } while (0)
+#define KS_STP_WRITE(ls_, tid_, mine_, total_) do { if (KS_STP_ON) { __syncthreads(); KS_STP(); const int nmk_ = __syncthreads_count((mine_) ? 1 : 0); \
         if ((tid_) == 0) { int *dst_ = (ls_).fail + 1 + 200000 + 12 * (int)blockIdx.x; dst_[0] = (int)(stp_[0] & 0x7fffffffull); \
             for (int k_ = 1; k_ < 8; ++k_) dst_[k_] = (int)(stp_[k_] - stp_[0]); dst_[8] = (total_); dst_[9] = nmk_; } } } while (0)
 #else
