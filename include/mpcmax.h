@@ -130,7 +130,8 @@ int mpc_knn_list_offsets(const mpc_shape *s, int64_t *out);
  * themselves done.  Tests assert which path a launch took. */
 int64_t mpc_knn_tail_counters_offset(const mpc_shape *s);
 
-/* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants,
+/* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants -- since version 107 the tile gather serves
+ * 'iwd' too: a member's weight is one hardware reciprocal of (d + 1e-9) * normaliser, 1 ulp --,
  * focus.py:157-163).  grad_flow_next may be NULL.  grad_traj [B][T+nb][n][2] is overwritten. */
 int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                     const float *grad_flow_next, const float *knn_state, float *grad_traj,
@@ -235,7 +236,9 @@ int mpc_event_splat_bwd(const mpc_shape *s, const float *events, const float *fl
  *   grad_iwe                : NULL for a forward-only call (then also set MPC_F_NO_BWD_RECORDS)
  * smooth_weight > 0 applies the smoothness term to flow_next when MPC_F_WANT_NEXT is set, else to flow_lut
  * (focus.py:232-246).  mpc_focus_bwd must follow mpc_focus_fwd on the same buffers and workspace;
- * grad_lut_scratch [like flow_lut] and grad_next_scratch [like flow_next, or NULL] are scratch. */
+ * grad_lut_scratch [like flow_lut] and grad_next_scratch [like flow_next, or NULL] are scratch (version 107: the tile gather and the far
+ * backward multiply the saved smoothness gradient by grad_out as they read it; grad_next_scratch is only written where the general
+ * gather serves the shape -- num_tref > 1 -- but must still be given with smoothness on flow_to_next and a grad_out). */
 typedef struct mpc_focus_buffers {
     const float *traj;        /* [B][T+nb][n][2]                      in  */
     const float *events;      /* [B][M][6]                            in  */
