@@ -1485,10 +1485,43 @@ __global__ __launch_bounds__(256) void k_knn_bwd_combine(const KnnParams p, cons
     }
 }
 
+// The same for num_tref == 1 WITH the flow_to_next term (both EVIMO2 configs), spread over the bins (round 6): a workgroup = 64 points
+// x four wavefronts, wavefront w takes the bins t = w, w + 4, ... (every load coalesced over the points, a[t - 1] read again instead of
+// carried), the four partial sums of d traj(t_ref) are added in wavefront order.  One thread per point walked all 41 bins of C4 one
+// after the other on 75 workgroups: 17 us of a 0.26 ms step (B = 1), a chain of dependent rounds on an idle chip.
+__global__ __launch_bounds__(256) void k_knn_bwd_combine_bins(const KnnParams p, const float2 *__restrict__ tmp_g,
+                                                              const float2 *__restrict__ tmp_a, float *__restrict__ gtraj) {
+    __shared__ float2 s_part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t gi = (size_t)blockIdx.x * 64 + lane;
+    const bool on = gi < (size_t)p.B * p.n;
+    const int b = on ? (int)(gi / p.n) : 0, i = on ? (int)(gi - (size_t)b * p.n) : 0;
+    float2 *g2 = reinterpret_cast<float2 *>(gtraj) + (size_t)b * (1 + p.nb) * p.n;
+    float sy = 0.f, sx = 0.f;
+    if (on) {
+#pragma unroll 4
+        for (int t = w; t < p.nb; t += 4) {
+            const float2 g = tmp_g[(size_t)(b * p.nb + t) * p.n + i];
+            const float2 a = tmp_a[(size_t)(b * p.nb + t) * p.n + i];
+            const float2 c = t > 0 ? tmp_a[(size_t)(b * p.nb + t - 1) * p.n + i] : make_float2(0.f, 0.f);
+            sy += g.x; sx += g.y;
+            g2[(size_t)(1 + t) * p.n + i] = make_float2(-g.x + c.x - a.x, -g.y + c.y - a.y);
+        }
+    }
+    s_part[w][lane] = make_float2(sy, sx);
+    __syncthreads();
+    if (w == 0 && on) {
+        const float2 p0 = s_part[0][lane], p1 = s_part[1][lane], p2 = s_part[2][lane], p3 = s_part[3][lane];
+        g2[i] = make_float2(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y);
+    }
+}
+
 // num_tref == 1 without the flow_to_next term, after a k_knn_bwd_tile that wrote d traj(t_mid) in place: only
 //   d traj(t_ref)[i] = sum_t g[t][i] = sum_t -(d traj(t_mid)[t][i])    (same order, same bits: a - (-g) == a + g)
 // is left -- 15 coalesced reads and one write per point instead of 15 + 16.
 __global__ __launch_bounds__(256) void k_knn_bwd_combine_direct(const KnnParams p, float *__restrict__ gtraj) {
+    // (one thread per point: with 15 bins the launch is bound by its 32 MB at C3; the bin-parallel form of k_knn_bwd_combine_bins was
+    // measured here too, round 6: 10.4 us against 9.8 at C3, 6.4 against 6.4 at B = 1)
     const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gi >= (size_t)p.B * p.n) return;
     const int b = (int)(gi / p.n), i = (int)(gi - (size_t)b * p.n);
@@ -1816,8 +1849,7 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
         }
         const int64_t totalb = (int64_t)s->B * s->n;
         if (direct) MPC_LAUNCH(k_knn_bwd_combine_direct, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, grad_traj);
-        else MPC_LAUNCH(k_knn_bwd_combine, dim3(mpc_cdiv(totalb, 256)), dim3(256), 0, st, p, tmp_g,
-                           grad_flow_next ? tmp_a : nullptr, grad_traj);
+        else MPC_LAUNCH(k_knn_bwd_combine_bins, dim3(mpc_cdiv(totalb, 64)), dim3(256), 0, st, p, tmp_g, tmp_a, grad_traj);          // (not direct: grad_flow_next given)
         MPC_CHECK_LAUNCH();
         return 0;
     }
