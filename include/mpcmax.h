@@ -131,7 +131,7 @@ int mpc_knn_list_offsets(const mpc_shape *s, int64_t *out);
 int64_t mpc_knn_tail_counters_offset(const mpc_shape *s);
 
 /* Backward of the above w.r.t. traj (indices carry no gradient; 'iwd' weights are constants -- since version 107 the tile gather serves
- * 'iwd' too: a member's weight is one hardware reciprocal of (d + 1e-9) * normaliser, 1 ulp --,
+ * 'iwd' too: a member's weight is one hardware reciprocal of (d + 1e-9), 1 ulp, on the query's gradient divided by its normaliser --,
  * focus.py:157-163).  grad_flow_next may be NULL.  grad_traj [B][T+nb][n][2] is overwritten. */
 int mpc_knn_lut_bwd(const mpc_shape *s, const float *traj, const float *grad_flow_lut,
                     const float *grad_flow_next, const float *knn_state, float *grad_traj,

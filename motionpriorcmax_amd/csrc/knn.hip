@@ -826,13 +826,14 @@ __global__ __launch_bounds__(TS * TS) void k_knn_bwd_points(const KnnParams p, c
 // window loop of k_knn_bwd_tile, CW columns wide (fully unrolled: the squared column offsets live in registers).
 // Membership is `d <= K-th distance` (callers: no excluded tie among the staged queries).
 // IWD ('iwd' interpolation, focus.py:155-163; round 6): a member's weight is (1 / (d + 1e-9)) / normaliser of the query instead of
-// 1 / K -- lwn holds the normalisers, and the weight is the membership flag times ONE hardware reciprocal of (d + 1e-9) * normaliser
+// 1 / K -- the staged gradient of a query cell is dL/dLUT / normaliser (divided once per staged cell, not per visited cell: no fourth array
+// in LDS, 12 bytes per cell as for 'mean'), and the weight is the membership flag times ONE hardware reciprocal of (d + 1e-9)
 // (v_rcp_f32: 1 ulp; the two IEEE divisions of the formula as written are ~20 instructions per visited cell in a loop of 6, and the
 // weights are constants of the backward: their rounding is a relative 2e-7 of the gradient).  The flow_to_next term stays a mean.
 template <int CW, bool L1, bool NEXT, bool IWD>
 __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2 pt, int x0, int y0, int nxw, int nyw, int nymax,
                                                 int ry0, int RW, int RP, int xb, const float *ldk, const float2 *lg,
-                                                const float2 *lgn, const float *lwn, float &ay, float &ax, float2 &an) {
+                                                const float2 *lgn, float &ay, float &ax, float2 &an) {
     float dx2[CW];
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
@@ -845,7 +846,7 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
         const float dy2 = (r < nyw) ? (L1 ? fabsf(dy) : dy * dy) : INFINITY;
         const int ro = __mul24(cyr - ry0, RP) + xb;
         MPC_EXPECT(ro >= 0 && ro + CW <= RW * RP + 16);          // (every lane reads CW cells of the row: the slack behind the last row is there for that)
-        const float *rdk = ldk + ro, *rwn = lwn + ro;
+        const float *rdk = ldk + ro;
         const float2 *rg = lg + ro, *rown = lgn + ro;
         // The gradients as ONE ds_read_b64 each (knn_lds_f2: a volatile load the compiler may not pair).  Left alone it pairs
         // the reads of neighbouring cells into ds_read2_b64, which the LDS serves at half the rate of two single reads (8
@@ -857,14 +858,13 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
 #pragma unroll
         for (int c0 = 0; c0 < CW; c0 += KNN_BW_CH) {
             float2 e[KNN_BW_CH], gq[KNN_BW_CH];
-            float dkc[KNN_BW_CH], wnc[KNN_BW_CH];
+            float dkc[KNN_BW_CH];
 #pragma unroll
             for (int c = 0; c < KNN_BW_CH; ++c) {
                 if (c0 + c < CW) {
                     e[c] = knn_lds_f2(rg + c0 + c);
                     if (NEXT) gq[c] = knn_lds_f2(rown + c0 + c);
                     dkc[c] = rdk[c0 + c];
-                    if (IWD) wnc[c] = rwn[c0 + c];
                 }
             }
 #pragma unroll
@@ -878,8 +878,8 @@ __device__ __forceinline__ void bwd_window_fast(const KnnParams &p, const float2
                     const float d = dy2 + dx2[c0 + c];
                     const float w = fminf(fmaxf(fmaf(dkc[c] - d, 0x1p100f, 1.f), 0.f), 1.f);
                     if (IWD) {
-                        // (d = inf beyond the window: the reciprocal is 0; a cell that is no query holds normaliser 1)
-                        const float wi = w * __builtin_amdgcn_rcpf((d + 1e-9f) * wnc[c]);
+                        // (d = inf beyond the window: the reciprocal is 0; the staged gradient of a query is dL/dLUT / normaliser)
+                        const float wi = w * __builtin_amdgcn_rcpf(d + 1e-9f);
                         ay = fmaf(wi, e[c].x, ay); ax = fmaf(wi, e[c].y, ax);
                     } else { ay = fmaf(w, e[c].x, ay); ax = fmaf(w, e[c].y, ax); }
                     if (NEXT) { an.x = fmaf(w, gq[c].x, an.x); an.y = fmaf(w, gq[c].y, an.y); }
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void k_knn_reach_tiles(const KnnParams p, cons
 }
 
 template <bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) void k_knn_bwd_tile(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
+__global__ __launch_bounds__(256, NEXT ? KNN_BW_OCC_NEXT : (IWD ? KNN_BW_OCC_IWD : KNN_BW_OCC)) void k_knn_bwd_tile(const KnnParams p, const knn_cs_t *__restrict__ cell_start,
                                                       const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                       const float *__restrict__ glut, const float *__restrict__ gnext,
                                                       const float *__restrict__ knn_state,
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
     // ---- phase 2 (after the reach is known; staging a guessed halo before it, so that the loads of the two phases
     //      travel together, measured slower: too many tiles stage twice): the K-th distance, K-th index | tie flag and
     //      dL/dLUT of the tile's query cells and the halo the reach asks for ------------------------------------------
-    float *ldk, *lwn; float2 *lg, *lgn;
+    float *ldk; float2 *lg, *lgn;
     int RQ = 0, RW = TS, RP = 32, ry0 = by_ * TS, rx0 = bx_ * TS;
     const bool has_next = NEXT && (gnext != nullptr) && (t < p.nb - 1);
     const float2 *gn2 = has_next ? reinterpret_cast<const float2 *>(gnext) + (size_t)(b * (p.nb - 1) + t) * p.G : nullptr;
@@ -1066,7 +1066,6 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
             lgn = nullptr;
             lg = reinterpret_cast<float2 *>(s_dyn + ncell * 4);          // (ncell is even: 8-byte aligned)
         }
-        lwn = IWD ? reinterpret_cast<float *>(s_dyn + ncell * (NEXT ? 20 : 12)) : nullptr;      // 'iwd': the queries' normalisers
         int tie = 0;
         for (int rr = tid >> 5; rr < RW; rr += 8) {
             const int yy = ry0 + rr;
@@ -1083,17 +1082,18 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
                     if (has_next) { gn = gn2[(size_t)yy * p.wq + xx]; if (gnext_scale != nullptr) gn = make_float2(gn.x * gns, gn.y * gns); }
                     if (ik & KNN_FAR_FLAG) dk = -1.f;        // served by the fallback kernel: k_knn_bwd_far adds its gradient
                     else tie |= ik & KNN_TIE_FLAG;
+                    // 'iwd': the query's normaliser goes into its staged gradient (a cell that is no member of anything holds 0: its
+                    // weight is 0, and 0 x a non-finite quotient would not be)
+                    if (IWD) g = (dk >= 0.f && wn > 0.f) ? make_float2(g.x / wn, g.y / wn) : make_float2(0.f, 0.f);
                     ik &= KNN_IDX_MASK;
                 }
                 ldk[MPC_IDX(rr * RP + cc, ncell)] = dk; lg[MPC_IDX(rr * RP + cc, ncell)] = g;
                 if (NEXT) lgn[MPC_IDX(rr * RP + cc, ncell)] = gn;
-                if (IWD) lwn[MPC_IDX(rr * RP + cc, ncell)] = (dk >= 0.f) ? wn : 1.f;
             }
         }
         if (tid < KNN_BW_WMAX) {                    // slack behind the last row: never a member
             ldk[MPC_IDX(RW * RP + tid, ncell)] = -1.f; lg[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f);
             if (NEXT) lgn[MPC_IDX(RW * RP + tid, ncell)] = make_float2(0.f, 0.f);
-            if (IWD) lwn[MPC_IDX(RW * RP + tid, ncell)] = 1.f;
         }
         const bool wt = __ballot(tie != 0) != 0ull;
         if ((tid & 63) == 0) s_tiew[tid >> 6] = wt ? 1 : 0;
@@ -1148,13 +1148,13 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
                 // windows wider than 8 columns (border tiles: clipped queries reach twice as far) go in two column chunks, 8 +
                 // 2 / 5 / 8: the squared column offsets of 16 columns, live across the row loop, do not fit the 64-register
                 // budget beside the single-read form of the gradient loads (bwd_window_fast)
-                if (nxmax <= 7) bwd_window_fast<7, L1, NEXT, IWD>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, lwn, ay, ax, an);
+                if (nxmax <= 7) bwd_window_fast<7, L1, NEXT, IWD>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
                 else {
-                    bwd_window_fast<8, L1, NEXT, IWD>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, lwn, ay, ax, an);
+                    bwd_window_fast<8, L1, NEXT, IWD>(p, pt, x0, y0, nxw, nyw, nymax, ry0, RW, RP, xb, ldk, lg, lgn, ay, ax, an);
                     if (nxmax > 8) {
-                        if (nxmax <= 10) bwd_window_fast<2, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, lwn, ay, ax, an);
-                        else if (nxmax <= 13) bwd_window_fast<5, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, lwn, ay, ax, an);
-                        else bwd_window_fast<8, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, lwn, ay, ax, an);
+                        if (nxmax <= 10) bwd_window_fast<2, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
+                        else if (nxmax <= 13) bwd_window_fast<5, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
+                        else bwd_window_fast<8, L1, NEXT, IWD>(p, pt, x0 + 8, y0, nxw - 8, nyw, nymax, ry0, RW, RP, xb + 8, ldk, lg, lgn, ay, ax, an);
                     }
                 }
             } else if (act) {
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256, (NEXT || IWD) ? KNN_BW_OCC_NEXT : KNN_BW_OCC) 
                         const bool in = (d < dk) || (d == dk && i <= (reinterpret_cast<const int *>(knn_state)[BQ + (size_t)bt * p.G + (size_t)cy * p.wq + cx] & KNN_IDX_MASK));
                         if (in) {
                             const float2 e = lg[ro + cx];
-                            if (IWD) { const float wi = __builtin_amdgcn_rcpf((d + 1e-9f) * lwn[ro + cx]); ay = fmaf(wi, e.x, ay); ax = fmaf(wi, e.y, ax); }
+                            if (IWD) { const float wi = __builtin_amdgcn_rcpf(d + 1e-9f); ay = fmaf(wi, e.x, ay); ax = fmaf(wi, e.y, ax); }
                             else { ay += e.x; ax += e.y; }
                             if (NEXT) { const float2 gq = lgn[ro + cx]; an.x += gq.x; an.y += gq.y; }
                         }
@@ -1800,8 +1800,8 @@ int mpc_knn_lut_bwd_ex(const mpc_shape *s, const float *traj, const float *grad_
     const int gxb = knn_tiles_x(s->wq, p.m), gyb = knn_tiles_y(s->hq, p.m), ntiles = gxb * gyb;
     if (knn_bwd_is_tile(s)) {
         const int RWm = 16 + 2 * KNN_RQ_MAX;
-        const size_t ldsb = grad_flow_next ? ((size_t)RWm * (RWm > KNN_BW_PITCH_NEXT ? RWm : KNN_BW_PITCH_NEXT) + KNN_BW_WMAX) * (p.iwd ? 24 : 20)
-                                           : ((size_t)RWm * KNN_BW_PITCH + KNN_BW_WMAX) * (p.iwd ? 16 : 12);
+        const size_t ldsb = grad_flow_next ? ((size_t)RWm * (RWm > KNN_BW_PITCH_NEXT ? RWm : KNN_BW_PITCH_NEXT) + KNN_BW_WMAX) * 20
+                                           : ((size_t)RWm * KNN_BW_PITCH + KNN_BW_WMAX) * 12;          // ('iwd': the same arrays -- the normaliser is in the staged gradient)
         const dim3 gridb(((int64_t)gxb * gyb * s->B * s->nb + 7) / 8 * 8);
         float2 *direct = (grad_flow_next == nullptr) ? reinterpret_cast<float2 *>(grad_traj) : nullptr;
         // The reach of every tile NOT as the first phase of every workgroup: the gather is a chain of phases per workgroup at

@@ -52,6 +52,17 @@ static_assert(KNN_FAR_WS * KNN_FAR_TH == KS_NT, "a block of queries of the secon
 static_assert(KNN_RCAP <= 6, "the packed chord widths of the main launch");
 static_assert(KNN_MARGIN > KNN_RCAP, "the strip kernel must not reach the outermost ring of the bucket grid");
 
+// 'iwd' weight of a neighbour at distance d (focus.py:159-161: 1 / (d + 1e-9)) on the strip path: ONE hardware reciprocal (v_rcp_f32,
+// 1 ulp) instead of the ~10 instructions of the IEEE division, per visited slot of pass 2 (round 6: `k_knn_strip<*, *, true>` 299 -> 270 us at
+// C3, 262 with the branch around a slot's arithmetic gone too; the weights' rounding is a relative 6e-8 of a term of a 32-term weighted
+// mean, the LUT is held to 1e-5 against the reference)
+#ifndef KS_IWD_PJ
+#define KS_IWD_PJ 4          // positions of pass 2 in flight together ('iwd')
+#endif
+#ifndef KS_IWD_RCP
+#define KS_IWD_RCP 1
+#endif
+__device__ __forceinline__ float ks_iwd_weight(float d) { return KS_IWD_RCP ? __builtin_amdgcn_rcpf(d + 1e-9f) : 1.f / (d + 1e-9f); }
 // value of lane `l` (wave-uniform l): v_readlane, no LDS round trip
 __device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ unsigned lane_u(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
@@ -583,27 +594,28 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                     near4[h] = ge2 & 0x80808080u;
                     E[g / 4] |= ((ge1 ^ ge2) >> (7 - j)) & (0x01010101u << j);      // (ge2 implies ge1: the xor is "at level bstar")
                 }
+                float2 pj[IWD ? KS_IWD_PJ : 1];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    if (IWD) {
-                        if (((near4[u >> 2] >> (8 * (u & 3))) & 0x80u) != 0u) {
-                            const float2 pj = pp[8 * g + u];
-                            const float d = pair_dist(qy, qx, pj.x, pj.y, L1);
-                            const float wgt = 1.f / (d + 1e-9f);                  // focus.py:159-161
-                            sy_ += wgt * fj[u].x; sx_ += wgt * fj[u].y; sw_ += wgt;
-                            if (do_next) { ny_ += 128.f * gj[u].x; nx_ += 128.f * gj[u].y; }
-                        }
-                    } else {
-                        // byte u & 3 of the word as a float, 128.0 or 0.0 (spelled out: with the bytes known to be 0x80 / 0 the
-                        // compiler rewrites the shift-and-mask form into a shift, an SDWA and, and a conversion of byte 0)
-                        float flag;
-                        if ((u & 3) == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                        else if ((u & 3) == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                        else if ((u & 3) == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                        else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
-                        sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_);
-                        if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
+                    if (IWD && (u % KS_IWD_PJ) == 0) {
+#pragma unroll
+                        for (int v = 0; v < KS_IWD_PJ; ++v) pj[v] = knn_lds_f2(pp + 8 * g + u + v);      // (positions requested together, no branch around them)
                     }
+                    // byte u & 3 of the word as a float, 128.0 or 0.0 (spelled out: with the bytes known to be 0x80 / 0 the
+                    // compiler rewrites the shift-and-mask form into a shift, an SDWA and, and a conversion of byte 0)
+                    float flag;
+                    if ((u & 3) == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    else if ((u & 3) == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    else if ((u & 3) == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(flag) : "v"(near4[u >> 2]));
+                    if (IWD) {
+                        // focus.py:159-161, branch-free (round 6): weight = flag x 1 / (d + 1e-9) -- 128 / (d + 1e-9) for a neighbour, 0 for
+                        // any other slot (a dummy slot's distance is finite); the factor 128, a power of two, is in numerator and
+                        // normaliser alike and leaves their quotient's bits alone
+                        const float wgt = flag * ks_iwd_weight(pair_dist(qy, qx, pj[IWD ? u % KS_IWD_PJ : 0].x, pj[IWD ? u % KS_IWD_PJ : 0].y, L1));
+                        sy_ = fmaf(wgt, fj[u].x, sy_); sx_ = fmaf(wgt, fj[u].y, sx_); sw_ += wgt;
+                    } else { sy_ = fmaf(flag, fj[u].x, sy_); sx_ = fmaf(flag, fj[u].y, sx_); }
+                    if (NEXT) { ny_ = fmaf(flag, gj[u].x, ny_); nx_ = fmaf(flag, gj[u].y, nx_); }
                 }
             }
         }
@@ -651,7 +663,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                         if (e != a) rank += ((dd[e] < dd[a]) | ((dd[e] == dd[a]) & (ii[e] < ii[a]))) ? 1 : 0;
                     if (light && a < inbin && rank < need) {
                         const float2 f = pf[jj[a]];
-                        if (IWD) { const float wgt = 1.f / (dd[a] + 1e-9f); sy_ += wgt * f.x; sx_ += wgt * f.y; sw_ += wgt; }
+                        if (IWD) { const float wgt = 128.f * ks_iwd_weight(dd[a]); sy_ = fmaf(wgt, f.x, sy_); sx_ = fmaf(wgt, f.y, sx_); sw_ += wgt; }
                         else { sy_ = fmaf(128.f, f.x, sy_); sx_ = fmaf(128.f, f.y, sx_); }       // (the sums carry the factor 128 of pass 2)
                         if (do_next) { const float2 g2 = pn[jj[a]]; ny_ = fmaf(128.f, g2.x, ny_); nx_ = fmaf(128.f, g2.y, nx_); }
                         if (rank == need - 1) { dK = dd[a]; iK = ii[a]; }
@@ -701,7 +713,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 for (int c = 0; c < NM; ++c) {
                     if (bb[c] && rc[c] < hneed) {
                         const float2 f = lflow[hs + 64 * c + lane];
-                        if (IWD) { const float wgt = 1.f / (dc[c] + 1e-9f); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
+                        if (IWD) { const float wgt = ks_iwd_weight(dc[c]); cy_ += wgt * f.x; cx_ += wgt * f.y; cw_ += wgt; } else { cy_ += f.x; cx_ += f.y; }
                         if (hnext) { const float2 g2 = lnext[hs + 64 * c + lane]; cny += g2.x; cnx += g2.y; }
                         if (rc[c] == hneed - 1) { cdk = dc[c]; cik = ic[c]; }
                     }
@@ -718,7 +730,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
                 for (int c = 0; c < NM; ++c) mytie = mytie || (bb[c] && dc[c] == cdk && ic[c] > cik);
                 const bool htie = __ballot(mytie) != 0ull;
                 if (lane == h) {
-                    if (IWD) { sy_ += cy_; sx_ += cx_; sw_ += cw_; }
+                    if (IWD) { sy_ = fmaf(128.f, cy_, sy_); sx_ = fmaf(128.f, cx_, sx_); sw_ = fmaf(128.f, cw_, sw_); }
                     else { sy_ = fmaf(128.f, cy_, sy_); sx_ = fmaf(128.f, cx_, sx_); }
                     ny_ = fmaf(128.f, cny, ny_); nx_ = fmaf(128.f, cnx, nx_);
                     dK = cdk; iK = cik; tie = htie;
@@ -729,7 +741,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
         if (live) {
             const size_t BQ = (size_t)p.B * p.nb * p.G;
             float2 ov; float norm = 0.f;
-            if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_; }
+            if (IWD) { ov.x = sy_ / sw_; ov.y = sx_ / sw_; norm = sw_ * 0.0078125f; }      // (the sums carry the factor 128 of pass 2; the normaliser is saved without it)
             // mean = sum / K (focus.py:166) with the factor 128 of pass 2 taken out first (exact).  K a power of two (the shipped
             // 32): the division is a multiplication by an exact reciprocal -- same bits, a tenth of the instructions
             const bool kpow2 = (p.K & (p.K - 1)) == 0;

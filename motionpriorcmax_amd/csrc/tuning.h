@@ -44,6 +44,9 @@
 #ifndef KNN_BW_OCC
 #define KNN_BW_OCC 7
 #endif
+#ifndef KNN_BW_OCC_IWD
+#define KNN_BW_OCC_IWD 7      // 'iwd' without the flow_to_next gradient (12 bytes of LDS per cell as for 'mean'): k_knn_bwd_tile at C3 155.1 us at six per CU, 148.6 at seven
+#endif
 #ifndef KNN_BW_OCC_NEXT
 #define KNN_BW_OCC_NEXT 6     // with the flow_to_next gradient (and for 'iwd'): 80 VGPRs, 23 KB of LDS per workgroup.  C4 batch 6, k_knn_bwd_tile:
                               // 8 per CU by registers (64, 31 spilled; the LDS -- 24 bytes per cell then -- allowed 5) 242 us; the K-th index
