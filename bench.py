@@ -926,7 +926,7 @@ def main():
                 nd[tag] = {'ms_per_step': round(1e2 * (time.perf_counter() - t0), 4)}
                 del Ln, trd_, evd_
             nd['note'] = ('same workload and inputs as the headline with one loss setting changed; iwd: strip forward, tile-gather backward with '
-                          'distance weights (round 6; the point gather k_knn_bwd_points before: 1.14 ms); dist_l1: tile kernel k_knn_query forward; '
+                          'distance weights (round 6; the point gather k_knn_bwd_points before: 1.14 ms); dist_l1: strip forward with 128 slots per query (round 6; the tile kernel k_knn_query before: 1.94 ms); '
                           'num_tref = 2: k_knn_query forward and k_knn_bwd_points backward (DESIGN.md section 4.1: what fast paths would need)')
             also['non_default_configs'] = nd
         except Exception as e:

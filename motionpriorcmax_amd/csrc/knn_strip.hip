@@ -38,6 +38,14 @@
 
 #define KS_NT 256
 #define KS_MAXCH 24                 // words of 4 slots per query on the fast path (96 slots)
+#ifndef KS_OCC_WIDE
+#define KS_OCC_WIDE 5               // workgroups per CU of the variants with the wider register set (flow_to_next, L1): 96 VGPRs
+#endif
+#ifndef KS_MAXCH_L1
+#define KS_MAXCH_L1 32              // ... with the L1 norm (128 slots): the ball of the ring bound is a diamond, HALF of its square -- a square that
+                                    // holds K points in its diamond holds ~2 K (99 slots at the DSEC density); eight more nearness words per lane,
+                                    // the 96-register budget of the flow_to_next variant (five workgroups per CU)
+#endif
 #define KS_BASECH 16                // words every bisection step counts; the rest only in wavefronts that use them
 #define KS_NLEV 64                  // nearness levels: 1 .. 63 over [0.4 upper, upper), 64 = nearer than that; byte 0 = not a candidate
 #define KS_LMAX 4                   // keys of the K-th level a lane ranks in registers; more: served by the whole wavefront
@@ -103,7 +111,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
 #define KS_SYNC() __syncthreads()
     KS_STP_DECL
     KS_STP();
-    constexpr int MAXCH = FARK ? KS_MAXCH_FAR : KS_MAXCH;      // words of four slots per query
+    constexpr int MAXCH = FARK ? KS_MAXCH_FAR : (L1 ? KS_MAXCH_L1 : KS_MAXCH);      // words of four slots per query
     (void)SPLIT;
     constexpr int RC = FARK ? KNN_RFAR : KNN_RCAP;
     constexpr int TH = KS_NT / WS;
@@ -852,7 +860,7 @@ __device__ __forceinline__ void strip_body(const KnnParams &p, const float *__re
 // 1-D grid of gx * gy * B * nb workgroups (gx strips, gy row blocks) in XCD-contiguous order, 256 threads,
 // dynamic LDS sized by the launcher
 template <int WS, bool L1, bool NEXT, bool IWD>
-__global__ __launch_bounds__(KS_NT, NEXT ? 5 : 6) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
+__global__ __launch_bounds__(KS_NT, (NEXT || L1) ? KS_OCC_WIDE : 6) void k_knn_strip(const KnnParams p, const float *__restrict__ traj,
                                                      const knn_cs_t *__restrict__ cell_start, const knn_cs_t *__restrict__ sat,
                                                      const float2 *__restrict__ spos, const knn_idx_t *__restrict__ sidx,
                                                      float *__restrict__ flow_lut, float *__restrict__ flow_next,
@@ -1314,7 +1322,8 @@ static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out,
     const double dens = (double)s->n / ((double)s->hq * s->wq);
     const double row_pts = dens * (WS + 2 * r_init);                       // points per region row of an inner strip
     // slots of an inner query: its rows, one dummy slot per even row; must leave room for denser places
-    if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * KS_MAXCH) return false;
+    const int maxch = (s->flags & MPC_F_DIST_L1) ? KS_MAXCH_L1 : KS_MAXCH;
+    if ((2 * r_init + 1) * (row_pts + 0.5) * 1.3 > 4 * maxch) return false;
     const int rows = (TH < s->hq ? TH : s->hq) + 2 * r_init;
     int cap = (int)(1.15 * rows * (row_pts + 0.5)) + 32;
     cap = (cap + 15) / 16 * 16;
@@ -1322,7 +1331,7 @@ static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out,
     auto lds_of = [&](int NR, int tail) {
         return (((size_t)NR * 8 + (size_t)(NR + 1) * 4 + 15) & ~(size_t)15) + (size_t)(cap + tail) * 8 * (next ? 3 : 2) + (size_t)cap * 2 + 16;
     };
-    const size_t lds = lds_of(TH + 2 * KNN_RCAP, KS_TAIL(KS_MAXCH)), lds_far = lds_of(TH + 2 * KNN_RFAR, KS_TAIL(KS_MAXCH_FAR));
+    const size_t lds = lds_of(TH + 2 * KNN_RCAP, KS_TAIL(maxch)), lds_far = lds_of(TH + 2 * KNN_RFAR, KS_TAIL(KS_MAXCH_FAR));
     if (lds_far > 64 * 1024) return false;
     *cap_out = cap; *lds_out = lds;
     if (lds_far_out) *lds_far_out = lds_far;
@@ -1331,7 +1340,7 @@ static bool strip_geometry(const mpc_shape *s, int r_init, int WS, int *cap_out,
 
 bool mpc_knn_strip_usable(const mpc_shape *s, int r_init) {
     int cap; size_t lds;
-    if (s->T != 1 || s->n >= 65536 || s->K < 1 || s->K > 4 * KS_MAXCH) return false;
+    if (s->T != 1 || s->n >= 65536 || s->K < 1 || s->K > 4 * ((s->flags & MPC_F_DIST_L1) ? KS_MAXCH_L1 : KS_MAXCH)) return false;
     if (s->hq < 2 * r_init + 2 || s->wq < 2 * r_init + 2) return false;       // tiny grids: the square is the whole grid
     return strip_geometry(s, r_init, 2, &cap, &lds);
 }

@@ -345,6 +345,35 @@ def test_knn_large_k_and_dense_points():
     np.testing.assert_allclose(got, ref, atol=2e-5)
 
 
+def test_knn_l1_distance_at_dsec_density_on_the_strip_path():
+    """dist_norm 'l1' at the DSEC density (480 x 640, one trajectory per 4 x 4 tile, K = 32): a square that holds K points in its diamond
+    holds ~2 K candidate slots -- since round 6 the strip kernel's L1 instantiations hold 128 per query and serve the configuration (the
+    general tile kernel before).  LUT against the brute-force oracle, gradient against autograd through it, and the launch that ran."""
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    shape, sp, K = (480, 640), 4, 32
+    g = torch.Generator().manual_seed(77)
+    times = torch.cat((torch.tensor([0.41]), O.bin_mid_times(2)))
+    coeff = torch.randn(1, 1, 2, shape[0], shape[1], generator=g) * 6.0
+    traj = O.trajectories_at(coeff, times, O.tile_mask(shape, 4), 1, 'polynomial')
+    cfg = dict(image_shape=shape, num_tref=1, num_bins=2, num_knn=K, smooth_weight=0.0, lut_superpixel_size=sp,
+               focus_loss_norm='l1', dist_norm='l1', scale_iwe_by_dt=True, mask_image_border=True,
+               polarity_aware_batching=True, interpolation_scheme='mean', smooth_type='on_flow_to_tref')
+    L = _loss_obj(cfg)
+    t = traj.to(_dev()).requires_grad_(True)
+    with ops.KernelTimer() as kt:
+        lut, _ = ops.KnnLutFn.apply(t, L._cfg)
+    ran = set(kt.summary())
+    assert 'k_knn_strip' in ran and 'k_knn_query' not in ran, ran
+    tr = traj.clone().requires_grad_(True)
+    ref, _ = O.interpolate_flow(tr[:, :1], tr[:, 1:], shape, sp, K, 'l1', 'mean')
+    np.testing.assert_allclose(lut.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    gl = torch.randn(lut.shape, generator=g)
+    lut.backward(gl.to(_dev()))
+    ref.backward(gl)
+    assert _rel_l2(t.grad.cpu().numpy(), tr.grad.numpy()) < 1e-5
+
+
 def test_knn_degenerate_point_sets():
     """Every trajectory collapsed onto a handful of spots (heavy distance ties, empty cells everywhere
     else: the whole-grid search path), and trajectories far outside the image."""
