@@ -927,7 +927,7 @@ def main():
                 del Ln, trd_, evd_
             nd['note'] = ('same workload and inputs as the headline with one loss setting changed; iwd: strip forward, tile-gather backward with '
                           'distance weights (round 6; the point gather k_knn_bwd_points before: 1.14 ms); dist_l1: strip forward with 128 slots per query (round 6; the tile kernel k_knn_query before: 1.94 ms); '
-                          'num_tref = 2: k_knn_query forward and k_knn_bwd_points backward (DESIGN.md section 4.1: what fast paths would need)')
+                          'num_tref = 2: the two reference times of a sample as two samples of the num_tref == 1 kernels (round 6, FocusLoss._calc_trefs_as_samples; the general kernels before: 3.73 ms)')
             also['non_default_configs'] = nd
         except Exception as e:
             also['non_default_configs'] = {'error': repr(e)[:200]}

@@ -28,6 +28,8 @@ class FocusLoss(base.TrajectoryLossBase):
             focus.py:90-91) or 'variance' (reference src/utils/loss.py:14-16).
         pyramid_levels (int, UNPINNED extension, default 1 = the reference): IWE pyramid of that many levels (2x2 averages of the
             raw IWE), the focus term summed over the levels (`ops.PyramidFocusFn`); BASELINE.json names one, the reference has none.
+        trefs_as_samples (bool, build-side switch, default True): with num_tref > 1 the T reference times of a sample run as T samples
+            of the num_tref == 1 kernels (`_calc_trefs_as_samples`); False: the general kernels (every stage in one launch for all T).
         static_shapes (bool, build-side extension, default False): capture `calc` + backward once per input shape into HIP
             graphs and replay them (ops.StaticFocusPlan): for small batches, whose eager step is bound by the host.
             `misc_metadata['iwes']` is then only valid until the next `calc`.
@@ -37,7 +39,7 @@ class FocusLoss(base.TrajectoryLossBase):
                  lut_superpixel_size, focus_loss_norm, dist_norm,
                  scale_iwe_by_dt, mask_image_border, polarity_aware_batching,
                  interpolation_scheme, smooth_type, loss_type='gradient_magnitude', profiler=None,
-                 static_shapes=False, pyramid_levels=1, auto_static_shapes=True, **kwargs):
+                 static_shapes=False, pyramid_levels=1, auto_static_shapes=True, trefs_as_samples=True, **kwargs):
         super().__init__()
         self.image_shape = image_shape
         self.num_tref = num_tref
@@ -68,6 +70,9 @@ class FocusLoss(base.TrajectoryLossBase):
         self._auto_key, self._auto_run = None, 0
         self._auto_never = set()              # shapes whose plan could not be captured: eager from then on
         self._tmid_dev = {}                   # bin mid-times per device (calc_per_event_basis)
+        # num_tref > 1 (not in the shipped yaml files): the T reference times of a sample as T samples of the num_tref == 1 path
+        # (_calc_trefs_as_samples); False: the general kernels (one launch for all reference times, global-atomic event path)
+        self.trefs_as_samples = bool(trefs_as_samples)
         self.is_needing_offsets = True
         self.imager = EventImageConverter(self.image_shape)
 
@@ -91,6 +96,26 @@ class FocusLoss(base.TrajectoryLossBase):
             polarity_split=bool(polarity_aware_batching),
             scheme_iwd=(interpolation_scheme == 'iwd'), smooth_on_next=(smooth_type == 'on_flow_to_next'),
             variance=(loss_type == 'variance'), atomic_path=bool(kwargs.get('debug_atomic_path', False)))
+        import dataclasses
+        self._cfg_t1 = dataclasses.replace(self._cfg, num_tref=1)
+
+    def _calc_trefs_as_samples(self, trajectories, events, t_ref, offsets):
+        """num_tref = T > 1 (focus.py:53-57, 66-113) on the kernels of the shipped num_tref == 1 configurations: sample b with its T
+        reference times IS T samples (b, 0) .. (b, T - 1) that share b's events and mid-time trajectories and differ in the
+        reference-time trajectory -- the same B * T images, the same B * T * num_bins look-up tables, hence the same objective
+        (loss.py: a mean over all images) and smoothness (a mean over all tables); the gradient of the shared rows is summed
+        by autograd through `repeat_interleave`.  The neighbour search runs T times over the same mid-time points -- twice the
+        work of an ideal T-flow kernel for T = 2, a third of the time of the general kernels (C3 shape: 3.73 -> ~1.3 ms).
+        Requires what focus.py:49-50 requires of num_tref > 1 anyway (no scale_iwe_by_dt, no polarity_aware_batching)."""
+        T = self.num_tref
+        b = events.shape[0]
+        n = trajectories.shape[2]
+        ref = trajectories[:, :T].reshape(b * T, 1, n, 2)
+        mid = trajectories[:, T:].repeat_interleave(T, dim=0)
+        traj_v = torch.cat((ref, mid), dim=1)
+        events_v = events.repeat_interleave(T, dim=0)
+        offs_v = offsets.repeat_interleave(T, dim=0) if torch.is_tensor(offsets) else offsets
+        return ops.FocusCalcFn.apply(traj_v, events_v, t_ref[:1], self._cfg_t1, -1, offs_v)
 
     def get_reconstruction_times(self, device):
         """Reference focus.py:53-64: [t_ref..., bin mid-times]."""
@@ -235,7 +260,10 @@ class FocusLoss(base.TrajectoryLossBase):
 
         t_ref = times[:self.num_tref]
         offsets = batch['event_offsets'] if 'event_offsets' in batch else None     # from order_events (optional)
-        if self.pyramid_levels > 1:
+        if self.num_tref > 1 and self.trefs_as_samples and not self._cfg.atomic_path and torch.is_tensor(events) and events.dim() == 3 \
+                and torch.is_tensor(trajectories) and trajectories.dim() == 4:
+            out = self._calc_trefs_as_samples(trajectories, events, t_ref, offsets)
+        elif self.pyramid_levels > 1:
             out = ops.PyramidFocusFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), self.pyramid_levels)
         elif self.static_shapes and ops.STAGE_TIMER is None and not torch.cuda.is_current_stream_capturing():
             out = ops.StaticFocusCalcFn.apply(trajectories, events, t_ref, self._cfg, int(num_pos_events), offsets, self._static_plans)

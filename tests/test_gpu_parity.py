@@ -169,6 +169,34 @@ def test_vs_oracle_seeded(kw):
     assert _rel_l2(tr_g.grad.cpu().numpy(), tr_o.grad.numpy()) < 1e-2
 
 
+@pytest.mark.parametrize('as_samples', [True, False])
+def test_num_tref_3_both_paths_vs_oracle(as_samples):
+    """num_tref = 3 through `calc`: the T reference times as T samples of the num_tref == 1 kernels (the default since round 6) and the
+    general kernels (trefs_as_samples=False), each against the CPU oracle; which kernels ran is asserted."""
+    from motionpriorcmax_amd import ops
+    from oracle import focus_oracle as O
+    cfg, ev, num_pos, traj, times = _oracle_case((96, 128), 2, 20000, 7, 8, seed=13, num_tref=3, scale_iwe_by_dt=False,
+                                                 polarity_aware_batching=False, smooth_weight=0.05)
+    Lo = O.FocusLossOracle(**cfg)
+    tr_o = traj.clone().requires_grad_(True)
+    lo, logo, misco = Lo.calc(tr_o, times, {'events': ev})
+    lo.backward()
+    dev = _dev()
+    L = _loss_obj(cfg, trefs_as_samples=as_samples)
+    tr_g = traj.to(dev).requires_grad_(True)
+    with ops.KernelTimer() as kt:
+        lg, logg, miscg = L.calc(tr_g, times.to(dev), {'events': ev.to(dev)})
+        lg.backward()
+    ran = set(kt.summary())
+    assert ('k_knn_strip' in ran and 'k_knn_bwd_tile' in ran and 'k_ev_bin' in ran) == as_samples, ran
+    assert abs(lg.item() - lo.item()) <= 1e-5 * abs(lo.item())
+    assert abs(logg['smoothness_loss'].item() - logo['smoothness_loss'].item()) <= 1e-5 * abs(logo['smoothness_loss'].item()) + 1e-12
+    io = misco['iwes'].numpy()
+    assert miscg['iwes'].shape == misco['iwes'].shape
+    np.testing.assert_allclose(miscg['iwes'].cpu().numpy(), io, rtol=0, atol=1e-5 * max(1.0, np.abs(io).max()))
+    assert _rel_l2(tr_g.grad.cpu().numpy(), tr_o.grad.numpy()) < 1e-2
+
+
 def test_tiled_and_atomic_paths_agree():
     from motionpriorcmax_amd import ops
     from oracle import focus_oracle as O
