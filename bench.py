@@ -898,7 +898,7 @@ def main():
                                          'note': 'the same C3-shaped step on a UNet-like smooth flow field (tools/realistic_probe.py, family unet)'}
             except Exception as e:
                 also['realistic_inputs'] = {'error': repr(e)[:300]}
-        # configurations outside the shipped yaml files (served by the general KNN kernels, not the strip kernels): timed once
+        # configurations outside the shipped yaml files: the headline's workload with one loss setting changed
         try:
             if args.no_nondefault:
                 raise RuntimeError('skipped (--no-nondefault)')
@@ -916,14 +916,17 @@ def main():
                     l_, _, _ = Ln.calc(trd_, tmd_, bn)
                     l_.backward()
                     trd_.grad = None
-                for _ in range(4):
+                for _ in range(6):
                     _st()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    _st()
-                torch.cuda.synchronize()
-                nd[tag] = {'ms_per_step': round(1e2 * (time.perf_counter() - t0), 4)}
+                blocks_ = []
+                for _ in range(3):                       # (median of three blocks of ten steps, as the headline)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(10):
+                        _st()
+                    torch.cuda.synchronize()
+                    blocks_.append(1e2 * (time.perf_counter() - t0))
+                nd[tag] = {'ms_per_step': round(sorted(blocks_)[1], 4)}
                 del Ln, trd_, evd_
             nd['note'] = ('same workload and inputs as the headline with one loss setting changed; iwd: strip forward, tile-gather backward with '
                           'distance weights (round 6; the point gather k_knn_bwd_points before: 1.14 ms); dist_l1: strip forward with 128 slots per query (round 6; the tile kernel k_knn_query before: 1.94 ms); '
