@@ -255,6 +255,32 @@ def test_c4_at_the_yaml_training_batch_of_six():
     assert _rel_l2(tg.grad, ta.grad) < 2e-3
 
 
+@pytest.mark.parametrize('norm', ['l2'])
+def test_num_tref_2_at_c3_size_two_implementations_agree(norm):
+    """num_tref = 2 at the C3 shape (B = 4 x 200k events): the reference times as samples of the num_tref == 1 kernels (strip search,
+    tile gather, LDS-tiled event path; `calc`'s default) against the general kernels (one launch per stage for both reference times,
+    global-atomic event path): loss, images and gradient of two independent implementations.  The 'l2' focus norm: no sign() whose
+    flips would loosen the gradient bound."""
+    import bench
+    from motionpriorcmax_amd import LossFactory
+    dev = _dev()
+    wl = dict(bench.WORKLOADS['C3']); wl['B'] = 4
+    ev, _, traj, times = bench.synth_inputs(wl, seed=3, trefs=(0.0, 1.0))
+    cfg = dict(bench.loss_config(wl), num_tref=2, scale_iwe_by_dt=False, polarity_aware_batching=False, focus_loss_norm=norm)
+    outs = []
+    for as_samples in (True, False):
+        L = LossFactory.get_loss_calculator('FOCUS', dict(cfg, trefs_as_samples=as_samples))
+        t = traj.to(dev).requires_grad_(True)
+        loss, log, misc = L.calc(t, times.to(dev), {'events': ev.to(dev)})
+        loss.backward()
+        outs.append((loss.item(), log['smoothness_loss'].item(), misc['iwes'], t.grad))
+    a, g = outs
+    assert a[2].shape == g[2].shape == (4, 2, 480, 640)
+    assert abs(a[0] - g[0]) <= 2e-6 * abs(g[0]) and abs(a[1] - g[1]) <= 1e-5 * abs(g[1]) + 1e-12
+    assert float((a[2] - g[2]).abs().max()) <= 1e-5 * float(g[2].abs().max())
+    assert _rel_l2(a[3], g[3]) < 1e-4
+
+
 @pytest.mark.parametrize('name,B', [('C2', 1), ('C3', 2), ('C4', 1)])
 def test_strip_kernel_serves_the_benchmark_shapes(name, B):
     """The KNN fast path (strip kernel) must serve nearly every query of the shapes the benchmark times; what it hands to
