@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which queries does the strip kernel hand to the fallback, and why?  python tools/fail_probe.py [family] [B]"""
+"""Which queries does the strip kernel hand to the fallback, and why?  python tools/fail_probe.py [family] [B] [loss key=value ...]"""
 import ctypes
 import os
 import sys
@@ -21,7 +21,8 @@ if fam == 'white':
     _, _, traj, _ = bench.synth_inputs(dict(wl, B=B), seed=1)
 else:
     traj, _ = synth.synth_trajectories(B, 3, wl['nb'], (bench.H, bench.W), bench.PATCH, fam, seed=11)
-L = LossFactory.get_loss_calculator('FOCUS', bench.loss_config(wl))
+over = dict(kv.split('=') for kv in sys.argv[3:])          # e.g. dist_norm=l1
+L = LossFactory.get_loss_calculator('FOCUS', dict(bench.loss_config(wl), **over))
 shape = ops.make_shape(L._cfg, B, 0, 0, traj.shape[2])
 ws = ops.alloc_workspace(shape, dev)
 ops.knn_lut_fwd(L._cfg, shape, traj.to(dev), ws)
