@@ -507,7 +507,7 @@ __device__ __forceinline__ void record_grad(float y, float x, float w, const flo
 // block are contiguous (offsets table) -- so the kernel reads the event rows themselves and redoes the warp instead of
 // reading records that the forward would have had to write (section 7 of DESIGN.md).
 template <bool ORDERED>
-__global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS) void k_lut_accum(const mpc_shape s, const BinLayout L,
+__global__ __launch_bounds__(ORDERED ? EV_LUT_THREADS_ORD : EV_LUT_THREADS, ORDERED ? 1 : EV_LUT_MINWAVES) void k_lut_accum(const mpc_shape s, const BinLayout L,
                                                     const float *__restrict__ gimg,
                                                     const float *__restrict__ scal,
                                                     const float *__restrict__ grad_out,

@@ -21,6 +21,11 @@
 #ifndef EV_LUT_THREADS
 #define EV_LUT_THREADS 512
 #endif
+#ifndef EV_LUT_MINWAVES
+#define EV_LUT_MINWAVES 6    // wavefronts per SIMD the register budget of k_lut_accum<false> is set for: 6 = three 512-thread workgroups per CU (what
+                             // its 46 KB LDS strips are sized for); the kernel had drifted to 81 VGPRs -- one over the 80 of six wavefronts, i.e. TWO
+                             // workgroups per CU (round 6, see profiles/HISTORY_r06.md)
+#endif
 #ifndef EV_LUT_THREADS_ORD
 #define EV_LUT_THREADS_ORD 1024      // ordered variant: 72 KB of LDS per workgroup -> two per CU; 1024 threads keep the CU's waves
 #endif
@@ -28,7 +33,8 @@
 #define EV_LUT_INFLIGHT_ORD 2
 #endif
 #ifndef EV_LUT_INFLIGHT
-#define EV_LUT_INFLIGHT 5   // 5 x 512 covers the largest bucket of C3 in one batch (4: 43.8 us, 5: 42.4, 6: 43.6, 8: 52.3)
+#define EV_LUT_INFLIGHT 4   // records of a thread in flight together.  Round 3, stage call: 4: 43.8 us, 5: 42.4, 6: 43.6, 8: 52.3; round 6, inside the step and at
+                            // three workgroups per CU (EV_LUT_MINWAVES): 4: 55.9 us at C3 / 44.7 at C4 batch 6, 5: 56.9 / 45.7, 6: 63.0 / 51.2
 #endif
 
 // ---- knn.hip -------------------------------------------------------------------------------------------------------
